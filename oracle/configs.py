@@ -1,0 +1,22 @@
+"""Named path configurations used by fixtures, tests and the CPU baseline.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  ``micro`` is a parity-only shape
+whose head widths (64 encoder / 32 decoder / 16 fusion q-k) match what the HIP
+attention kernels are specialised for; ``tiny`` is BASELINE.json configs[0];
+``base`` is configs[1] (the bench workload); ``base_as`` configs[2]; ``large``
+configs[3].
+"""
+from .avmae_oracle import PathConfig
+
+CONFIGS = {
+    'micro': PathConfig(embed_dim=128, depth=2, num_heads=2, image_size=(64, 64), audio_size=(32, 112),
+                        fusion_tkns=(4, 3, 2), fusion_layers=(0, 1), fusion_mlp_ratio=1.0, fusion_attn_ratio=0.25,
+                        fusion_num_heads=2, decoder_dim=64, decoder_depth=2, decoder_heads=2),
+    'tiny': PathConfig(embed_dim=192, depth=12, num_heads=3, image_size=(64, 64), audio_size=(128, 128),
+                       fusion_tkns=(16, 8, 8), fusion_layers=tuple(range(12)), fusion_mlp_ratio=1.0,
+                       fusion_attn_ratio=0.25, fusion_num_heads=3),
+    'base': PathConfig(),
+    'base_m75': PathConfig(audio_mask_ratio=0.75),
+    'base_as': PathConfig(fusion_mlp_ratio=4.0, fusion_attn_ratio=1.0),
+    'large': PathConfig(embed_dim=1024, depth=24, num_heads=16, fusion_layers=tuple(range(24)), fusion_num_heads=16),
+}

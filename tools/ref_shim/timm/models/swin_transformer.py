@@ -1,0 +1,24 @@
+"""Names models/swin.py imports at module scope (models/avmae.py:6 imports swin unconditionally)."""
+import torch
+
+
+def window_partition(x, window_size):
+    B, H, W, C = x.shape
+    x = x.view(B, H // window_size, window_size, W // window_size, window_size, C)
+    return x.permute(0, 1, 3, 2, 4, 5).contiguous().view(-1, window_size, window_size, C)
+
+
+def window_reverse(windows, window_size, H, W):
+    C = windows.shape[-1]
+    x = windows.view(-1, H // window_size, W // window_size, window_size, window_size, C)
+    return x.permute(0, 1, 3, 2, 4, 5).contiguous().view(-1, H, W, C)
+
+
+def get_relative_position_index(win_h, win_w):
+    coords = torch.stack(torch.meshgrid([torch.arange(win_h), torch.arange(win_w)], indexing='ij'))
+    cf = torch.flatten(coords, 1)
+    rel = (cf[:, :, None] - cf[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += win_h - 1
+    rel[:, :, 1] += win_w - 1
+    rel[:, :, 0] *= 2 * win_w - 1
+    return rel.sum(-1)

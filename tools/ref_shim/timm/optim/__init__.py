@@ -1,0 +1,1 @@
+from . import optim_factory  # noqa: F401

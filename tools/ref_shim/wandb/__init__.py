@@ -1,0 +1,1 @@
+# empty stand-in: util/misc.py imports wandb at module scope
