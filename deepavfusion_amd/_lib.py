@@ -1,0 +1,71 @@
+"""ctypes binding of libdavfusion_hip.so (the C ABI declared in include/dav_kernels.h).
+
+The product path has NO fallback: if the shared library is missing or a kernel
+returns an error code, a RuntimeError is raised.  Build it with
+``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C deepavfusion_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdavfusion_hip.so')
+
+_p, _i, _l, _f, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
+
+# name -> argtypes (must match include/dav_kernels.h)
+SIGNATURES = {
+    'dav_abi_version': [],
+    'dav_gemm_nt_bf16': [_p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _f, _i, _p],
+    'dav_gemm_tn_bf16': [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _i, _p],
+    'dav_attn_fwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _i, _l, _i, _l, _i, _l, _i, _f, _p],
+    'dav_attn_bwd': [_p] * 10 + [_i] * 6 + [_l, _i] * 8 + [_f, _p],
+    'dav_layernorm_fwd': [_p, _l, _i, _p, _l, _i, _i, _i, _p, _p, _f, _p, _p, _p, _p, _p],
+    'dav_layernorm_bwd': [_p, _l, _i, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p,
+                          _p, _l, _i, _p, _l, _p, _l,
+                          _p, _l, _i, _p, _l, _p, _l,
+                          _p, _p, _p],
+    'dav_mask_build': [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p],
+    'dav_patch_gather': [_p, _i, _i, _i, _i, _p, _i, _p, _p],
+    'dav_unshuffle_fwd': [_p, _p, _p, _p, _i, _i, _i, _i, _p, _l, _i, _p],
+    'dav_rows_gather_cast': [_p, _l, _i, _p, _i, _i, _i, _p, _p],
+    'dav_unshuffle_bwd_reduce': [_p, _l, _i, _p, _i, _i, _i, _i, _p, _p, _p],
+    'dav_patch_mse_fwd': [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
+    'dav_patch_mse_bwd': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p],
+    'dav_pair_expand': [_p, _p, _i, _i, _i, _i, _p, _p],
+    'dav_pair_reduce': [_p, _i, _i, _i, _i, _p, _p, _p],
+    'dav_cast_bf16': [_p, _p, _l, _p],
+    'dav_cast_transpose_bf16': [_p, _p, _i, _i, _p],
+    'dav_l2norm_workspace_bytes': [_l],
+    'dav_l2norm': [_p, _l, _f, _p, _p, _sz, _p],
+    'dav_adamw_flat': [_p, _p, _p, _p, _p, _l, _p, _p, _i, _f, _f, _f, _p, _f, _p],
+}
+
+ERRORS = {-1: 'bad shape', -2: 'unsupported dtype', -3: 'insufficient workspace', -4: 'HIP error', -5: 'misaligned pointer/stride'}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library once; raise if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f'{LIB_PATH} is missing: the DeepAVFusion HIP kernels are not built '
+                           '(run __graft_entry__.build() or make -C deepavfusion_amd/csrc). There is no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)           # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = _sz if name.endswith('workspace_bytes') else _i
+    if lib.dav_abi_version() != 1:
+        raise RuntimeError('libdavfusion_hip.so ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        raise RuntimeError(f'{what} failed: {ERRORS.get(code, code)}')

@@ -1,0 +1,221 @@
+"""Whole-path drivers + the single autograd node that exposes them.
+
+``avmae_apply`` runs the complete AVMAE step (masking -> patch embed -> 12 fused layers ->
+final norms -> two MAE decoders -> masked per-patch MSE) on the HIP engine and returns the
+reference's 4-tuple; the backward of that one node runs the hand-written backward and
+accumulates parameter gradients in place.  ``encoder_apply`` does the same for
+``DeepAVFusion.forward`` alone (kNN probe / downstream heads).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import engine as E
+from . import ops
+from .ops import BF16, F32
+
+
+def _f32c(x):
+    return x.detach().to(dtype=F32).contiguous()
+
+
+def _ids32(ids):
+    return None if ids is None else ids.to(torch.int32).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# encoder (models/deepavfusion.py:88-118)
+# ------------------------------------------------------------------------------------------------
+def encoder_fwd(enc, image, audio, ik32, ak32, want_f32=False, collect_embs=False):
+    B = image.shape[0]
+    x_i, t_pi = E.patch_embed_fwd(enc.image, image, ik32)
+    x_a, t_pa = E.patch_embed_fwd(enc.audio, audio, ak32)
+    x_f = enc.fusion_tokens.detach().expand(B, -1, -1).contiguous()
+    Hi, Ha, Hf = enc.image.num_heads, enc.audio.num_heads, enc.fusion_num_heads
+    layers, embs = [], []
+    for l, (bi, ba, fb) in enumerate(zip(enc.image.blocks, enc.audio.blocks, enc.fusion_blocks)):
+        if fb is None:
+            x_i, ti = E.block_fwd(bi, x_i, None, Hi, bi.norm1.eps)
+            x_a, ta = E.block_fwd(ba, x_a, None, Ha, ba.norm1.eps)
+            tf = None
+        else:
+            n_i, ti = E.block_fwd(bi, x_i, x_f, Hi, bi.norm1.eps)
+            n_a, ta = E.block_fwd(ba, x_a, x_f, Ha, ba.norm1.eps)
+            x_f, tf = E.fusion_block_fwd(fb, x_f, x_i, x_a, Hf, enc.num_fusion)    # reads the layer INPUT x_i / x_a (:106-107)
+            x_i, x_a = n_i, n_a
+        layers.append((ti, ta, tf))
+        if collect_embs:
+            embs.append((x_i, x_a, x_f))
+    xi_b, xi32, st_i = E.ln_fwd(enc.image.norm, None, x_i, B, want_f32=want_f32)
+    xa_b, xa32, st_a = E.ln_fwd(enc.audio.norm, None, x_a, B, want_f32=want_f32)
+    xf_b, xf32, st_f = E.ln_fwd(enc.fusion_norm, None, x_f, B, want_f32=want_f32)
+    tape = dict(t_pi=t_pi, t_pa=t_pa, layers=layers, x_i=x_i, x_a=x_a, x_f=x_f, st_i=st_i, st_a=st_a, st_f=st_f, B=B)
+    return (xi_b, xa_b, xf_b), (xi32, xa32, xf32), embs, tape
+
+
+def encoder_bwd(enc, t, dxi_b=None, dxa_b=None, dxf_b=None, dxi32=None, dxa32=None, dxf32=None):
+    """Gradients w.r.t. the three NORMED outputs (bf16 and/or fp32 parts) -> parameter gradients."""
+    B = t['B']
+    dev = t['x_i'].device
+
+    def final_norm(norm, x, st, dy_b, dy32):
+        g = torch.empty_like(x)
+        gb = torch.empty(x.shape, dtype=BF16, device=dev)
+        if dy_b is None and dy32 is None:
+            return g.zero_(), gb.zero_()
+        E.ln_bwd(norm, None, x, B, st, dy_bf16=dy_b, dy_f32=dy32, dx1=g, dx1_bf16=gb)
+        return g, gb
+    g_i, g_ib = final_norm(enc.image.norm, t['x_i'], t['st_i'], dxi_b, dxi32)
+    g_a, g_ab = final_norm(enc.audio.norm, t['x_a'], t['st_a'], dxa_b, dxa32)
+    g_f, g_fb = final_norm(enc.fusion_norm, t['x_f'], t['st_f'], dxf_b, dxf32)
+    blocks = list(zip(enc.image.blocks, enc.audio.blocks, enc.fusion_blocks))
+    for (bi, ba, fb), (ti, ta, tf) in zip(reversed(blocks), reversed(t['layers'])):
+        if fb is None:
+            g_i, g_ib, _ = E.block_bwd(bi, ti, g_i, g_ib)
+            g_a, g_ab, _ = E.block_bwd(ba, ta, g_a, g_ab)
+        else:
+            dx_f, dx_i, dx_a = E.fusion_block_bwd(fb, tf, g_f, g_fb)
+            g_i, g_ib, dx_f = E.block_bwd(bi, ti, g_i, g_ib, dx_fus=dx_f, dx_fus_acc=1, dx_mod=dx_i, dx_mod_acc=1)
+            g_a, g_ab, dx_f = E.block_bwd(ba, ta, g_a, g_ab, dx_fus=dx_f, dx_fus_acc=1, dx_mod=dx_a, dx_mod_acc=1)
+            g_f, g_fb = dx_f, None
+    E.patch_embed_bwd(enc.image, t['t_pi'], g_i, g_ib)
+    E.patch_embed_bwd(enc.audio, t['t_pa'], g_a, g_ab)
+    E.gbuf(enc.fusion_tokens).add_(g_f.sum(dim=0, keepdim=True))          # backward of .expand(B, -1, -1)
+    E._ready(enc.fusion_tokens)
+
+
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, enc, image, audio, ik32, ak32, return_embs, *params):
+        need_tape = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        _, f32s, embs, tape = encoder_fwd(enc, image, audio, ik32, ak32, want_f32=True, collect_embs=return_embs)
+        ctx.enc, ctx.tape = enc, (tape if need_tape else None)
+        B = image.shape[0]
+        outs = [x.view(B, -1, x.shape[-1]) for x in f32s]
+        flat_embs = [e for tri in embs for e in tri]
+        ctx.mark_non_differentiable(*flat_embs)
+        return (*outs, *flat_embs)
+
+    @staticmethod
+    def backward(ctx, gi, ga, gf, *_):
+        c = lambda g: None if g is None else g.contiguous().view(-1, g.shape[-1])
+        encoder_bwd(ctx.enc, ctx.tape, dxi32=c(gi), dxa32=c(ga), dxf32=c(gf))
+        ctx.tape = None
+        return (None,) * (6 + len(ctx.enc._param_list))
+
+
+def encoder_apply(enc, image, audio, image_ids_keep, audio_ids_keep, return_embs):
+    enc._param_list = [p for p in enc.parameters()]
+    out = _EncoderFn.apply(enc, _f32c(image), _f32c(audio), _ids32(image_ids_keep), _ids32(audio_ids_keep),
+                           bool(return_embs), *enc._param_list)
+    if not return_embs:
+        return out[0], out[1], out[2]
+    rest = out[3:]
+    embs = [tuple(rest[3 * i:3 * i + 3]) for i in range(len(rest) // 3)]     # per-layer (x_image, x_audio, x_fusion), detached
+    return out[0], out[1], out[2], embs
+
+
+# ------------------------------------------------------------------------------------------------
+# small stand-alone pieces of the reference API
+# ------------------------------------------------------------------------------------------------
+class _PatchTokensFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vit, x, ids32, *params):
+        tok, tape = E.patch_embed_fwd(vit, x, ids32)
+        ctx.vit, ctx.tape = vit, tape
+        return tok
+
+    @staticmethod
+    def backward(ctx, g):
+        E.patch_embed_bwd(ctx.vit, ctx.tape, g.contiguous(), None)
+        return (None,) * (3 + 2)
+
+
+def patch_tokens(vit, x, ids_keep):
+    return _PatchTokensFn.apply(vit, _f32c(x), _ids32(ids_keep), vit.patch_embed.proj.weight, vit.patch_embed.proj.bias)
+
+
+class _FusionBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fb, xmm, xv, xa, *params):
+        out, tape = E.fusion_block_fwd(fb, xmm, xv, xa, fb.num_heads, fb.fusion_tkns)
+        ctx.fb, ctx.tape, ctx.np = fb, tape, len(params)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        dx_f, dx_i, dx_a = E.fusion_block_bwd(ctx.fb, ctx.tape, g.contiguous(), None)
+        return (None, dx_f, dx_i, dx_a) + (None,) * ctx.np
+
+
+def fusion_block(fb, xmm, xv, xa):
+    c = lambda x: x.to(dtype=F32).contiguous()
+    return _FusionBlockFn.apply(fb, c(xmm), c(xv), c(xa), *list(fb.parameters()))
+
+
+# ------------------------------------------------------------------------------------------------
+# the whole AVMAE step (models/avmae.py:216-236)
+# ------------------------------------------------------------------------------------------------
+def avmae_fwd(model, image, audio, noise_i, noise_a):
+    enc = model.encoder
+    B = image.shape[0]
+    Li, La = model.image_gs[0] * model.image_gs[1], model.audio_gs[0] * model.audio_gs[1]
+    nki, nka = int(Li * (1 - model.image_mask_ratio)), int(La * (1 - model.audio_mask_ratio))     # models/avmae.py:132
+    ik, im, ir, ik32, ir32 = ops.mask_build(noise_i, nki)
+    ak, am, ar, ak32, ar32 = ops.mask_build(noise_a, nka)
+    (xi_b, xa_b, xf_b), _, _, t_enc = encoder_fwd(enc, image, audio, ik32, ak32)
+    nF = enc.fusion_tokens.shape[1]
+    dec_i, dec_a = model.decoder('image'), model.decoder('audio')
+    pred_i, t_di = E.decoder_fwd(dec_i, xi_b, xf_b, ir32, B, nki, nF)
+    loss_i, t_li = E.loss_fwd(image, pred_i, im, model.image_norm_loss)
+    pred_a, t_da = E.decoder_fwd(dec_a, xa_b, xf_b, ar32, B, nka, nF)
+    loss_a, t_la = E.loss_fwd(audio, pred_a, am, model.audio_norm_loss)
+    tape = dict(image=image, audio=audio, im=im, am=am, ik32=ik32, ak32=ak32, t_enc=t_enc, t_di=t_di, t_da=t_da, t_li=t_li,
+                t_la=t_la, pred_i=pred_i, pred_a=pred_a, B=B)
+    aux = dict(image_ids_keep=ik, image_mask=im, image_ids_restore=ir, audio_ids_keep=ak, audio_mask=am, audio_ids_restore=ar)
+    return (loss_i, loss_a, pred_i, pred_a), tape, aux
+
+
+def avmae_bwd(model, t, g_li, g_la, g_pi=None, g_pa=None):
+    B = t['B']
+    dec_i, dec_a = model.decoder('image'), model.decoder('audio')
+    dpi = E.loss_bwd(t['image'], t['pred_i'], t['im'], t['t_li'], g_li)
+    if g_pi is not None:
+        dpi = (dpi.float() + g_pi.reshape(dpi.shape)).to(BF16)
+    dxi_b, dxf_i = E.decoder_bwd(dec_i, t['t_di'], dpi, t['ik32'], B)
+    dpa = E.loss_bwd(t['audio'], t['pred_a'], t['am'], t['t_la'], g_la)
+    if g_pa is not None:
+        dpa = (dpa.float() + g_pa.reshape(dpa.shape)).to(BF16)
+    dxa_b, dxf_a = E.decoder_bwd(dec_a, t['t_da'], dpa, t['ak32'], B)
+    dxf32 = dxf_i.float() + dxf_a.float()            # both decoders read the same normed fusion tokens
+    encoder_bwd(model.encoder, t['t_enc'], dxi_b=dxi_b, dxa_b=dxa_b, dxf32=dxf32)
+
+
+class _AVMAEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, image, audio, noise_i, noise_a, *params):
+        need_tape = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        outs, tape, aux = avmae_fwd(model, image, audio, noise_i, noise_a)
+        ctx.model, ctx.tape, ctx.np = model, (tape if need_tape else None), len(params)
+        model._last_masks = aux
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_li, g_la, g_pi, g_pa):
+        z = lambda g: g.contiguous() if g is not None else torch.zeros((), dtype=F32, device=ctx.tape['image'].device)
+        avmae_bwd(ctx.model, ctx.tape, z(g_li), z(g_la), g_pi, g_pa)
+        ctx.tape = None
+        return (None,) * (5 + ctx.np)
+
+
+def avmae_apply(model, image, audio, noise_image=None, noise_audio=None):
+    B, dev = image.shape[0], image.device
+    Li, La = model.image_gs[0] * model.image_gs[1], model.audio_gs[0] * model.audio_gs[1]
+    if noise_image is None:
+        noise_image = torch.rand(B, Li, device=dev)           # models/avmae.py:127
+    if noise_audio is None:
+        noise_audio = torch.rand(B, La, device=dev)
+    params = getattr(model, '_param_list', None)
+    if params is None:
+        params = model._param_list = [p for p in model.parameters()]
+    return _AVMAEFn.apply(model, _f32c(image), _f32c(audio), _f32c(noise_image), _f32c(noise_audio), *params)

@@ -1,0 +1,448 @@
+// Softmax attention for gfx950 (MI355X), bf16 in / fp32 softmax / bf16 out.
+//
+// One workgroup per (batch, head).  All keys/values of that head live in LDS (the path's sequences
+// are 8..352 rows: SURVEY.md section 8), each wave owns 16-row tiles and keeps the softmax in
+// registers: scores are produced TRANSPOSED (S^T = K.Q^T on the 16x16x32 bf16 MFMA) so that a
+// lane's four accumulators are four keys of ONE query row -> the row max/sum are a few lane-local
+// ops plus two cross-lane shuffles, and the probabilities feed the second MFMA (O^T = V^T.P^T)
+// straight from registers with no LDS round trip.
+//
+// Covers every attention on the pre-training path through strides only:
+//   * timm Attention inside Block (models/vits.py:32-34, models/avmae.py:53-55,83-85) incl. the
+//     "fusion tokens are context rows, their query rows are dropped" use at models/deepavfusion.py:104-105
+//     (queries start nF rows into the fused qkv buffer, keys/values cover all rows)
+//   * CrossAttention                     models/fusion_blocks.py:46-59
+//   * the factorised pair attention      models/fusion_blocks.py:250-258 (q/k width 16, v width 64,
+//     scale (D/heads)^-0.5 passed by the caller)
+#include "common.h"
+#include "dav_kernels.h"
+
+namespace {
+
+struct AttnParams {
+  const bf16_t *Q, *K, *V;
+  bf16_t* O;          // [B, Nq, H*DV]-style through o_bs / o_rs
+  float* LSE;         // [B, H, Nq]  log-sum-exp of the scaled scores
+  int B, H, Nq, Nk;
+  long q_bs, k_bs, v_bs, o_bs;
+  int q_rs, k_rs, v_rs, o_rs;
+  float scale;
+  // backward only
+  const bf16_t* dO; long do_bs; int do_rs;
+  const bf16_t* Of;   // forward output (for delta), same strides as O
+  float* Delta;       // [B, H, Nq]
+  bf16_t *dQ, *dK, *dV;
+  long dq_bs, dk_bs, dv_bs;
+  int dq_rs, dk_rs, dv_rs;
+};
+
+template <int RB> __device__ __forceinline__ int row_swz(int row) {
+  return RB == 128 ? ((row >> 1) & 7) : ((row >> 2) & 3);
+}
+
+// stage `nrows` rows of COLS bf16 (global row stride rs) into a swizzled row-major LDS tile with
+// COLSP columns and nrows_p rows (zero padded); optionally also a transposed copy T[col][row]
+// (row stride t_stride bytes).
+template <int COLS, int COLSP, bool TRANSPOSED_TOO, bool ROWMAJOR = true>
+__device__ __forceinline__ void stage_tile(char* dst, char* dstT, int t_stride, const bf16_t* src, int nrows,
+                                           int nrows_p, int rs, int tid, int nthreads) {
+  constexpr int CPR = COLSP / 8, RB = COLSP * 2;
+  const int total = nrows_p * CPR;
+  for (int c = tid; c < total; c += nthreads) {
+    const int row = c / CPR, ch = c % CPR;
+    uint4 v = uint4{0, 0, 0, 0};
+    if (row < nrows && ch * 8 < COLS) v = *reinterpret_cast<const uint4*>(src + (long)row * rs + ch * 8);
+    if (ROWMAJOR) *reinterpret_cast<uint4*>(dst + row * RB + ((ch ^ row_swz<RB>(row)) << 4)) = v;
+    if (TRANSPOSED_TOO && ch * 8 < COLS) {
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const bf16_t x = (bf16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
+        *reinterpret_cast<bf16_t*>(dstT + (ch * 8 + e) * t_stride + row * 2) = x;
+      }
+    }
+  }
+}
+
+// 16-byte fragment (8 consecutive columns of one row) out of a swizzled row-major tile
+template <int RB>
+__device__ __forceinline__ bf16x8 tile_frag(const char* tile, int row, int kk, int g) {
+  const int slot = (kk * 4 + g) ^ row_swz<RB>(row);
+  return *reinterpret_cast<const bf16x8*>(tile + row * RB + (slot << 4));
+}
+
+// fragment of a transposed tile T[col][row]: keys/rows {r0+4g..+3} and {r0+16+4g..+3} of column `col`
+__device__ __forceinline__ bf16x8 tile_frag_t(const char* tileT, int t_stride, int col, int r0, int g) {
+  union { uint2 h[2]; bf16x8 v; } u;
+  const char* base = tileT + col * t_stride + (r0 + 4 * g) * 2;
+  u.h[0] = *reinterpret_cast<const uint2*>(base);
+  u.h[1] = *reinterpret_cast<const uint2*>(base + 32);
+  return u.v;
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
+  union { uint32_t w[4]; bf16x8 v; } u;
+  u.w[0] = pack2bf(a[0], a[1]); u.w[1] = pack2bf(a[2], a[3]);
+  u.w[2] = pack2bf(b[0], b[1]); u.w[3] = pack2bf(b[2], b[3]);
+  return u.v;
+}
+
+// 8 consecutive bf16 of a global row, zero when !ok
+__device__ __forceinline__ bf16x8 gfrag(const bf16_t* rowptr, int col, bool ok) {
+  union { uint4 q; bf16x8 v; } u;
+  u.q = ok ? *reinterpret_cast<const uint4*>(rowptr + col) : uint4{0, 0, 0, 0};
+  return u.v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int DQK, int DV>
+__global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
+  constexpr int DQKP = DQK < 32 ? 32 : DQK, KRB = DQKP * 2, KS = DQKP / 32, VC = DV / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int Nkp = (p.Nk + 31) & ~31;
+  const int vt_stride = Nkp * 2 + 16;
+  char* Ks = smem;
+  char* Vt = smem + Nkp * KRB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  const int fr = lane & 15, g = lane >> 4;
+
+  stage_tile<DQK, DQKP, false>(Ks, nullptr, 0, p.K + b * p.k_bs + h * DQK, p.Nk, Nkp, p.k_rs, tid, blockDim.x);
+  stage_tile<DV, DV, true, false>(nullptr, Vt, vt_stride, p.V + b * p.v_bs + h * DV, p.Nk, Nkp, p.v_rs, tid, blockDim.x);
+  __syncthreads();
+
+  const int nqt = (p.Nq + 15) >> 4;
+  for (int qt = wave; qt < nqt; qt += nw) {
+    const int q = qt * 16 + fr;
+    const bool qok = q < p.Nq;
+    const bf16_t* qrow = p.Q + b * p.q_bs + (long)(qok ? q : p.Nq - 1) * p.q_rs + h * DQK;
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) qf[kk] = gfrag(qrow, kk * 32 + 8 * g, kk * 32 + 8 * g < DQK);
+
+    float m = -1e30f, lsum = 0.f;
+    f32x4 oacc[VC];
+#pragma unroll
+    for (int c = 0; c < VC; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < Nkp; k0 += 32) {
+      f32x4 st[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+          st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag<KRB>(Ks, k0 + t * 16 + fr, kk, g), qf[kk], st[t], 0, 0, 0);
+      }
+      float mx = -1e30f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = k0 + t * 16 + 4 * g + r;
+          st[t][r] = key < p.Nk ? st[t][r] * p.scale : -1e30f;
+          mx = fmaxf(mx, st[t][r]);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(m, mx);
+      const float alpha = __expf(m - mn);
+      m = mn;
+      float ps = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          st[t][r] = __expf(st[t][r] - mn);
+          ps += st[t][r];
+        }
+      lsum = lsum * alpha + ps;
+      const bf16x8 pf = pack8(st[0], st[1]);
+#pragma unroll
+      for (int c = 0; c < VC; ++c) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oacc[c][r] *= alpha;
+        oacc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag_t(Vt, vt_stride, c * 16 + fr, k0, g), pf, oacc[c], 0, 0, 0);
+      }
+    }
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    const float inv = 1.f / lsum;
+    if (qok) {
+      bf16_t* orow = p.O + b * p.o_bs + (long)q * p.o_rs + h * DV;
+#pragma unroll
+      for (int c = 0; c < VC; ++c) {
+        uint2 w;
+        w.x = pack2bf(oacc[c][0] * inv, oacc[c][1] * inv);
+        w.y = pack2bf(oacc[c][2] * inv, oacc[c][3] * inv);
+        *reinterpret_cast<uint2*>(orow + c * 16 + 4 * g) = w;
+      }
+      if (g == 0 && p.LSE) p.LSE[((long)b * p.H + h) * p.Nq + q] = m + __logf(lsum);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, part 1: dQ (waves own query tiles) + delta
+// ------------------------------------------------------------------------------------------------
+template <int DQK, int DV>
+__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
+  constexpr int DQKP = DQK < 32 ? 32 : DQK, KRB = DQKP * 2, KS = DQKP / 32, VRB = DV * 2, VS = DV / 32, QC = DQK / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int Nkp = (p.Nk + 31) & ~31;
+  const int kt_stride = Nkp * 2 + 16;
+  char* Ks = smem;                   // [Nkp][DQKP]
+  char* Vs = Ks + Nkp * KRB;         // [Nkp][DV]
+  char* Kt = Vs + Nkp * VRB;         // [DQK][Nkp] (+16 B)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  const int fr = lane & 15, g = lane >> 4;
+
+  stage_tile<DQK, DQKP, true>(Ks, Kt, kt_stride, p.K + b * p.k_bs + h * DQK, p.Nk, Nkp, p.k_rs, tid, blockDim.x);
+  stage_tile<DV, DV, false>(Vs, nullptr, 0, p.V + b * p.v_bs + h * DV, p.Nk, Nkp, p.v_rs, tid, blockDim.x);
+  __syncthreads();
+
+  const int nqt = (p.Nq + 15) >> 4;
+  for (int qt = wave; qt < nqt; qt += nw) {
+    const int q = qt * 16 + fr;
+    const bool qok = q < p.Nq;
+    const int qc = qok ? q : p.Nq - 1;
+    const bf16_t* qrow = p.Q + b * p.q_bs + (long)qc * p.q_rs + h * DQK;
+    const bf16_t* dorow = p.dO + b * p.do_bs + (long)qc * p.do_rs + h * DV;
+    const bf16_t* orow = p.Of + b * p.o_bs + (long)qc * p.o_rs + h * DV;
+    bf16x8 qf[KS], dof[VS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) qf[kk] = gfrag(qrow, kk * 32 + 8 * g, kk * 32 + 8 * g < DQK);
+    float delta = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < VS; ++kk) {
+      dof[kk] = gfrag(dorow, kk * 32 + 8 * g, true);
+      const bf16x8 of = gfrag(orow, kk * 32 + 8 * g, true);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) delta += (float)dof[kk][e] * (float)of[e];
+    }
+    delta += __shfl_xor(delta, 16, 64);
+    delta += __shfl_xor(delta, 32, 64);
+    const long sidx = ((long)b * p.H + h) * p.Nq + qc;
+    const float lse = p.LSE[sidx];
+    if (qok && g == 0) p.Delta[sidx] = delta;
+
+    f32x4 dq[QC];
+#pragma unroll
+    for (int c = 0; c < QC; ++c) dq[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < Nkp; k0 += 32) {
+      f32x4 st[2], dp[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+          st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag<KRB>(Ks, k0 + t * 16 + fr, kk, g), qf[kk], st[t], 0, 0, 0);
+#pragma unroll
+        for (int kk = 0; kk < VS; ++kk)
+          dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag<VRB>(Vs, k0 + t * 16 + fr, kk, g), dof[kk], dp[t], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = k0 + t * 16 + 4 * g + r;
+          const float pr = key < p.Nk ? __expf(st[t][r] * p.scale - lse) : 0.f;
+          st[t][r] = pr * (dp[t][r] - delta);     // dS^T
+        }
+      }
+      const bf16x8 dsf = pack8(st[0], st[1]);
+#pragma unroll
+      for (int c = 0; c < QC; ++c)
+        dq[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag_t(Kt, kt_stride, c * 16 + fr, k0, g), dsf, dq[c], 0, 0, 0);
+    }
+    if (qok) {
+      bf16_t* dqrow = p.dQ + b * p.dq_bs + (long)q * p.dq_rs + h * DQK;
+#pragma unroll
+      for (int c = 0; c < QC; ++c) {
+        uint2 w;
+        w.x = pack2bf(dq[c][0] * p.scale, dq[c][1] * p.scale);
+        w.y = pack2bf(dq[c][2] * p.scale, dq[c][3] * p.scale);
+        *reinterpret_cast<uint2*>(dqrow + c * 16 + 4 * g) = w;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, part 2: dK, dV (waves own key tiles)
+// ------------------------------------------------------------------------------------------------
+template <int DQK, int DV>
+__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
+  constexpr int DQKP = DQK < 32 ? 32 : DQK, QRB = DQKP * 2, KS = DQKP / 32, ORB = DV * 2, VS = DV / 32, QC = DQK / 16, VC = DV / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int Nqp = (p.Nq + 31) & ~31;
+  const int t_stride = Nqp * 2 + 16;
+  char* Qs = smem;                      // [Nqp][DQKP]
+  char* dOs = Qs + Nqp * QRB;           // [Nqp][DV]
+  char* Qt = dOs + Nqp * ORB;           // [DQK][Nqp]
+  char* dOt = Qt + DQK * t_stride;      // [DV][Nqp]
+  float* lse_s = reinterpret_cast<float*>(dOt + DV * t_stride);   // [Nqp]
+  float* del_s = lse_s + Nqp;                                     // [Nqp]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  const int fr = lane & 15, g = lane >> 4;
+
+  stage_tile<DQK, DQKP, true>(Qs, Qt, t_stride, p.Q + b * p.q_bs + h * DQK, p.Nq, Nqp, p.q_rs, tid, blockDim.x);
+  stage_tile<DV, DV, true>(dOs, dOt, t_stride, p.dO + b * p.do_bs + h * DV, p.Nq, Nqp, p.do_rs, tid, blockDim.x);
+  for (int i = tid; i < Nqp; i += blockDim.x) {
+    const long sidx = ((long)b * p.H + h) * p.Nq + i;
+    lse_s[i] = i < p.Nq ? p.LSE[sidx] : 1e30f;      // exp(s - 1e30) == 0 for padded query rows
+    del_s[i] = i < p.Nq ? p.Delta[sidx] : 0.f;
+  }
+  __syncthreads();
+
+  const int nkt = (p.Nk + 15) >> 4;
+  for (int kt = wave; kt < nkt; kt += nw) {
+    const int key = kt * 16 + fr;
+    const bool kok = key < p.Nk;
+    const int kc = kok ? key : p.Nk - 1;
+    const bf16_t* krow = p.K + b * p.k_bs + (long)kc * p.k_rs + h * DQK;
+    const bf16_t* vrow = p.V + b * p.v_bs + (long)kc * p.v_rs + h * DV;
+    bf16x8 kf[KS], vf[VS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) kf[kk] = gfrag(krow, kk * 32 + 8 * g, kk * 32 + 8 * g < DQK);
+#pragma unroll
+    for (int kk = 0; kk < VS; ++kk) vf[kk] = gfrag(vrow, kk * 32 + 8 * g, true);
+
+    f32x4 dk[QC], dv[VC];
+#pragma unroll
+    for (int c = 0; c < QC; ++c) dk[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < VC; ++c) dv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int q0 = 0; q0 < Nqp; q0 += 32) {
+      f32x4 s[2], dp[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag<QRB>(Qs, q0 + t * 16 + fr, kk, g), kf[kk], s[t], 0, 0, 0);
+#pragma unroll
+        for (int kk = 0; kk < VS; ++kk)
+          dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag<ORB>(dOs, q0 + t * 16 + fr, kk, g), vf[kk], dp[t], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qi = q0 + t * 16 + 4 * g + r;
+          const float pr = __expf(s[t][r] * p.scale - lse_s[qi]);
+          s[t][r] = pr;                              // P[q][key]
+          dp[t][r] = pr * (dp[t][r] - del_s[qi]);    // dS[q][key]
+        }
+      }
+      const bf16x8 pf = pack8(s[0], s[1]);
+      const bf16x8 dsf = pack8(dp[0], dp[1]);
+#pragma unroll
+      for (int c = 0; c < VC; ++c)
+        dv[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag_t(dOt, t_stride, c * 16 + fr, q0, g), pf, dv[c], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < QC; ++c)
+        dk[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag_t(Qt, t_stride, c * 16 + fr, q0, g), dsf, dk[c], 0, 0, 0);
+    }
+    if (kok) {
+      bf16_t* dkrow = p.dK + b * p.dk_bs + (long)key * p.dk_rs + h * DQK;
+      bf16_t* dvrow = p.dV + b * p.dv_bs + (long)key * p.dv_rs + h * DV;
+#pragma unroll
+      for (int c = 0; c < QC; ++c) {
+        uint2 w;
+        w.x = pack2bf(dk[c][0] * p.scale, dk[c][1] * p.scale);
+        w.y = pack2bf(dk[c][2] * p.scale, dk[c][3] * p.scale);
+        *reinterpret_cast<uint2*>(dkrow + c * 16 + 4 * g) = w;
+      }
+#pragma unroll
+      for (int c = 0; c < VC; ++c) {
+        uint2 w;
+        w.x = pack2bf(dv[c][0], dv[c][1]);
+        w.y = pack2bf(dv[c][2], dv[c][3]);
+        *reinterpret_cast<uint2*>(dvrow + c * 16 + 4 * g) = w;
+      }
+    }
+  }
+}
+
+template <int DQK> constexpr int padqk() { return DQK < 32 ? 32 : DQK; }
+
+template <int DQK, int DV>
+int launch_fwd(const AttnParams& p, hipStream_t stream) {
+  const int Nkp = (p.Nk + 31) & ~31;
+  const size_t lds = (size_t)Nkp * padqk<DQK>() * 2 + (size_t)DV * (Nkp * 2 + 16);
+  if (lds > 160 * 1024) return DAV_ERR_SHAPE;
+  int nw = (p.Nq + 15) / 16; nw = nw > 8 ? 8 : nw; nw = nw < 1 ? 1 : nw;
+  auto kern = attn_fwd_kernel<DQK, DV>;
+  if (lds > 64 * 1024) HIP_CHECK_RET(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(p.B * p.H), dim3(nw * 64), lds, stream, p);
+  return dav_launch_status();
+}
+
+template <int DQK, int DV>
+int launch_bwd(const AttnParams& p, hipStream_t stream) {
+  const int Nkp = (p.Nk + 31) & ~31, Nqp = (p.Nq + 31) & ~31;
+  const size_t lds1 = (size_t)Nkp * padqk<DQK>() * 2 + (size_t)Nkp * DV * 2 + (size_t)DQK * (Nkp * 2 + 16);
+  const size_t lds2 = (size_t)Nqp * padqk<DQK>() * 2 + (size_t)Nqp * DV * 2 + (size_t)(DQK + DV) * (Nqp * 2 + 16) + (size_t)Nqp * 8;
+  if (lds1 > 160 * 1024 || lds2 > 160 * 1024) return DAV_ERR_SHAPE;
+  int nw1 = (p.Nq + 15) / 16; nw1 = nw1 > 8 ? 8 : nw1; nw1 = nw1 < 1 ? 1 : nw1;
+  int nw2 = (p.Nk + 15) / 16; nw2 = nw2 > 8 ? 8 : nw2; nw2 = nw2 < 1 ? 1 : nw2;
+  auto k1 = attn_bwd_dq_kernel<DQK, DV>;
+  auto k2 = attn_bwd_dkv_kernel<DQK, DV>;
+  if (lds1 > 64 * 1024) HIP_CHECK_RET(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+  if (lds2 > 64 * 1024) HIP_CHECK_RET(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+  hipLaunchKernelGGL(k1, dim3(p.B * p.H), dim3(nw1 * 64), lds1, stream, p);
+  hipLaunchKernelGGL(k2, dim3(p.B * p.H), dim3(nw2 * 64), lds2, stream, p);
+  return dav_launch_status();
+}
+
+bool strides_ok(const AttnParams& p, bool bwd) {
+  auto a8 = [](long v) { return (v & 7) == 0; };
+  bool ok = a8(p.q_bs) && a8(p.k_bs) && a8(p.v_bs) && a8(p.o_bs) && a8(p.q_rs) && a8(p.k_rs) && a8(p.v_rs) && a8(p.o_rs);
+  ok = ok && !(((uintptr_t)p.Q | (uintptr_t)p.K | (uintptr_t)p.V | (uintptr_t)p.O) & 15);
+  if (bwd) {
+    ok = ok && a8(p.do_bs) && a8(p.do_rs) && a8(p.dq_bs) && a8(p.dk_bs) && a8(p.dv_bs) && a8(p.dq_rs) && a8(p.dk_rs) && a8(p.dv_rs);
+    ok = ok && !(((uintptr_t)p.dO | (uintptr_t)p.dQ | (uintptr_t)p.dK | (uintptr_t)p.dV) & 15);
+  }
+  return ok;
+}
+
+}  // namespace
+
+extern "C" int dav_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int Nq,
+                            int Nk, int dqk, int dv, long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs,
+                            long o_bs, int o_rs, float scale, hipStream_t stream) {
+  if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return DAV_ERR_SHAPE;
+  AttnParams p = {};
+  p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (bf16_t*)O; p.LSE = LSE;
+  p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.q_bs = q_bs; p.k_bs = k_bs; p.v_bs = v_bs; p.o_bs = o_bs;
+  p.q_rs = q_rs; p.k_rs = k_rs; p.v_rs = v_rs; p.o_rs = o_rs; p.scale = scale;
+  if (!strides_ok(p, false)) return DAV_ERR_ALIGN;
+  if (dqk == 64 && dv == 64) return launch_fwd<64, 64>(p, stream);
+  if (dqk == 32 && dv == 32) return launch_fwd<32, 32>(p, stream);
+  if (dqk == 16 && dv == 64) return launch_fwd<16, 64>(p, stream);
+  return DAV_ERR_SHAPE;
+}
+
+extern "C" int dav_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
+                            float* Delta, void* dQ, void* dK, void* dV, int B, int H, int Nq, int Nk, int dqk, int dv,
+                            long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs,
+                            long do_bs, int do_rs, long dq_bs, int dq_rs, long dk_bs, int dk_rs, long dv_bs, int dv_rs,
+                            float scale, hipStream_t stream) {
+  if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return DAV_ERR_SHAPE;
+  AttnParams p = {};
+  p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.Of = (const bf16_t*)O; p.O = nullptr;
+  p.dO = (const bf16_t*)dO; p.LSE = const_cast<float*>(LSE); p.Delta = Delta;
+  p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV;
+  p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.q_bs = q_bs; p.k_bs = k_bs; p.v_bs = v_bs; p.o_bs = o_bs;
+  p.q_rs = q_rs; p.k_rs = k_rs; p.v_rs = v_rs; p.o_rs = o_rs; p.do_bs = do_bs; p.do_rs = do_rs;
+  p.dq_bs = dq_bs; p.dk_bs = dk_bs; p.dv_bs = dv_bs; p.dq_rs = dq_rs; p.dk_rs = dk_rs; p.dv_rs = dv_rs; p.scale = scale;
+  p.O = (bf16_t*)O;   // only for the alignment check
+  if (!strides_ok(p, true)) return DAV_ERR_ALIGN;
+  if (dqk == 64 && dv == 64) return launch_bwd<64, 64>(p, stream);
+  if (dqk == 32 && dv == 32) return launch_bwd<32, 32>(p, stream);
+  if (dqk == 16 && dv == 64) return launch_bwd<16, 64>(p, stream);
+  return DAV_ERR_SHAPE;
+}

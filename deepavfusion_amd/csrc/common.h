@@ -1,0 +1,64 @@
+// Shared device helpers for the DeepAVFusion gfx950 (CDNA4 / MI355X) kernels.
+// wave = 64 lanes everywhere; bf16 storage, fp32 accumulate.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DAV_OK 0
+#define DAV_ERR_SHAPE (-1)
+#define DAV_ERR_DTYPE (-2)
+#define DAV_ERR_WORKSPACE (-3)
+#define DAV_ERR_HIP (-4)
+#define DAV_ERR_ALIGN (-5)
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef unsigned short bf16_t;   // raw storage type used in the C ABI
+
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+#define GLB_PTR(T, p) ((const __attribute__((address_space(1))) T*)(p))
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even fp32 -> bf16 (NaN kept quiet)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// exact (erf) GELU and its derivative, as nn.GELU() default
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+#define HIP_CHECK_RET(expr)                    \
+  do {                                         \
+    hipError_t _e = (expr);                    \
+    if (_e != hipSuccess) return DAV_ERR_HIP;  \
+  } while (0)
+
+static inline int dav_launch_status() { return hipGetLastError() == hipSuccess ? DAV_OK : DAV_ERR_HIP; }

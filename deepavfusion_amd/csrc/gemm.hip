@@ -1,0 +1,424 @@
+// bf16 MFMA GEMMs for gfx950 (MI355X): fp32 accumulate, fused epilogues.
+//
+//   gemm_nt : C[M,N] = epi( A[M,K] . B[N,K]^T )        forward linears and dgrad (with a W^T copy)
+//   gemm_tn : C[N,K] (+)= A[Mc,N]^T . B[Mc,K]          weight gradients (contraction over token rows)
+//
+// Both tile 128x128 (or 64-wide variants) per 256-thread workgroup = 4 waves in 2x2, each wave
+// computing 16x16x32 bf16 MFMA fragments out of XOR-swizzled LDS tiles (conflict-free ds_read_b128 /
+// ds_read_b64_tr_b16).  K step is 64.  Row maps let A / C / the residual address sub-ranges of
+// [B, rows, D] activations directly (no cat/split/gather copies).
+//
+// Replaces the cuBLAS/rocBLAS calls behind F.linear in timm Block / Mlp / Attention and
+// models/fusion_blocks.py:41-44,227-232; models/avmae.py:31,59-60,88.
+#include "common.h"
+#include "dav_kernels.h"
+
+namespace {
+
+struct RowMap {
+  int rpb, bs, off;   // rpb == 0: identity; else row(m) = (m / rpb) * bs + off + m % rpb
+};
+__device__ __forceinline__ long map_row(int m, const RowMap& r) {
+  return r.rpb > 0 ? (long)(m / r.rpb) * r.bs + r.off + (m % r.rpb) : (long)m;
+}
+
+struct NTParams {
+  const bf16_t* A; const bf16_t* B;
+  int M, N, K, lda, ldb;
+  RowMap amap;
+  const float* bias;
+  int act;                       // 0 none, 1 gelu (pre-activation optionally to C2), 2 multiply by gelu'(aux)
+  const bf16_t* aux; int ldaux;  // act == 2
+  const float* res; int ldres; RowMap rmap; const int* res_rows;   // fp32 residual (optional row gather list)
+  void* C; int ldc; int c_bf16; RowMap cmap;
+  bf16_t* C2; int ldc2; int c2_mode;   // second bf16 output [M, ldc2]: 1 pre-activation, 2 post-activation/pre-residual, 3 final value
+  int beta;                      // C (fp32) += result
+  float alpha;
+};
+
+struct TNParams {
+  const bf16_t* A; const bf16_t* B;   // A[Mc, N] (lda), B[Mc, K] (ldb)
+  int Mc, N, K, lda, ldb;
+  RowMap amap, bmap;
+  float* C; int ldc;                  // fp32 [N, K]
+  int beta;                           // 0: overwrite (only legal with splits == 1), 1: accumulate
+  int splits;                         // split of the contraction over blockIdx.y (atomic accumulate)
+  float* bias_grad;                   // optional: column sums of A accumulated into [N]
+};
+
+// ------------------------------------------------------------------------------------------------
+// NT kernel
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, bool GLDS>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTParams p) {
+  constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
+  constexpr int A_CH = BM * 8 / 256, B_CH = BN * 8 / 256;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* As = smem;                 // [2][BM][128B]
+  char* Bs = smem + 2 * A_BYTES;   // [2][BN][128B]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  // XCD-aware remap: consecutive workgroup ids round-robin over the 8 XCDs, so give each XCD a
+  // contiguous chunk of the tile space (neighbouring tiles share A rows / B rows in that XCD's L2).
+  int bid = blockIdx.x;
+  {
+    const int nwg = tiles_m * tiles_n;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int bm = bid / tiles_n, bn = bid % tiles_n;
+  const int m0 = bm * BM, n0 = bn * BN;
+
+  const bf16_t* a_src[A_CH];
+  const bf16_t* b_src[B_CH];
+  int a_k[A_CH], b_k[B_CH];
+#pragma unroll
+  for (int i = 0; i < A_CH; ++i) {
+    const int c = tid + 256 * i, row = c >> 3, ls = (c & 7) ^ ((row >> 1) & 7);
+    int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;
+    a_src[i] = p.A + map_row(gm, p.amap) * p.lda + ls * 8;
+    a_k[i] = ls * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < B_CH; ++i) {
+    const int c = tid + 256 * i, row = c >> 3, ls = (c & 7) ^ ((row >> 1) & 7);
+    int gn = n0 + row; gn = gn < p.N ? gn : p.N - 1;
+    b_src[i] = p.B + (long)gn * p.ldb + ls * 8;
+    b_k[i] = ls * 8;
+  }
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.K + 63) >> 6;
+  uint4 ra[A_CH], rb[B_CH];
+
+  auto load_regs = [&](int kt) {
+    const int k0 = kt << 6;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i)
+      ra[i] = (k0 + a_k[i] < p.K) ? *reinterpret_cast<const uint4*>(a_src[i] + k0) : uint4{0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i)
+      rb[i] = (k0 + b_k[i] < p.K) ? *reinterpret_cast<const uint4*>(b_src[i] + k0) : uint4{0, 0, 0, 0};
+  };
+  auto store_regs = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) *reinterpret_cast<uint4*>(As + buf * A_BYTES + (tid + 256 * i) * 16) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) *reinterpret_cast<uint4*>(Bs + buf * B_BYTES + (tid + 256 * i) * 16) = rb[i];
+  };
+  auto dma_tile = [&](int kt, int buf) {   // global -> LDS DMA, 16 B per lane, LDS image lane-linear
+    const int k0 = kt << 6;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(void, a_src[i] + k0),
+                                       LDS_PTR(void, As + buf * A_BYTES + (wave * 64 + 256 * i) * 16), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(void, b_src[i] + k0),
+                                       LDS_PTR(void, Bs + buf * B_BYTES + (wave * 64 + 256 * i) * 16), 16, 0, 0);
+  };
+
+  if (GLDS) {
+    dma_tile(0, 0);
+  } else {
+    load_regs(0);
+    store_regs(0);
+  }
+  __syncthreads();
+
+  const int fr = lane & 15, fg = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const bool more = kt + 1 < nk;
+    if (more) {
+      if (GLDS) dma_tile(kt + 1, buf ^ 1); else load_regs(kt + 1);
+    }
+    const char* Ab = As + buf * A_BYTES;
+    const char* Bb = Bs + buf * B_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[FM], bfr[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int row = wm * WM + i * 16 + fr;
+        const int ps = (kk * 4 + fg) ^ ((row >> 1) & 7);
+        af[i] = *reinterpret_cast<const bf16x8*>(Ab + row * 128 + ps * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int row = wn * WN + j * 16 + fr;
+        const int ps = (kk * 4 + fg) ^ ((row >> 1) & 7);
+        bfr[j] = *reinterpret_cast<const bf16x8*>(Bb + row * 128 + ps * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (more && !GLDS) store_regs(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------------
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wm * WM + i * 16 + fg * 4 + r;
+      if (m >= p.M) continue;
+      const long crow = map_row(m, p.cmap);
+      long rrow = 0;
+      if (p.res) rrow = p.res_rows ? (long)p.res_rows[m] : map_row(m, p.rmap);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int n = n0 + wn * WN + j * 16 + fr;
+        if (n >= p.N) continue;
+        float v = acc[i][j][r] * p.alpha;
+        if (p.bias) v += p.bias[n];
+        if (p.c2_mode == 1) p.C2[(long)m * p.ldc2 + n] = f2bf(v);
+        if (p.act == 1) v = gelu_f(v);
+        else if (p.act == 2) v *= gelu_grad_f(bf2f(p.aux[(long)m * p.ldaux + n]));
+        if (p.c2_mode == 2) p.C2[(long)m * p.ldc2 + n] = f2bf(v);
+        if (p.res) v += p.res[rrow * p.ldres + n];
+        if (p.C) {
+          if (p.c_bf16) {
+            reinterpret_cast<bf16_t*>(p.C)[crow * p.ldc + n] = f2bf(v);
+          } else {
+            float* c = reinterpret_cast<float*>(p.C) + crow * p.ldc + n;
+            if (p.beta) v += *c;
+            *c = v;
+          }
+        }
+        if (p.c2_mode == 3) p.C2[(long)m * p.ldc2 + n] = f2bf(v);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TN kernel (weight gradient).  LDS tiles are [64 contraction rows][128 cols] bf16 (256 B rows);
+// MFMA fragments want 8 consecutive contraction rows per lane -> ds_read_b64_tr_b16 (hardware
+// 4x4 transpose), two per fragment.  32-byte granules of a row are XOR-swizzled by
+// f(row) = (row & 3) | ((row >> 3) & 1) << 2 so the 8 rows a 32-lane half touches hit distinct banks.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int tn_swz(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+template <bool TR>
+__device__ __forceinline__ bf16x8 tn_frag(const char* tile, int mk, int colbase, int lane) {
+  const int g = lane >> 4, li = lane & 15;
+  if (TR) {
+    union { s16x4 h[2]; bf16x8 v; } u;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = mk + 8 * g + 4 * h + (li >> 2);
+      const int colb = (colbase + 4 * (li & 3)) * 2;
+      const int addr = row * 256 + ((((colb >> 5) ^ tn_swz(row)) << 5) | (colb & 31));
+      u.h[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tile + addr));
+    }
+    return u.v;
+  } else {
+    union { bf16_t e[8]; bf16x8 v; } u;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int row = mk + 8 * g + e;
+      const int colb = (colbase + li) * 2;
+      const int addr = row * 256 + ((((colb >> 5) ^ tn_swz(row)) << 5) | (colb & 31));
+      u.e[e] = *reinterpret_cast<const bf16_t*>(tile + addr);
+    }
+    return u.v;
+  }
+}
+
+template <bool TR>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TNParams p) {
+  constexpr int TILE_BYTES = 64 * 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* As = smem;                    // [2][64][256B]
+  char* Bs = smem + 2 * TILE_BYTES;   // [2][64][256B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_k = (p.K + 127) / 128;
+  const int bn = blockIdx.x / tiles_k, bk = blockIdx.x % tiles_k;
+  const int n0 = bn * 128, k0 = bk * 128;
+
+  // contraction range of this split (multiples of 64 rows)
+  const int steps_total = (p.Mc + 63) >> 6;
+  const int steps_per = (steps_total + p.splits - 1) / p.splits;
+  const int s_begin = blockIdx.y * steps_per;
+  int s_end = s_begin + steps_per; s_end = s_end < steps_total ? s_end : steps_total;
+  if (s_begin >= s_end) return;
+
+  const int c16 = tid & 15, rbase = tid >> 4;   // chunk column (8 elems), rows rbase + 16*i
+  const bool a_ok = n0 + c16 * 8 < p.N, b_ok = k0 + c16 * 8 < p.K;
+  uint4 ra[4], rb[4];
+  auto load_regs = [&](int s) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = (s << 6) + rbase + 16 * i;
+      const bool ok = m < p.Mc;
+      ra[i] = (ok && a_ok) ? *reinterpret_cast<const uint4*>(p.A + map_row(m, p.amap) * p.lda + n0 + c16 * 8) : uint4{0, 0, 0, 0};
+      rb[i] = (ok && b_ok) ? *reinterpret_cast<const uint4*>(p.B + map_row(m, p.bmap) * p.ldb + k0 + c16 * 8) : uint4{0, 0, 0, 0};
+    }
+  };
+  auto store_regs = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = rbase + 16 * i;
+      const int addr = row * 256 + ((((c16 >> 1) ^ tn_swz(row)) << 5) | ((c16 & 1) << 4));
+      *reinterpret_cast<uint4*>(As + buf * TILE_BYTES + addr) = ra[i];
+      *reinterpret_cast<uint4*>(Bs + buf * TILE_BYTES + addr) = rb[i];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = p.bias_grad != nullptr && bk == 0;
+
+  load_regs(s_begin);
+  store_regs(0);
+  __syncthreads();
+  for (int s = s_begin; s < s_end; ++s) {
+    const int buf = (s - s_begin) & 1;
+    const bool more = s + 1 < s_end;
+    if (do_bias) {   // column sums of the A tile this thread staged (its 4 rows x 8 columns)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t w[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          bsum[2 * e] += __uint_as_float(w[e] << 16);
+          bsum[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+        }
+      }
+    }
+    if (more) load_regs(s + 1);
+    const char* Ab = As + buf * TILE_BYTES;
+    const char* Bb = Bs + buf * TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = tn_frag<TR>(Ab, kk * 32, wm * 64 + i * 16, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = tn_frag<TR>(Bb, kk * 32, wn * 64 + j * 16, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_regs(buf ^ 1);
+    __syncthreads();
+  }
+
+  const int fr = lane & 15, fg = lane >> 4;
+  const bool atomic = p.splits > 1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + wm * 64 + i * 16 + fg * 4 + r;
+      if (n >= p.N) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = k0 + wn * 64 + j * 16 + fr;
+        if (k >= p.K) continue;
+        float* c = p.C + (long)n * p.ldc + k;
+        if (atomic) unsafeAtomicAdd(c, acc[i][j][r]);
+        else if (p.beta) *c += acc[i][j][r];
+        else *c = acc[i][j][r];
+      }
+    }
+
+  if (do_bias) {
+    // reduce the 16 row-groups (threads with equal c16) through LDS, then one atomic per column
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);   // [16 rowgroups][128 cols]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rbase * 128 + c16 * 8 + e] = bsum[e];
+    __syncthreads();
+    if (tid < 128 && n0 + tid < p.N) {
+      float s = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) s += red[g * 128 + tid];
+      unsafeAtomicAdd(p.bias_grad + n0 + tid, s);
+    }
+  }
+}
+
+RowMap mk(const int* m) { return m ? RowMap{m[0], m[1], m[2]} : RowMap{0, 0, 0}; }
+
+}  // namespace
+
+extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int K, int lda, int ldb,
+                                const int* a_rowmap, const float* bias, int act, const void* aux, int ldaux,
+                                const float* res, int ldres, const int* res_rowmap, const int* res_rows,
+                                void* C, int ldc, int c_is_bf16, const int* c_rowmap, void* C2, int ldc2, int c2_mode,
+                                int beta, float alpha, int variant, hipStream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || (K & 7) || (lda & 7) || (ldb & 7)) return DAV_ERR_SHAPE;
+  if (((uintptr_t)A | (uintptr_t)B) & 15) return DAV_ERR_ALIGN;
+  if (beta && c_is_bf16) return DAV_ERR_DTYPE;
+  if (!C && !C2) return DAV_ERR_SHAPE;
+  if (C2 && (c2_mode < 1 || c2_mode > 3)) return DAV_ERR_SHAPE;
+  NTParams p;
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb;
+  p.amap = mk(a_rowmap); p.bias = bias; p.act = act; p.aux = (const bf16_t*)aux; p.ldaux = ldaux;
+  p.res = res; p.ldres = ldres; p.rmap = mk(res_rowmap); p.res_rows = res_rows;
+  p.C = C; p.ldc = ldc; p.c_bf16 = c_is_bf16; p.cmap = mk(c_rowmap); p.C2 = (bf16_t*)C2; p.ldc2 = ldc2; p.c2_mode = C2 ? c2_mode : 0;
+  p.beta = beta; p.alpha = alpha;
+  const bool glds_ok = (K & 63) == 0;
+  const bool use_glds = glds_ok && !(variant & 1);
+  // narrow-N problems (and anything that would leave most CUs idle) use 64-wide tiles
+  const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+  const bool small = (variant & 2) || N <= 64 || tiles128 < 256;
+  if (small) {
+    const int grid = ((M + 63) / 64) * ((N + 63) / 64);
+    const size_t lds = 2 * 64 * 128 * 2;
+    if (use_glds) hipLaunchKernelGGL((gemm_nt_kernel<64, 64, true>), dim3(grid), dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL((gemm_nt_kernel<64, 64, false>), dim3(grid), dim3(256), lds, stream, p);
+  } else {
+    const int grid = (int)tiles128;
+    const size_t lds = 2 * 128 * 128 * 2;
+    if (use_glds) hipLaunchKernelGGL((gemm_nt_kernel<128, 128, true>), dim3(grid), dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL((gemm_nt_kernel<128, 128, false>), dim3(grid), dim3(256), lds, stream, p);
+  }
+  return dav_launch_status();
+}
+
+extern "C" int dav_gemm_tn_bf16(const void* A, const void* B, int Mc, int N, int K, int lda, int ldb,
+                                const int* a_rowmap, const int* b_rowmap, float* C, int ldc, int beta,
+                                float* bias_grad, int variant, hipStream_t stream) {
+  if (Mc <= 0 || N <= 0 || K <= 0 || (N & 7) || (K & 7) || (lda & 7) || (ldb & 7)) return DAV_ERR_SHAPE;
+  if (((uintptr_t)A | (uintptr_t)B) & 15) return DAV_ERR_ALIGN;
+  TNParams p;
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.Mc = Mc; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb;
+  p.amap = mk(a_rowmap); p.bmap = mk(b_rowmap); p.C = C; p.ldc = ldc; p.beta = beta; p.bias_grad = bias_grad;
+  const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+  const int steps = (Mc + 63) / 64;
+  int splits = 1;
+  if (beta) {   // accumulate mode may split the contraction (atomic adds into the live gradient)
+    splits = (1024 + tiles - 1) / tiles;
+    if (splits > steps) splits = steps;
+    if (splits > 64) splits = 64;
+    if (splits < 1) splits = 1;
+  }
+  p.splits = splits;
+  const size_t lds = 4 * 64 * 256;
+  if (variant & 1) hipLaunchKernelGGL((gemm_tn_kernel<false>), dim3(tiles, splits), dim3(256), lds, stream, p);
+  else hipLaunchKernelGGL((gemm_tn_kernel<true>), dim3(tiles, splits), dim3(256), lds, stream, p);
+  return dav_launch_status();
+}

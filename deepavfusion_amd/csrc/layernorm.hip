@@ -1,0 +1,221 @@
+// LayerNorm forward / backward for gfx950: one 64-lane wave per row, float4 loads, shuffle
+// reductions, fp32 statistics.  HBM-bound.
+//
+// The forward can read its rows from TWO fp32 sources per batch element (segment 0 = r0 rows,
+// segment 1 = r1 rows) — this is the `torch.cat((x_fusion, x_image), dim=1)` of
+// models/deepavfusion.py:104-105 folded into norm1 of the modality block (timm Block.norm1), with
+// batch stride 0 allowed for the `fusion_tokens.expand(B, -1, -1)` of :97.  The backward scatters
+// the row gradients back to the two sources (store or accumulate, optional fp32 residual-gradient
+// add and bf16 copy for the next dgrad GEMM) and accumulates dgamma / dbeta with one atomic per
+// column per workgroup.
+//
+// eps differs by call site (1e-6 encoder blocks, 1e-5 fusion blocks / decoders): SURVEY Appendix A.1.
+#include "common.h"
+#include "dav_kernels.h"
+
+namespace {
+
+constexpr int MAXC = 8;   // float4 chunks per lane -> D <= 2048
+
+struct LNSeg {
+  const float* x; long bs; int rows;      // source rows of this segment (batch stride in elements)
+};
+
+struct LNFwd {
+  LNSeg s0, s1;
+  int B, D;
+  const float *gamma, *beta;
+  float eps;
+  bf16_t* y;        // [B*(r0+r1), D] bf16 (may be null)
+  float* y32;       // same rows, fp32 (may be null)
+  float *mean, *rstd;
+};
+
+struct LNDst {
+  float* dx; long bs; int rows;   // destination gradient rows of this segment
+  int accumulate;                 // 1: dx += ..., 0: dx = ...
+  const float* res; long res_bs;  // optional fp32 residual gradient added on top (same row layout)
+  bf16_t* dx_bf16; long bf_bs;    // optional bf16 copy of the written value
+};
+
+struct LNBwd {
+  LNSeg s0, s1;
+  LNDst d0, d1;
+  int B, D;
+  const bf16_t* dy;     // [B*R, D] bf16 (may be null)
+  const float* dy32;    // [B*R, D] fp32 (may be null); total dy = dy + dy32
+  const float *gamma, *mean, *rstd;
+  float *dgamma, *dbeta;   // accumulated (atomics)
+};
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LNFwd p) {
+  const int lane = threadIdx.x & 63;
+  const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int R = p.s0.rows + p.s1.rows, rows = p.B * R, nch = p.D >> 2;
+  for (int row = gw; row < rows; row += nwaves) {
+    const int b = row / R, j = row % R;
+    const float* x = j < p.s0.rows ? p.s0.x + b * p.s0.bs + (long)j * p.D : p.s1.x + b * p.s1.bs + (long)(j - p.s0.rows) * p.D;
+    float4 v[MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        v[i] = reinterpret_cast<const float4*>(x)[c];
+        s += v[i].x + v[i].y + v[i].z + v[i].w;
+      }
+    }
+    const float mean = wave_sum(s) / p.D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        const float a = v[i].x - mean, bb = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+        q += a * a + bb * bb + cc * cc + d * d;
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / p.D + p.eps);
+    if (lane == 0) { p.mean[row] = mean; p.rstd[row] = rstd; }
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        const float4 gm = reinterpret_cast<const float4*>(p.gamma)[c];
+        const float4 bt = reinterpret_cast<const float4*>(p.beta)[c];
+        float4 o;
+        o.x = (v[i].x - mean) * rstd * gm.x + bt.x;
+        o.y = (v[i].y - mean) * rstd * gm.y + bt.y;
+        o.z = (v[i].z - mean) * rstd * gm.z + bt.z;
+        o.w = (v[i].w - mean) * rstd * gm.w + bt.w;
+        if (p.y) {
+          uint2 w; w.x = pack2bf(o.x, o.y); w.y = pack2bf(o.z, o.w);
+          reinterpret_cast<uint2*>(p.y + (long)row * p.D)[c] = w;
+        }
+        if (p.y32) reinterpret_cast<float4*>(p.y32 + (long)row * p.D)[c] = o;
+      }
+    }
+  }
+}
+
+// dgamma/dbeta of the 4 waves are combined through dynamic LDS (2 * 4 * D floats) before the atomics.
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwd p) {
+  extern __shared__ __attribute__((aligned(16))) float lds_red[];   // [2][4][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int R = p.s0.rows + p.s1.rows, rows = p.B * R, nch = p.D >> 2;
+  float4 dg[MAXC], db[MAXC];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) { dg[i] = float4{0.f, 0.f, 0.f, 0.f}; db[i] = float4{0.f, 0.f, 0.f, 0.f}; }
+
+  for (int row = gw; row < rows; row += nwaves) {
+    const int b = row / R, j = row % R;
+    const bool seg0 = j < p.s0.rows;
+    const int jj = seg0 ? j : j - p.s0.rows;
+    const float* x = seg0 ? p.s0.x + b * p.s0.bs + (long)jj * p.D : p.s1.x + b * p.s1.bs + (long)jj * p.D;
+    const LNDst& d = seg0 ? p.d0 : p.d1;
+    const float mean = p.mean[row], rstd = p.rstd[row];
+    float4 xh[MAXC], gy[MAXC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        const float4 xv = reinterpret_cast<const float4*>(x)[c];
+        float4 dyv = float4{0.f, 0.f, 0.f, 0.f};
+        if (p.dy) {
+          const uint2 w = reinterpret_cast<const uint2*>(p.dy + (long)row * p.D)[c];
+          dyv.x = __uint_as_float(w.x << 16); dyv.y = __uint_as_float(w.x & 0xffff0000u);
+          dyv.z = __uint_as_float(w.y << 16); dyv.w = __uint_as_float(w.y & 0xffff0000u);
+        }
+        if (p.dy32) {
+          const float4 t = reinterpret_cast<const float4*>(p.dy32 + (long)row * p.D)[c];
+          dyv.x += t.x; dyv.y += t.y; dyv.z += t.z; dyv.w += t.w;
+        }
+        const float4 gm = reinterpret_cast<const float4*>(p.gamma)[c];
+        xh[i].x = (xv.x - mean) * rstd; xh[i].y = (xv.y - mean) * rstd;
+        xh[i].z = (xv.z - mean) * rstd; xh[i].w = (xv.w - mean) * rstd;
+        dg[i].x += dyv.x * xh[i].x; dg[i].y += dyv.y * xh[i].y; dg[i].z += dyv.z * xh[i].z; dg[i].w += dyv.w * xh[i].w;
+        db[i].x += dyv.x; db[i].y += dyv.y; db[i].z += dyv.z; db[i].w += dyv.w;
+        gy[i].x = dyv.x * gm.x; gy[i].y = dyv.y * gm.y; gy[i].z = dyv.z * gm.z; gy[i].w = dyv.w * gm.w;
+        s1 += gy[i].x + gy[i].y + gy[i].z + gy[i].w;
+        s2 += gy[i].x * xh[i].x + gy[i].y * xh[i].y + gy[i].z * xh[i].z + gy[i].w * xh[i].w;
+      }
+    }
+    s1 = wave_sum(s1) / p.D;
+    s2 = wave_sum(s2) / p.D;
+    if (d.dx == nullptr) continue;   // caller does not need this segment's input gradient
+    float* dxr = d.dx + b * d.bs + (long)jj * p.D;
+    const float* rr = d.res ? d.res + b * d.res_bs + (long)jj * p.D : nullptr;
+    bf16_t* br = d.dx_bf16 ? d.dx_bf16 + b * d.bf_bs + (long)jj * p.D : nullptr;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        float4 o;
+        o.x = rstd * (gy[i].x - s1 - xh[i].x * s2);
+        o.y = rstd * (gy[i].y - s1 - xh[i].y * s2);
+        o.z = rstd * (gy[i].z - s1 - xh[i].z * s2);
+        o.w = rstd * (gy[i].w - s1 - xh[i].w * s2);
+        if (rr) { const float4 t = reinterpret_cast<const float4*>(rr)[c]; o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+        if (d.accumulate) { const float4 t = reinterpret_cast<const float4*>(dxr)[c]; o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+        reinterpret_cast<float4*>(dxr)[c] = o;
+        if (br) { uint2 w; w.x = pack2bf(o.x, o.y); w.y = pack2bf(o.z, o.w); reinterpret_cast<uint2*>(br)[c] = w; }
+      }
+    }
+  }
+
+  if (p.dgamma == nullptr) return;
+  float* rg = lds_red + (size_t)wave * p.D;
+  float* rb = lds_red + (size_t)(4 + wave) * p.D;
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) { reinterpret_cast<float4*>(rg)[c] = dg[i]; reinterpret_cast<float4*>(rb)[c] = db[i]; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < p.D; c += blockDim.x) {
+    const float g = lds_red[c] + lds_red[p.D + c] + lds_red[2 * p.D + c] + lds_red[3 * p.D + c];
+    const float bsum = lds_red[4 * p.D + c] + lds_red[5 * p.D + c] + lds_red[6 * p.D + c] + lds_red[7 * p.D + c];
+    unsafeAtomicAdd(p.dgamma + c, g);
+    unsafeAtomicAdd(p.dbeta + c, bsum);
+  }
+}
+
+int ln_grid(int rows) {
+  int g = (rows + 3) / 4;
+  return g > 1024 ? 1024 : (g < 1 ? 1 : g);
+}
+
+}  // namespace
+
+extern "C" int dav_layernorm_fwd(const float* x0, long x0_bs, int r0, const float* x1, long x1_bs, int r1, int B, int D,
+                                 const float* gamma, const float* beta, float eps, void* y_bf16, float* y_f32,
+                                 float* mean, float* rstd, hipStream_t stream) {
+  if (B <= 0 || D <= 0 || (D & 3) || D > MAXC * 256 || r0 < 0 || r1 < 0 || r0 + r1 <= 0) return DAV_ERR_SHAPE;
+  LNFwd p;
+  p.s0 = LNSeg{x0, x0_bs, r0}; p.s1 = LNSeg{x1, x1_bs, r1}; p.B = B; p.D = D; p.gamma = gamma; p.beta = beta;
+  p.eps = eps; p.y = (bf16_t*)y_bf16; p.y32 = y_f32; p.mean = mean; p.rstd = rstd;
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(ln_grid(B * (r0 + r1))), dim3(256), 0, stream, p);
+  return dav_launch_status();
+}
+
+extern "C" int dav_layernorm_bwd(const float* x0, long x0_bs, int r0, const float* x1, long x1_bs, int r1, int B, int D,
+                                 const void* dy_bf16, const float* dy_f32, const float* gamma, const float* mean,
+                                 const float* rstd,
+                                 float* dx0, long dx0_bs, int acc0, const float* res0, long res0_bs, void* dx0_bf16, long dx0_bf_bs,
+                                 float* dx1, long dx1_bs, int acc1, const float* res1, long res1_bs, void* dx1_bf16, long dx1_bf_bs,
+                                 float* dgamma, float* dbeta, hipStream_t stream) {
+  if (B <= 0 || D <= 0 || (D & 3) || D > MAXC * 256 || r0 < 0 || r1 < 0 || r0 + r1 <= 0) return DAV_ERR_SHAPE;
+  if (!dy_bf16 && !dy_f32) return DAV_ERR_SHAPE;
+  LNBwd p;
+  p.s0 = LNSeg{x0, x0_bs, r0}; p.s1 = LNSeg{x1, x1_bs, r1}; p.B = B; p.D = D;
+  p.d0 = LNDst{dx0, dx0_bs, r0, acc0, res0, res0_bs, (bf16_t*)dx0_bf16, dx0_bf_bs};
+  p.d1 = LNDst{dx1, dx1_bs, r1, acc1, res1, res1_bs, (bf16_t*)dx1_bf16, dx1_bf_bs};
+  p.dy = (const bf16_t*)dy_bf16; p.dy32 = dy_f32; p.gamma = gamma; p.mean = mean; p.rstd = rstd;
+  p.dgamma = dgamma; p.dbeta = dbeta;
+  int grid = ln_grid(B * (r0 + r1));
+  if (grid > 256) grid = 256;   // fewer, longer-lived workgroups: one dgamma/dbeta atomic set each
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), (size_t)8 * D * sizeof(float), stream, p);
+  return dav_launch_status();
+}

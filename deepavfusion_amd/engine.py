@@ -1,0 +1,470 @@
+"""Explicit forward/backward of the AVMAE pre-training step on the HIP kernels.
+
+Every function here launches kernels of libdavfusion_hip.so through ``ops`` on torch's
+current stream and keeps its own "tape" (a dict of saved activations) for the
+hand-written backward.  Nothing goes through autograd inside; ``autograd_bridge``
+exposes the whole step (or the encoder alone) as ONE autograd node so that
+``loss.backward()`` / the reference's ``Trainer.step`` flow keeps working.
+
+Precision: fp32 residual stream and master weights, bf16 GEMM/attention operands,
+fp32 accumulation, fp32 LayerNorm / softmax / loss.
+
+Weight gradients are accumulated IN PLACE into ``param.grad`` (fp32) by the wgrad GEMM
+epilogues (the bridge returns ``None`` for parameters): no per-parameter autograd
+accumulation pass, and a data-parallel reducer is told when a parameter's gradient is
+final through ``set_grad_ready_hook``.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from . import ops
+from .ops import BF16, F32
+
+_GRAD_READY: Optional[Callable[[torch.nn.Parameter], None]] = None
+
+
+def set_grad_ready_hook(fn: Optional[Callable[[torch.nn.Parameter], None]]):
+    """Called once per parameter per backward, right after its last gradient kernel was enqueued."""
+    global _GRAD_READY
+    _GRAD_READY = fn
+
+
+def _ready(*params):
+    if _GRAD_READY is not None:
+        for p in params:
+            if p is not None and p.requires_grad:
+                _GRAD_READY(p)
+
+
+def gbuf(p: torch.nn.Parameter) -> torch.Tensor:
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    return p.grad
+
+
+# ------------------------------------------------------------------------------------------------
+# bf16 weight cache (W and W^T) — refreshed when the fp32 master changes
+# ------------------------------------------------------------------------------------------------
+def wcache(p: torch.nn.Parameter, force: bool = False):
+    c = p.__dict__.get('_dav_cache')
+    ver, ptr = p._version, p.data_ptr()
+    if c is None or force or c[0] != ver or c[1] != ptr:
+        w2 = p.detach().reshape(p.shape[0], -1)
+        if c is not None and c[2].shape == w2.shape and c[2].device == w2.device:
+            wb, wtb = c[2], c[3]
+        else:
+            wb = torch.empty(w2.shape, dtype=BF16, device=p.device)
+            wtb = torch.empty((w2.shape[1], w2.shape[0]), dtype=BF16, device=p.device)
+        ops.cast_bf16(w2, wb)
+        ops.cast_transpose_bf16(w2, wtb)
+        c = (ver, ptr, wb, wtb)
+        p.__dict__['_dav_cache'] = c
+    return c[2], c[3]
+
+
+def refresh_weight_cache(module: torch.nn.Module):
+    """Re-cast every >=2-D weight (call at the top of a captured step so replays see fresh weights)."""
+    for p in module.parameters():
+        if p.ndim >= 2 and p.shape[0] > 1 and '_dav_cache' in p.__dict__:
+            wcache(p, force=True)
+
+
+def _e(shape, dtype, dev):
+    return torch.empty(shape, dtype=dtype, device=dev)
+
+
+# ------------------------------------------------------------------------------------------------
+# primitives
+# ------------------------------------------------------------------------------------------------
+def ln_fwd(norm, x0, x1, B, eps=None, want_f32=False, want_bf16=True):
+    """LayerNorm over rows [x0 rows | x1 rows] per batch element. x*: fp32 [B, r, D] (contiguous) or None."""
+    D = norm.weight.shape[0]
+    r0 = x0.shape[1] if x0 is not None else 0
+    r1 = x1.shape[1] if x1 is not None else 0
+    if x0 is None:
+        x0, r0, x1, r1 = x1, r1, None, 0
+    dev = x0.device
+    M = B * (r0 + r1)
+    y = _e((M, D), BF16, dev) if want_bf16 else None
+    y32 = _e((M, D), F32, dev) if want_f32 else None
+    mean, rstd = _e((M,), F32, dev), _e((M,), F32, dev)
+    ops.layernorm_fwd(x0, r0 * D, r0, x1, r1 * D, r1, B, D, norm.weight, norm.bias, norm.eps if eps is None else eps,
+                      y, y32, mean, rstd)
+    return y, y32, (mean, rstd)
+
+
+def ln_bwd(norm, x0, x1, B, stats, dy_bf16=None, dy_f32=None, *, dx0=None, acc0=0, res0=None, dx0_bf16=None,
+           dx1=None, acc1=0, res1=None, dx1_bf16=None):
+    D = norm.weight.shape[0]
+    r0 = x0.shape[1] if x0 is not None else 0
+    r1 = x1.shape[1] if x1 is not None else 0
+    if x0 is None:
+        x0, r0, x1, r1 = x1, r1, None, 0
+        dx0, acc0, res0, dx0_bf16, dx1, acc1, res1, dx1_bf16 = dx1, acc1, res1, dx1_bf16, None, 0, None, None
+    ops.layernorm_bwd(x0, r0 * D, r0, x1, r1 * D, r1, B, D, dy_bf16, dy_f32, norm.weight, stats[0], stats[1],
+                      dx0, r0 * D, acc0, res0, r0 * D, dx0_bf16, r0 * D,
+                      dx1, r1 * D, acc1, res1, r1 * D, dx1_bf16, r1 * D,
+                      gbuf(norm.weight), gbuf(norm.bias))
+    _ready(norm.weight, norm.bias)
+
+
+def lin_fwd(lin, a, M, *, a_rowmap=None, lda=None, act=0, res=None, res_rowmap=None, out=None, out_bf16=False,
+            c_rowmap=None, ldc=None, C2=None, c2_mode=0, w_col_off=0, k=None, use_bias=True):
+    """y = a @ W[:, w_col_off : w_col_off+k]^T (+ bias) with the fused epilogue of dav_gemm_nt_bf16."""
+    W, _ = wcache(lin.weight)
+    N, Kfull = W.shape
+    K = Kfull if k is None else k
+    dev = a.device
+    if out is None:
+        out = _e((M, N), BF16 if out_bf16 else F32, dev)
+    Bw = W if w_col_off == 0 else W.view(-1)[w_col_off:]
+    ops.gemm_nt(a, Bw, M, N, K, lda=lda if lda is not None else K, ldb=Kfull, a_rowmap=a_rowmap,
+                bias=lin.bias if use_bias else None, act=act, res=res, ldres=N, res_rowmap=res_rowmap,
+                C_out=out, ldc=ldc if ldc is not None else N, c_bf16=out.dtype == BF16, c_rowmap=c_rowmap,
+                C2=C2, ldc2=N, c2_mode=c2_mode)
+    return out
+
+
+def lin_bwd(lin, dy, a, M, *, dy_rowmap=None, a_rowmap=None, lda=None, need_dx=True, gelu_aux=None, dx=None, dx_bf16=True,
+            dx_rowmap=None, dx_beta=0, dx_C2=None, dx_c2_mode=0, w_col_off=0, k=None, use_bias=True, final=True):
+    """Backward of lin_fwd: dx = dy @ W (optionally * GELU'(aux)), dW += dy^T a, db += colsum(dy).
+
+    dy: bf16 [*, N]; a: bf16 [*, K] (the forward input).  Returns dx (bf16 [M, K] unless given)."""
+    W, WT = wcache(lin.weight)
+    N, Kfull = W.shape
+    K = Kfull if k is None else k
+    dev = dy.device
+    if need_dx:
+        if dx is None:
+            dx = _e((M, K), BF16 if dx_bf16 else F32, dev)
+        Bt = WT if w_col_off == 0 else WT[w_col_off:]          # W^T rows = input features
+        ops.gemm_nt(dy, Bt, M, K, N, lda=N, ldb=N, a_rowmap=dy_rowmap, act=2 if gelu_aux is not None else 0,
+                    aux=gelu_aux, ldaux=K, C_out=dx, ldc=K, c_bf16=dx.dtype == BF16, c_rowmap=dx_rowmap, beta=dx_beta,
+                    C2=dx_C2, ldc2=K, c2_mode=dx_c2_mode)
+    gw = gbuf(lin.weight)
+    gwv = gw.view(N, -1)
+    Cw = gwv if w_col_off == 0 else gwv.view(-1)[w_col_off:]
+    ops.gemm_tn(dy, a, M, N, K, Cw, lda=N, ldb=lda if lda is not None else K, ldc=Kfull, a_rowmap=dy_rowmap,
+                b_rowmap=a_rowmap, beta=1, bias_grad=gbuf(lin.bias) if (use_bias and lin.bias is not None) else None)
+    if final:
+        _ready(lin.weight, lin.bias)
+    return dx
+
+
+def attention_fwd(q, k, v, B, H, Nq, Nk, dqk, dv, scale, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, dev):
+    """q/k/v are (tensor, element_offset) pairs into bf16 buffers. Returns O [B*Nq, H*dv] bf16 and LSE."""
+    O = _e((B * Nq, H * dv), BF16, dev)
+    LSE = _e((B, H, Nq), F32, dev)
+    ops.attn_fwd(q[0].data_ptr() + 2 * q[1], k[0].data_ptr() + 2 * k[1], v[0].data_ptr() + 2 * v[1], O, LSE, B, H, Nq, Nk,
+                 dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, Nq * H * dv, H * dv, scale)
+    return O, LSE
+
+
+def attention_bwd(q, k, v, O, dO, LSE, dq, dk, dvv, B, H, Nq, Nk, dqk, dv, scale, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs,
+                  dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs):
+    Delta = torch.empty_like(LSE)
+    p = lambda t: t[0].data_ptr() + 2 * t[1]
+    ops.attn_bwd(p(q), p(k), p(v), O, dO, LSE, Delta, p(dq), p(dk), p(dvv), B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs,
+                 v_bs, v_rs, Nq * H * dv, H * dv, Nq * H * dv, H * dv, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, scale)
+
+
+def to_bf16(x):
+    y = torch.empty(x.shape, dtype=BF16, device=x.device)
+    ops.cast_bf16(x.contiguous(), y)
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
+# timm Block (pre-LN) with optional fusion-token context rows
+# ------------------------------------------------------------------------------------------------
+def block_fwd(blk, x_mod, x_fus, heads, eps):
+    """x_mod fp32 [B,n,D]; x_fus fp32 [B,nF,D] or None (context rows: keys/values only —
+    models/deepavfusion.py:104-105).  Returns (x_out fp32 [B,n,D], tape)."""
+    B, n, D = x_mod.shape
+    nF = x_fus.shape[1] if x_fus is not None else 0
+    R, hd, dev = nF + n, D // heads, x_mod.device
+    M, Mq = B * R, B * n
+    h1, _, st1 = ln_fwd(blk.norm1, x_fus, x_mod, B, eps)
+    qkv = lin_fwd(blk.attn.qkv, h1, M, out_bf16=True)                                       # [B*R, 3D]
+    o, lse = attention_fwd((qkv, nF * 3 * D), (qkv, D), (qkv, 2 * D), B, heads, n, R, hd, hd, hd ** -0.5,
+                           R * 3 * D, 3 * D, R * 3 * D, 3 * D, R * 3 * D, 3 * D, dev)
+    x1 = lin_fwd(blk.attn.proj, o, Mq, res=x_mod).view(B, n, D)
+    h2, _, st2 = ln_fwd(blk.norm2, None, x1, B, eps)
+    Hd = blk.mlp.fc1.weight.shape[0]
+    z = _e((Mq, Hd), BF16, dev)
+    u = lin_fwd(blk.mlp.fc1, h2, Mq, act=1, out_bf16=True, C2=z, c2_mode=1)
+    x2 = lin_fwd(blk.mlp.fc2, u, Mq, res=x1).view(B, n, D)
+    tape = dict(x_mod=x_mod, x_fus=x_fus, h1=h1, st1=st1, qkv=qkv, o=o, lse=lse, x1=x1, h2=h2, st2=st2, z=z, u=u,
+                heads=heads, nF=nF)
+    return x2, tape
+
+
+def block_bwd(blk, t, g2, g2b, *, dx_fus=None, dx_fus_acc=0, dx_mod=None, dx_mod_acc=0, need_dx=True):
+    """g2 fp32 [B,n,D] (+ bf16 twin g2b or None).  Writes/accumulates the fusion-row gradient into dx_fus
+    and the modality-row gradient (incl. the residual path) into dx_mod; returns (dx_mod, dx_mod_bf16, dx_fus)."""
+    x_mod, x_fus, heads, nF = t['x_mod'], t['x_fus'], t['heads'], t['nF']
+    B, n, D = x_mod.shape
+    R, hd, dev = nF + n, D // heads, x_mod.device
+    M, Mq = B * R, B * n
+    if g2b is None:
+        g2b = to_bf16(g2)
+    dz = lin_bwd(blk.mlp.fc2, g2b, t['u'], Mq, gelu_aux=t['z'])                              # [Mq, Hd] bf16 (already * GELU')
+    dh2 = lin_bwd(blk.mlp.fc1, dz, t['h2'], Mq)
+    g1 = _e((B, n, D), F32, dev)
+    g1b = _e((Mq, D), BF16, dev)
+    ln_bwd(blk.norm2, None, t['x1'], B, t['st2'], dy_bf16=dh2, dx1=g1, res1=g2, dx1_bf16=g1b)
+    do = lin_bwd(blk.attn.proj, g1b, t['o'], Mq)
+    dqkv = torch.zeros((M, 3 * D), dtype=BF16, device=dev) if nF > 0 else _e((M, 3 * D), BF16, dev)
+    qkv = t['qkv']
+    attention_bwd((qkv, nF * 3 * D), (qkv, D), (qkv, 2 * D), t['o'], do, t['lse'],
+                  (dqkv, nF * 3 * D), (dqkv, D), (dqkv, 2 * D), B, heads, n, R, hd, hd, hd ** -0.5,
+                  R * 3 * D, 3 * D, R * 3 * D, 3 * D, R * 3 * D, 3 * D,
+                  R * 3 * D, 3 * D, R * 3 * D, 3 * D, R * 3 * D, 3 * D)
+    dh1 = lin_bwd(blk.attn.qkv, dqkv, t['h1'], M)
+    if not need_dx:
+        ln_bwd(blk.norm1, x_fus, x_mod, B, t['st1'], dy_bf16=dh1)
+        return None, None, None
+    if dx_mod is None:
+        dx_mod = _e((B, n, D), F32, dev)
+        dx_mod_acc = 0
+    dx_mod_b = _e((Mq, D), BF16, dev)
+    if nF > 0 and dx_fus is None:
+        dx_fus = _e((B, nF, D), F32, dev)
+        dx_fus_acc = 0
+    ln_bwd(blk.norm1, x_fus, x_mod, B, t['st1'], dy_bf16=dh1, dx0=dx_fus, acc0=dx_fus_acc,
+           dx1=dx_mod, acc1=dx_mod_acc, res1=g1, dx1_bf16=dx_mod_b)
+    return dx_mod, dx_mod_b, dx_fus
+
+
+# ------------------------------------------------------------------------------------------------
+# FusionBlock_FactorizedAVInteractions (models/fusion_blocks.py:216-289)
+# ------------------------------------------------------------------------------------------------
+def _cross_fwd(ca, xq_b, q_rowmap, nq, xkv_b, nk, B, D, heads, dev):
+    """CrossAttention (models/fusion_blocks.py:46-59) up to (not incl.) proj. xq_b rows come from the
+    normed fusion tokens through q_rowmap; xkv_b is the normed modality [B*nk, D]."""
+    hd = D // heads
+    q = lin_fwd(ca.q, xq_b, B * nq, a_rowmap=q_rowmap, out_bf16=True)                        # [B*nq, D]
+    kv = lin_fwd(ca.kv, xkv_b, B * nk, out_bf16=True)                                        # [B*nk, 2D]
+    o, lse = attention_fwd((q, 0), (kv, 0), (kv, D), B, heads, nq, nk, hd, hd, hd ** -0.5,
+                           nq * D, D, nk * 2 * D, 2 * D, nk * 2 * D, 2 * D, dev)
+    return dict(q=q, kv=kv, o=o, lse=lse)
+
+
+def _cross_bwd(ca, c, do, xq_b, q_rowmap, nq, xkv_b, nk, B, D, heads, dxq_out, dxq_rowmap):
+    """do: bf16 [B*nq, D] grad wrt the attention output (pre-proj). Returns d(xkv normed) bf16 [B*nk, D];
+    writes d(xq normed) into rows of dxq_out through dxq_rowmap."""
+    hd, dev = D // heads, do.device
+    dq = _e((B * nq, D), BF16, dev)
+    dkv = _e((B * nk, 2 * D), BF16, dev)
+    attention_bwd((c['q'], 0), (c['kv'], 0), (c['kv'], D), c['o'], do, c['lse'], (dq, 0), (dkv, 0), (dkv, D),
+                  B, heads, nq, nk, hd, hd, hd ** -0.5, nq * D, D, nk * 2 * D, 2 * D, nk * 2 * D, 2 * D,
+                  nq * D, D, nk * 2 * D, 2 * D, nk * 2 * D, 2 * D)
+    lin_bwd(ca.q, dq, xq_b, B * nq, a_rowmap=q_rowmap, dx=dxq_out, dx_rowmap=dxq_rowmap)
+    return lin_bwd(ca.kv, dkv, xkv_b, B * nk)
+
+
+def fusion_block_fwd(fb, x_f, x_i, x_a, heads, tkns):
+    B, nF, D = x_f.shape
+    nI, nA = x_i.shape[1], x_a.shape[1]
+    nmm, nv, na = tkns
+    dev, at = x_f.device, fb.attn
+    Da = at.q.weight.shape[0]
+    # norm-then-residual: the residual base is the NORMED xmm (models/fusion_blocks.py:281-283)
+    xmm_b, xmm32, st_mm = ln_fwd(fb.norm1_mm, None, x_f, B, want_f32=True)
+    xv_b, _, st_v = ln_fwd(fb.norm1_img, None, x_i, B)
+    xa_b, _, st_a = ln_fwd(fb.norm1_aud, None, x_a, B)
+    rm2, rmv, rma = (nmm, nF, 0), (nv, nF, nmm), (na, nF, nmm + nv)
+    cv = _cross_fwd(at.attn_v, xmm_b, rmv, nv, xv_b, nI, B, D, heads, dev)
+    ca = _cross_fwd(at.attn_a, xmm_b, rma, na, xa_b, nA, B, D, heads, dev)
+    xmm1 = _e((B, nF, D), F32, dev)
+    # proj of the two aggregations: fp32 result lands in its rows of xmm1 (+ normed-xmm residual),
+    # bf16 twin of the pre-residual value feeds the pair projections
+    xvo_b, xao_b = _e((B * nv, D), BF16, dev), _e((B * na, D), BF16, dev)
+    lin_fwd(at.attn_v.proj, cv['o'], B * nv, res=xmm32, res_rowmap=rmv, out=xmm1, c_rowmap=rmv, C2=xvo_b, c2_mode=2)
+    lin_fwd(at.attn_a.proj, ca['o'], B * na, res=xmm32, res_rowmap=rma, out=xmm1, c_rowmap=rma, C2=xao_b, c2_mode=2)
+    # all (v, a) pairs: Linear(cat(xv_i, xa_j)) = W[:, :D] xv_i + W[:, D:] xa_j + b  (never materialised)
+    kv_p = lin_fwd(at.k, xvo_b, B * nv, k=D)
+    ka_p = lin_fwd(at.k, xao_b, B * na, k=D, w_col_off=D, use_bias=False)
+    vv_p = lin_fwd(at.v, xvo_b, B * nv, k=D)
+    va_p = lin_fwd(at.v, xao_b, B * na, k=D, w_col_off=D, use_bias=False)
+    P = nv * na
+    Kp, Vp = _e((B * P, Da), BF16, dev), _e((B * P, D), BF16, dev)
+    ops.pair_expand(kv_p, ka_p, B, nv, na, Da, Kp)
+    ops.pair_expand(vv_p, va_p, B, nv, na, D, Vp)
+    q2 = lin_fwd(at.q, xmm_b, B * nmm, a_rowmap=rm2, out_bf16=True)                          # [B*nmm, Da]
+    scale = (D // heads) ** -0.5                                                             # NOT (Da/heads)^-0.5 (:220-222)
+    o2, lse2 = attention_fwd((q2, 0), (Kp, 0), (Vp, 0), B, heads, nmm, P, Da // heads, D // heads, scale,
+                             nmm * Da, Da, P * Da, Da, P * D, D, dev)
+    lin_fwd(at.proj, o2, B * nmm, res=xmm32, res_rowmap=rm2, out=xmm1, c_rowmap=rm2)
+    h2, _, st2 = ln_fwd(fb.norm2, None, xmm1, B)
+    Hd = fb.mlp.fc1.weight.shape[0]
+    z = _e((B * nF, Hd), BF16, dev)
+    u = lin_fwd(fb.mlp.fc1, h2, B * nF, act=1, out_bf16=True, C2=z, c2_mode=1)
+    out = lin_fwd(fb.mlp.fc2, u, B * nF, res=xmm1).view(B, nF, D)
+    tape = dict(x_f=x_f, x_i=x_i, x_a=x_a, xmm_b=xmm_b, st_mm=st_mm, xv_b=xv_b, st_v=st_v, xa_b=xa_b, st_a=st_a, cv=cv, ca=ca,
+                xvo_b=xvo_b, xao_b=xao_b, Kp=Kp, Vp=Vp, q2=q2, o2=o2, lse2=lse2, xmm1=xmm1, h2=h2, st2=st2, z=z, u=u,
+                heads=heads, tkns=tkns)
+    return out, tape
+
+
+def fusion_block_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
+    """g fp32 [B,nF,D] grad of the block output.  Returns (dx_f fp32 + bf16 twin, dx_i, dx_a);
+    dx_i / dx_a are freshly STORED (fp32 [B,n,D]) unless buffers are passed."""
+    x_f, x_i, x_a, heads = t['x_f'], t['x_i'], t['x_a'], t['heads']
+    B, nF, D = x_f.shape
+    nI, nA = x_i.shape[1], x_a.shape[1]
+    nmm, nv, na = t['tkns']
+    dev, at = x_f.device, fb.attn
+    Da = at.q.weight.shape[0]
+    P = nv * na
+    rm2, rmv, rma = (nmm, nF, 0), (nv, nF, nmm), (na, nF, nmm + nv)
+    if gb is None:
+        gb = to_bf16(g)
+    dz = lin_bwd(fb.mlp.fc2, gb, t['u'], B * nF, gelu_aux=t['z'])
+    dh2 = lin_bwd(fb.mlp.fc1, dz, t['h2'], B * nF)
+    g1 = _e((B, nF, D), F32, dev)
+    g1b = _e((B * nF, D), BF16, dev)
+    ln_bwd(fb.norm2, None, t['xmm1'], B, t['st2'], dy_bf16=dh2, dx1=g1, res1=g, dx1_bf16=g1b)
+    # d(normed xmm) from the three projections of its row groups lands in one bf16 buffer
+    dxmm_b = _e((B * nF, D), BF16, dev)
+    # --- pair attention branch (rows [0, nmm)) ---
+    do2 = lin_bwd(at.proj, g1b, t['o2'], B * nmm, dy_rowmap=rm2)                              # [B*nmm, D]
+    dq2, dKp, dVp = _e((B * nmm, Da), BF16, dev), _e((B * P, Da), BF16, dev), _e((B * P, D), BF16, dev)
+    attention_bwd((t['q2'], 0), (t['Kp'], 0), (t['Vp'], 0), t['o2'], do2, t['lse2'], (dq2, 0), (dKp, 0), (dVp, 0),
+                  B, heads, nmm, P, Da // heads, D // heads, (D // heads) ** -0.5, nmm * Da, Da, P * Da, Da, P * D, D,
+                  nmm * Da, Da, P * Da, Da, P * D, D)
+    lin_bwd(at.q, dq2, t['xmm_b'], B * nmm, a_rowmap=rm2, dx=dxmm_b, dx_rowmap=rm2)
+    dkv_p, dka_p = _e((B * nv, Da), BF16, dev), _e((B * na, Da), BF16, dev)
+    dvv_p, dva_p = _e((B * nv, D), BF16, dev), _e((B * na, D), BF16, dev)
+    ops.pair_reduce(dKp, B, nv, na, Da, dkv_p, dka_p)
+    ops.pair_reduce(dVp, B, nv, na, D, dvv_p, dva_p)
+    # d(xv_out) = g1[rows v] + dkv_p Wk[:, :D] + dvv_p Wv[:, :D]   (fp32 accumulate, bf16 twin on the last GEMM)
+    dxvo = g1.view(B, nF, D)[:, nmm:nmm + nv].contiguous().view(B * nv, D)
+    dxao = g1.view(B, nF, D)[:, nmm + nv:].contiguous().view(B * na, D)
+    dxvo_b, dxao_b = _e((B * nv, D), BF16, dev), _e((B * na, D), BF16, dev)
+    lin_bwd(at.k, dkv_p, t['xvo_b'], B * nv, k=D, dx=dxvo, dx_beta=1, final=False)
+    lin_bwd(at.v, dvv_p, t['xvo_b'], B * nv, k=D, dx=dxvo, dx_beta=1, dx_C2=dxvo_b, dx_c2_mode=3, final=False)
+    lin_bwd(at.k, dka_p, t['xao_b'], B * na, k=D, w_col_off=D, use_bias=False, dx=dxao, dx_beta=1)
+    lin_bwd(at.v, dva_p, t['xao_b'], B * na, k=D, w_col_off=D, use_bias=False, dx=dxao, dx_beta=1, dx_C2=dxao_b, dx_c2_mode=3)
+    # --- the two aggregation cross-attentions ---
+    dov = lin_bwd(at.attn_v.proj, dxvo_b, t['cv']['o'], B * nv)
+    doa = lin_bwd(at.attn_a.proj, dxao_b, t['ca']['o'], B * na)
+    dxv_b = _cross_bwd(at.attn_v, t['cv'], dov, t['xmm_b'], rmv, nv, t['xv_b'], nI, B, D, heads, dxmm_b, rmv)
+    dxa_b = _cross_bwd(at.attn_a, t['ca'], doa, t['xmm_b'], rma, na, t['xa_b'], nA, B, D, heads, dxmm_b, rma)
+    # --- the three input LayerNorms ---
+    acc_i, acc_a = (1 if dx_i is not None else 0), (1 if dx_a is not None else 0)
+    if dx_i is None:
+        dx_i = _e((B, nI, D), F32, dev)
+    if dx_a is None:
+        dx_a = _e((B, nA, D), F32, dev)
+    ln_bwd(fb.norm1_img, None, x_i, B, t['st_v'], dy_bf16=dxv_b, dx1=dx_i, acc1=acc_i)
+    ln_bwd(fb.norm1_aud, None, x_a, B, t['st_a'], dy_bf16=dxa_b, dx1=dx_a, acc1=acc_a)
+    dx_f = _e((B, nF, D), F32, dev)
+    ln_bwd(fb.norm1_mm, None, x_f, B, t['st_mm'], dy_bf16=dxmm_b, dy_f32=g1, dx1=dx_f)
+    return dx_f, dx_i, dx_a
+
+
+# ------------------------------------------------------------------------------------------------
+# patch embedding of the kept patches (timm PatchEmbed + pos_embed + gather; models/vits.py:91-100)
+# ------------------------------------------------------------------------------------------------
+def patch_embed_fwd(vit, img, ids_keep32):
+    B, C, H, W = img.shape
+    pe = vit.patch_embed
+    L = pe.num_patches
+    nk = ids_keep32.shape[1] if ids_keep32 is not None else L
+    D = vit.embed_dim
+    K = C * 256
+    A = _e((B * nk, K), BF16, img.device)
+    ops.patch_gather(img, ids_keep32, nk, A)
+    Wb, _ = wcache(pe.proj.weight)
+    tok = _e((B, nk, D), F32, img.device)
+    ops.gemm_nt(A, Wb, B * nk, D, K, bias=pe.proj.bias, res=vit.pos_embed, ldres=D,
+                res_rows=ids_keep32, res_rowmap=None if ids_keep32 is not None else (L, 0, 0), C_out=tok)
+    return tok, dict(A=A, nk=nk)
+
+
+def patch_embed_bwd(vit, t, g, gb):
+    pe = vit.patch_embed
+    D = vit.embed_dim
+    A = t['A']
+    M, K = A.shape
+    if gb is None:
+        gb = to_bf16(g)
+    ops.gemm_tn(gb, A, M, D, K, gbuf(pe.proj.weight).view(D, K), beta=1, bias_grad=gbuf(pe.proj.bias))
+    _ready(pe.proj.weight, pe.proj.bias)
+
+
+# ------------------------------------------------------------------------------------------------
+# MAE decoder (models/avmae.py:147-180, decoder_arch='plain')
+# ------------------------------------------------------------------------------------------------
+def decoder_fwd(dec, x_b, xf_b, ids_restore32, B, nk, nF):
+    """dec: namespace with embed, mask_token, pos_embed, blocks, norm, pred, heads.  x_b bf16 [B*nk, D]
+    (normed encoder tokens), xf_b bf16 [B*nF, D].  Returns pred fp32 [B, L, P]."""
+    L = ids_restore32.shape[1]
+    Dd = dec.embed.weight.shape[0]
+    dev = x_b.device
+    emb = lin_fwd(dec.embed, x_b, B * nk)                                                    # fp32 [B*nk, Dd]
+    x = _e((B, nF + L, Dd), F32, dev)
+    lin_fwd(dec.embed, xf_b, B * nF, out=x, c_rowmap=(nF, nF + L, 0))                        # embed is shared (:158)
+    ops.unshuffle_fwd(emb, dec.mask_token, dec.pos_embed, ids_restore32, B, L, nk, Dd, x, (nF + L) * Dd, nF)
+    tapes = []
+    for blk in dec.blocks:
+        x, bt = block_fwd(blk, x, None, dec.heads, blk.norm1.eps)
+        tapes.append(bt)
+    # decoder_norm + pred on the patch rows only (x[:, nF:]) — the LN reads them through the batch stride
+    D_ = Dd
+    hN = _e((B * L, D_), BF16, dev)
+    mean, rstd = _e((B * L,), F32, dev), _e((B * L,), F32, dev)
+    xs = x.view(-1)[nF * Dd:]
+    ops.layernorm_fwd(xs, (nF + L) * Dd, L, None, 0, 0, B, Dd, dec.norm.weight, dec.norm.bias, dec.norm.eps, hN, None, mean, rstd)
+    pred = lin_fwd(dec.pred, hN, B * L)
+    P = pred.shape[1]
+    tape = dict(x_b=x_b, xf_b=xf_b, x_last=x, tapes=tapes, hN=hN, stN=(mean, rstd), ids_restore32=ids_restore32, nk=nk, nF=nF, L=L)
+    return pred.view(B, L, P), tape
+
+
+def decoder_bwd(dec, t, dpred_b, ids_keep32, B):
+    nk, nF, L = t['nk'], t['nF'], t['L']
+    Dd = dec.embed.weight.shape[0]
+    dev = dpred_b.device
+    dhN = lin_bwd(dec.pred, dpred_b, t['hN'], B * L)
+    g = torch.zeros((B, nF + L, Dd), dtype=F32, device=dev)
+    gb = torch.zeros((B * (nF + L), Dd), dtype=BF16, device=dev)
+    xs = t['x_last'].view(-1)[nF * Dd:]
+    ops.layernorm_bwd(xs, (nF + L) * Dd, L, None, 0, 0, B, Dd, dhN, None, dec.norm.weight, t['stN'][0], t['stN'][1],
+                      g.view(-1)[nF * Dd:], (nF + L) * Dd, 0, None, 0, gb.view(-1)[nF * Dd:], (nF + L) * Dd,
+                      None, 0, 0, None, 0, None, 0, gbuf(dec.norm.weight), gbuf(dec.norm.bias))
+    _ready(dec.norm.weight, dec.norm.bias)
+    for blk, bt in zip(reversed(list(dec.blocks)), reversed(t['tapes'])):
+        g, gb, _ = block_bwd(blk, bt, g, gb)
+    d_emb = _e((B * nk, Dd), BF16, dev)
+    d_embf = _e((B * nF, Dd), BF16, dev)
+    ops.rows_gather_cast(g, (nF + L) * Dd, nF, ids_keep32, B, nk, Dd, d_emb)
+    ops.rows_gather_cast(g, (nF + L) * Dd, 0, None, B, nF, Dd, d_embf)
+    ops.unshuffle_bwd_reduce(g, (nF + L) * Dd, nF, t['ids_restore32'], B, L, nk, Dd, gbuf(dec.pos_embed), gbuf(dec.mask_token))
+    _ready(dec.pos_embed, dec.mask_token)
+    dx_b = lin_bwd(dec.embed, d_emb, t['x_b'], B * nk, final=False)
+    dxf_b = lin_bwd(dec.embed, d_embf, t['xf_b'], B * nF)
+    return dx_b, dxf_b
+
+
+# ------------------------------------------------------------------------------------------------
+# loss (models/avmae.py:182-214)
+# ------------------------------------------------------------------------------------------------
+def loss_fwd(img, pred, mask, norm_pix):
+    B, L = mask.shape
+    dev = img.device
+    lp, tm, tr = _e((B * L,), F32, dev), _e((B * L,), F32, dev), _e((B * L,), F32, dev)
+    loss, msum = _e((1,), F32, dev), _e((1,), F32, dev)
+    ops.patch_mse_fwd(img, pred, mask, norm_pix, lp, tm, tr, loss, msum)
+    return loss.view(()), dict(tm=tm, tr=tr, msum=msum)
+
+
+def loss_bwd(img, pred, mask, t, gout):
+    B, L, P = pred.shape
+    dpred = _e((B * L, P), BF16, img.device)
+    ops.patch_mse_bwd(img, pred, mask, t['tm'], t['tr'], t['msum'], gout, dpred)
+    return dpred

@@ -1,0 +1,53 @@
+"""Parameter holders for the factorised audio-visual fusion block (reference models/fusion_blocks.py:33-59, 216-289)."""
+import torch.nn as nn
+
+from .vits import Mlp
+
+
+class CrossAttention(nn.Module):
+    """models/fusion_blocks.py:33-59."""
+    def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.q = nn.Linear(dim, dim, bias=qkv_bias)
+        self.kv = nn.Linear(dim, dim * 2, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+
+class CrossAttention_FactorizedAVInteractions(nn.Module):
+    """models/fusion_blocks.py:216-263.  q/k are dim*dim_ratio wide, v and proj stay full width, and the
+    softmax scale is (dim/num_heads)^-0.5 whatever dim_ratio is (:220-222)."""
+    def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0., proj_drop=0., dim_ratio=1., fusion_tkns=(8, 4, 4)):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.dim = int(dim * dim_ratio)
+        self.fusion_tkns = tuple(fusion_tkns)
+        self.attn_v = CrossAttention(dim, num_heads=num_heads, qkv_bias=qkv_bias)
+        self.attn_a = CrossAttention(dim, num_heads=num_heads, qkv_bias=qkv_bias)
+        self.q = nn.Linear(dim, self.dim, bias=qkv_bias)
+        self.k = nn.Linear(dim * 2, self.dim, bias=qkv_bias)
+        self.v = nn.Linear(dim * 2, dim, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+
+class FusionBlock_FactorizedAVInteractions(nn.Module):
+    """models/fusion_blocks.py:266-289."""
+    def __init__(self, dim, num_heads, attn_ratio=0.25, mlp_ratio=4., qkv_bias=False, fusion_tkns=(8, 4, 4), drop=0.,
+                 attn_drop=0., drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+        super().__init__()
+        if drop or attn_drop or drop_path:
+            raise NotImplementedError('dropout / drop-path are fine-tuning options outside the pre-training path')
+        self.num_heads, self.fusion_tkns = num_heads, tuple(fusion_tkns)
+        self.norm1_mm = norm_layer(dim)
+        self.norm1_aud = norm_layer(dim)
+        self.norm1_img = norm_layer(dim)
+        self.attn = CrossAttention_FactorizedAVInteractions(dim, num_heads=num_heads, qkv_bias=qkv_bias, dim_ratio=attn_ratio,
+                                                            fusion_tkns=fusion_tkns)
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+
+    def forward(self, xmm, xv, xa):
+        from ..autograd_bridge import fusion_block
+        return fusion_block(self, xmm, xv, xa)

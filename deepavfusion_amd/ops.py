@@ -1,0 +1,171 @@
+"""Thin torch-tensor wrappers over the C ABI (include/dav_kernels.h).
+
+PyTorch is used here only for device memory and streams: every wrapper passes raw
+device pointers plus torch's *current* HIP stream to the HIP library, so the calls
+are ordered with surrounding torch work and can be captured in a hipGraph.
+There is no fallback path: a missing library or a non-CUDA tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('deepavfusion_amd kernels need tensors on an MI355X (cuda) device; there is no CPU fallback')
+    return t.data_ptr()
+
+
+def _rm(m: Optional[Sequence[int]]):
+    return (C.c_int * 3)(*m) if m is not None else None
+
+
+def gemm_nt(A, B, M, N, K, *, lda=None, ldb=None, a_rowmap=None, bias=None, act=0, aux=None, ldaux=0, res=None, ldres=0,
+            res_rowmap=None, res_rows=None, C_out=None, ldc=None, c_bf16=False, c_rowmap=None, C2=None, ldc2=0, c2_mode=0,
+            beta=0, alpha=1.0, variant=0):
+    """C[M,N] = epi(A[M,K] . B[N,K]^T); see dav_gemm_nt_bf16."""
+    lib = _lib.load()
+    _lib.check(lib.dav_gemm_nt_bf16(_ptr(A), _ptr(B), M, N, K, lda if lda is not None else K, ldb if ldb is not None else K,
+                                    _rm(a_rowmap), _ptr(bias), act, _ptr(aux), ldaux, _ptr(res), ldres, _rm(res_rowmap),
+                                    _ptr(res_rows), _ptr(C_out), ldc if ldc is not None else N, int(c_bf16), _rm(c_rowmap),
+                                    _ptr(C2), ldc2, c2_mode, beta, float(alpha), variant, _stream()), 'dav_gemm_nt_bf16')
+
+
+def gemm_tn(A, B, Mc, N, K, C_out, *, lda=None, ldb=None, ldc=None, a_rowmap=None, b_rowmap=None, beta=1, bias_grad=None,
+            variant=0):
+    """C[N,K] (+)= A[Mc,N]^T . B[Mc,K]; see dav_gemm_tn_bf16."""
+    lib = _lib.load()
+    _lib.check(lib.dav_gemm_tn_bf16(_ptr(A), _ptr(B), Mc, N, K, lda if lda is not None else N, ldb if ldb is not None else K,
+                                    _rm(a_rowmap), _rm(b_rowmap), _ptr(C_out), ldc if ldc is not None else K, beta,
+                                    _ptr(bias_grad), variant, _stream()), 'dav_gemm_tn_bf16')
+
+
+def attn_fwd(q_ptr, k_ptr, v_ptr, O, LSE, B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, scale):
+    lib = _lib.load()
+    _lib.check(lib.dav_attn_fwd(q_ptr, k_ptr, v_ptr, _ptr(O), _ptr(LSE), B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs,
+                                v_bs, v_rs, o_bs, o_rs, float(scale), _stream()), 'dav_attn_fwd')
+
+
+def attn_bwd(q_ptr, k_ptr, v_ptr, O, dO, LSE, Delta, dq_ptr, dk_ptr, dv_ptr, B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs,
+             v_bs, v_rs, o_bs, o_rs, do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, scale):
+    lib = _lib.load()
+    _lib.check(lib.dav_attn_bwd(q_ptr, k_ptr, v_ptr, _ptr(O), _ptr(dO), _ptr(LSE), _ptr(Delta), dq_ptr, dk_ptr, dv_ptr,
+                                B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, do_bs, do_rs,
+                                dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, float(scale), _stream()), 'dav_attn_bwd')
+
+
+def layernorm_fwd(x0, x0_bs, r0, x1, x1_bs, r1, B, D, gamma, beta, eps, y_bf16, y_f32, mean, rstd):
+    lib = _lib.load()
+    _lib.check(lib.dav_layernorm_fwd(_ptr(x0), x0_bs, r0, _ptr(x1), x1_bs, r1, B, D, _ptr(gamma), _ptr(beta), float(eps),
+                                     _ptr(y_bf16), _ptr(y_f32), _ptr(mean), _ptr(rstd), _stream()), 'dav_layernorm_fwd')
+
+
+def layernorm_bwd(x0, x0_bs, r0, x1, x1_bs, r1, B, D, dy_bf16, dy_f32, gamma, mean, rstd,
+                  dx0=None, dx0_bs=0, acc0=0, res0=None, res0_bs=0, dx0_bf16=None, dx0_bf_bs=0,
+                  dx1=None, dx1_bs=0, acc1=0, res1=None, res1_bs=0, dx1_bf16=None, dx1_bf_bs=0, dgamma=None, dbeta=None):
+    lib = _lib.load()
+    _lib.check(lib.dav_layernorm_bwd(_ptr(x0), x0_bs, r0, _ptr(x1), x1_bs, r1, B, D, _ptr(dy_bf16), _ptr(dy_f32),
+                                     _ptr(gamma), _ptr(mean), _ptr(rstd),
+                                     _ptr(dx0), dx0_bs, acc0, _ptr(res0), res0_bs, _ptr(dx0_bf16), dx0_bf_bs,
+                                     _ptr(dx1), dx1_bs, acc1, _ptr(res1), res1_bs, _ptr(dx1_bf16), dx1_bf_bs,
+                                     _ptr(dgamma), _ptr(dbeta), _stream()), 'dav_layernorm_bwd')
+
+
+def mask_build(noise: torch.Tensor, len_keep: int):
+    """AVMAE.random_masking for given noise -> (ids_keep i64, mask f32, ids_restore i64, ids_keep i32, ids_restore i32)."""
+    lib = _lib.load()
+    N, L = noise.shape
+    dev = noise.device
+    ids_keep = torch.empty(N, len_keep, dtype=torch.int64, device=dev)
+    ids_restore = torch.empty(N, L, dtype=torch.int64, device=dev)
+    mask = torch.empty(N, L, dtype=F32, device=dev)
+    ids_keep32 = torch.empty(N, len_keep, dtype=torch.int32, device=dev)
+    ids_restore32 = torch.empty(N, L, dtype=torch.int32, device=dev)
+    _lib.check(lib.dav_mask_build(_ptr(noise.contiguous()), N, L, len_keep, _ptr(ids_keep), _ptr(ids_restore), _ptr(mask),
+                                  _ptr(ids_keep32), _ptr(ids_restore32), _stream()), 'dav_mask_build')
+    return ids_keep, mask, ids_restore, ids_keep32, ids_restore32
+
+
+def patch_gather(img, ids_keep32, nk, out):
+    lib = _lib.load()
+    B, Cc, H, W = img.shape
+    _lib.check(lib.dav_patch_gather(_ptr(img), B, Cc, H, W, _ptr(ids_keep32), nk, _ptr(out), _stream()), 'dav_patch_gather')
+
+
+def unshuffle_fwd(emb, mask_token, pos, ids_restore32, B, L, nk, D, out, out_bs, out_row_off):
+    lib = _lib.load()
+    _lib.check(lib.dav_unshuffle_fwd(_ptr(emb), _ptr(mask_token), _ptr(pos), _ptr(ids_restore32), B, L, nk, D, _ptr(out),
+                                     out_bs, out_row_off, _stream()), 'dav_unshuffle_fwd')
+
+
+def rows_gather_cast(x, x_bs, row_off, ids32, B, n, D, out):
+    lib = _lib.load()
+    _lib.check(lib.dav_rows_gather_cast(_ptr(x), x_bs, row_off, _ptr(ids32), B, n, D, _ptr(out), _stream()), 'dav_rows_gather_cast')
+
+
+def unshuffle_bwd_reduce(dx, dx_bs, row_off, ids_restore32, B, L, nk, D, dpos, dmask_token):
+    lib = _lib.load()
+    _lib.check(lib.dav_unshuffle_bwd_reduce(_ptr(dx), dx_bs, row_off, _ptr(ids_restore32), B, L, nk, D, _ptr(dpos),
+                                            _ptr(dmask_token), _stream()), 'dav_unshuffle_bwd_reduce')
+
+
+def patch_mse_fwd(img, pred, mask, norm_pix, loss_patch, tmean, trstd, loss, mask_sum):
+    lib = _lib.load()
+    B, Cc, H, W = img.shape
+    _lib.check(lib.dav_patch_mse_fwd(_ptr(img), _ptr(pred), _ptr(mask), B, Cc, H, W, int(norm_pix), _ptr(loss_patch),
+                                     _ptr(tmean), _ptr(trstd), _ptr(loss), _ptr(mask_sum), _stream()), 'dav_patch_mse_fwd')
+
+
+def patch_mse_bwd(img, pred, mask, tmean, trstd, mask_sum, gout, dpred_bf16):
+    lib = _lib.load()
+    B, Cc, H, W = img.shape
+    _lib.check(lib.dav_patch_mse_bwd(_ptr(img), _ptr(pred), _ptr(mask), _ptr(tmean), _ptr(trstd), _ptr(mask_sum), _ptr(gout),
+                                     B, Cc, H, W, _ptr(dpred_bf16), _stream()), 'dav_patch_mse_bwd')
+
+
+def pair_expand(Pv, Pa, B, nv, na, Wd, out):
+    lib = _lib.load()
+    _lib.check(lib.dav_pair_expand(_ptr(Pv), _ptr(Pa), B, nv, na, Wd, _ptr(out), _stream()), 'dav_pair_expand')
+
+
+def pair_reduce(d, B, nv, na, Wd, dPv, dPa):
+    lib = _lib.load()
+    _lib.check(lib.dav_pair_reduce(_ptr(d), B, nv, na, Wd, _ptr(dPv), _ptr(dPa), _stream()), 'dav_pair_reduce')
+
+
+def cast_bf16(x, y):
+    lib = _lib.load()
+    _lib.check(lib.dav_cast_bf16(_ptr(x), _ptr(y), x.numel(), _stream()), 'dav_cast_bf16')
+
+
+def cast_transpose_bf16(x2d, y):
+    lib = _lib.load()
+    R, Cc = x2d.shape
+    _lib.check(lib.dav_cast_transpose_bf16(_ptr(x2d), _ptr(y), R, Cc, _stream()), 'dav_cast_transpose_bf16')
+
+
+def l2norm(x_flat, out, workspace, scale=1.0):
+    lib = _lib.load()
+    _lib.check(lib.dav_l2norm(_ptr(x_flat), x_flat.numel(), float(scale), _ptr(out), _ptr(workspace),
+                              workspace.numel() * workspace.element_size(), _stream()), 'dav_l2norm')
+
+
+def adamw_flat(p, g, m, v, p_bf16, seg_end, hyper, nseg, beta1, beta2, eps, bias_corr, grad_scale=1.0):
+    lib = _lib.load()
+    _lib.check(lib.dav_adamw_flat(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(p_bf16), p.numel(), _ptr(seg_end), _ptr(hyper), nseg,
+                                  float(beta1), float(beta2), float(eps), _ptr(bias_corr), float(grad_scale), _stream()),
+               'dav_adamw_flat')

@@ -1,0 +1,137 @@
+/* C ABI of libdavfusion_hip.so — the MI355X (gfx950) kernels behind the DeepAVFusion / AVMAE
+ * pre-training step.
+ *
+ * The reference (stoneMo/DeepAVFusion) has no FFI of its own: every device op on this path is a
+ * stock ATen call issued from Python.  This header is the boundary one level below the Python
+ * modules that mirror the reference's classes: each entry point replaces the ATen/cuDNN/cuBLAS/SDPA
+ * work behind the reference lines cited on it (paths relative to the reference repo).
+ *
+ * Conventions:
+ *  - plain pointers and sizes only; the caller owns every buffer (inputs, outputs, workspaces);
+ *    the library never allocates, frees or keeps a pointer past return;
+ *  - all work is enqueued on `stream`; no host synchronisation, no host callbacks; safe to call from
+ *    several host threads on distinct streams, and inside hipGraph stream capture;
+ *  - return 0 on success, a negative DAV_ERR_* code otherwise (never aborts);
+ *  - "bf16" buffers are raw uint16 bfloat16; index tensors are int64 where the reference exposes
+ *    them (ids_keep / ids_restore) with int32 twins for in-kernel use; row strides are in elements.
+ *  - a "row map" is an int[3] {rows_per_batch, batch_stride_rows, row_offset} (NULL = identity):
+ *    logical row m -> physical row (m / rpb) * bs + off + m % rpb.  It lets a GEMM read or write a
+ *    sub-range of a [B, rows, D] activation without cat/split copies.
+ */
+#ifndef DAV_KERNELS_H_
+#define DAV_KERNELS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __HIPCC__
+#include <hip/hip_runtime.h>
+#else
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DAV_ABI_VERSION 1
+int dav_abi_version(void);
+
+/* ---- GEMM --------------------------------------------------------------------------------- */
+/* C[M,N] = epi(alpha * A[M,K] . B[N,K]^T): every nn.Linear forward on the path (timm Attention.qkv/proj,
+ * Mlp.fc1/fc2; models/fusion_blocks.py:41-44 q/kv/proj, :227-232 q/k/v/proj; models/avmae.py:31,59
+ * decoder_embed, :60,88 decoder_pred; the patch-embed conv of models/vits.py:27 as a GEMM over
+ * gathered patches) and, with B = W^T, their input gradients.
+ * epilogue order: v = alpha*acc + bias[n]; [C2 mode 1]; act 1 = exact GELU, act 2 = v *= GELU'(aux[m,n])
+ * (fc1 backward); [C2 mode 2]; + fp32 residual (row map or explicit row list: the block residual adds
+ * and "+ pos_embed[ids_keep]"); beta != 0 adds the old fp32 C; store C (fp32 or bf16, through
+ * c_rowmap; may be NULL); [C2 mode 3].  C2 is a dense bf16 [M, ldc2] twin for the next GEMM.
+ * variant bit0: register-staged loads instead of global->LDS DMA; bit1: force 64x64 tiles. */
+int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const int* a_rowmap,
+                     const float* bias, int act, const void* aux, int ldaux, const float* res, int ldres,
+                     const int* res_rowmap, const int* res_rows, void* C, int ldc, int c_is_bf16, const int* c_rowmap,
+                     void* C2, int ldc2, int c2_mode, int beta, float alpha, int variant, hipStream_t stream);
+
+/* C[N,K] (+)= A[Mc,N]^T . B[Mc,K] in fp32: the weight gradient of every nn.Linear above (autograd of
+ * F.linear).  beta != 0 accumulates into the live gradient (split over the contraction with fp32
+ * atomics); bias_grad (optional) receives the column sums of A (atomic accumulate).
+ * variant bit0: scalar LDS reads instead of ds_read_b64_tr_b16. */
+int dav_gemm_tn_bf16(const void* A, const void* B, int Mc, int N, int K, int lda, int ldb, const int* a_rowmap,
+                     const int* b_rowmap, float* C, int ldc, int beta, float* bias_grad, int variant, hipStream_t stream);
+
+/* ---- attention ---------------------------------------------------------------------------- */
+/* softmax(scale * Q K^T) V per (batch, head); element (b, n, h, d) of X is X[b*x_bs + n*x_rs + h*dX + d].
+ * (dqk, dv) in {(64,64), (32,32), (16,64)}.  Replaces F.scaled_dot_product_attention inside timm
+ * Attention (models/vits.py:32-34 blocks, models/avmae.py:53-55,83-85 decoder blocks), CrossAttention
+ * (models/fusion_blocks.py:50-56) and the factorised pair attention (:250-258).
+ * LSE [B,H,Nq] (log-sum-exp of the scaled scores) is saved for the backward. */
+int dav_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int Nq, int Nk, int dqk,
+                 int dv, long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, float scale,
+                 hipStream_t stream);
+/* Delta [B,H,Nq] is scratch written by the first kernel and read by the second. */
+int dav_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, float* Delta,
+                 void* dQ, void* dK, void* dV, int B, int H, int Nq, int Nk, int dqk, int dv, long q_bs, int q_rs, long k_bs,
+                 int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, long do_bs, int do_rs, long dq_bs, int dq_rs, long dk_bs,
+                 int dk_rs, long dv_bs, int dv_rs, float scale, hipStream_t stream);
+
+/* ---- LayerNorm ---------------------------------------------------------------------------- */
+/* nn.LayerNorm over D on rows taken from two fp32 sources per batch element (r0 rows of x0, then r1
+ * rows of x1; r1 may be 0): folds torch.cat((x_fusion, x_mod), 1) of models/deepavfusion.py:104-105
+ * into Block.norm1.  Writes bf16 and/or fp32 outputs ([B*(r0+r1), D]) and the row statistics. */
+int dav_layernorm_fwd(const float* x0, long x0_bs, int r0, const float* x1, long x1_bs, int r1, int B, int D,
+                      const float* gamma, const float* beta, float eps, void* y_bf16, float* y_f32, float* mean, float* rstd,
+                      hipStream_t stream);
+/* total dy = dy_bf16 + dy_f32 (either may be NULL).  For each source segment s: dx_s (=|+=) LN'(dy)
+ * (+ res_s), optional bf16 copy; dx_s NULL skips the segment.  dgamma/dbeta are accumulated. */
+int dav_layernorm_bwd(const float* x0, long x0_bs, int r0, const float* x1, long x1_bs, int r1, int B, int D,
+                      const void* dy_bf16, const float* dy_f32, const float* gamma, const float* mean, const float* rstd,
+                      float* dx0, long dx0_bs, int acc0, const float* res0, long res0_bs, void* dx0_bf16, long dx0_bf_bs,
+                      float* dx1, long dx1_bs, int acc1, const float* res1, long res1_bs, void* dx1_bf16, long dx1_bf_bs,
+                      float* dgamma, float* dbeta, hipStream_t stream);
+
+/* ---- masking / gather / scatter ------------------------------------------------------------ */
+/* AVMAE.random_masking (models/avmae.py:120-142) for given noise [N,L]: argsort twice, keep the first
+ * len_keep, un-shuffled 0/1 mask.  Bit-exact with torch.argsort for tie-free noise. */
+int dav_mask_build(const float* noise, int N, int L, int len_keep, int64_t* ids_keep, int64_t* ids_restore, float* mask,
+                   int* ids_keep32, int* ids_restore32, hipStream_t stream);
+/* im2row of the kept 16x16 patches only (timm PatchEmbed + the gather of models/vits.py:100):
+ * A[b*nk+t, c*256+py*16+px] bf16; ids NULL = all patches in order. */
+int dav_patch_gather(const float* img, int B, int C, int H, int W, const int* ids_keep32, int nk, void* A_bf16, hipStream_t stream);
+/* models/avmae.py:161-165: out[b, off+r] = (restore[b,r] < nk ? emb[b*nk+restore[b,r]] : mask_token) + pos[r] */
+int dav_unshuffle_fwd(const float* emb, const float* mask_token, const float* pos, const int* ids_restore32, int B, int L, int nk,
+                      int D, float* out, long out_bs, int out_row_off, hipStream_t stream);
+/* out[b*n+t] = bf16(x[b, row_off + (ids ? ids[b*n+t] : t)]) — backward of the gather / of x[:, nF:] slices */
+int dav_rows_gather_cast(const float* x, long x_bs, int row_off, const int* ids32, int B, int n, int D, void* out_bf16,
+                         hipStream_t stream);
+/* dpos[r] += sum_b dx[b, off+r]; dmask_token += sum over masked (b, r) */
+int dav_unshuffle_bwd_reduce(const float* dx, long dx_bs, int row_off, const int* ids_restore32, int B, int L, int nk, int D,
+                             float* dpos, float* dmask_token, hipStream_t stream);
+
+/* ---- loss --------------------------------------------------------------------------------- */
+/* AVMAE.patchify + forward_loss (models/avmae.py:182-214) without a patchified target tensor:
+ * per-patch MSE against the (optionally norm-pix, unbiased variance) target read from NCHW,
+ * loss = sum(loss_patch * mask) / sum(mask). */
+int dav_patch_mse_fwd(const float* img, const float* pred, const float* mask, int B, int C, int H, int W, int norm_pix,
+                      float* loss_patch, float* tmean, float* trstd, float* loss, float* mask_sum, hipStream_t stream);
+int dav_patch_mse_bwd(const float* img, const float* pred, const float* mask, const float* tmean, const float* trstd,
+                      const float* mask_sum, const float* gout, int B, int C, int H, int W, void* dpred_bf16, hipStream_t stream);
+
+/* ---- factorised (v,a) pairs (models/fusion_blocks.py:245-252) ------------------------------- */
+int dav_pair_expand(const float* Pv, const float* Pa, int B, int nv, int na, int Wd, void* out_bf16, hipStream_t stream);
+int dav_pair_reduce(const void* d_bf16, int B, int nv, int na, int Wd, void* dPv_bf16, void* dPa_bf16, hipStream_t stream);
+
+/* ---- casts, grad norm, optimizer ----------------------------------------------------------- */
+int dav_cast_bf16(const float* x, void* y_bf16, long n, hipStream_t stream);
+int dav_cast_transpose_bf16(const float* x, void* y_bf16, int R, int C, hipStream_t stream);   /* y[c,r] = x[r,c] */
+/* get_grad_norm_ (util/misc.py:151-163) over one flat fp32 buffer: out = scale * ||x||_2 */
+size_t dav_l2norm_workspace_bytes(long n);
+int dav_l2norm(const float* x, long n, float scale, float* out, void* workspace, size_t workspace_bytes, hipStream_t stream);
+/* torch.optim.AdamW(betas=(0.9,0.95)) step (train.py:93) over flat param/grad/state buffers with
+ * per-segment {lr, weight_decay}; bias_corr = {1-beta1^t, sqrt(1-beta2^t)} in device memory. */
+int dav_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, long n, const long* seg_end, const float* hyper,
+                   int nseg, float beta1, float beta2, float eps, const float* bias_corr, float grad_scale, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DAV_KERNELS_H_ */

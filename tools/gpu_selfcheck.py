@@ -1,0 +1,348 @@
+#!/usr/bin/env python3
+"""Run every HIP kernel against a torch fp32 reference on the GPU box and print the errors.
+Diagnostic companion of tests/ (never aborts on the first failure).  Usage: python tools/gpu_selfcheck.py [filter]"""
+import math
+import os
+import sys
+import traceback
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from deepavfusion_amd import ops  # noqa: E402
+
+dev = torch.device('cuda')
+BF16, F32 = torch.bfloat16, torch.float32
+RESULTS = []
+
+
+def rel(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / max(float(b.norm()), 1e-30))
+
+
+def report(name, err, tol):
+    ok = err <= tol and math.isfinite(err)
+    RESULTS.append((name, err, tol, ok))
+    print(f'{"PASS" if ok else "FAIL"} {name}: err={err:.3e} tol={tol:.1e}', flush=True)
+
+
+def check(fn):
+    def run():
+        try:
+            fn()
+            torch.cuda.synchronize()
+        except Exception:
+            traceback.print_exc()
+            RESULTS.append((fn.__name__, float('nan'), 0, False))
+            print(f'FAIL {fn.__name__}: exception', flush=True)
+    run.__name__ = fn.__name__
+    return run
+
+
+def rnd(*shape, dtype=F32, scale=1.0, seed=None):
+    g = torch.Generator(device='cpu')
+    g.manual_seed(seed if seed is not None else (hash(shape) & 0xffff))
+    return (torch.randn(*shape, generator=g) * scale).to(device=dev, dtype=dtype)
+
+
+@check
+def gemm_nt():
+    for (M, N, K) in [(162, 192, 64), (5184, 2304, 768), (130, 768, 3072), (64, 48, 192), (512, 512, 48), (4032, 768, 256), (37, 100, 136)]:
+        for variant in (0, 1, 2, 3):
+            A, Bm = rnd(M, K, dtype=BF16, seed=1), rnd(N, K, dtype=BF16, scale=0.05, seed=2)
+            bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+            ref = A.float() @ Bm.float().t() + bias
+            C = torch.empty(M, N, device=dev)
+            ops.gemm_nt(A, Bm, M, N, K, bias=bias, C_out=C, variant=variant)
+            report(f'gemm_nt {M}x{N}x{K} v{variant} bias', rel(C, ref), 1e-4)
+            # gelu + preact twin, bf16 out
+            U = torch.empty(M, N, device=dev, dtype=BF16)
+            Z = torch.empty(M, N, device=dev, dtype=BF16)
+            ops.gemm_nt(A, Bm, M, N, K, bias=bias, act=1, C_out=U, c_bf16=True, C2=Z, ldc2=N, c2_mode=1, variant=variant)
+            report(f'gemm_nt {M}x{N}x{K} v{variant} gelu', rel(U, torch.nn.functional.gelu(ref)), 6e-3)
+            report(f'gemm_nt {M}x{N}x{K} v{variant} preact', rel(Z, ref), 6e-3)
+            # residual + beta accumulate + bf16 twin of the final value
+            C = torch.full((M, N), 0.5, device=dev)
+            T = torch.empty(M, N, device=dev, dtype=BF16)
+            ops.gemm_nt(A, Bm, M, N, K, res=res, ldres=N, C_out=C, beta=1, C2=T, ldc2=N, c2_mode=3, variant=variant)
+            report(f'gemm_nt {M}x{N}x{K} v{variant} res+beta', rel(C, ref - bias + res + 0.5), 1e-4)
+            report(f'gemm_nt {M}x{N}x{K} v{variant} twin', rel(T, ref - bias + res + 0.5), 6e-3)
+    # act 2 (multiply by gelu'(aux)) and row maps
+    M, N, K = 3 * 7, 128, 64
+    Bsz, rpb, tot = 3, 7, 11
+    Afull = rnd(Bsz * tot, K, dtype=BF16, seed=5)
+    Bm = rnd(N, K, dtype=BF16, scale=0.1, seed=6)
+    aux = rnd(M, N, dtype=BF16, seed=7)
+    Asub = Afull.view(Bsz, tot, K)[:, 4:, :].reshape(M, K)
+    x = aux.float().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    ref = (Asub.float() @ Bm.float().t()) * x.grad
+    Cfull = torch.zeros(Bsz * tot, N, device=dev)
+    resfull = rnd(Bsz * tot, N, seed=8)
+    ops.gemm_nt(Afull, Bm, M, N, K, a_rowmap=(rpb, tot, 4), act=2, aux=aux, ldaux=N, res=resfull, ldres=N, res_rowmap=(rpb, tot, 2),
+                C_out=Cfull, c_rowmap=(rpb, tot, 1))
+    ref_full = torch.zeros_like(Cfull).view(Bsz, tot, N)
+    ref_full[:, 1:8] = ref.view(Bsz, rpb, N) + resfull.view(Bsz, tot, N)[:, 2:9]
+    report('gemm_nt rowmaps+act2', rel(Cfull, ref_full.view(-1, N)), 1e-4)
+    rows = torch.randint(0, 5, (M,), device=dev, dtype=torch.int32)
+    pos = rnd(5, N, seed=9)
+    C = torch.empty(M, N, device=dev)
+    ops.gemm_nt(Asub.contiguous(), Bm, M, N, K, res=pos, ldres=N, res_rows=rows, C_out=C)
+    report('gemm_nt res_rows', rel(C, Asub.float() @ Bm.float().t() + pos[rows.long()]), 1e-4)
+    # B sub-matrix (column offset, ldb)
+    Bw = rnd(N, 2 * K, dtype=BF16, scale=0.1, seed=10)
+    C = torch.empty(M, N, device=dev)
+    ops.gemm_nt(Asub.contiguous(), Bw.view(-1)[K:], M, N, K, ldb=2 * K, C_out=C)
+    report('gemm_nt ldb/offset', rel(C, Asub.float() @ Bw[:, K:].float().t()), 1e-4)
+
+
+@check
+def gemm_tn():
+    for (Mc, N, K) in [(162, 192, 64), (5184, 768, 768), (100, 48, 192), (4032, 256, 768), (77, 136, 200), (6080, 3072, 768)]:
+        for variant in (0, 1):
+            A, Bm = rnd(Mc, N, dtype=BF16, seed=11), rnd(Mc, K, dtype=BF16, seed=12)
+            ref = A.float().t() @ Bm.float()
+            C = torch.zeros(N, K, device=dev)
+            bg = torch.zeros(N, device=dev)
+            ops.gemm_tn(A, Bm, Mc, N, K, C, beta=1, bias_grad=bg, variant=variant)
+            report(f'gemm_tn {Mc}x{N}x{K} v{variant} acc', rel(C, ref), 2e-4)
+            report(f'gemm_tn {Mc}x{N}x{K} v{variant} bias_grad', rel(bg, A.float().sum(0)), 2e-4)
+            C = torch.full((N, K), 7.0, device=dev)
+            ops.gemm_tn(A, Bm, Mc, N, K, C, beta=0, variant=variant)
+            report(f'gemm_tn {Mc}x{N}x{K} v{variant} store', rel(C, ref), 2e-4)
+    # row maps + ldc sub-block
+    Bsz, rpb, tot, N, K = 3, 5, 9, 64, 128
+    Af, Bf = rnd(Bsz * tot, N, dtype=BF16, seed=13), rnd(Bsz * tot, K, dtype=BF16, seed=14)
+    As = Af.view(Bsz, tot, N)[:, 2:7].reshape(-1, N)
+    Bs = Bf.view(Bsz, tot, K)[:, 4:9].reshape(-1, K)
+    Cw = torch.zeros(N, 2 * K, device=dev)
+    ops.gemm_tn(Af, Bf, Bsz * rpb, N, K, Cw.view(-1)[K:], ldc=2 * K, a_rowmap=(rpb, tot, 2), b_rowmap=(rpb, tot, 4), beta=1)
+    ref = torch.zeros_like(Cw)
+    ref[:, K:] = As.float().t() @ Bs.float()
+    report('gemm_tn rowmaps+ldc', rel(Cw, ref), 2e-4)
+
+
+def ref_attn(q, k, v, scale):
+    s = (q @ k.transpose(-2, -1)) * scale
+    return s.softmax(-1) @ v
+
+
+@check
+def attention():
+    for (B, H, Nq, Nk, dqk, dv, off) in [(2, 3, 49, 81, 64, 64, 32), (3, 2, 8, 49, 64, 64, 0), (2, 16, 228, 228, 32, 32, 0),
+                                        (2, 2, 352, 352, 32, 32, 0), (2, 12, 16, 64, 16, 64, 0), (3, 2, 4, 6, 16, 64, 0),
+                                        (2, 2, 5, 13, 64, 64, 8), (1, 1, 1, 1, 32, 32, 0), (2, 12, 63, 95, 64, 64, 32)]:
+        scale = 0.125 if dqk == 16 else dqk ** -0.5
+        # fused layout when dqk == dv: buffer [B, Nk, 3, H, d]; queries are rows off.. of the same buffer
+        if dqk == dv:
+            buf = rnd(B, Nk, 3, H, dqk, dtype=BF16, seed=21)
+            assert Nq + off == Nk or off == 0
+            qo = off if Nq + off == Nk else 0
+            qt = (buf, qo * 3 * H * dqk); kt = (buf, H * dqk); vt = (buf, 2 * H * dqk)
+            strides = (Nk * 3 * H * dqk, 3 * H * dqk) * 3
+            q = buf[:, qo:qo + Nq, 0].permute(0, 2, 1, 3).float()
+            k = buf[:, :, 1].permute(0, 2, 1, 3).float()
+            v = buf[:, :, 2].permute(0, 2, 1, 3).float()
+        else:
+            qb, kb, vb = rnd(B, Nq, H, dqk, dtype=BF16, seed=22), rnd(B, Nk, H, dqk, dtype=BF16, seed=23), rnd(B, Nk, H, dv, dtype=BF16, seed=24)
+            qt, kt, vt = (qb, 0), (kb, 0), (vb, 0)
+            strides = (Nq * H * dqk, H * dqk, Nk * H * dqk, H * dqk, Nk * H * dv, H * dv)
+            q, k, v = qb.permute(0, 2, 1, 3).float(), kb.permute(0, 2, 1, 3).float(), vb.permute(0, 2, 1, 3).float()
+        q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
+        ref = ref_attn(q, k, v, scale)
+        O = torch.empty(B * Nq, H * dv, device=dev, dtype=BF16)
+        LSE = torch.empty(B, H, Nq, device=dev)
+        p = lambda t: t[0].data_ptr() + 2 * t[1]
+        ops.attn_fwd(p(qt), p(kt), p(vt), O, LSE, B, H, Nq, Nk, dqk, dv, *strides, Nq * H * dv, H * dv, scale)
+        tag = f'attn B{B} H{H} {Nq}x{Nk} d{dqk}/{dv}'
+        report(tag + ' fwd', rel(O.view(B, Nq, H, dv).permute(0, 2, 1, 3), ref), 1e-2)
+        lse_ref = torch.logsumexp((q @ k.transpose(-2, -1)) * scale, -1)
+        report(tag + ' lse', rel(LSE, lse_ref), 1e-4)
+        dO = rnd(B * Nq, H * dv, dtype=BF16, seed=25)
+        ref.backward(dO.view(B, Nq, H, dv).permute(0, 2, 1, 3).float())
+        if dqk == dv:
+            dbuf = torch.zeros_like(buf)
+            dqt = (dbuf, qt[1]); dkt = (dbuf, kt[1]); dvt = (dbuf, vt[1])
+        else:
+            dqb, dkb, dvb = torch.zeros_like(qb), torch.zeros_like(kb), torch.zeros_like(vb)
+            dqt, dkt, dvt = (dqb, 0), (dkb, 0), (dvb, 0)
+        Delta = torch.empty_like(LSE)
+        ops.attn_bwd(p(qt), p(kt), p(vt), O, dO, LSE, Delta, p(dqt), p(dkt), p(dvt), B, H, Nq, Nk, dqk, dv, *strides,
+                     Nq * H * dv, H * dv, Nq * H * dv, H * dv, *strides, scale)
+        if dqk == dv:
+            gq = dbuf[:, qo:qo + Nq, 0].permute(0, 2, 1, 3); gk = dbuf[:, :, 1].permute(0, 2, 1, 3); gv = dbuf[:, :, 2].permute(0, 2, 1, 3)
+        else:
+            gq, gk, gv = dqb.permute(0, 2, 1, 3), dkb.permute(0, 2, 1, 3), dvb.permute(0, 2, 1, 3)
+        report(tag + ' dq', rel(gq, q.grad), 2e-2)
+        report(tag + ' dk', rel(gk, k.grad), 2e-2)
+        report(tag + ' dv', rel(gv, v.grad), 2e-2)
+
+
+@check
+def layernorm():
+    for (B, r0, r1, D) in [(3, 4, 9, 128), (2, 0, 81, 768), (64, 32, 49, 768), (2, 0, 228, 512), (3, 5, 0, 192), (2, 3, 3, 1024)]:
+        x0 = rnd(B, max(r0, 1), D, seed=31)[:, :r0].contiguous() if r0 else None
+        x1 = rnd(B, max(r1, 1), D, seed=32)[:, :r1].contiguous() if r1 else None
+        g, bt = rnd(D, seed=33) * 0.1 + 1, rnd(D, seed=34) * 0.1
+        xs = [t for t in (x0, x1) if t is not None]
+        xc = torch.cat(xs, 1).clone().requires_grad_(True)
+        gp, bp = g.clone().requires_grad_(True), bt.clone().requires_grad_(True)
+        ref = torch.nn.functional.layer_norm(xc, (D,), gp, bp, 1e-6)
+        R = r0 + r1
+        y, y32 = torch.empty(B * R, D, device=dev, dtype=BF16), torch.empty(B * R, D, device=dev)
+        mean, rstd = torch.empty(B * R, device=dev), torch.empty(B * R, device=dev)
+        a0, a1 = (x0, x1) if x0 is not None else (x1, None)
+        n0, n1 = (r0, r1) if x0 is not None else (r1, 0)
+        ops.layernorm_fwd(a0, n0 * D, n0, a1, n1 * D, n1, B, D, g, bt, 1e-6, y, y32, mean, rstd)
+        tag = f'ln B{B} {r0}+{r1} D{D}'
+        report(tag + ' fwd32', rel(y32, ref.view(-1, D)), 1e-5)
+        report(tag + ' fwd16', rel(y, ref.view(-1, D)), 5e-3)
+        dy = rnd(B * R, D, dtype=BF16, seed=35)
+        dy32 = rnd(B * R, D, seed=36)
+        ref.backward((dy.float() + dy32).view(B, R, D))
+        dx0 = torch.full((B, n0, D), 1.0, device=dev)
+        res0 = rnd(B, n0, D, seed=37)
+        tw0 = torch.empty(B, n0, D, device=dev, dtype=BF16)
+        dx1 = torch.empty(B, max(n1, 1), D, device=dev)[:, :n1].contiguous() if n1 else None
+        dg, db = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+        ops.layernorm_bwd(a0, n0 * D, n0, a1, n1 * D, n1, B, D, dy, dy32, g, mean, rstd,
+                          dx0, n0 * D, 1, res0, n0 * D, tw0, n0 * D, dx1, n1 * D, 0, None, 0, None, 0, dg, db)
+        report(tag + ' dx0(acc+res)', rel(dx0, xc.grad[:, :n0] + 1.0 + res0), 1e-4)
+        report(tag + ' dx0 twin', rel(tw0, xc.grad[:, :n0] + 1.0 + res0), 5e-3)
+        if n1:
+            report(tag + ' dx1', rel(dx1, xc.grad[:, n0:]), 1e-4)
+        report(tag + ' dgamma', rel(dg, gp.grad), 1e-4)
+        report(tag + ' dbeta', rel(db, bp.grad), 1e-4)
+
+
+@check
+def masking():
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'masking.npz'))
+    for t in sorted({k.split('.')[0] for k in g.files}):
+        noise = torch.from_numpy(g[f'{t}.noise']).to(dev)
+        lk = g[f'{t}.ids_keep'].shape[1]
+        ik, mask, ir, ik32, ir32 = ops.mask_build(noise, lk)
+        ok = (np.array_equal(ik.cpu().numpy(), g[f'{t}.ids_keep']) and np.array_equal(ir.cpu().numpy(), g[f'{t}.ids_restore'])
+              and np.array_equal(mask.cpu().numpy(), g[f'{t}.mask']) and np.array_equal(ik32.cpu().numpy(), g[f'{t}.ids_keep'])
+              and np.array_equal(ir32.cpu().numpy(), g[f'{t}.ids_restore']))
+        report(f'mask_build {t} bit-exact', 0.0 if ok else 1.0, 0.0)
+    noise = torch.rand(64, 320, device=dev)
+    ik, mask, ir, _, _ = ops.mask_build(noise, 63)
+    sh = torch.argsort(noise, dim=1)
+    ok = torch.equal(ik, sh[:, :63]) and torch.equal(ir, torch.argsort(sh, dim=1))
+    report('mask_build vs torch.argsort 64x320', 0.0 if ok else 1.0, 0.0)
+
+
+@check
+def misc_kernels():
+    from oracle import avmae_oracle as O
+    B, C, H, W, nk = 3, 3, 64, 96, 5
+    img = rnd(B, C, H, W, seed=41)
+    L = (H // 16) * (W // 16)
+    ids = torch.stack([torch.randperm(L)[:nk] for _ in range(B)]).to(dev).to(torch.int32)
+    A = torch.empty(B * nk, C * 256, device=dev, dtype=BF16)
+    ops.patch_gather(img, ids, nk, A)
+    cols = img.reshape(B, C, H // 16, 16, W // 16, 16).permute(0, 2, 4, 1, 3, 5).reshape(B, L, C * 256)
+    ref = cols.gather(1, ids.long().unsqueeze(-1).expand(-1, -1, C * 256)).reshape(B * nk, -1)
+    report('patch_gather', rel(A, ref), 4e-3)
+    A2 = torch.empty(B * L, C * 256, device=dev, dtype=BF16)
+    ops.patch_gather(img, None, L, A2)
+    report('patch_gather all', rel(A2, cols.reshape(B * L, -1)), 4e-3)
+    # unshuffle
+    D, nF = 64, 3
+    emb, mt, pos = rnd(B * nk, D, seed=42), rnd(D, seed=43), rnd(L, D, seed=44)
+    restore = torch.stack([torch.randperm(L) for _ in range(B)]).to(dev)
+    out = torch.zeros(B, nF + L, D, device=dev)
+    ops.unshuffle_fwd(emb, mt, pos, restore.to(torch.int32), B, L, nk, D, out, (nF + L) * D, nF)
+    full = torch.cat([emb.view(B, nk, D), mt.view(1, 1, D).expand(B, L - nk, D)], 1)
+    ref = full.gather(1, restore.unsqueeze(-1).expand(-1, -1, D)) + pos
+    report('unshuffle_fwd', rel(out[:, nF:], ref), 1e-6)
+    gx = rnd(B, nF + L, D, seed=45)
+    keep = torch.argsort(restore, dim=1)[:, :nk].to(torch.int32)
+    o = torch.empty(B * nk, D, device=dev, dtype=BF16)
+    ops.rows_gather_cast(gx, (nF + L) * D, nF, keep, B, nk, D, o)
+    report('rows_gather_cast', rel(o.view(B, nk, D), gx[:, nF:].gather(1, keep.long().unsqueeze(-1).expand(-1, -1, D))), 4e-3)
+    dpos, dmt = torch.zeros(L, D, device=dev), torch.zeros(D, device=dev)
+    ops.unshuffle_bwd_reduce(gx, (nF + L) * D, nF, restore.to(torch.int32), B, L, nk, D, dpos, dmt)
+    report('unshuffle dpos', rel(dpos, gx[:, nF:].sum(0)), 1e-5)
+    msk = (restore >= nk).float().unsqueeze(-1)
+    report('unshuffle dmask_token', rel(dmt, (gx[:, nF:] * msk).sum((0, 1))), 1e-5)
+    # loss
+    for Cc in (3, 1):
+        im = rnd(B, Cc, H, W, seed=46)
+        P = 256 * Cc
+        pred = rnd(B, L, P, seed=47).requires_grad_(True)
+        mask = (torch.rand(B, L, device=dev) > 0.3).float()
+        for norm in (True, False):
+            tgt = O.patchify(im, (16, 16))
+            ref = O.forward_loss(tgt, pred, mask, norm)
+            gsc = torch.tensor(0.7, device=dev)
+            pred.grad = None
+            (ref * gsc).backward()
+            lp, tm, tr = torch.empty(B * L, device=dev), torch.empty(B * L, device=dev), torch.empty(B * L, device=dev)
+            loss, ms = torch.empty(1, device=dev), torch.empty(1, device=dev)
+            ops.patch_mse_fwd(im, pred.detach(), mask, norm, lp, tm, tr, loss, ms)
+            report(f'patch_mse fwd C{Cc} norm{int(norm)}', abs(float(loss) - float(ref)) / abs(float(ref)), 1e-5)
+            dp = torch.empty(B * L, P, device=dev, dtype=BF16)
+            ops.patch_mse_bwd(im, pred.detach(), mask, tm, tr, ms, gsc, dp)
+            report(f'patch_mse bwd C{Cc} norm{int(norm)}', rel(dp.view(B, L, P), pred.grad), 5e-3)
+    # pairs
+    nv, na, Wd = 3, 2, 64
+    Pv, Pa = rnd(B * nv, Wd, seed=48), rnd(B * na, Wd, seed=49)
+    out = torch.empty(B * nv * na, Wd, device=dev, dtype=BF16)
+    ops.pair_expand(Pv, Pa, B, nv, na, Wd, out)
+    ref = (Pv.view(B, nv, 1, Wd) + Pa.view(B, 1, na, Wd)).reshape(-1, Wd)
+    report('pair_expand', rel(out, ref), 4e-3)
+    d = rnd(B * nv * na, Wd, dtype=BF16, seed=50)
+    dPv, dPa = torch.empty(B * nv, Wd, device=dev, dtype=BF16), torch.empty(B * na, Wd, device=dev, dtype=BF16)
+    ops.pair_reduce(d, B, nv, na, Wd, dPv, dPa)
+    d4 = d.float().view(B, nv, na, Wd)
+    report('pair_reduce v', rel(dPv, d4.sum(2).reshape(-1, Wd)), 4e-3)
+    report('pair_reduce a', rel(dPa, d4.sum(1).reshape(-1, Wd)), 4e-3)
+    # casts / norm / adamw
+    x = rnd(1000, 77, seed=51)
+    y = torch.empty(1000, 77, device=dev, dtype=BF16)
+    ops.cast_bf16(x, y)
+    report('cast_bf16 exact', float((y != x.to(BF16)).sum()), 0.0)
+    yt = torch.empty(77, 1000, device=dev, dtype=BF16)
+    ops.cast_transpose_bf16(x, yt)
+    report('cast_transpose exact', float((yt != x.t().to(BF16)).sum()), 0.0)
+    flat = rnd(1234567, seed=52)
+    out, ws = torch.empty(1, device=dev), torch.empty(1024, device=dev)
+    ops.l2norm(flat, out, ws, 0.5)
+    report('l2norm', abs(float(out) - 0.5 * float(flat.double().norm())) / float(flat.double().norm()), 1e-6)
+    n = 100003
+    p0, g0 = rnd(n, seed=53), rnd(n, seed=54)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([{'params': [pr], 'weight_decay': 0.05}], lr=1e-2, betas=(0.9, 0.95))
+    p, m, v = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    pb = torch.empty(n, device=dev, dtype=BF16)
+    seg = torch.tensor([40000, n], device=dev, dtype=torch.int64)
+    hyper = torch.tensor([1e-2, 0.05, 1e-2, 0.05], device=dev)
+    for step in range(1, 4):
+        pr.grad = g0 * step
+        opt.step()
+        bc = torch.tensor([1 - 0.9 ** step, math.sqrt(1 - 0.95 ** step)], device=dev)
+        ops.adamw_flat(p, g0 * step, m, v, pb, seg, hyper, 2, 0.9, 0.95, 1e-8, bc)
+    report('adamw_flat vs torch.optim.AdamW', rel(p, pr.detach()), 1e-6)
+    report('adamw bf16 mirror', rel(pb, p), 4e-3)
+
+
+def main():
+    flt = sys.argv[1] if len(sys.argv) > 1 else ''
+    print('device:', torch.cuda.get_device_name(0), flush=True)
+    for fn in (gemm_nt, gemm_tn, attention, layernorm, masking, misc_kernels):
+        if flt in fn.__name__:
+            fn()
+    bad = [r for r in RESULTS if not r[3]]
+    print(f'\n{len(RESULTS) - len(bad)}/{len(RESULTS)} checks passed')
+    for r in bad:
+        print('  FAILED:', r[0], r[1])
+    return 1 if bad else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())
