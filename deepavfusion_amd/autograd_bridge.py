@@ -86,8 +86,8 @@ def encoder_bwd(enc, t, dxi_b=None, dxa_b=None, dxf_b=None, dxi32=None, dxa32=No
 
 class _EncoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, enc, image, audio, ik32, ak32, return_embs, *params):
-        need_tape = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    def forward(ctx, enc, image, audio, ik32, ak32, return_embs, need_tape, *params):
+        ctx.set_materialize_grads(False)
         _, f32s, embs, tape = encoder_fwd(enc, image, audio, ik32, ak32, want_f32=True, collect_embs=return_embs)
         ctx.enc, ctx.tape = enc, (tape if need_tape else None)
         B = image.shape[0]
@@ -98,16 +98,19 @@ class _EncoderFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gi, ga, gf, *_):
+        if ctx.tape is None:
+            raise RuntimeError('backward through DeepAVFusion.forward called without a saved tape')
         c = lambda g: None if g is None else g.contiguous().view(-1, g.shape[-1])
         encoder_bwd(ctx.enc, ctx.tape, dxi32=c(gi), dxa32=c(ga), dxf32=c(gf))
         ctx.tape = None
-        return (None,) * (6 + len(ctx.enc._param_list))
+        return (None,) * (7 + len(ctx.enc._param_list))
 
 
 def encoder_apply(enc, image, audio, image_ids_keep, audio_ids_keep, return_embs):
     enc._param_list = [p for p in enc.parameters()]
+    need_tape = torch.is_grad_enabled() and any(p.requires_grad for p in enc._param_list)
     out = _EncoderFn.apply(enc, _f32c(image), _f32c(audio), _ids32(image_ids_keep), _ids32(audio_ids_keep),
-                           bool(return_embs), *enc._param_list)
+                           bool(return_embs), need_tape, *enc._param_list)
     if not return_embs:
         return out[0], out[1], out[2]
     rest = out[3:]
@@ -121,6 +124,7 @@ def encoder_apply(enc, image, audio, image_ids_keep, audio_ids_keep, return_embs
 class _PatchTokensFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, vit, x, ids32, *params):
+        ctx.set_materialize_grads(False)
         tok, tape = E.patch_embed_fwd(vit, x, ids32)
         ctx.vit, ctx.tape = vit, tape
         return tok
@@ -138,6 +142,7 @@ def patch_tokens(vit, x, ids_keep):
 class _FusionBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, fb, xmm, xv, xa, *params):
+        ctx.set_materialize_grads(False)
         out, tape = E.fusion_block_fwd(fb, xmm, xv, xa, fb.num_heads, fb.fusion_tkns)
         ctx.fb, ctx.tape, ctx.np = fb, tape, len(params)
         return out
@@ -193,8 +198,8 @@ def avmae_bwd(model, t, g_li, g_la, g_pi=None, g_pa=None):
 
 class _AVMAEFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, image, audio, noise_i, noise_a, *params):
-        need_tape = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    def forward(ctx, model, image, audio, noise_i, noise_a, need_tape, *params):
+        ctx.set_materialize_grads(False)
         outs, tape, aux = avmae_fwd(model, image, audio, noise_i, noise_a)
         ctx.model, ctx.tape, ctx.np = model, (tape if need_tape else None), len(params)
         model._last_masks = aux
@@ -205,7 +210,7 @@ class _AVMAEFn(torch.autograd.Function):
         z = lambda g: g.contiguous() if g is not None else torch.zeros((), dtype=F32, device=ctx.tape['image'].device)
         avmae_bwd(ctx.model, ctx.tape, z(g_li), z(g_la), g_pi, g_pa)
         ctx.tape = None
-        return (None,) * (5 + ctx.np)
+        return (None,) * (6 + ctx.np)
 
 
 def avmae_apply(model, image, audio, noise_image=None, noise_audio=None):
@@ -218,4 +223,5 @@ def avmae_apply(model, image, audio, noise_image=None, noise_audio=None):
     params = getattr(model, '_param_list', None)
     if params is None:
         params = model._param_list = [p for p in model.parameters()]
-    return _AVMAEFn.apply(model, _f32c(image), _f32c(audio), _f32c(noise_image), _f32c(noise_audio), *params)
+    need_tape = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    return _AVMAEFn.apply(model, _f32c(image), _f32c(audio), _f32c(noise_image), _f32c(noise_audio), need_tape, *params)

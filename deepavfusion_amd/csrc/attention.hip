@@ -376,7 +376,11 @@ int launch_fwd(const AttnParams& p, hipStream_t stream) {
   if (lds > 160 * 1024) return DAV_ERR_SHAPE;
   int nw = (p.Nq + 15) / 16; nw = nw > 8 ? 8 : nw; nw = nw < 1 ? 1 : nw;
   auto kern = attn_fwd_kernel<DQK, DV>;
-  if (lds > 64 * 1024) HIP_CHECK_RET(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  static bool big_lds = false;     // raise the dynamic-LDS cap once per kernel (160 KiB on gfx950)
+  if (lds > 64 * 1024 && !big_lds) {
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    big_lds = true;
+  }
   hipLaunchKernelGGL(kern, dim3(p.B * p.H), dim3(nw * 64), lds, stream, p);
   return dav_launch_status();
 }
@@ -391,8 +395,15 @@ int launch_bwd(const AttnParams& p, hipStream_t stream) {
   int nw2 = (p.Nk + 15) / 16; nw2 = nw2 > 8 ? 8 : nw2; nw2 = nw2 < 1 ? 1 : nw2;
   auto k1 = attn_bwd_dq_kernel<DQK, DV>;
   auto k2 = attn_bwd_dkv_kernel<DQK, DV>;
-  if (lds1 > 64 * 1024) HIP_CHECK_RET(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-  if (lds2 > 64 * 1024) HIP_CHECK_RET(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+  static bool big1 = false, big2 = false;
+  if (lds1 > 64 * 1024 && !big1) {
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    big1 = true;
+  }
+  if (lds2 > 64 * 1024 && !big2) {
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    big2 = true;
+  }
   hipLaunchKernelGGL(k1, dim3(p.B * p.H), dim3(nw1 * 64), lds1, stream, p);
   hipLaunchKernelGGL(k2, dim3(p.B * p.H), dim3(nw2 * 64), lds2, stream, p);
   return dav_launch_status();
