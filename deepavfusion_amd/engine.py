@@ -65,6 +65,15 @@ def wcache(p: torch.nn.Parameter, force: bool = False):
     return c[2], c[3]
 
 
+def invalidate_weight_cache(params):
+    """Mark the bf16 copies stale (the flat AdamW kernel updates the fp32 masters without touching
+    torch's version counters)."""
+    for p in params:
+        c = p.__dict__.get('_dav_cache')
+        if c is not None:
+            p.__dict__['_dav_cache'] = (-1,) + tuple(c[1:])
+
+
 def refresh_weight_cache(module: torch.nn.Module):
     """Re-cast every >=2-D weight (call at the top of a captured step so replays see fresh weights)."""
     for p in module.parameters():

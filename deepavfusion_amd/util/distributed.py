@@ -1,0 +1,209 @@
+"""Process-group bootstrap and the data-parallel gradient reducer (reference util/distributed.py,
+and the DistributedDataParallel wrap of util/misc.py:32-34).
+
+One process per GPU; ``torch.distributed`` backend "nccl" is RCCL on ROCm and runs over xGMI inside a
+node.  The reducer all-reduces contiguous slices ("buckets") of the flat gradient buffer on a side
+stream as soon as every parameter of a bucket has its final gradient (the engine calls
+``grad_ready``), so communication overlaps the rest of the hand-written backward; there is no
+flatten/unflatten copy and no per-parameter autograd hook.  Buckets are sized for xGMI
+(large messages: 7 links x ~153 GB/s per GPU are only reached by multi-MB collectives).
+The reference launcher's NCCL_P2P_DISABLE=1 is deliberately NOT carried over (it would disable xGMI).
+"""
+from __future__ import annotations
+
+import builtins
+import contextlib
+import datetime
+import os
+import random
+import sys
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .. import engine
+
+
+def is_dist_avail_and_initialized():
+    return dist.is_available() and dist.is_initialized()
+
+
+def get_world_size():
+    return dist.get_world_size() if is_dist_avail_and_initialized() else 1
+
+
+def get_rank():
+    return dist.get_rank() if is_dist_avail_and_initialized() else 0
+
+
+def is_main_process():
+    return get_rank() == 0
+
+
+def save_on_master(*args, **kwargs):
+    if is_main_process():
+        torch.save(*args, **kwargs)
+
+
+def setup_for_distributed(is_master, log_fn=None):
+    """Rank-0-only, time-stamped print that is also appended to a log file (util/distributed.py:13-34)."""
+    builtin_print = builtins.print
+
+    def print(*args, **kwargs):
+        force = kwargs.pop('force', False) or (get_rank() % 8 == 0)
+        if is_master or force:
+            msg = f'[{datetime.datetime.now().time()}] ' + ' '.join(str(a) for a in args)
+            builtin_print(msg, **kwargs)
+            sys.stdout.flush()
+            if log_fn is not None:
+                with open(log_fn, 'a') as f:
+                    f.write(msg + '\n')
+    builtins.print = print
+
+
+def init_distributed_mode(local_rank, args, log_fn=None):
+    """util/distributed.py:66-100 with env:// support (torchrun) next to the reference's explicit dist_url."""
+    ngpus = torch.cuda.device_count()
+    env = args.env
+    env.distributed = ngpus > 0 and (env.world_size * max(ngpus, 1) > 1 or int(os.environ.get('WORLD_SIZE', '1')) > 1)
+    if not env.distributed:
+        setup_for_distributed(is_master=True, log_fn=log_fn)
+        env.world_size, env.rank = 1, 0
+        if ngpus > 0:
+            torch.cuda.set_device(local_rank)
+        return
+    if 'RANK' in os.environ and 'WORLD_SIZE' in os.environ:      # launched by torch.distributed.run
+        env.rank, env.world_size = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+        local_rank = int(os.environ.get('LOCAL_RANK', local_rank))
+        url = 'env://'
+    else:
+        env.world_size = ngpus * env.world_size
+        env.rank = env.rank * ngpus + local_rank
+        url = env.dist_url
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group(backend='nccl', init_method=url, world_size=env.world_size, rank=env.rank)
+    dist.barrier()
+    setup_for_distributed(env.rank == 0, log_fn=log_fn)
+    if getattr(env, 'seed', None) is not None:
+        seed = env.seed + get_rank()          # per-rank stream -> different masks per rank (util/distributed.py:90-94)
+        random.seed(seed)
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+
+
+@torch.no_grad()
+def concat_all_gather(tensor):
+    if not is_dist_avail_and_initialized():
+        return tensor
+    out = [torch.ones_like(tensor) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, tensor, async_op=False)
+    return torch.cat(out, dim=0)
+
+
+class GradReducer:
+    """Bucketed, overlapped all-reduce(avg) of FlatParams.flat_g over the data-parallel group."""
+
+    def __init__(self, flat, bucket_mb: float = 64.0, first_bucket_mb: float = 8.0, process_group=None):
+        self.flat = flat
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if is_dist_avail_and_initialized() else 1
+        self.buckets = self._make_buckets(flat, int(first_bucket_mb * 2 ** 20 // 4), int(bucket_mb * 2 ** 20 // 4))
+        self._bucket_of = {}
+        for bi, (lo, hi, plist) in enumerate(self.buckets):
+            for p in plist:
+                self._bucket_of[id(p)] = bi
+        self._pending = [len(b[2]) for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self.enabled = True
+        self.comm_stream = torch.cuda.Stream() if flat.flat_g.is_cuda else None
+        self.launch_order: List[int] = []
+
+    @staticmethod
+    def _make_buckets(flat, first_elems, cap_elems):
+        buckets, lo, cur, cap = [], 0, [], first_elems
+        ends = flat.seg_end.tolist()
+        for p, end in zip(flat.params, ends):
+            cur.append(p)
+            if end - lo >= cap:
+                buckets.append((lo, end, cur))
+                lo, cur, cap = end, [], cap_elems
+        if cur:
+            buckets.append((lo, flat.total, cur))
+        return buckets
+
+    def begin_backward(self):
+        self._pending = [len(b[2]) for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self.launch_order = []
+
+    def grad_ready(self, p):
+        """Engine hook: the last gradient kernel of ``p`` has been enqueued on the compute stream."""
+        bi = self._bucket_of.get(id(p))
+        if bi is None or not self.enabled:
+            return
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0 and not self._launched[bi]:
+            self._launch(bi)
+
+    def _launch(self, bi):
+        self._launched[bi] = True
+        self.launch_order.append(bi)
+        if self.world == 1:
+            return
+        lo, hi, _ = self.buckets[bi]
+        view = self.flat.flat_g[lo:hi]
+        if self.comm_stream is not None:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group)
+        else:                                     # gloo (CPU tests): no AVG op
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+            view.div_(self.world)
+
+    def finish(self):
+        """Launch whatever is still pending (in bucket order) and make the compute stream wait for the reductions."""
+        if not self.enabled:
+            return
+        for bi in range(len(self.buckets)):
+            if not self._launched[bi]:
+                self._launch(bi)
+        if self.comm_stream is not None and self.world > 1:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+    def reduce_all_now(self):
+        """Non-overlapped variant: all-reduce every bucket after the backward finished."""
+        self.begin_backward()
+        self.finish()
+
+
+class DataParallel(torch.nn.Module):
+    """Stand-in for ``DistributedDataParallel(model)`` (util/misc.py:34): same forward, ``no_sync()`` for gradient
+    accumulation (util/misc.py:144-148), parameters broadcast from rank 0 at construction."""
+
+    def __init__(self, module: torch.nn.Module, flat, bucket_mb: float = 64.0, process_group=None):
+        super().__init__()
+        self.module = module
+        self.reducer = GradReducer(flat, bucket_mb=bucket_mb, process_group=process_group)
+        if self.reducer.world > 1:
+            dist.broadcast(flat.flat_p, src=0, group=process_group)           # C2 in SURVEY.md section 2c
+            for b in module.buffers():
+                dist.broadcast(b, src=0, group=process_group)
+            for p in module.parameters():
+                if not p.requires_grad:
+                    dist.broadcast(p.data, src=0, group=process_group)
+        engine.set_grad_ready_hook(self.reducer.grad_ready)
+
+    def forward(self, *args, **kwargs):
+        self.reducer.begin_backward()
+        return self.module(*args, **kwargs)
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        old = self.reducer.enabled
+        self.reducer.enabled = False
+        try:
+            yield
+        finally:
+            self.reducer.enabled = old

@@ -1,0 +1,123 @@
+"""Flat fp32 parameter / gradient / optimizer-state buffers and the fused AdamW on them.
+
+One contiguous fp32 buffer holds every trainable parameter (``p.data`` become views), a second one
+every gradient (``p.grad`` views: the wgrad GEMMs accumulate straight into it), so that
+  * zero_grad is one memset, the global grad norm one reduction (K11 in SURVEY.md section 2c),
+  * the data-parallel all-reduce runs on contiguous bucket slices with no flatten/unflatten copies,
+  * AdamW (train.py:93: torch.optim.AdamW(betas=(0.9, 0.95))) is ONE kernel (dav_adamw_flat) that also
+    could refresh the bf16 weight mirror.
+Parameters are laid out in REVERSE registration order (decoders first, patch embeds last): that is
+the order in which the hand-written backward finishes their gradients, so leading buckets are
+complete early and their all-reduce overlaps the rest of the backward.
+"""
+from __future__ import annotations
+
+import math
+from typing import Iterable, List, Optional
+
+import torch
+
+from .. import engine, ops
+
+ALIGN = 64   # elements (256 B): keeps every view 16-byte aligned for float4 / DMA access
+
+
+class FlatParams:
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError('no trainable parameters')
+        dev = self.params[0].device
+        if dev.type != 'cuda':
+            raise RuntimeError('FlatParams needs the model on an MI355X (cuda) device')
+        self.offsets, off = [], 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.total = off
+        self.flat_p = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(off, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, self.offsets):
+            v = self.flat_p[o:o + p.numel()].view(p.shape)
+            v.copy_(p.data)
+            p.data = v
+            p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+        self.seg_end = torch.tensor([o + (p.numel() + ALIGN - 1) // ALIGN * ALIGN for p, o in zip(self.params, self.offsets)],
+                                    dtype=torch.int64, device=dev)
+        self._norm_ws = torch.empty(1024, dtype=torch.float32, device=dev)
+        self._norm_out = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    def reattach_grads(self):
+        """Re-point p.grad at the flat buffer (after something set grads to None)."""
+        for p, o in zip(self.params, self.offsets):
+            p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+
+    def grad_norm(self, scale: float = 1.0) -> torch.Tensor:
+        """Global L2 norm of all gradients (util/misc.py:151-163) as a device scalar; no host sync."""
+        ops.l2norm(self.flat_g, self._norm_out, self._norm_ws, scale)
+        return self._norm_out
+
+
+class FlatAdamW(torch.optim.Optimizer):
+    """AdamW with decoupled weight decay on FlatParams; accepts the param groups of train.py:89-93
+    (incl. the extra 'pretrained' / 'lr_scale' keys util/lr_sched.py reads)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.01, model: Optional[torch.nn.Module] = None):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        in_groups = {id(p) for g in self.param_groups for p in g['params']}
+        if model is not None:
+            ordered = [p for p in reversed(list(model.parameters())) if id(p) in in_groups and p.requires_grad]
+        else:
+            ordered = [p for g in self.param_groups for p in g['params'] if p.requires_grad]
+        self.flat = FlatParams(ordered)
+        dev = self.flat.flat_p.device
+        self.exp_avg = torch.zeros_like(self.flat.flat_p)
+        self.exp_avg_sq = torch.zeros_like(self.flat.flat_p)
+        self._group_of = {}
+        for gi, g in enumerate(self.param_groups):
+            for p in g['params']:
+                self._group_of[id(p)] = gi
+        n = len(self.flat.params)
+        self._hyper_host = torch.zeros(n, 2, dtype=torch.float32).pin_memory()
+        self._hyper = torch.zeros(n, 2, dtype=torch.float32, device=dev)
+        self._bc_host = torch.zeros(2, dtype=torch.float32).pin_memory()
+        self._bc = torch.ones(2, dtype=torch.float32, device=dev)
+        self._gidx = torch.tensor([self._group_of[id(p)] for p in self.flat.params], dtype=torch.long)
+        self.step_count = 0
+        for p, o in zip(self.flat.params, self.flat.offsets):    # torch-compatible per-parameter state (views)
+            self.state[p] = dict(step=torch.tensor(0.), exp_avg=self.exp_avg[o:o + p.numel()].view(p.shape),
+                                 exp_avg_sq=self.exp_avg_sq[o:o + p.numel()].view(p.shape))
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.flat.zero_grad()
+
+    def prepare_step(self):
+        """Host side of a step (kept outside hipGraph capture): bump t, upload per-tensor {lr, wd} and bias corrections."""
+        self.step_count += 1
+        lrs = torch.tensor([g['lr'] for g in self.param_groups], dtype=torch.float32)
+        wds = torch.tensor([g['weight_decay'] for g in self.param_groups], dtype=torch.float32)
+        self._hyper_host[:, 0] = lrs[self._gidx]
+        self._hyper_host[:, 1] = wds[self._gidx]
+        b1, b2 = self.defaults['betas']
+        self._bc_host[0] = 1 - b1 ** self.step_count
+        self._bc_host[1] = math.sqrt(1 - b2 ** self.step_count)
+        self._hyper.copy_(self._hyper_host, non_blocking=True)
+        self._bc.copy_(self._bc_host, non_blocking=True)
+        for st in self.state.values():
+            st['step'] += 1
+
+    def launch_step(self, grad_scale: float = 1.0):
+        """Device side of a step: one kernel over all parameters (capturable)."""
+        b1, b2 = self.defaults['betas']
+        f = self.flat
+        ops.adamw_flat(f.flat_p, f.flat_g, self.exp_avg, self.exp_avg_sq, None, f.seg_end, self._hyper, len(f.params),
+                       b1, b2, self.defaults['eps'], self._bc, grad_scale)
+        engine.invalidate_weight_cache(f.params)      # fp32 masters changed behind torch's back
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale: float = 1.0):
+        self.prepare_step()
+        self.launch_step(grad_scale)

@@ -1,0 +1,225 @@
+"""Training-step runtime (reference util/misc.py: Trainer :27-148, get_grad_norm_ :151-163,
+CheckpointManager :222-309) on the MI355X path.
+
+Differences that are deliberate (and documented in DESIGN.md):
+  * bf16 compute with fp32 master weights instead of fp16 autocast + GradScaler: ``autocast()`` is a
+    null context, ``get_scale()`` is 1.0 so ``train_one_epoch`` keeps logging ``amp_scale``;
+  * DistributedDataParallel is replaced by ``util.distributed.DataParallel`` (bucketed RCCL all-reduce
+    on the flat gradient buffer, launched by the hand-written backward);
+  * the per-step global grad norm is ONE reduction over the flat gradient buffer; ``Trainer.step``
+    still returns it as a Python float (host sync) like the reference, ``GraphedStep`` keeps it on device.
+"""
+from __future__ import annotations
+
+import contextlib
+import copy
+import math
+import os
+
+import torch
+
+from .. import engine
+from . import distributed as dist_utils
+from .flat import FlatAdamW
+
+
+def get_grad_norm_(parameters, norm_type: float = 2.0) -> torch.Tensor:
+    """util/misc.py:151-163 (generic per-tensor form; the Trainer uses the flat single-kernel form)."""
+    if isinstance(parameters, torch.Tensor):
+        parameters = [parameters]
+    grads = [p.grad.detach() for p in parameters if p.grad is not None]
+    if not grads:
+        return torch.tensor(0.)
+    if norm_type == math.inf:
+        return max(g.abs().max() for g in grads)
+    return torch.norm(torch.stack([torch.norm(g, norm_type) for g in grads]), norm_type)
+
+
+class Trainer:
+    def __init__(self, model, criterion=None, optimizer=None, accum_iter=1, use_amp=True, distributed=False, bucket_mb=64.0):
+        self.distributed = distributed
+        self.model_without_ddp = model
+        self.n_steps = torch.tensor([0])
+        self.flat = optimizer.flat if isinstance(optimizer, FlatAdamW) else None
+        if self.distributed:
+            if self.flat is None:
+                raise RuntimeError('data-parallel training needs FlatAdamW (flat gradient buffer for the RCCL reducer)')
+            model = dist_utils.DataParallel(model, self.flat, bucket_mb=bucket_mb)
+        self.model = model
+        self.criterion = criterion
+        self.optimizer = optimizer
+        self.scaler = None               # bf16: no loss scaling
+        self.use_amp = use_amp
+        self.accum_iter = accum_iter
+        self.accums = 0
+        self.eval_model = self.model_without_ddp
+        self.zero_grad()
+
+    def module_dict(self):
+        d = {'state_dict': self.model_without_ddp, 'n_steps': self.n_steps}
+        if self.criterion is not None:
+            d['criterion'] = self.criterion
+        if self.optimizer is not None:
+            d['optimizer'] = self.optimizer
+        return d
+
+    def zero_grad(self):
+        if self.flat is not None:
+            self.flat.zero_grad()
+        elif self.optimizer is not None:
+            self.optimizer.zero_grad(set_to_none=False)
+        self.accums = 0
+
+    def get_scale(self):
+        return 1.
+
+    def grad_norm_tensor(self) -> torch.Tensor:
+        if self.flat is not None:
+            return self.flat.grad_norm(1.0 / max(self.accums, 1))
+        return get_grad_norm_(self.model_without_ddp.parameters()) / max(self.accums, 1)
+
+    def backward(self, loss, create_graph=False):
+        loss.backward(create_graph=create_graph)
+        self.accums += 1
+        if self.distributed and self.model.reducer.enabled:
+            self.model.reducer.finish()
+        return self.grad_norm_tensor().item(), self.get_scale()
+
+    def step(self, loss, create_graph=False, clip_grad=None, skip_grad=None):
+        """util/misc.py:96-136 (skip_grad's backup/restore path is not on the pre-training path)."""
+        if skip_grad is not None:
+            raise NotImplementedError('skip_grad is never enabled by train.py')
+        norm, scale = self.backward(loss, create_graph=create_graph)
+        if self.accums == self.accum_iter:
+            gscale = 1.0 / self.accum_iter if self.accum_iter > 1 else 1.0
+            if clip_grad is not None:
+                total = norm * self.accums * gscale
+                gscale *= min(1.0, clip_grad / (total + 1e-6))
+            if isinstance(self.optimizer, FlatAdamW):
+                self.optimizer.step(grad_scale=gscale)
+            else:
+                if gscale != 1.0:
+                    for g in self.optimizer.param_groups:
+                        for p in g['params']:
+                            if p.grad is not None:
+                                p.grad.mul_(gscale)
+                self.optimizer.step()
+                engine.invalidate_weight_cache(self.model_without_ddp.parameters())
+            self.zero_grad()
+            self.n_steps += 1
+        return norm, scale
+
+    def autocast(self):
+        return contextlib.nullcontext()
+
+    def autosync(self):
+        if self.distributed and self.accums < self.accum_iter - 1:
+            return self.model.no_sync()
+        return contextlib.nullcontext()
+
+
+class GraphedStep:
+    """One pre-training step (bf16 weight refresh -> forward -> backward -> grad norm -> AdamW) captured as a
+    single hipGraph and replayed per iteration: ~2000 small kernel launches become one graph launch.
+    With world_size > 1 the graph ends after the backward; the bucketed RCCL all-reduce, the norm and AdamW
+    are enqueued eagerly behind it."""
+
+    def __init__(self, trainer: Trainer, image_shape, audio_shape, warmup: int = 2):
+        assert trainer.accum_iter == 1 and isinstance(trainer.optimizer, FlatAdamW)
+        self.tr = trainer
+        self.model = trainer.model_without_ddp
+        self.opt = trainer.optimizer
+        dev = self.opt.flat.flat_p.device
+        self.image = torch.zeros(image_shape, device=dev)
+        self.audio = torch.zeros(audio_shape, device=dev)
+        self.world = dist_utils.get_world_size()
+        self.reducer = trainer.model.reducer if trainer.distributed else None
+        saved_hook = engine._GRAD_READY
+        engine.set_grad_ready_hook(None)          # collectives stay outside the graph
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._fwd_bwd()
+                self.opt.flat.zero_grad()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.opt.flat.zero_grad()
+            engine.refresh_weight_cache(self.model)
+            self.loss_image, self.loss_audio = self._fwd_bwd()
+            if self.world == 1:
+                self.grad_norm = self.opt.flat.grad_norm().clone()
+                self.opt.launch_step()
+        engine.set_grad_ready_hook(saved_hook)
+        self.opt.flat.zero_grad()
+
+    def _fwd_bwd(self):
+        li, la = self.model(self.image, self.audio)[:2]
+        (li + la).backward()
+        return li.detach(), la.detach()
+
+    def __call__(self, image, audio):
+        self.image.copy_(image, non_blocking=True)
+        self.audio.copy_(audio, non_blocking=True)
+        self.opt.prepare_step()
+        self.graph.replay()
+        if self.world > 1:
+            self.reducer.reduce_all_now()
+            self.grad_norm = self.opt.flat.grad_norm()
+            self.opt.launch_step()
+        self.tr.n_steps += 1
+        return self.loss_image, self.loss_audio, self.grad_norm
+
+
+class CheckpointManager:
+    """util/misc.py:222-309: rank-0 ``checkpoint_latest.pth`` (+ numbered every save_freq) holding
+    {'state_dict', 'optimizer', 'n_steps', 'epoch'}; ``resume()`` restores them and returns the start epoch."""
+
+    def __init__(self, modules, ckpt_dir, epochs, save_freq=None):
+        self.modules, self.ckpt_dir, self.epochs, self.save_freq = modules, ckpt_dir, epochs, save_freq
+        self.world_size, self.rank = dist_utils.get_world_size(), dist_utils.get_rank()
+        if self.rank == 0:
+            os.makedirs(ckpt_dir, exist_ok=True)
+
+    def _state(self):
+        out = {}
+        for k, m in self.modules.items():
+            if isinstance(m, torch.Tensor):
+                out[k] = m.clone().cpu()
+            elif isinstance(m, FlatAdamW):
+                out[k] = dict(step_count=m.step_count, exp_avg=m.exp_avg.cpu(), exp_avg_sq=m.exp_avg_sq.cpu(),
+                              param_groups=[{kk: vv for kk, vv in g.items() if kk != 'params'} for g in m.param_groups])
+            else:
+                out[k] = copy.deepcopy({kk: (vv.cpu() if isinstance(vv, torch.Tensor) else vv) for kk, vv in m.state_dict().items()})
+        return out
+
+    def checkpoint(self, epoch, save_dict=None):
+        if self.rank != 0:
+            return
+        state = self._state()
+        state.update(save_dict or {})
+        path = os.path.join(self.ckpt_dir, 'checkpoint_latest.pth')
+        torch.save(state, path)
+        if self.save_freq and (epoch % self.save_freq == 0 or epoch == self.epochs):
+            torch.save(state, os.path.join(self.ckpt_dir, f'checkpoint_{epoch:04d}.pth'))
+
+    def resume(self):
+        path = os.path.join(self.ckpt_dir, 'checkpoint_latest.pth')
+        if not os.path.isfile(path):
+            return (0,)
+        ckpt = torch.load(path, map_location='cpu')
+        for k, m in self.modules.items():
+            if k not in ckpt:
+                continue
+            if isinstance(m, torch.Tensor):
+                m.copy_(ckpt[k])
+            elif isinstance(m, FlatAdamW):
+                m.step_count = ckpt[k]['step_count']
+                m.exp_avg.copy_(ckpt[k]['exp_avg'])
+                m.exp_avg_sq.copy_(ckpt[k]['exp_avg_sq'])
+            else:
+                m.load_state_dict(ckpt[k])
+        engine.invalidate_weight_cache(self.modules['state_dict'].parameters())
+        return (ckpt.get('epoch', 0),)
