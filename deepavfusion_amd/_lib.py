@@ -9,6 +9,9 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  (must be imported first: the library has to bind to the HIP runtime torch ships,
+#                      a second libamdhip64 in the process sees no device)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdavfusion_hip.so')
 
@@ -17,6 +20,7 @@ _p, _i, _l, _f, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 # name -> argtypes (must match include/dav_kernels.h)
 SIGNATURES = {
     'dav_abi_version': [],
+    'dav_last_error_string': [],
     'dav_gemm_nt_bf16': [_p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _f, _i, _p],
     'dav_gemm_tn_bf16': [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _i, _p],
     'dav_attn_fwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _i, _l, _i, _l, _i, _l, _i, _f, _p],
@@ -59,7 +63,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)           # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
-        fn.restype = _sz if name.endswith('workspace_bytes') else _i
+        fn.restype = _sz if name.endswith('workspace_bytes') else (C.c_char_p if name == 'dav_last_error_string' else _i)
     if lib.dav_abi_version() != 1:
         raise RuntimeError('libdavfusion_hip.so ABI version mismatch')
     _lib = lib
@@ -68,4 +72,7 @@ def load():
 
 def check(code: int, what: str):
     if code != 0:
-        raise RuntimeError(f'{what} failed: {ERRORS.get(code, code)}')
+        detail = ''
+        if code == -4 and _lib is not None:
+            detail = f" ({_lib.dav_last_error_string().decode()})"
+        raise RuntimeError(f'{what} failed: {ERRORS.get(code, code)}{detail}')

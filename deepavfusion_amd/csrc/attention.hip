@@ -381,7 +381,7 @@ int launch_fwd(const AttnParams& p, hipStream_t stream) {
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     big_lds = true;
   }
-  hipLaunchKernelGGL(kern, dim3(p.B * p.H), dim3(nw * 64), lds, stream, p);
+  DAV_LAUNCH(kern, dim3(p.B * p.H), dim3(nw * 64), lds, stream, p);
   return dav_launch_status();
 }
 
@@ -404,8 +404,8 @@ int launch_bwd(const AttnParams& p, hipStream_t stream) {
     HIP_CHECK_RET(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     big2 = true;
   }
-  hipLaunchKernelGGL(k1, dim3(p.B * p.H), dim3(nw1 * 64), lds1, stream, p);
-  hipLaunchKernelGGL(k2, dim3(p.B * p.H), dim3(nw2 * 64), lds2, stream, p);
+  DAV_LAUNCH(k1, dim3(p.B * p.H), dim3(nw1 * 64), lds1, stream, p);
+  DAV_LAUNCH(k2, dim3(p.B * p.H), dim3(nw2 * 64), lds2, stream, p);
   return dav_launch_status();
 }
 

@@ -61,4 +61,20 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     if (_e != hipSuccess) return DAV_ERR_HIP;  \
   } while (0)
 
-static inline int dav_launch_status() { return hipGetLastError() == hipSuccess ? DAV_OK : DAV_ERR_HIP; }
+// Launch bookkeeping: hipGetLastError() is sticky process-wide state that other HIP users in the process
+// (e.g. torch's event queries -> hipErrorNotReady) also write, so clear it right before each launch and
+// latch only errors produced by OUR launches.
+inline thread_local int dav_launch_failed = 0;
+inline thread_local int dav_last_hip_error = 0;
+#define DAV_LAUNCH(...)                                        \
+  do {                                                         \
+    (void)hipGetLastError();                                   \
+    hipLaunchKernelGGL(__VA_ARGS__);                           \
+    const hipError_t _le = hipGetLastError();                  \
+    if (_le != hipSuccess) { dav_launch_failed = 1; dav_last_hip_error = (int)_le; } \
+  } while (0)
+static inline int dav_launch_status() {
+  const int f = dav_launch_failed;
+  dav_launch_failed = 0;
+  return f ? DAV_ERR_HIP : DAV_OK;
+}

@@ -206,6 +206,196 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// NT kernel, second generation: STAGES-deep LDS ring filled by global->LDS DMA that stays in flight
+// across k-steps (counted s_waitcnt vmcnt + raw s_barrier, one barrier per k-step), WM_ x WN_ waves,
+// and an epilogue staged through LDS so that every global access of C / residual / C2 is a full
+// 16-byte-per-lane row segment.  Requires K % 64 == 0 and N % 4 == 0.
+// ------------------------------------------------------------------------------------------------
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int WM_, int WN_, int STAGES>
+__global__ __launch_bounds__(WM_* WN_ * 64) void gemm_nt2_kernel(NTParams p) {
+  constexpr int NT = WM_ * WN_ * 64;
+  constexpr int WTM = BM / WM_, WTN = BN / WN_, FM = WTM / 16, FN = WTN / 16;
+  constexpr int A_CH = BM * 8 / NT, B_CH = BN * 8 / NT, LPT = A_CH + B_CH;
+  constexpr int A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128;
+  static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/threads mismatch");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN_, wn = wave % WN_;
+  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+  int bid = blockIdx.x;
+  {
+    const int nwg = tiles_m * tiles_n;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  // Each XCD owns a contiguous range of virtual tile ids.  Tiles are ordered panel by panel (a panel = up to
+  // ~8 tile columns), row-major inside a panel, so an XCD's ~T/8 tiles form a compact rows x panel-width
+  // block whose A rows and B columns (a few MB) stay resident in that XCD's 4 MB L2.
+  int bm, bn;
+  {
+    const int npan = (tiles_n + 7) >> 3;
+    const int wn = (tiles_n + npan - 1) / npan;
+    const int per = tiles_m * wn;
+    const int pnl = bid / per, rem = bid - pnl * per;
+    const int wp = (tiles_n - pnl * wn) < wn ? (tiles_n - pnl * wn) : wn;
+    bm = rem / wp;
+    bn = pnl * wn + rem % wp;
+  }
+  const int m0 = bm * BM, n0 = bn * BN;
+
+  const bf16_t* a_src[A_CH];
+  const bf16_t* b_src[B_CH];
+#pragma unroll
+  for (int i = 0; i < A_CH; ++i) {
+    const int c = tid + NT * i, row = c >> 3, ls = (c & 7) ^ ((row >> 1) & 7);
+    int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;
+    a_src[i] = p.A + map_row(gm, p.amap) * p.lda + ls * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < B_CH; ++i) {
+    const int c = tid + NT * i, row = c >> 3, ls = (c & 7) ^ ((row >> 1) & 7);
+    int gn = n0 + row; gn = gn < p.N ? gn : p.N - 1;
+    b_src[i] = p.B + (long)gn * p.ldb + ls * 8;
+  }
+  auto dma_tile = [&](int kt) {
+    const int k0 = kt << 6;
+    char* st = smem + (kt % STAGES) * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(void, a_src[i] + k0), LDS_PTR(void, st + (wave * 64 + NT * i) * 16), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(void, b_src[i] + k0), LDS_PTR(void, st + A_BYTES + (wave * 64 + NT * i) * 16), 16, 0, 0);
+  };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K >> 6;
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) dma_tile(s);
+
+  const int fr = lane & 15, fg = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt must have landed; up to STAGES-2 younger tiles may stay in flight
+    const int younger = nk - 1 - kt;
+    if (STAGES >= 3 && younger >= STAGES - 2) wait_vmcnt<(STAGES - 2) * LPT>();
+    else if (STAGES >= 4 && younger == 1) wait_vmcnt<LPT>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();          // everyone's pieces of tile kt are in LDS; stage (kt-1)%STAGES is free
+    if (kt + STAGES - 1 < nk) dma_tile(kt + STAGES - 1);
+    const char* Ab = smem + (kt % STAGES) * STAGE_BYTES;
+    const char* Bb = Ab + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[FM], bfr[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int row = wm * WTM + i * 16 + fr;
+        af[i] = *reinterpret_cast<const bf16x8*>(Ab + row * 128 + (((kk * 4 + fg) ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int row = wn * WTN + j * 16 + fr;
+        bfr[j] = *reinterpret_cast<const bf16x8*>(Bb + row * 128 + (((kk * 4 + fg) ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: registers -> (alpha, bias, activation) -> this wave's LDS patch -> coalesced rows ----
+  __syncthreads();                          // all waves finished reading the last stage
+  constexpr int LDW = WTN + 4;              // floats per patch row (+4: 2-way ds_write conflicts only)
+  float* patch = reinterpret_cast<float*>(smem) + wave * (WTM * LDW);
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int n = n0 + wn * WTN + j * 16 + fr;
+      const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) patch[(i * 16 + fg * 4 + r) * LDW + j * 16 + fr] = acc[i][j][r] * p.alpha + bv;
+    }
+  constexpr int CPR = WTN / 4;              // float4 chunks per patch row
+  constexpr int RPI = 64 / CPR;             // rows per wave-instruction
+  const int cc = lane % CPR, rr = lane / CPR;
+  const int n = n0 + wn * WTN + cc * 4;
+  if (n < p.N) {
+#pragma unroll 4
+    for (int it = 0; it < WTM / RPI; ++it) {
+      const int lr = it * RPI + rr;
+      const int m = m0 + wm * WTM + lr;
+      if (m >= p.M) continue;
+      float4 v = *reinterpret_cast<const float4*>(patch + lr * LDW + cc * 4);
+      if (p.c2_mode == 1) {
+        uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
+        *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
+      }
+      if (p.act == 1) {
+        v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w);
+      } else if (p.act == 2) {
+        const uint2 a = *reinterpret_cast<const uint2*>(p.aux + (long)m * p.ldaux + n);
+        v.x *= gelu_grad_f(__uint_as_float(a.x << 16)); v.y *= gelu_grad_f(__uint_as_float(a.x & 0xffff0000u));
+        v.z *= gelu_grad_f(__uint_as_float(a.y << 16)); v.w *= gelu_grad_f(__uint_as_float(a.y & 0xffff0000u));
+      }
+      if (p.c2_mode == 2) {
+        uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
+        *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
+      }
+      if (p.res) {
+        const long rrow = p.res_rows ? (long)p.res_rows[m] : map_row(m, p.rmap);
+        const float4 t = *reinterpret_cast<const float4*>(p.res + rrow * p.ldres + n);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+      if (p.C) {
+        const long crow = map_row(m, p.cmap);
+        if (p.c_bf16) {
+          uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
+          *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + crow * p.ldc + n) = w;
+        } else {
+          float4* c = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + crow * p.ldc + n);
+          if (p.beta) { const float4 o = *c; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+          *c = v;
+        }
+      }
+      if (p.c2_mode == 3) {
+        uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
+        *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM_, int WN_, int STAGES>
+void launch_nt2(const NTParams& p, hipStream_t stream) {
+  constexpr int NT = WM_ * WN_ * 64;
+  constexpr size_t ring = (size_t)STAGES * (BM + BN) * 128;
+  constexpr size_t epi = (size_t)WM_ * WN_ * (BM / WM_) * (BN / WN_ + 4) * 4;
+  constexpr size_t lds = ring > epi ? ring : epi;
+  auto kern = gemm_nt2_kernel<BM, BN, WM_, WN_, STAGES>;
+  static bool big = false;
+  if (lds > 64 * 1024 && !big) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    big = true;
+  }
+  const int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  DAV_LAUNCH(kern, dim3(grid), dim3(NT), lds, stream, p);
+}
+
+// ------------------------------------------------------------------------------------------------
 // TN kernel (weight gradient).  LDS tiles are [64 contraction rows][128 cols] bf16 (256 B rows);
 // MFMA fragments want 8 consecutive contraction rows per lane -> ds_read_b64_tr_b16 (hardware
 // 4x4 transpose), two per fragment.  32-byte granules of a row are XOR-swizzled by
@@ -362,6 +552,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TNParams p) {
 
 RowMap mk(const int* m) { return m ? RowMap{m[0], m[1], m[2]} : RowMap{0, 0, 0}; }
 
+// tile configuration heuristic for the second-generation NT kernel (see launch_nt2 cases)
+int nt_auto_config(int M, int N, int K) {
+  // measured on MI355X over the ViT-B step's shapes (tools/gemm_bench.py): occupancy beats pipeline depth,
+  // so 2-stage rings everywhere; 8 waves on 128x128 when there are enough tiles to fill 2 blocks per CU.
+  (void)K;
+  const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+  if (N <= 64 || t128 < 200) return 5;        // 64x64, 4 waves
+  if (t128 < 400) return 8;                   // 128x64, 4 waves
+  return 3;                                   // 128x128, 8 waves (2 x 4)
+}
+
 }  // namespace
 
 extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int K, int lda, int ldb,
@@ -381,6 +582,29 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
   p.C = C; p.ldc = ldc; p.c_bf16 = c_is_bf16; p.cmap = mk(c_rowmap); p.C2 = (bf16_t*)C2; p.ldc2 = ldc2; p.c2_mode = C2 ? c2_mode : 0;
   p.beta = beta; p.alpha = alpha;
   const bool glds_ok = (K & 63) == 0;
+  const bool vec_ok = glds_ok && (N & 3) == 0 && (ldc & 3) == 0 && (!res || (ldres & 3) == 0) && (!C2 || (ldc2 & 3) == 0) &&
+                      (!aux || (ldaux & 3) == 0) && !(((uintptr_t)C | (uintptr_t)C2 | (uintptr_t)res) & 15) && !((uintptr_t)aux & 7);
+  int cfg = variant >> 4;
+  if (vec_ok && !(variant & 15)) {
+    if (cfg == 0) cfg = nt_auto_config(M, N, K);
+    switch (cfg) {
+      case 1: launch_nt2<128, 128, 2, 2, 2>(p, stream); return dav_launch_status();
+      case 2: launch_nt2<128, 128, 2, 2, 3>(p, stream); return dav_launch_status();
+      case 3: launch_nt2<128, 128, 2, 4, 2>(p, stream); return dav_launch_status();
+      case 4: launch_nt2<128, 128, 2, 4, 3>(p, stream); return dav_launch_status();
+      case 5: launch_nt2<64, 64, 2, 2, 2>(p, stream); return dav_launch_status();
+      case 6: launch_nt2<64, 64, 2, 2, 3>(p, stream); return dav_launch_status();
+      case 7: launch_nt2<64, 64, 2, 2, 4>(p, stream); return dav_launch_status();
+      case 8: launch_nt2<128, 64, 2, 2, 2>(p, stream); return dav_launch_status();
+      case 9: launch_nt2<128, 64, 2, 2, 3>(p, stream); return dav_launch_status();
+      case 10: launch_nt2<128, 64, 4, 1, 3>(p, stream); return dav_launch_status();
+      case 11: launch_nt2<64, 128, 2, 2, 3>(p, stream); return dav_launch_status();
+      case 12: launch_nt2<128, 128, 2, 2, 4>(p, stream); return dav_launch_status();
+      case 13: launch_nt2<256, 128, 4, 2, 2>(p, stream); return dav_launch_status();
+      case 14: launch_nt2<256, 128, 4, 2, 3>(p, stream); return dav_launch_status();
+      default: break;
+    }
+  }
   const bool use_glds = glds_ok && !(variant & 1);
   // narrow-N problems (and anything that would leave most CUs idle) use 64-wide tiles
   const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
@@ -388,13 +612,13 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
   if (small) {
     const int grid = ((M + 63) / 64) * ((N + 63) / 64);
     const size_t lds = 2 * 64 * 128 * 2;
-    if (use_glds) hipLaunchKernelGGL((gemm_nt_kernel<64, 64, true>), dim3(grid), dim3(256), lds, stream, p);
-    else hipLaunchKernelGGL((gemm_nt_kernel<64, 64, false>), dim3(grid), dim3(256), lds, stream, p);
+    if (use_glds) DAV_LAUNCH((gemm_nt_kernel<64, 64, true>), dim3(grid), dim3(256), lds, stream, p);
+    else DAV_LAUNCH((gemm_nt_kernel<64, 64, false>), dim3(grid), dim3(256), lds, stream, p);
   } else {
     const int grid = (int)tiles128;
     const size_t lds = 2 * 128 * 128 * 2;
-    if (use_glds) hipLaunchKernelGGL((gemm_nt_kernel<128, 128, true>), dim3(grid), dim3(256), lds, stream, p);
-    else hipLaunchKernelGGL((gemm_nt_kernel<128, 128, false>), dim3(grid), dim3(256), lds, stream, p);
+    if (use_glds) DAV_LAUNCH((gemm_nt_kernel<128, 128, true>), dim3(grid), dim3(256), lds, stream, p);
+    else DAV_LAUNCH((gemm_nt_kernel<128, 128, false>), dim3(grid), dim3(256), lds, stream, p);
   }
   return dav_launch_status();
 }
@@ -418,7 +642,7 @@ extern "C" int dav_gemm_tn_bf16(const void* A, const void* B, int Mc, int N, int
   }
   p.splits = splits;
   const size_t lds = 4 * 64 * 256;
-  if (variant & 1) hipLaunchKernelGGL((gemm_tn_kernel<false>), dim3(tiles, splits), dim3(256), lds, stream, p);
-  else hipLaunchKernelGGL((gemm_tn_kernel<true>), dim3(tiles, splits), dim3(256), lds, stream, p);
+  if (variant & 1) DAV_LAUNCH((gemm_tn_kernel<false>), dim3(tiles, splits), dim3(256), lds, stream, p);
+  else DAV_LAUNCH((gemm_tn_kernel<true>), dim3(tiles, splits), dim3(256), lds, stream, p);
   return dav_launch_status();
 }

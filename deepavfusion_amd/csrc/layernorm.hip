@@ -196,7 +196,7 @@ extern "C" int dav_layernorm_fwd(const float* x0, long x0_bs, int r0, const floa
   LNFwd p;
   p.s0 = LNSeg{x0, x0_bs, r0}; p.s1 = LNSeg{x1, x1_bs, r1}; p.B = B; p.D = D; p.gamma = gamma; p.beta = beta;
   p.eps = eps; p.y = (bf16_t*)y_bf16; p.y32 = y_f32; p.mean = mean; p.rstd = rstd;
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3(ln_grid(B * (r0 + r1))), dim3(256), 0, stream, p);
+  DAV_LAUNCH(ln_fwd_kernel, dim3(ln_grid(B * (r0 + r1))), dim3(256), 0, stream, p);
   return dav_launch_status();
 }
 
@@ -216,6 +216,6 @@ extern "C" int dav_layernorm_bwd(const float* x0, long x0_bs, int r0, const floa
   p.dgamma = dgamma; p.dbeta = dbeta;
   int grid = ln_grid(B * (r0 + r1));
   if (grid > 256) grid = 256;   // fewer, longer-lived workgroups: one dgamma/dbeta atomic set each
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), (size_t)8 * D * sizeof(float), stream, p);
+  DAV_LAUNCH(ln_bwd_kernel, dim3(grid), dim3(256), (size_t)8 * D * sizeof(float), stream, p);
   return dav_launch_status();
 }

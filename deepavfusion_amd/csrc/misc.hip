@@ -356,7 +356,7 @@ extern "C" int dav_mask_build(const float* noise, int N, int L, int len_keep, in
   int P = 1;
   while (P < L) P <<= 1;
   int nt = P / 2 < 64 ? 64 : (P / 2 > 1024 ? 1024 : P / 2);
-  hipLaunchKernelGGL(mask_build_kernel, dim3(N), dim3(nt), (size_t)P * 8, stream, noise, L, P, len_keep, ids_keep,
+  DAV_LAUNCH(mask_build_kernel, dim3(N), dim3(nt), (size_t)P * 8, stream, noise, L, P, len_keep, ids_keep,
                      ids_restore, mask, ids_keep32, ids_restore32);
   return dav_launch_status();
 }
@@ -364,7 +364,7 @@ extern "C" int dav_mask_build(const float* noise, int N, int L, int len_keep, in
 extern "C" int dav_patch_gather(const float* img, int B, int C, int H, int W, const int* ids_keep32, int nk, void* A,
                                 hipStream_t stream) {
   if (B <= 0 || C <= 0 || (H & 15) || (W & 15) || nk <= 0) return DAV_ERR_SHAPE;
-  hipLaunchKernelGGL(patch_gather_kernel, dim3(wave_grid((long)B * nk)), dim3(256), 0, stream, img, B, C, H, W, ids_keep32,
+  DAV_LAUNCH(patch_gather_kernel, dim3(wave_grid((long)B * nk)), dim3(256), 0, stream, img, B, C, H, W, ids_keep32,
                      nk, (bf16_t*)A);
   return dav_launch_status();
 }
@@ -372,7 +372,7 @@ extern "C" int dav_patch_gather(const float* img, int B, int C, int H, int W, co
 extern "C" int dav_unshuffle_fwd(const float* emb, const float* mask_token, const float* pos, const int* ids_restore32, int B,
                                  int L, int nk, int D, float* out, long out_bs, int out_row_off, hipStream_t stream) {
   if (B <= 0 || L <= 0 || (D & 3)) return DAV_ERR_SHAPE;
-  hipLaunchKernelGGL(unshuffle_fwd_kernel, dim3(wave_grid((long)B * L)), dim3(256), 0, stream, emb, mask_token, pos,
+  DAV_LAUNCH(unshuffle_fwd_kernel, dim3(wave_grid((long)B * L)), dim3(256), 0, stream, emb, mask_token, pos,
                      ids_restore32, B, L, nk, D, out, out_bs, out_row_off);
   return dav_launch_status();
 }
@@ -380,7 +380,7 @@ extern "C" int dav_unshuffle_fwd(const float* emb, const float* mask_token, cons
 extern "C" int dav_rows_gather_cast(const float* x, long x_bs, int row_off, const int* ids32, int B, int n, int D, void* out,
                                     hipStream_t stream) {
   if (B <= 0 || n <= 0 || (D & 3)) return DAV_ERR_SHAPE;
-  hipLaunchKernelGGL(rows_gather_cast_kernel, dim3(wave_grid((long)B * n)), dim3(256), 0, stream, x, x_bs, row_off, ids32, B, n,
+  DAV_LAUNCH(rows_gather_cast_kernel, dim3(wave_grid((long)B * n)), dim3(256), 0, stream, x, x_bs, row_off, ids32, B, n,
                      D, (bf16_t*)out);
   return dav_launch_status();
 }
@@ -388,7 +388,7 @@ extern "C" int dav_rows_gather_cast(const float* x, long x_bs, int row_off, cons
 extern "C" int dav_unshuffle_bwd_reduce(const float* dx, long dx_bs, int row_off, const int* ids_restore32, int B, int L, int nk,
                                         int D, float* dpos, float* dmask_token, hipStream_t stream) {
   if (B <= 0 || L <= 0 || D <= 0) return DAV_ERR_SHAPE;
-  hipLaunchKernelGGL(unshuffle_bwd_reduce_kernel, dim3(L), dim3(256), 0, stream, dx, dx_bs, row_off, ids_restore32, B, L, nk, D,
+  DAV_LAUNCH(unshuffle_bwd_reduce_kernel, dim3(L), dim3(256), 0, stream, dx, dx_bs, row_off, ids_restore32, B, L, nk, D,
                      dpos, dmask_token);
   return dav_launch_status();
 }
@@ -398,9 +398,9 @@ extern "C" int dav_patch_mse_fwd(const float* img, const float* pred, const floa
                                  hipStream_t stream) {
   if (B <= 0 || (H & 15) || (W & 15) || (C != 1 && C != 3)) return DAV_ERR_SHAPE;
   const long rows = (long)B * (H >> 4) * (W >> 4);
-  if (C == 3) hipLaunchKernelGGL(patch_mse_fwd_kernel<3>, dim3(wave_grid(rows)), dim3(256), 0, stream, img, pred, B, H, W, norm_pix, loss_patch, tmean, trstd);
-  else hipLaunchKernelGGL(patch_mse_fwd_kernel<1>, dim3(wave_grid(rows)), dim3(256), 0, stream, img, pred, B, H, W, norm_pix, loss_patch, tmean, trstd);
-  hipLaunchKernelGGL(masked_mean_kernel, dim3(1), dim3(1024), 0, stream, loss_patch, mask, (int)rows, loss, mask_sum);
+  if (C == 3) DAV_LAUNCH(patch_mse_fwd_kernel<3>, dim3(wave_grid(rows)), dim3(256), 0, stream, img, pred, B, H, W, norm_pix, loss_patch, tmean, trstd);
+  else DAV_LAUNCH(patch_mse_fwd_kernel<1>, dim3(wave_grid(rows)), dim3(256), 0, stream, img, pred, B, H, W, norm_pix, loss_patch, tmean, trstd);
+  DAV_LAUNCH(masked_mean_kernel, dim3(1), dim3(1024), 0, stream, loss_patch, mask, (int)rows, loss, mask_sum);
   return dav_launch_status();
 }
 
@@ -409,8 +409,8 @@ extern "C" int dav_patch_mse_bwd(const float* img, const float* pred, const floa
                                  hipStream_t stream) {
   if (B <= 0 || (H & 15) || (W & 15) || (C != 1 && C != 3)) return DAV_ERR_SHAPE;
   const long rows = (long)B * (H >> 4) * (W >> 4);
-  if (C == 3) hipLaunchKernelGGL(patch_mse_bwd_kernel<3>, dim3(wave_grid(rows)), dim3(256), 0, stream, img, pred, mask, tmean, trstd, mask_sum, gout, B, H, W, (bf16_t*)dpred_bf16);
-  else hipLaunchKernelGGL(patch_mse_bwd_kernel<1>, dim3(wave_grid(rows)), dim3(256), 0, stream, img, pred, mask, tmean, trstd, mask_sum, gout, B, H, W, (bf16_t*)dpred_bf16);
+  if (C == 3) DAV_LAUNCH(patch_mse_bwd_kernel<3>, dim3(wave_grid(rows)), dim3(256), 0, stream, img, pred, mask, tmean, trstd, mask_sum, gout, B, H, W, (bf16_t*)dpred_bf16);
+  else DAV_LAUNCH(patch_mse_bwd_kernel<1>, dim3(wave_grid(rows)), dim3(256), 0, stream, img, pred, mask, tmean, trstd, mask_sum, gout, B, H, W, (bf16_t*)dpred_bf16);
   return dav_launch_status();
 }
 
@@ -418,7 +418,7 @@ extern "C" int dav_pair_expand(const float* Pv, const float* Pa, int B, int nv, 
   if (B <= 0 || nv <= 0 || na <= 0 || (Wd & 3)) return DAV_ERR_SHAPE;
   const long total = (long)B * nv * na * (Wd >> 2);
   long g = (total + 255) / 256; g = g > 4096 ? 4096 : g;
-  hipLaunchKernelGGL(pair_expand_kernel, dim3((int)g), dim3(256), 0, stream, Pv, Pa, B, nv, na, Wd, (bf16_t*)out_bf16);
+  DAV_LAUNCH(pair_expand_kernel, dim3((int)g), dim3(256), 0, stream, Pv, Pa, B, nv, na, Wd, (bf16_t*)out_bf16);
   return dav_launch_status();
 }
 
@@ -426,7 +426,7 @@ extern "C" int dav_pair_reduce(const void* d_bf16, int B, int nv, int na, int Wd
   if (B <= 0 || nv <= 0 || na <= 0 || Wd <= 0) return DAV_ERR_SHAPE;
   const long total = (long)B * (nv + na) * Wd;
   long g = (total + 255) / 256; g = g > 4096 ? 4096 : g;
-  hipLaunchKernelGGL(pair_reduce_kernel, dim3((int)g), dim3(256), 0, stream, (const bf16_t*)d_bf16, B, nv, na, Wd, (bf16_t*)dPv_bf16, (bf16_t*)dPa_bf16);
+  DAV_LAUNCH(pair_reduce_kernel, dim3((int)g), dim3(256), 0, stream, (const bf16_t*)d_bf16, B, nv, na, Wd, (bf16_t*)dPv_bf16, (bf16_t*)dPa_bf16);
   return dav_launch_status();
 }
 
@@ -435,15 +435,15 @@ extern "C" int dav_cast_bf16(const float* x, void* y_bf16, long n, hipStream_t s
   const long n4 = n >> 2;
   if (n4 > 0) {
     long g = (n4 + 255) / 256; g = g > 8192 ? 8192 : g;
-    hipLaunchKernelGGL(cast_bf16_kernel, dim3((int)g), dim3(256), 0, stream, x, (bf16_t*)y_bf16, n4);
+    DAV_LAUNCH(cast_bf16_kernel, dim3((int)g), dim3(256), 0, stream, x, (bf16_t*)y_bf16, n4);
   }
-  if (n & 3) hipLaunchKernelGGL(cast_bf16_tail_kernel, dim3(1), dim3(64), 0, stream, x, (bf16_t*)y_bf16, n4 << 2, n);
+  if (n & 3) DAV_LAUNCH(cast_bf16_tail_kernel, dim3(1), dim3(64), 0, stream, x, (bf16_t*)y_bf16, n4 << 2, n);
   return dav_launch_status();
 }
 
 extern "C" int dav_cast_transpose_bf16(const float* x, void* y_bf16, int R, int C, hipStream_t stream) {
   if (R <= 0 || C <= 0) return DAV_ERR_SHAPE;
-  hipLaunchKernelGGL(cast_transpose_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, stream, x, (bf16_t*)y_bf16, R, C);
+  DAV_LAUNCH(cast_transpose_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, stream, x, (bf16_t*)y_bf16, R, C);
   return dav_launch_status();
 }
 
@@ -454,8 +454,8 @@ extern "C" int dav_l2norm(const float* x, long n, float scale, float* out, void*
   if (n <= 0) return DAV_ERR_SHAPE;
   if (workspace_bytes < 1024 * sizeof(float)) return DAV_ERR_WORKSPACE;
   long g = ((n >> 2) + 255) / 256; g = g > 1024 ? 1024 : (g < 1 ? 1 : g);
-  hipLaunchKernelGGL(sumsq_partial_kernel, dim3((int)g), dim3(256), 0, stream, x, n, (float*)workspace);
-  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(1024), 0, stream, (const float*)workspace, (int)g, scale, out);
+  DAV_LAUNCH(sumsq_partial_kernel, dim3((int)g), dim3(256), 0, stream, x, n, (float*)workspace);
+  DAV_LAUNCH(sumsq_final_kernel, dim3(1), dim3(1024), 0, stream, (const float*)workspace, (int)g, scale, out);
   return dav_launch_status();
 }
 
@@ -464,7 +464,7 @@ extern "C" int dav_adamw_flat(float* p, const float* g, float* m, float* v, void
                               float grad_scale, hipStream_t stream) {
   if (n <= 0 || nseg <= 0) return DAV_ERR_SHAPE;
   long g2 = (n + 4095) / 4096; g2 = g2 > 16384 ? 16384 : g2;
-  hipLaunchKernelGGL(adamw_flat_kernel, dim3((int)g2), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, n, seg_end, hyper, nseg,
+  DAV_LAUNCH(adamw_flat_kernel, dim3((int)g2), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, n, seg_end, hyper, nseg,
                      beta1, beta2, eps, bias_corr, grad_scale);
   return dav_launch_status();
 }

@@ -36,6 +36,8 @@ extern "C" {
 
 #define DAV_ABI_VERSION 1
 int dav_abi_version(void);
+/* text of the last HIP error latched by a kernel launch of the calling thread (diagnostics) */
+const char* dav_last_error_string(void);
 
 /* ---- GEMM --------------------------------------------------------------------------------- */
 /* C[M,N] = epi(alpha * A[M,K] . B[N,K]^T): every nn.Linear forward on the path (timm Attention.qkv/proj,
