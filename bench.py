@@ -67,6 +67,7 @@ def main():
     ap.add_argument('--config', default='base')
     ap.add_argument('--no-graph', action='store_true', help='eager kernel launches instead of hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true', help='skip the dominant-kernel replay (clean per-step profiles)')
     a = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -168,7 +169,7 @@ def main():
 
     # ---- roofline of the dominant kernel (gemm_nt_kernel<128,128>): replay this step's launch mix --------------
     big = [(M, N, K) for (M, N, K) in gemm_log if N > 64 and ((M + 127) // 128) * ((N + 127) // 128) >= 256 and K % 64 == 0]
-    if big:
+    if big and not a.no_roofline:
         bufs = {}
         for (M, N, K) in set(big):
             bufs[(M, N, K)] = (torch.randn(M, K, device=dev).bfloat16(), (torch.randn(N, K, device=dev) * 0.05).bfloat16(),

@@ -29,7 +29,8 @@ SIGNATURES = {
     'dav_layernorm_bwd': [_p, _l, _i, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p,
                           _p, _l, _i, _p, _l, _p, _l,
                           _p, _l, _i, _p, _l, _p, _l,
-                          _p, _p, _p],
+                          _p, _p, _p, _sz, _p],
+    'dav_layernorm_bwd_workspace_bytes': [_i, _i],
     'dav_mask_build': [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p],
     'dav_patch_gather': [_p, _i, _i, _i, _i, _p, _i, _p, _p],
     'dav_unshuffle_fwd': [_p, _p, _p, _p, _i, _i, _i, _i, _p, _l, _i, _p],

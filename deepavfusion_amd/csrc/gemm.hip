@@ -31,6 +31,7 @@ struct NTParams {
   const bf16_t* aux; int ldaux;  // act == 2
   const float* res; int ldres; RowMap rmap; const int* res_rows;   // fp32 residual (optional row gather list)
   void* C; int ldc; int c_bf16; RowMap cmap;
+  int b_kn;                      // B is given as [K, N] row-major (ldb = its row stride) instead of [N, K]
   bf16_t* C2; int ldc2; int c2_mode;   // second bf16 output [M, ldc2]: 1 pre-activation, 2 post-activation/pre-residual, 3 final value
   int beta;                      // C (fp32) += result
   float alpha;
@@ -211,11 +212,28 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTParams p) {
 // and an epilogue staged through LDS so that every global access of C / residual / C2 is a full
 // 16-byte-per-lane row segment.  Requires K % 64 == 0 and N % 4 == 0.
 // ------------------------------------------------------------------------------------------------
+template <int RB> __device__ __forceinline__ int tn2_swz(int row) {
+  return RB == 256 ? ((row & 3) | (((row >> 3) & 1) << 2)) : (((row >> 1) & 1) | (((row >> 3) & 1) << 1));
+}
+template <int RB>
+__device__ __forceinline__ bf16x8 tn2_frag(const char* tile, int mk, int colbase, int lane) {
+  const int g = lane >> 4, li = lane & 15;
+  union { s16x4 h[2]; bf16x8 v; } u;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = mk + 8 * g + 4 * h + (li >> 2);
+    const int colb = (colbase + 4 * (li & 3)) * 2;
+    const int addr = row * RB + ((((colb >> 5) ^ tn2_swz<RB>(row)) << 5) | (colb & 31));
+    u.h[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tile + addr));
+  }
+  return u.v;
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WM_, int WN_, int STAGES>
+template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT>
 __global__ __launch_bounds__(WM_* WN_ * 64) void gemm_nt2_kernel(NTParams p) {
   constexpr int NT = WM_ * WN_ * 64;
   constexpr int WTM = BM / WM_, WTN = BN / WN_, FM = WTM / 16, FN = WTN / 16;
@@ -256,11 +274,22 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void gemm_nt2_kernel(NTParams p) {
     int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;
     a_src[i] = p.A + map_row(gm, p.amap) * p.lda + ls * 8;
   }
+  // B tile: NT mode = [BN rows][64 k] (128-byte rows, as A); BT mode (B given as [K, N], the dgrad reading W
+  // itself) = [64 k rows][BN cols] (BN*2-byte rows) read back with the transposing ds_read_b64_tr_b16.
+  constexpr int BRB = BN * 2, BCPR = BN / 8;
 #pragma unroll
   for (int i = 0; i < B_CH; ++i) {
-    const int c = tid + NT * i, row = c >> 3, ls = (c & 7) ^ ((row >> 1) & 7);
-    int gn = n0 + row; gn = gn < p.N ? gn : p.N - 1;
-    b_src[i] = p.B + (long)gn * p.ldb + ls * 8;
+    const int c = tid + NT * i;
+    if (!BT) {
+      const int row = c >> 3, ls = (c & 7) ^ ((row >> 1) & 7);
+      int gn = n0 + row; gn = gn < p.N ? gn : p.N - 1;
+      b_src[i] = p.B + (long)gn * p.ldb + ls * 8;
+    } else {
+      const int row = c / BCPR, pc = c % BCPR;
+      const int lc = (((pc >> 1) ^ tn2_swz<BRB>(row)) << 1) | (pc & 1);
+      int gc = n0 + lc * 8; gc = gc < p.N ? gc : p.N - 8;
+      b_src[i] = p.B + (long)row * p.ldb + gc;
+    }
   }
   auto dma_tile = [&](int kt) {
     const int k0 = kt << 6;
@@ -270,7 +299,8 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void gemm_nt2_kernel(NTParams p) {
       __builtin_amdgcn_global_load_lds(GLB_PTR(void, a_src[i] + k0), LDS_PTR(void, st + (wave * 64 + NT * i) * 16), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < B_CH; ++i)
-      __builtin_amdgcn_global_load_lds(GLB_PTR(void, b_src[i] + k0), LDS_PTR(void, st + A_BYTES + (wave * 64 + NT * i) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(void, BT ? b_src[i] + (long)k0 * p.ldb : b_src[i] + k0),
+                                       LDS_PTR(void, st + A_BYTES + (wave * 64 + NT * i) * 16), 16, 0, 0);
   };
 
   f32x4 acc[FM][FN];
@@ -305,8 +335,12 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void gemm_nt2_kernel(NTParams p) {
       }
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
-        const int row = wn * WTN + j * 16 + fr;
-        bfr[j] = *reinterpret_cast<const bf16x8*>(Bb + row * 128 + (((kk * 4 + fg) ^ ((row >> 1) & 7)) << 4));
+        if (!BT) {
+          const int row = wn * WTN + j * 16 + fr;
+          bfr[j] = *reinterpret_cast<const bf16x8*>(Bb + row * 128 + (((kk * 4 + fg) ^ ((row >> 1) & 7)) << 4));
+        } else {
+          bfr[j] = tn2_frag<BRB>(Bb, kk * 32, wn * WTN + j * 16, lane);
+        }
       }
 #pragma unroll
       for (int i = 0; i < FM; ++i)
@@ -379,13 +413,13 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void gemm_nt2_kernel(NTParams p) {
   }
 }
 
-template <int BM, int BN, int WM_, int WN_, int STAGES>
+template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT = false>
 void launch_nt2(const NTParams& p, hipStream_t stream) {
   constexpr int NT = WM_ * WN_ * 64;
   constexpr size_t ring = (size_t)STAGES * (BM + BN) * 128;
   constexpr size_t epi = (size_t)WM_ * WN_ * (BM / WM_) * (BN / WN_ + 4) * 4;
   constexpr size_t lds = ring > epi ? ring : epi;
-  auto kern = gemm_nt2_kernel<BM, BN, WM_, WN_, STAGES>;
+  auto kern = gemm_nt2_kernel<BM, BN, WM_, WN_, STAGES, BT>;
   static bool big = false;
   if (lds > 64 * 1024 && !big) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -550,6 +584,115 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TNParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// TN kernel, second generation (contraction rows Mc % 64 == 0): 2-stage LDS ring filled by
+// global->LDS DMA (source-side swizzle), T x T output tiles (T = 128 with 8 waves, T = 64 with 4),
+// tr-read fragments, bias gradient as one extra MFMA against a fragment of ones, split-K with fp32
+// atomics into the live gradient.
+// ------------------------------------------------------------------------------------------------
+template <int T, int WM_, int WN_>
+__global__ __launch_bounds__(WM_* WN_ * 64) void gemm_tn2_kernel(TNParams p) {
+  constexpr int NT = WM_ * WN_ * 64, RB = T * 2, CPRW = T / 8;      // 16-byte chunks per tile row
+  constexpr int TILE_BYTES = 64 * RB, STAGE_BYTES = 2 * TILE_BYTES;
+  constexpr int CH = 64 * CPRW / NT;                                // chunks per thread per operand
+  constexpr int WTN = T / WM_, WTK = T / WN_, FM = WTN / 16, FN = WTK / 16;
+  static_assert(64 * CPRW % NT == 0, "tile/threads mismatch");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN_, wn = wave % WN_;
+  const int tiles_k = (p.K + T - 1) / T;
+  const int bn = blockIdx.x / tiles_k, bk = blockIdx.x % tiles_k;
+  const int n0 = bn * T, k0 = bk * T;
+  const int steps_total = p.Mc >> 6;
+  const int steps_per = (steps_total + p.splits - 1) / p.splits;
+  const int s_begin = blockIdx.y * steps_per;
+  int s_end = s_begin + steps_per; s_end = s_end < steps_total ? s_end : steps_total;
+  if (s_begin >= s_end) return;
+
+  int a_col[CH], b_col[CH], rowi[CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int c = tid + NT * i, row = c / CPRW, pc = c % CPRW;
+    const int lc = (((pc >> 1) ^ tn2_swz<RB>(row)) << 1) | (pc & 1);
+    int ac = n0 + lc * 8; ac = ac < p.N ? ac : p.N - 8;     // out-of-range output columns: any valid data (discarded)
+    int bc = k0 + lc * 8; bc = bc < p.K ? bc : p.K - 8;
+    a_col[i] = ac; b_col[i] = bc; rowi[i] = row;
+  }
+  auto dma_tile = [&](int s, int stage) {
+    char* st = smem + stage * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int m = (s << 6) + rowi[i];
+      __builtin_amdgcn_global_load_lds(GLB_PTR(void, p.A + map_row(m, p.amap) * p.lda + a_col[i]),
+                                       LDS_PTR(void, st + (wave * 64 + NT * i) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(void, p.B + map_row(m, p.bmap) * p.ldb + b_col[i]),
+                                       LDS_PTR(void, st + TILE_BYTES + (wave * 64 + NT * i) * 16), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[FM][FN], accb[FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool do_bias = p.bias_grad != nullptr && bk == 0 && wn == 0;
+  union { uint32_t w[4]; bf16x8 v; } ones;
+  ones.w[0] = ones.w[1] = ones.w[2] = ones.w[3] = 0x3f803f80u;
+
+  dma_tile(s_begin, 0);
+  for (int s = s_begin; s < s_end; ++s) {
+    const int stage = (s - s_begin) & 1;
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (s + 1 < s_end) dma_tile(s + 1, stage ^ 1);
+    const char* Ab = smem + stage * STAGE_BYTES;
+    const char* Bb = Ab + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[FM], bfr[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[i] = tn2_frag<RB>(Ab, kk * 32, wm * WTN + i * 16, lane);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bfr[j] = tn2_frag<RB>(Bb, kk * 32, wn * WTK + j * 16, lane);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones.v, accb[i], 0, 0, 0);
+      }
+    }
+  }
+
+  const int fr = lane & 15, fg = lane >> 4;
+  const bool atomic = p.splits > 1 || p.beta;
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + wm * WTN + i * 16 + fg * 4 + r;
+      if (n >= p.N) continue;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int k = k0 + wn * WTK + j * 16 + fr;
+        if (k >= p.K) continue;
+        float* c = p.C + (long)n * p.ldc + k;
+        if (atomic) unsafeAtomicAdd(c, acc[i][j][r]);
+        else *c = acc[i][j][r];
+      }
+      if (do_bias && fr == 0) unsafeAtomicAdd(p.bias_grad + n, accb[i][r]);
+    }
+}
+
+template <int T, int WM_, int WN_>
+void launch_tn2(const TNParams& p, int tiles, hipStream_t stream) {
+  DAV_LAUNCH((gemm_tn2_kernel<T, WM_, WN_>), dim3(tiles, p.splits), dim3(WM_ * WN_ * 64), (size_t)2 * 2 * 64 * T * 2, stream, p);
+}
+
 RowMap mk(const int* m) { return m ? RowMap{m[0], m[1], m[2]} : RowMap{0, 0, 0}; }
 
 // tile configuration heuristic for the second-generation NT kernel (see launch_nt2 cases)
@@ -570,7 +713,10 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
                                 const float* res, int ldres, const int* res_rowmap, const int* res_rows,
                                 void* C, int ldc, int c_is_bf16, const int* c_rowmap, void* C2, int ldc2, int c2_mode,
                                 int beta, float alpha, int variant, hipStream_t stream) {
+  const int b_kn = (variant >> 12) & 1;   // bit 12: B is [K, N] row-major (dgrad reading W itself)
+  variant &= 0xfff;
   if (M <= 0 || N <= 0 || K <= 0 || (K & 7) || (lda & 7) || (ldb & 7)) return DAV_ERR_SHAPE;
+  if (b_kn && ((N & 7) || (K & 63))) return DAV_ERR_SHAPE;
   if (((uintptr_t)A | (uintptr_t)B) & 15) return DAV_ERR_ALIGN;
   if (beta && c_is_bf16) return DAV_ERR_DTYPE;
   if (!C && !C2) return DAV_ERR_SHAPE;
@@ -580,11 +726,21 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
   p.amap = mk(a_rowmap); p.bias = bias; p.act = act; p.aux = (const bf16_t*)aux; p.ldaux = ldaux;
   p.res = res; p.ldres = ldres; p.rmap = mk(res_rowmap); p.res_rows = res_rows;
   p.C = C; p.ldc = ldc; p.c_bf16 = c_is_bf16; p.cmap = mk(c_rowmap); p.C2 = (bf16_t*)C2; p.ldc2 = ldc2; p.c2_mode = C2 ? c2_mode : 0;
-  p.beta = beta; p.alpha = alpha;
+  p.beta = beta; p.alpha = alpha; p.b_kn = b_kn;
   const bool glds_ok = (K & 63) == 0;
   const bool vec_ok = glds_ok && (N & 3) == 0 && (ldc & 3) == 0 && (!res || (ldres & 3) == 0) && (!C2 || (ldc2 & 3) == 0) &&
                       (!aux || (ldaux & 3) == 0) && !(((uintptr_t)C | (uintptr_t)C2 | (uintptr_t)res) & 15) && !((uintptr_t)aux & 7);
   int cfg = variant >> 4;
+  if (b_kn) {
+    if (!vec_ok) return DAV_ERR_SHAPE;
+    if (cfg == 0) cfg = nt_auto_config(M, N, K);
+    switch (cfg) {
+      case 3: launch_nt2<128, 128, 2, 4, 2, true>(p, stream); break;
+      case 8: launch_nt2<128, 64, 2, 2, 2, true>(p, stream); break;
+      default: launch_nt2<64, 64, 2, 2, 2, true>(p, stream); break;
+    }
+    return dav_launch_status();
+  }
   if (vec_ok && !(variant & 15)) {
     if (cfg == 0) cfg = nt_auto_config(M, N, K);
     switch (cfg) {
@@ -631,8 +787,21 @@ extern "C" int dav_gemm_tn_bf16(const void* A, const void* B, int Mc, int N, int
   TNParams p;
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.Mc = Mc; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb;
   p.amap = mk(a_rowmap); p.bmap = mk(b_rowmap); p.C = C; p.ldc = ldc; p.beta = beta; p.bias_grad = bias_grad;
-  const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
   const int steps = (Mc + 63) / 64;
+  const int cfg = variant >> 4;           // 0 auto, 1 = 128x128 tiles, 2 = 64x64 tiles (benchmark knob)
+  if (!(variant & 15) && (Mc & 63) == 0 && (beta || cfg)) {
+    const int t128 = ((N + 127) / 128) * ((K + 127) / 128), t64 = ((N + 63) / 64) * ((K + 63) / 64);
+    const bool big = cfg ? cfg == 1 : (Mc >= 20000 && t128 >= 48);   // 64x64 tiles win except on the longest contractions
+    const int tiles = big ? t128 : t64;
+    int splits = beta ? (768 + tiles - 1) / tiles : 1;
+    const int max_splits = steps / 6 > 0 ? steps / 6 : 1;      // at least ~6 k-steps of 64 rows per split
+    if (splits > max_splits) splits = max_splits;
+    p.splits = splits;
+    if (big) launch_tn2<128, 2, 4>(p, tiles, stream);
+    else launch_tn2<64, 2, 2>(p, tiles, stream);
+    return dav_launch_status();
+  }
+  const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
   int splits = 1;
   if (beta) {   // accumulate mode may split the contraction (atomic adds into the live gradient)
     splits = (1024 + tiles - 1) / tiles;

@@ -15,7 +15,7 @@
 
 namespace {
 
-constexpr int MAXC = 8;   // float4 chunks per lane -> D <= 2048
+constexpr int MAXC_LIMIT = 8;   // float4 chunks per lane -> D <= 2048 (kernels are instantiated for 1, 2, 3, 4, 8)
 
 struct LNSeg {
   const float* x; long bs; int rows;      // source rows of this segment (batch stride in elements)
@@ -45,9 +45,11 @@ struct LNBwd {
   const bf16_t* dy;     // [B*R, D] bf16 (may be null)
   const float* dy32;    // [B*R, D] fp32 (may be null); total dy = dy + dy32
   const float *gamma, *mean, *rstd;
-  float *dgamma, *dbeta;   // accumulated (atomics)
+  float *dgamma, *dbeta;   // accumulated
+  float* partial;          // workspace [gridDim.x][2*D]
 };
 
+template <int MAXC>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(LNFwd p) {
   const int lane = threadIdx.x & 63;
   const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -98,10 +100,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LNFwd p) {
   }
 }
 
-// dgamma/dbeta of the 4 waves are combined through dynamic LDS (2 * 4 * D floats) before the atomics.
+// dgamma/dbeta: the 4 waves of a workgroup combine their partial sums in LDS and write ONE partial row
+// [2*D] per workgroup to the caller's workspace; ln_bwd_reduce_kernel then sums the rows (no same-address
+// atomics, which serialise in L2 when hundreds of workgroups hit the same 2*D words).
+template <int MAXC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwd p) {
-  extern __shared__ __attribute__((aligned(16))) float lds_red[];   // [2][4][D]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  extern __shared__ __attribute__((aligned(16))) float lds_red[];   // [2][D]
+  const int lane = threadIdx.x & 63;
   const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
   const int R = p.s0.rows + p.s1.rows, rows = p.B * R, nch = p.D >> 2;
   float4 dg[MAXC], db[MAXC];
@@ -166,20 +171,53 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwd p) {
   }
 
   if (p.dgamma == nullptr) return;
-  float* rg = lds_red + (size_t)wave * p.D;
-  float* rb = lds_red + (size_t)(4 + wave) * p.D;
+  for (int c = threadIdx.x; c < 2 * p.D; c += blockDim.x) lds_red[c] = 0.f;
+  __syncthreads();
 #pragma unroll
   for (int i = 0; i < MAXC; ++i) {
     const int c = lane + 64 * i;
-    if (c < nch) { reinterpret_cast<float4*>(rg)[c] = dg[i]; reinterpret_cast<float4*>(rb)[c] = db[i]; }
+    if (c < nch) {
+      atomicAdd(lds_red + 4 * c + 0, dg[i].x); atomicAdd(lds_red + 4 * c + 1, dg[i].y);
+      atomicAdd(lds_red + 4 * c + 2, dg[i].z); atomicAdd(lds_red + 4 * c + 3, dg[i].w);
+      atomicAdd(lds_red + p.D + 4 * c + 0, db[i].x); atomicAdd(lds_red + p.D + 4 * c + 1, db[i].y);
+      atomicAdd(lds_red + p.D + 4 * c + 2, db[i].z); atomicAdd(lds_red + p.D + 4 * c + 3, db[i].w);
+    }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < p.D; c += blockDim.x) {
-    const float g = lds_red[c] + lds_red[p.D + c] + lds_red[2 * p.D + c] + lds_red[3 * p.D + c];
-    const float bsum = lds_red[4 * p.D + c] + lds_red[5 * p.D + c] + lds_red[6 * p.D + c] + lds_red[7 * p.D + c];
-    unsafeAtomicAdd(p.dgamma + c, g);
-    unsafeAtomicAdd(p.dbeta + c, bsum);
+  float* part = p.partial + (size_t)blockIdx.x * 2 * p.D;
+  for (int c = threadIdx.x; c < 2 * p.D; c += blockDim.x) part[c] = lds_red[c];
+}
+
+// 64 columns x 16 row-lanes per workgroup: every thread sums its share of the partial rows with 4 independent
+// accumulators (loads in flight), the 16 row-lanes are combined through LDS.
+__global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* partial, int nrows, int D, float* dgamma, float* dbeta) {
+  __shared__ float red[16][65];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < 2 * D) {
+    int r = ty;
+    for (; r + 48 < nrows; r += 64) {
+      s0 += partial[(size_t)r * 2 * D + c];
+      s1 += partial[(size_t)(r + 16) * 2 * D + c];
+      s2 += partial[(size_t)(r + 32) * 2 * D + c];
+      s3 += partial[(size_t)(r + 48) * 2 * D + c];
+    }
+    for (; r < nrows; r += 16) s0 += partial[(size_t)r * 2 * D + c];
   }
+  red[ty][tx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ty == 0 && c < 2 * D) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += red[i][tx];
+    if (c < D) dgamma[c] += s; else dbeta[c - D] += s;
+  }
+}
+
+int ln_bwd_grid(int rows) {
+  int g = (rows + 3) / 4;
+  return g > 512 ? 512 : (g < 1 ? 1 : g);
 }
 
 int ln_grid(int rows) {
@@ -192,12 +230,21 @@ int ln_grid(int rows) {
 extern "C" int dav_layernorm_fwd(const float* x0, long x0_bs, int r0, const float* x1, long x1_bs, int r1, int B, int D,
                                  const float* gamma, const float* beta, float eps, void* y_bf16, float* y_f32,
                                  float* mean, float* rstd, hipStream_t stream) {
-  if (B <= 0 || D <= 0 || (D & 3) || D > MAXC * 256 || r0 < 0 || r1 < 0 || r0 + r1 <= 0) return DAV_ERR_SHAPE;
+  if (B <= 0 || D <= 0 || (D & 3) || D > MAXC_LIMIT * 256 || r0 < 0 || r1 < 0 || r0 + r1 <= 0) return DAV_ERR_SHAPE;
   LNFwd p;
   p.s0 = LNSeg{x0, x0_bs, r0}; p.s1 = LNSeg{x1, x1_bs, r1}; p.B = B; p.D = D; p.gamma = gamma; p.beta = beta;
   p.eps = eps; p.y = (bf16_t*)y_bf16; p.y32 = y_f32; p.mean = mean; p.rstd = rstd;
-  DAV_LAUNCH(ln_fwd_kernel, dim3(ln_grid(B * (r0 + r1))), dim3(256), 0, stream, p);
+  const int nch = (D / 4 + 63) / 64, g = ln_grid(B * (r0 + r1));
+  if (nch <= 1) DAV_LAUNCH(ln_fwd_kernel<1>, dim3(g), dim3(256), 0, stream, p);
+  else if (nch == 2) DAV_LAUNCH(ln_fwd_kernel<2>, dim3(g), dim3(256), 0, stream, p);
+  else if (nch == 3) DAV_LAUNCH(ln_fwd_kernel<3>, dim3(g), dim3(256), 0, stream, p);
+  else if (nch == 4) DAV_LAUNCH(ln_fwd_kernel<4>, dim3(g), dim3(256), 0, stream, p);
+  else DAV_LAUNCH(ln_fwd_kernel<8>, dim3(g), dim3(256), 0, stream, p);
   return dav_launch_status();
+}
+
+extern "C" size_t dav_layernorm_bwd_workspace_bytes(int rows, int D) {
+  return (size_t)ln_bwd_grid(rows) * 2 * D * sizeof(float);
 }
 
 extern "C" int dav_layernorm_bwd(const float* x0, long x0_bs, int r0, const float* x1, long x1_bs, int r1, int B, int D,
@@ -205,17 +252,25 @@ extern "C" int dav_layernorm_bwd(const float* x0, long x0_bs, int r0, const floa
                                  const float* rstd,
                                  float* dx0, long dx0_bs, int acc0, const float* res0, long res0_bs, void* dx0_bf16, long dx0_bf_bs,
                                  float* dx1, long dx1_bs, int acc1, const float* res1, long res1_bs, void* dx1_bf16, long dx1_bf_bs,
-                                 float* dgamma, float* dbeta, hipStream_t stream) {
-  if (B <= 0 || D <= 0 || (D & 3) || D > MAXC * 256 || r0 < 0 || r1 < 0 || r0 + r1 <= 0) return DAV_ERR_SHAPE;
+                                 float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (B <= 0 || D <= 0 || (D & 3) || D > MAXC_LIMIT * 256 || r0 < 0 || r1 < 0 || r0 + r1 <= 0) return DAV_ERR_SHAPE;
   if (!dy_bf16 && !dy_f32) return DAV_ERR_SHAPE;
+  if (dgamma && workspace_bytes < dav_layernorm_bwd_workspace_bytes(B * (r0 + r1), D)) return DAV_ERR_WORKSPACE;
   LNBwd p;
   p.s0 = LNSeg{x0, x0_bs, r0}; p.s1 = LNSeg{x1, x1_bs, r1}; p.B = B; p.D = D;
   p.d0 = LNDst{dx0, dx0_bs, r0, acc0, res0, res0_bs, (bf16_t*)dx0_bf16, dx0_bf_bs};
   p.d1 = LNDst{dx1, dx1_bs, r1, acc1, res1, res1_bs, (bf16_t*)dx1_bf16, dx1_bf_bs};
   p.dy = (const bf16_t*)dy_bf16; p.dy32 = dy_f32; p.gamma = gamma; p.mean = mean; p.rstd = rstd;
   p.dgamma = dgamma; p.dbeta = dbeta;
-  int grid = ln_grid(B * (r0 + r1));
-  if (grid > 256) grid = 256;   // fewer, longer-lived workgroups: one dgamma/dbeta atomic set each
-  DAV_LAUNCH(ln_bwd_kernel, dim3(grid), dim3(256), (size_t)8 * D * sizeof(float), stream, p);
+  p.partial = (float*)workspace;
+  const int grid = ln_bwd_grid(B * (r0 + r1));
+  const int nch = (D / 4 + 63) / 64;
+  const size_t lds = (size_t)2 * D * sizeof(float);
+  if (nch <= 1) DAV_LAUNCH(ln_bwd_kernel<1>, dim3(grid), dim3(256), lds, stream, p);
+  else if (nch == 2) DAV_LAUNCH(ln_bwd_kernel<2>, dim3(grid), dim3(256), lds, stream, p);
+  else if (nch == 3) DAV_LAUNCH(ln_bwd_kernel<3>, dim3(grid), dim3(256), lds, stream, p);
+  else if (nch == 4) DAV_LAUNCH(ln_bwd_kernel<4>, dim3(grid), dim3(256), lds, stream, p);
+  else DAV_LAUNCH(ln_bwd_kernel<8>, dim3(grid), dim3(256), lds, stream, p);
+  if (dgamma) DAV_LAUNCH(ln_bwd_reduce_kernel, dim3((2 * D + 63) / 64), dim3(1024), 0, stream, (const float*)workspace, grid, D, dgamma, dbeta);
   return dav_launch_status();
 }

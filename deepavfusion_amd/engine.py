@@ -48,36 +48,70 @@ def gbuf(p: torch.nn.Parameter) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------
 # bf16 weight cache (W and W^T) — refreshed when the fp32 master changes
 # ------------------------------------------------------------------------------------------------
-def wcache(p: torch.nn.Parameter, force: bool = False):
+class _WCache:
+    """bf16 copy of a weight (and, lazily, of its transpose).  ``managed`` copies are views into the
+    optimizer's flat bf16 mirror that the fused AdamW kernel rewrites every step."""
+    __slots__ = ('ver', 'ptr', 'wb', 'wtb', 'wt_ver', 'managed')
+
+    def __init__(self):
+        self.ver = self.ptr = self.wt_ver = None
+        self.wb = self.wtb = None
+        self.managed = False
+
+
+def wcache(p: torch.nn.Parameter, force: bool = False) -> torch.Tensor:
+    """bf16 [out, in] copy of ``p`` (re-cast when the fp32 master changed)."""
     c = p.__dict__.get('_dav_cache')
+    if c is None:
+        c = p.__dict__['_dav_cache'] = _WCache()
+    if c.managed and not force:
+        return c.wb
     ver, ptr = p._version, p.data_ptr()
-    if c is None or force or c[0] != ver or c[1] != ptr:
+    if force or c.wb is None or c.ver != ver or c.ptr != ptr:
         w2 = p.detach().reshape(p.shape[0], -1)
-        if c is not None and c[2].shape == w2.shape and c[2].device == w2.device:
-            wb, wtb = c[2], c[3]
-        else:
-            wb = torch.empty(w2.shape, dtype=BF16, device=p.device)
-            wtb = torch.empty((w2.shape[1], w2.shape[0]), dtype=BF16, device=p.device)
-        ops.cast_bf16(w2, wb)
-        ops.cast_transpose_bf16(w2, wtb)
-        c = (ver, ptr, wb, wtb)
-        p.__dict__['_dav_cache'] = c
-    return c[2], c[3]
+        if c.wb is None or c.wb.shape != w2.shape or c.wb.device != w2.device:
+            c.wb = torch.empty(w2.shape, dtype=BF16, device=p.device)
+        ops.cast_bf16(w2, c.wb)
+        c.ver, c.ptr = ver, ptr
+    return c.wb
+
+
+def wcache_t(p: torch.nn.Parameter) -> torch.Tensor:
+    """bf16 [in, out] transposed copy — only for the rare dgrad whose contraction is not a multiple of 64."""
+    wcache(p)
+    c = p.__dict__['_dav_cache']
+    stamp = (c.ver, c.ptr) if not c.managed else ('managed', p.__dict__.get('_dav_epoch', 0))
+    if c.wtb is None or c.wt_ver != stamp:
+        w2 = p.detach().reshape(p.shape[0], -1)
+        if c.wtb is None:
+            c.wtb = torch.empty((w2.shape[1], w2.shape[0]), dtype=BF16, device=p.device)
+        ops.cast_transpose_bf16(w2, c.wtb)
+        c.wt_ver = stamp
+    return c.wtb
 
 
 def invalidate_weight_cache(params):
-    """Mark the bf16 copies stale (the flat AdamW kernel updates the fp32 masters without touching
-    torch's version counters)."""
+    """Mark un-managed bf16 copies stale (fp32 masters changed behind torch's version counters)."""
     for p in params:
         c = p.__dict__.get('_dav_cache')
         if c is not None:
-            p.__dict__['_dav_cache'] = (-1,) + tuple(c[1:])
+            c.ver = None
+            p.__dict__['_dav_epoch'] = p.__dict__.get('_dav_epoch', 0) + 1
+
+
+def adopt_weight_mirror(p: torch.nn.Parameter, view_bf16: torch.Tensor):
+    """Make ``view_bf16`` (kept in sync by the optimizer) the bf16 copy of ``p``."""
+    c = p.__dict__.get('_dav_cache')
+    if c is None:
+        c = p.__dict__['_dav_cache'] = _WCache()
+    c.wb, c.managed = view_bf16.view(p.shape[0], -1), True
 
 
 def refresh_weight_cache(module: torch.nn.Module):
-    """Re-cast every >=2-D weight (call at the top of a captured step so replays see fresh weights)."""
+    """Re-cast every un-managed cached weight (top of a captured step when no optimizer mirror exists)."""
     for p in module.parameters():
-        if p.ndim >= 2 and p.shape[0] > 1 and '_dav_cache' in p.__dict__:
+        c = p.__dict__.get('_dav_cache')
+        if c is not None and not c.managed and c.wb is not None:
             wcache(p, force=True)
 
 
@@ -123,7 +157,7 @@ def ln_bwd(norm, x0, x1, B, stats, dy_bf16=None, dy_f32=None, *, dx0=None, acc0=
 def lin_fwd(lin, a, M, *, a_rowmap=None, lda=None, act=0, res=None, res_rowmap=None, out=None, out_bf16=False,
             c_rowmap=None, ldc=None, C2=None, c2_mode=0, w_col_off=0, k=None, use_bias=True):
     """y = a @ W[:, w_col_off : w_col_off+k]^T (+ bias) with the fused epilogue of dav_gemm_nt_bf16."""
-    W, _ = wcache(lin.weight)
+    W = wcache(lin.weight)
     N, Kfull = W.shape
     K = Kfull if k is None else k
     dev = a.device
@@ -142,17 +176,21 @@ def lin_bwd(lin, dy, a, M, *, dy_rowmap=None, a_rowmap=None, lda=None, need_dx=T
     """Backward of lin_fwd: dx = dy @ W (optionally * GELU'(aux)), dW += dy^T a, db += colsum(dy).
 
     dy: bf16 [*, N]; a: bf16 [*, K] (the forward input).  Returns dx (bf16 [M, K] unless given)."""
-    W, WT = wcache(lin.weight)
+    W = wcache(lin.weight)
     N, Kfull = W.shape
     K = Kfull if k is None else k
     dev = dy.device
     if need_dx:
         if dx is None:
             dx = _e((M, K), BF16 if dx_bf16 else F32, dev)
-        Bt = WT if w_col_off == 0 else WT[w_col_off:]          # W^T rows = input features
-        ops.gemm_nt(dy, Bt, M, K, N, lda=N, ldb=N, a_rowmap=dy_rowmap, act=2 if gelu_aux is not None else 0,
+        if N % 64 == 0:      # read W [N, K] itself as the [contraction, out] operand (transposing LDS reads)
+            Bt, ldb, variant = (W if w_col_off == 0 else W.view(-1)[w_col_off:]), Kfull, 1 << 12
+        else:
+            WT = wcache_t(lin.weight)
+            Bt, ldb, variant = (WT if w_col_off == 0 else WT[w_col_off:]), N, 0
+        ops.gemm_nt(dy, Bt, M, K, N, lda=N, ldb=ldb, a_rowmap=dy_rowmap, act=2 if gelu_aux is not None else 0,
                     aux=gelu_aux, ldaux=K, C_out=dx, ldc=K, c_bf16=dx.dtype == BF16, c_rowmap=dx_rowmap, beta=dx_beta,
-                    C2=dx_C2, ldc2=K, c2_mode=dx_c2_mode)
+                    C2=dx_C2, ldc2=K, c2_mode=dx_c2_mode, variant=variant)
     gw = gbuf(lin.weight)
     gwv = gw.view(N, -1)
     Cw = gwv if w_col_off == 0 else gwv.view(-1)[w_col_off:]
@@ -388,7 +426,7 @@ def patch_embed_fwd(vit, img, ids_keep32):
     K = C * 256
     A = _e((B * nk, K), BF16, img.device)
     ops.patch_gather(img, ids_keep32, nk, A)
-    Wb, _ = wcache(pe.proj.weight)
+    Wb = wcache(pe.proj.weight)
     tok = _e((B, nk, D), F32, img.device)
     ops.gemm_nt(A, Wb, B * nk, D, K, bias=pe.proj.bias, res=vit.pos_embed, ldres=D,
                 res_rows=ids_keep32, res_rowmap=None if ids_keep32 is not None else (L, 0, 0), C_out=tok)

@@ -78,11 +78,15 @@ def layernorm_bwd(x0, x0_bs, r0, x1, x1_bs, r1, B, D, dy_bf16, dy_f32, gamma, me
                   dx0=None, dx0_bs=0, acc0=0, res0=None, res0_bs=0, dx0_bf16=None, dx0_bf_bs=0,
                   dx1=None, dx1_bs=0, acc1=0, res1=None, res1_bs=0, dx1_bf16=None, dx1_bf_bs=0, dgamma=None, dbeta=None):
     lib = _lib.load()
+    ws = None
+    if dgamma is not None:
+        ws = torch.empty(lib.dav_layernorm_bwd_workspace_bytes(B * (r0 + r1), D) // 4, dtype=F32, device=dgamma.device)
     _lib.check(lib.dav_layernorm_bwd(_ptr(x0), x0_bs, r0, _ptr(x1), x1_bs, r1, B, D, _ptr(dy_bf16), _ptr(dy_f32),
                                      _ptr(gamma), _ptr(mean), _ptr(rstd),
                                      _ptr(dx0), dx0_bs, acc0, _ptr(res0), res0_bs, _ptr(dx0_bf16), dx0_bf_bs,
                                      _ptr(dx1), dx1_bs, acc1, _ptr(res1), res1_bs, _ptr(dx1_bf16), dx1_bf_bs,
-                                     _ptr(dgamma), _ptr(dbeta), _stream()), 'dav_layernorm_bwd')
+                                     _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()),
+               'dav_layernorm_bwd')
 
 
 def mask_build(noise: torch.Tensor, len_keep: int):

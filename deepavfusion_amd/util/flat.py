@@ -76,6 +76,12 @@ class FlatAdamW(torch.optim.Optimizer):
         dev = self.flat.flat_p.device
         self.exp_avg = torch.zeros_like(self.flat.flat_p)
         self.exp_avg_sq = torch.zeros_like(self.flat.flat_p)
+        # bf16 mirror of every master weight, rewritten by the AdamW kernel itself: the GEMMs read views of it
+        self.flat_bf16 = torch.empty(self.flat.total, dtype=torch.bfloat16, device=dev)
+        for p, o in zip(self.flat.params, self.flat.offsets):
+            if p.ndim >= 2 and p.shape[0] > 1:
+                engine.adopt_weight_mirror(p, self.flat_bf16[o:o + p.numel()])
+        self.sync_bf16()
         self._group_of = {}
         for gi, g in enumerate(self.param_groups):
             for p in g['params']:
@@ -93,6 +99,11 @@ class FlatAdamW(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none: bool = False):
         self.flat.zero_grad()
+
+    def sync_bf16(self):
+        """Re-derive the bf16 mirror from the fp32 masters (after load_state_dict / resume)."""
+        ops.cast_bf16(self.flat.flat_p, self.flat_bf16)
+        engine.invalidate_weight_cache(self.flat.params)
 
     def prepare_step(self):
         """Host side of a step (kept outside hipGraph capture): bump t, upload per-tensor {lr, wd} and bias corrections."""
@@ -113,7 +124,7 @@ class FlatAdamW(torch.optim.Optimizer):
         """Device side of a step: one kernel over all parameters (capturable)."""
         b1, b2 = self.defaults['betas']
         f = self.flat
-        ops.adamw_flat(f.flat_p, f.flat_g, self.exp_avg, self.exp_avg_sq, None, f.seg_end, self._hyper, len(f.params),
+        ops.adamw_flat(f.flat_p, f.flat_g, self.exp_avg, self.exp_avg_sq, self.flat_bf16, f.seg_end, self._hyper, len(f.params),
                        b1, b2, self.defaults['eps'], self._bc, grad_scale)
         engine.invalidate_weight_cache(f.params)      # fp32 masters changed behind torch's back
 

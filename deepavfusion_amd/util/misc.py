@@ -219,7 +219,11 @@ class CheckpointManager:
                 m.step_count = ckpt[k]['step_count']
                 m.exp_avg.copy_(ckpt[k]['exp_avg'])
                 m.exp_avg_sq.copy_(ckpt[k]['exp_avg_sq'])
+                m.sync_bf16()
             else:
                 m.load_state_dict(ckpt[k])
         engine.invalidate_weight_cache(self.modules['state_dict'].parameters())
+        for m in self.modules.values():
+            if isinstance(m, FlatAdamW):
+                m.sync_bf16()
         return (ckpt.get('epoch', 0),)

@@ -48,7 +48,9 @@ const char* dav_last_error_string(void);
  * (fc1 backward); [C2 mode 2]; + fp32 residual (row map or explicit row list: the block residual adds
  * and "+ pos_embed[ids_keep]"); beta != 0 adds the old fp32 C; store C (fp32 or bf16, through
  * c_rowmap; may be NULL); [C2 mode 3].  C2 is a dense bf16 [M, ldc2] twin for the next GEMM.
- * variant bit0: register-staged loads instead of global->LDS DMA; bit1: force 64x64 tiles. */
+ * variant bit12: B is given as [K, N] row-major (ldb = row stride; K % 64 == 0, N % 8 == 0) — the dgrad reads
+ * W itself through transposing LDS reads, no W^T copy; bits 4-11: explicit tile configuration (benchmarks);
+ * bit0: register-staged loads instead of global->LDS DMA; bit1: force 64x64 tiles (first-generation kernel). */
 int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const int* a_rowmap,
                      const float* bias, int act, const void* aux, int ldaux, const float* res, int ldres,
                      const int* res_rowmap, const int* res_rows, void* C, int ldc, int c_is_bf16, const int* c_rowmap,
@@ -84,12 +86,14 @@ int dav_layernorm_fwd(const float* x0, long x0_bs, int r0, const float* x1, long
                       const float* gamma, const float* beta, float eps, void* y_bf16, float* y_f32, float* mean, float* rstd,
                       hipStream_t stream);
 /* total dy = dy_bf16 + dy_f32 (either may be NULL).  For each source segment s: dx_s (=|+=) LN'(dy)
- * (+ res_s), optional bf16 copy; dx_s NULL skips the segment.  dgamma/dbeta are accumulated. */
+ * (+ res_s), optional bf16 copy; dx_s NULL skips the segment.  dgamma/dbeta are accumulated (+=) from
+ * per-workgroup partial rows staged in `workspace` (two kernels, no atomics). */
 int dav_layernorm_bwd(const float* x0, long x0_bs, int r0, const float* x1, long x1_bs, int r1, int B, int D,
                       const void* dy_bf16, const float* dy_f32, const float* gamma, const float* mean, const float* rstd,
                       float* dx0, long dx0_bs, int acc0, const float* res0, long res0_bs, void* dx0_bf16, long dx0_bf_bs,
                       float* dx1, long dx1_bs, int acc1, const float* res1, long res1_bs, void* dx1_bf16, long dx1_bf_bs,
-                      float* dgamma, float* dbeta, hipStream_t stream);
+                      float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, hipStream_t stream);
+size_t dav_layernorm_bwd_workspace_bytes(int rows, int D);   /* rows = B * (r0 + r1) */
 
 /* ---- masking / gather / scatter ------------------------------------------------------------ */
 /* AVMAE.random_masking (models/avmae.py:120-142) for given noise [N,L]: argsort twice, keep the first

@@ -92,6 +92,14 @@ def gemm_nt():
     C = torch.empty(M, N, device=dev)
     ops.gemm_nt(Asub.contiguous(), Bm, M, N, K, res=pos, ldres=N, res_rows=rows, C_out=C)
     report('gemm_nt res_rows', rel(C, Asub.float() @ Bm.float().t() + pos[rows.long()]), 1e-4)
+    # B given as [K, N] (dgrad reading W itself), incl. column offset / ldb and all tile configs
+    for (M2, N2, K2) in [(300, 768, 192), (5184, 768, 2304), (2048, 136, 64), (4032, 3072, 768)]:
+        A2 = rnd(M2, K2, dtype=BF16, seed=15)
+        Wkn = rnd(K2, 2 * N2, dtype=BF16, scale=0.05, seed=16)
+        for cfg in (0, 3, 8, 5):
+            C = torch.empty(M2, N2, device=dev)
+            ops.gemm_nt(A2, Wkn.view(-1)[N2:], M2, N2, K2, ldb=2 * N2, C_out=C, variant=(1 << 12) | (cfg << 4))
+            report(f'gemm_nt b_kn {M2}x{N2}x{K2} cfg{cfg}', rel(C, A2.float() @ Wkn[:, N2:].float()), 1e-4)
     # B sub-matrix (column offset, ldb)
     Bw = rnd(N, 2 * K, dtype=BF16, scale=0.1, seed=10)
     C = torch.empty(M, N, device=dev)
@@ -101,8 +109,8 @@ def gemm_nt():
 
 @check
 def gemm_tn():
-    for (Mc, N, K) in [(162, 192, 64), (5184, 768, 768), (100, 48, 192), (4032, 256, 768), (77, 136, 200), (6080, 3072, 768)]:
-        for variant in (0, 1):
+    for (Mc, N, K) in [(162, 192, 64), (5184, 768, 768), (100, 48, 192), (4032, 256, 768), (77, 136, 200), (6080, 3072, 768), (3136, 192, 768), (128, 72, 40)]:
+        for variant in (0, 1, 2, 16, 32):
             A, Bm = rnd(Mc, N, dtype=BF16, seed=11), rnd(Mc, K, dtype=BF16, seed=12)
             ref = A.float().t() @ Bm.float()
             C = torch.zeros(N, K, device=dev)
