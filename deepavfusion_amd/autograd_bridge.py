@@ -8,11 +8,30 @@ accumulates parameter gradients in place.  ``encoder_apply`` does the same for
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import engine as E
 from . import ops
 from .ops import BF16, F32
+
+
+_SIDE_STREAMS = {}
+
+
+def _streams(dev):
+    """(main, side_a, side_f): the three independent blocks of a layer (image tower, audio tower, fusion block)
+    run on three HIP streams — inside a captured step they become parallel branches of the hipGraph.
+    DAV_STREAMS=0 serialises everything on the current stream."""
+    main = torch.cuda.current_stream(dev)
+    if os.environ.get('DAV_STREAMS', '1') == '0':
+        return main, main, main
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+    sa, sf = _SIDE_STREAMS[key]
+    return main, sa, sf
 
 
 def _f32c(x):
@@ -33,16 +52,24 @@ def encoder_fwd(enc, image, audio, ik32, ak32, want_f32=False, collect_embs=Fals
     x_f = enc.fusion_tokens.detach().expand(B, -1, -1).contiguous()
     Hi, Ha, Hf = enc.image.num_heads, enc.audio.num_heads, enc.fusion_num_heads
     layers, embs = [], []
+    main, sa, sf = _streams(image.device)
     for l, (bi, ba, fb) in enumerate(zip(enc.image.blocks, enc.audio.blocks, enc.fusion_blocks)):
+        sa.wait_stream(main)
+        sf.wait_stream(main)
         if fb is None:
+            with torch.cuda.stream(sa):
+                x_a, ta = E.block_fwd(ba, x_a, None, Ha, ba.norm1.eps)
             x_i, ti = E.block_fwd(bi, x_i, None, Hi, bi.norm1.eps)
-            x_a, ta = E.block_fwd(ba, x_a, None, Ha, ba.norm1.eps)
             tf = None
         else:
+            with torch.cuda.stream(sa):
+                n_a, ta = E.block_fwd(ba, x_a, x_f, Ha, ba.norm1.eps)
+            with torch.cuda.stream(sf):
+                n_f, tf = E.fusion_block_fwd(fb, x_f, x_i, x_a, Hf, enc.num_fusion)  # reads the layer INPUT x_i / x_a (:106-107)
             n_i, ti = E.block_fwd(bi, x_i, x_f, Hi, bi.norm1.eps)
-            n_a, ta = E.block_fwd(ba, x_a, x_f, Ha, ba.norm1.eps)
-            x_f, tf = E.fusion_block_fwd(fb, x_f, x_i, x_a, Hf, enc.num_fusion)    # reads the layer INPUT x_i / x_a (:106-107)
-            x_i, x_a = n_i, n_a
+            x_i, x_a, x_f = n_i, n_a, n_f
+        main.wait_stream(sa)
+        main.wait_stream(sf)
         layers.append((ti, ta, tf))
         if collect_embs:
             embs.append((x_i, x_a, x_f))
@@ -69,15 +96,27 @@ def encoder_bwd(enc, t, dxi_b=None, dxa_b=None, dxf_b=None, dxi32=None, dxa32=No
     g_a, g_ab = final_norm(enc.audio.norm, t['x_a'], t['st_a'], dxa_b, dxa32)
     g_f, g_fb = final_norm(enc.fusion_norm, t['x_f'], t['st_f'], dxf_b, dxf32)
     blocks = list(zip(enc.image.blocks, enc.audio.blocks, enc.fusion_blocks))
+    main, sa, sf = _streams(dev)
     for (bi, ba, fb), (ti, ta, tf) in zip(reversed(blocks), reversed(t['layers'])):
+        sa.wait_stream(main)
+        sf.wait_stream(main)
         if fb is None:
+            with torch.cuda.stream(sa):
+                g_a, g_ab, _ = E.block_bwd(ba, ta, g_a, g_ab)
             g_i, g_ib, _ = E.block_bwd(bi, ti, g_i, g_ib)
-            g_a, g_ab, _ = E.block_bwd(ba, ta, g_a, g_ab)
+            main.wait_stream(sa)
         else:
-            dx_f, dx_i, dx_a = E.fusion_block_bwd(fb, tf, g_f, g_fb)
-            g_i, g_ib, dx_f = E.block_bwd(bi, ti, g_i, g_ib, dx_fus=dx_f, dx_fus_acc=1, dx_mod=dx_i, dx_mod_acc=1)
-            g_a, g_ab, dx_f = E.block_bwd(ba, ta, g_a, g_ab, dx_fus=dx_f, dx_fus_acc=1, dx_mod=dx_a, dx_mod_acc=1)
-            g_f, g_fb = dx_f, None
+            # the fusion block's backward (many tiny kernels) runs beside the two tower blocks; their last
+            # LayerNorm backward accumulates into the buffers it produces, so that kernel waits for it
+            with torch.cuda.stream(sf):
+                dx_f, dx_i, dx_a = E.fusion_block_bwd(fb, tf, g_f, g_fb)
+            with torch.cuda.stream(sa):
+                g_a, g_ab, dxf_a = E.block_bwd(ba, ta, g_a, g_ab, dx_mod=dx_a, dx_mod_acc=1,
+                                               before_ln1=lambda: sa.wait_stream(sf))
+            g_i, g_ib, dx_f = E.block_bwd(bi, ti, g_i, g_ib, dx_fus=dx_f, dx_fus_acc=1, dx_mod=dx_i, dx_mod_acc=1,
+                                          before_ln1=lambda: main.wait_stream(sf))
+            main.wait_stream(sa)
+            g_f, g_fb = (dx_f + dxf_a) if sa is not main else dx_f.add_(dxf_a), None
     E.patch_embed_bwd(enc.image, t['t_pi'], g_i, g_ib)
     E.patch_embed_bwd(enc.audio, t['t_pa'], g_a, g_ab)
     E.gbuf(enc.fusion_tokens).add_(g_f.sum(dim=0, keepdim=True))          # backward of .expand(B, -1, -1)
@@ -171,10 +210,14 @@ def avmae_fwd(model, image, audio, noise_i, noise_a):
     (xi_b, xa_b, xf_b), _, _, t_enc = encoder_fwd(enc, image, audio, ik32, ak32)
     nF = enc.fusion_tokens.shape[1]
     dec_i, dec_a = model.decoder('image'), model.decoder('audio')
+    main, sa, _ = _streams(image.device)
+    sa.wait_stream(main)
+    with torch.cuda.stream(sa):
+        pred_a, t_da = E.decoder_fwd(dec_a, xa_b, xf_b, ar32, B, nka, nF)
+        loss_a, t_la = E.loss_fwd(audio, pred_a, am, model.audio_norm_loss)
     pred_i, t_di = E.decoder_fwd(dec_i, xi_b, xf_b, ir32, B, nki, nF)
     loss_i, t_li = E.loss_fwd(image, pred_i, im, model.image_norm_loss)
-    pred_a, t_da = E.decoder_fwd(dec_a, xa_b, xf_b, ar32, B, nka, nF)
-    loss_a, t_la = E.loss_fwd(audio, pred_a, am, model.audio_norm_loss)
+    main.wait_stream(sa)
     tape = dict(image=image, audio=audio, im=im, am=am, ik32=ik32, ak32=ak32, t_enc=t_enc, t_di=t_di, t_da=t_da, t_li=t_li,
                 t_la=t_la, pred_i=pred_i, pred_a=pred_a, B=B)
     aux = dict(image_ids_keep=ik, image_mask=im, image_ids_restore=ir, audio_ids_keep=ak, audio_mask=am, audio_ids_restore=ar)
@@ -184,14 +227,18 @@ def avmae_fwd(model, image, audio, noise_i, noise_a):
 def avmae_bwd(model, t, g_li, g_la, g_pi=None, g_pa=None):
     B = t['B']
     dec_i, dec_a = model.decoder('image'), model.decoder('audio')
+    main, sa, _ = _streams(t['image'].device)
+    sa.wait_stream(main)
+    with torch.cuda.stream(sa):
+        dpa = E.loss_bwd(t['audio'], t['pred_a'], t['am'], t['t_la'], g_la)
+        if g_pa is not None:
+            dpa = (dpa.float() + g_pa.reshape(dpa.shape)).to(BF16)
+        dxa_b, dxf_a = E.decoder_bwd(dec_a, t['t_da'], dpa, t['ak32'], B)
     dpi = E.loss_bwd(t['image'], t['pred_i'], t['im'], t['t_li'], g_li)
     if g_pi is not None:
         dpi = (dpi.float() + g_pi.reshape(dpi.shape)).to(BF16)
     dxi_b, dxf_i = E.decoder_bwd(dec_i, t['t_di'], dpi, t['ik32'], B)
-    dpa = E.loss_bwd(t['audio'], t['pred_a'], t['am'], t['t_la'], g_la)
-    if g_pa is not None:
-        dpa = (dpa.float() + g_pa.reshape(dpa.shape)).to(BF16)
-    dxa_b, dxf_a = E.decoder_bwd(dec_a, t['t_da'], dpa, t['ak32'], B)
+    main.wait_stream(sa)
     dxf32 = dxf_i.float() + dxf_a.float()            # both decoders read the same normed fusion tokens
     encoder_bwd(model.encoder, t['t_enc'], dxi_b=dxi_b, dxa_b=dxa_b, dxf32=dxf32)
 

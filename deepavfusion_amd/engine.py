@@ -249,7 +249,7 @@ def block_fwd(blk, x_mod, x_fus, heads, eps):
     return x2, tape
 
 
-def block_bwd(blk, t, g2, g2b, *, dx_fus=None, dx_fus_acc=0, dx_mod=None, dx_mod_acc=0, need_dx=True):
+def block_bwd(blk, t, g2, g2b, *, dx_fus=None, dx_fus_acc=0, dx_mod=None, dx_mod_acc=0, need_dx=True, before_ln1=None):
     """g2 fp32 [B,n,D] (+ bf16 twin g2b or None).  Writes/accumulates the fusion-row gradient into dx_fus
     and the modality-row gradient (incl. the residual path) into dx_mod; returns (dx_mod, dx_mod_bf16, dx_fus)."""
     x_mod, x_fus, heads, nF = t['x_mod'], t['x_fus'], t['heads'], t['nF']
@@ -281,6 +281,8 @@ def block_bwd(blk, t, g2, g2b, *, dx_fus=None, dx_fus_acc=0, dx_mod=None, dx_mod
     if nF > 0 and dx_fus is None:
         dx_fus = _e((B, nF, D), F32, dev)
         dx_fus_acc = 0
+    if before_ln1 is not None:
+        before_ln1()          # e.g. wait for the stream that produced the buffers this LayerNorm accumulates into
     ln_bwd(blk.norm1, x_fus, x_mod, B, t['st1'], dy_bf16=dh1, dx0=dx_fus, acc0=dx_fus_acc,
            dx1=dx_mod, acc1=dx_mod_acc, res1=g1, dx1_bf16=dx_mod_b)
     return dx_mod, dx_mod_b, dx_fus
