@@ -1,4 +1,4 @@
-"""Build AVMAE(DeepAVFusion(...)) from a shape configuration (same fields as oracle.configs.PathConfig /
+"""Build AVMAE(DeepAVFusion(...)) from a shape configuration (deepavfusion_amd.configs.PathConfig:
 the reference's configs/deepavfusion.yaml model section)."""
 from .models.avmae import AVMAE
 from .models.deepavfusion import DeepAVFusion

@@ -182,10 +182,10 @@ class DataParallel(torch.nn.Module):
     """Stand-in for ``DistributedDataParallel(model)`` (util/misc.py:34): same forward, ``no_sync()`` for gradient
     accumulation (util/misc.py:144-148), parameters broadcast from rank 0 at construction."""
 
-    def __init__(self, module: torch.nn.Module, flat, bucket_mb: float = 64.0, process_group=None):
+    def __init__(self, module: torch.nn.Module, flat, bucket_mb: float = 64.0, first_bucket_mb: float = 8.0, process_group=None):
         super().__init__()
         self.module = module
-        self.reducer = GradReducer(flat, bucket_mb=bucket_mb, process_group=process_group)
+        self.reducer = GradReducer(flat, bucket_mb=bucket_mb, first_bucket_mb=first_bucket_mb, process_group=process_group)
         if self.reducer.world > 1:
             dist.broadcast(flat.flat_p, src=0, group=process_group)           # C2 in SURVEY.md section 2c
             for b in module.buffers():

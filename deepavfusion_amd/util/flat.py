@@ -27,9 +27,7 @@ class FlatParams:
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError('no trainable parameters')
-        dev = self.params[0].device
-        if dev.type != 'cuda':
-            raise RuntimeError('FlatParams needs the model on an MI355X (cuda) device')
+        dev = self.params[0].device          # CPU is accepted for the host-logic / gloo tests; kernels need cuda
         self.offsets, off = [], 0
         for p in self.params:
             self.offsets.append(off)

@@ -1,0 +1,131 @@
+"""CPU: the C-ABI library loads and exports every symbol include/dav_kernels.h declares; host logic
+(lr schedule, param groups, sin-cos tables, state-dict contract, FLOP model) matches the golden fixtures."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from deepavfusion_amd import _lib
+    hdr = open(os.path.join(ROOT, 'include', 'dav_kernels.h')).read()
+    declared = set(re.findall(r'\b(dav_[a-z0-9_]+)\s*\(', hdr))
+    assert len(declared) >= 20
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in include/dav_kernels.h but not exported'
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.dav_abi_version() == 1
+
+
+def test_no_cpu_fallback():
+    from deepavfusion_amd import ops
+    x = torch.zeros(4, 8)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        ops.cast_bf16(x, torch.zeros(4, 8, dtype=torch.bfloat16))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'deepavfusion_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'oracle' not in src, f'{f} mentions the oracle'
+
+
+def test_state_dict_contract_matches_reference_shapes():
+    from deepavfusion_amd.build_model import build_avmae
+    from deepavfusion_amd.configs import CONFIGS
+    from oracle import avmae_oracle as O
+    from oracle.configs import CONFIGS as OC
+    for name in ('micro', 'tiny'):
+        m = build_avmae(CONFIGS[name])
+        shapes = O.state_shapes(OC[name])           # pinned by strict load into the reference (tools/gen_golden.py)
+        sd = m.state_dict()
+        assert set(sd) == set(shapes)
+        assert all(tuple(v.shape) == tuple(shapes[k]) for k, v in sd.items())
+        assert [n for n, p in m.named_parameters() if not p.requires_grad] == list(O.FROZEN)
+        m.load_state_dict(O.closed_form_state(OC[name], 0), strict=True)
+    for a, b in zip(CONFIGS.values(), OC.values()):
+        assert (a.embed_dim, a.depth, a.fusion_tkns, a.decoder_dim, a.audio_mask_ratio) == (b.embed_dim, b.depth, b.fusion_tkns, b.decoder_dim, b.audio_mask_ratio)
+
+
+def test_sincos_tables(golden):
+    from deepavfusion_amd.util.pos_embed import get_2d_sincos_pos_embed
+    g = golden('posembed')
+    n = 0
+    for k in g.files:
+        if not k.startswith('2d_'):
+            continue
+        _, dim, grid = k.split('_')[:3]
+        grid = tuple(int(x) for x in grid.split('x'))
+        full = get_2d_sincos_pos_embed(int(dim), grid).astype(np.float32)
+        if k.endswith('_sub'):
+            assert np.allclose(full[::3, ::5], g[k], atol=1e-6)
+        elif k.endswith('_sum'):
+            assert abs(full.astype(np.float64).sum() - float(g[k])) < 1e-3
+        else:
+            assert np.allclose(full, g[k], atol=1e-6)
+        n += 1
+    assert n >= 10
+
+
+class _NS(dict):
+    __getattr__ = dict.__getitem__
+
+
+def test_lr_schedule_and_param_groups(golden):
+    from deepavfusion_amd.build_model import build_avmae
+    from deepavfusion_amd.configs import CONFIGS
+    from deepavfusion_amd.util import lr_sched
+    g = golden('lr_groups')
+    model = build_avmae(CONFIGS['micro'])
+    nd = [n for n, p in model.named_parameters() if 'bias' in n or 'norm' in n]
+    groups = lr_sched.param_groups_pretrained(model, 0.05, no_weight_decay_list=nd, image_pt='', audio_pt='')
+    name_of = {id(p): n for n, p in model.named_parameters()}
+    assert len(groups) == int(g['n_groups'])
+    for gi, grp in enumerate(groups):
+        assert sorted(name_of[id(p)] for p in grp['params']) == sorted(g[f'group{gi}.names'].tolist())
+        assert grp['weight_decay'] == float(g[f'group{gi}.weight_decay'])
+        assert bool(grp.get('pretrained', False)) == bool(g[f'group{gi}.pretrained'])
+    opt = torch.optim.AdamW(groups, lr=1e-3, betas=(0.9, 0.95))
+    args = _NS(opt=_NS(lr=1e-3, warmup_epochs=2, epochs=10, pt_warmup_epochs='10/2', pt_lr_mult_start=0, pt_lr_mult_end=1))
+    for e, row in zip(g['epochs'], g['lr_table']):
+        lr = lr_sched.adjust_learning_rate(opt, float(e), args)
+        assert abs(lr - row[0]) < 1e-12
+        for gi, pg in enumerate(opt.param_groups):
+            assert abs(pg['lr'] - row[1 + gi]) < 1e-12
+
+
+def test_flop_model_matches_survey_table():
+    import bench
+    from deepavfusion_amd.configs import CONFIGS
+    gf = {k: 3 * bench.necessary_fwd_flops_per_pair(CONFIGS[k]) / 1e9 for k in ('base', 'base_m75', 'base_as', 'large')}
+    for k, ref in (('base', 176.7), ('base_m75', 187.2), ('base_as', 185.9), ('large', 377.8)):
+        assert abs(gf[k] - ref) / ref < 0.01, (k, gf[k], ref)
+
+
+def test_len_keep_truncation_quirk():
+    assert int(320 * (1 - 0.8)) == 63 and int(196 * (1 - 0.75)) == 49 and int(320 * (1 - 0.75)) == 80
+
+
+def test_bucket_layout_follows_backward_order():
+    from deepavfusion_amd.build_model import build_avmae
+    from deepavfusion_amd.configs import CONFIGS
+    from deepavfusion_amd.util.distributed import GradReducer
+    from deepavfusion_amd.util.flat import FlatParams
+    model = build_avmae(CONFIGS['micro'])
+    flat = FlatParams(reversed(list(model.parameters())))
+    names = {id(p): n for n, p in model.named_parameters()}
+    assert names[id(flat.params[0])].startswith('image_decoder_pred')        # first gradient the backward finishes
+    order = [names[id(p)] for p in flat.params]
+    assert order.index('encoder.image.patch_embed.proj.weight') > order.index('encoder.image.blocks.0.norm1.weight') > order.index('encoder.image.blocks.1.norm1.weight') > order.index('image_decoder_embed.weight')
+    assert all(p.grad.data_ptr() == flat.flat_g.data_ptr() + 4 * o for p, o in zip(flat.params, flat.offsets))
+    red = GradReducer(flat, bucket_mb=1.0, first_bucket_mb=0.25)
+    assert sum(len(b[2]) for b in red.buckets) == len(flat.params) and red.buckets[-1][1] == flat.total
+    assert all(b[0] % 64 == 0 for b in red.buckets)

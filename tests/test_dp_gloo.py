@@ -1,0 +1,86 @@
+"""CPU, world_size 2 over gloo: the bucketed gradient reducer (the DDP replacement of util/misc.py:32-34)
+averages the flat gradient buffer, launches buckets in the same order on every rank, honours no_sync()."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from deepavfusion_amd.util.distributed import DataParallel, get_rank, get_world_size
+    from deepavfusion_amd.util.flat import FlatParams
+    torch.manual_seed(100 + rank)                     # different init per rank: the wrapper must broadcast rank 0's
+    model = torch.nn.Sequential(torch.nn.Linear(40, 300), torch.nn.LayerNorm(300), torch.nn.Linear(300, 300), torch.nn.Linear(300, 7))
+    flat = FlatParams(reversed(list(model.parameters())))
+    dp = DataParallel(model, flat, bucket_mb=0.02, first_bucket_mb=0.005)
+    dp.reducer.comm_stream = None
+    assert get_world_size() == world and get_rank() == rank
+    ref = [p.detach().clone() for p in flat.params]
+    gathered = [torch.zeros_like(flat.flat_p) for _ in range(world)]
+    dist.all_gather(gathered, flat.flat_p)
+    assert all(torch.equal(g, gathered[0]) for g in gathered), 'parameters not broadcast'
+    assert len(dp.reducer.buckets) >= 3
+
+    def fake_backward(scale):
+        dp.reducer.begin_backward()
+        for i, p in enumerate(flat.params):           # the engine's order == flat order
+            p.grad.add_(torch.full_like(p, scale * (rank + 1) * (i + 1)))
+            dp.reducer.grad_ready(p)
+        dp.reducer.finish()
+    fake_backward(1.0)
+    mean_rank = sum(r + 1 for r in range(world)) / world
+    for i, p in enumerate(flat.params):
+        assert torch.allclose(p.grad, torch.full_like(p, mean_rank * (i + 1))), i
+    order1 = list(dp.reducer.launch_order)
+    assert order1 == sorted(order1) and len(order1) == len(dp.reducer.buckets)
+    # gradient accumulation: first micro-step under no_sync() stays local, second one reduces the sum
+    flat.zero_grad()
+    with dp.no_sync():
+        fake_backward(1.0)
+    for i, p in enumerate(flat.params):
+        assert torch.allclose(p.grad, torch.full_like(p, float((rank + 1) * (i + 1))))
+    fake_backward(2.0)
+    for i, p in enumerate(flat.params):
+        assert torch.allclose(p.grad, torch.full_like(p, 3.0 * mean_rank * (i + 1)))
+    # N-rank averaged gradients == single-process gradient of the concatenated batch (mean loss)
+    flat.zero_grad()
+    torch.manual_seed(7)
+    xs = torch.randn(world * 4, 40)
+    x = xs[rank * 4:(rank + 1) * 4]
+    dp.reducer.begin_backward()
+    model(x).pow(2).mean().backward()
+    for p in flat.params:
+        dp.reducer.grad_ready(p)
+    dp.reducer.finish()
+    g_dp = flat.flat_g.clone()
+    flat.zero_grad()
+    model(xs).pow(2).mean().backward()
+    assert torch.allclose(g_dp, flat.flat_g, rtol=1e-4, atol=1e-6)
+    q.put((rank, order1))
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_world2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=5) for _ in range(world))
+    assert res[0] == res[1]          # identical collective order on every rank

@@ -62,7 +62,7 @@ def run(name, B, seed):
         tot_r += float(g_ref.double().norm()) ** 2
     worst.sort(reverse=True)
     print(f'   grad-norm hip={tot_h ** 0.5:.6f} ref={tot_r ** 0.5:.6f}; worst rel-L2 grads:')
-    for e, n, gn in worst[:12]:
+    for e, n, gn in worst[:22]:
         print(f'      {e:.3e}  |g|={gn:.3e}  {n}')
     med = sorted(w[0] for w in worst)[len(worst) // 2]
     print(f'   median grad rel-L2 {med:.3e} over {len(worst)} tensors')
