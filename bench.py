@@ -109,7 +109,7 @@ def main():
         orig = ops.gemm_nt
 
         def logged(A, Bm, M, N, K, **kw):
-            gemm_log.append((M, N, K))
+            gemm_log.append((M, N, K, (kw.get('variant', 0) >> 12) & 1))
             return orig(A, Bm, M, N, K, **kw)
         ops.gemm_nt = logged
 
@@ -168,16 +168,19 @@ def main():
     }
 
     # ---- roofline of the dominant kernel (gemm_nt_kernel<128,128>): replay this step's launch mix --------------
-    big = [(M, N, K) for (M, N, K) in gemm_log if N > 64 and ((M + 127) // 128) * ((N + 127) // 128) >= 256 and K % 64 == 0]
+    # the launches the library's dispatch (gemm.hip: nt_auto_config) sends to the 128x128 / 8-wave kernel
+    big = [(M, N, K, kn) for (M, N, K, kn) in gemm_log if N > 64 and N % 4 == 0 and K % 64 == 0 and ((M + 127) // 128) * ((N + 127) // 128) >= 400]
     if big and not a.no_roofline:
         bufs = {}
-        for (M, N, K) in set(big):
-            bufs[(M, N, K)] = (torch.randn(M, K, device=dev).bfloat16(), (torch.randn(N, K, device=dev) * 0.05).bfloat16(),
-                               torch.empty(M, N, device=dev, dtype=torch.bfloat16))
+        for (M, N, K, kn) in set(big):
+            Bm = (torch.randn(K, N, device=dev) * 0.05).bfloat16() if kn else (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+            bufs[(M, N, K, kn)] = (torch.randn(M, K, device=dev).bfloat16(), Bm, torch.empty(M, N, device=dev, dtype=torch.bfloat16))
+
         def replay():
-            for (M, N, K) in big:
-                A, Bm, C = bufs[(M, N, K)]
-                ops.gemm_nt(A, Bm, M, N, K, C_out=C, c_bf16=True)
+            for key in big:
+                M, N, K, kn = key
+                A, Bm, C = bufs[key]
+                ops.gemm_nt(A, Bm, M, N, K, ldb=N if kn else K, C_out=C, c_bf16=True, variant=kn << 12)
         replay()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
@@ -188,11 +191,15 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         total_ms = e0.elapsed_time(e1) / reps
-        fl = sum(2.0 * M * N * K for (M, N, K) in big)
+        fl = sum(2.0 * M * N * K for (M, N, K, _) in big)
         ach = fl / (total_ms * 1e-3) / 1e12
-        result['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_nt_kernel<128,128,glds>', 'achieved': round(ach, 1),
+        traffic = None          # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KiB), see profiles/
+        tf = os.path.join(ROOT, 'profiles', 'dominant_kernel_traffic.json')
+        if os.path.exists(tf):
+            traffic = json.load(open(tf)).get(a.config, {}).get('hbm_bytes_per_launch')
+        result['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_nt2_kernel<128,128,2,4,2> (fwd + b_kn dgrad)', 'achieved': round(ach, 1),
                               'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-                              'traffic': None, 'launches_per_step': len(big),
+                              'traffic': traffic, 'launches_per_step': len(big),
                               'avg_launch_us': round(total_ms * 1e3 / len(big), 2),
                               'avg_gflop_per_launch': round(fl / len(big) / 1e9, 3)}
 
