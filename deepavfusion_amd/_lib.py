@@ -21,8 +21,10 @@ _p, _i, _l, _f, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 SIGNATURES = {
     'dav_abi_version': [],
     'dav_last_error_string': [],
+    'dav_tune': [_i, _i],
     'dav_gemm_nt_bf16': [_p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _f, _i, _p],
     'dav_gemm_tn_bf16': [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _i, _p],
+    'dav_gemm_tn_grouped_bf16': [_p, _i, _p],
     'dav_attn_fwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _i, _l, _i, _l, _i, _l, _i, _f, _p],
     'dav_attn_bwd': [_p] * 10 + [_i] * 6 + [_l, _i] * 8 + [_f, _p],
     'dav_layernorm_fwd': [_p, _l, _i, _p, _l, _i, _i, _i, _p, _p, _f, _p, _p, _p, _p, _p],
@@ -31,6 +33,7 @@ SIGNATURES = {
                           _p, _l, _i, _p, _l, _p, _l,
                           _p, _p, _p, _sz, _p],
     'dav_layernorm_bwd_workspace_bytes': [_i, _i],
+    'dav_layernorm_bwd_reduce_grouped': [_p, _i, _p],
     'dav_mask_build': [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p],
     'dav_patch_gather': [_p, _i, _i, _i, _i, _p, _i, _p, _p],
     'dav_unshuffle_fwd': [_p, _p, _p, _p, _i, _i, _i, _i, _p, _l, _i, _p],
@@ -46,6 +49,16 @@ SIGNATURES = {
     'dav_l2norm': [_p, _l, _f, _p, _p, _sz, _p],
     'dav_adamw_flat': [_p, _p, _p, _p, _p, _l, _p, _p, _i, _f, _f, _f, _p, _f, _p],
 }
+
+class DavLnReduce(C.Structure):
+    _fields_ = [('workspace', C.c_void_p), ('dgamma', C.c_void_p), ('dbeta', C.c_void_p), ('rows', C.c_int), ('D', C.c_int)]
+
+
+class DavTnProblem(C.Structure):
+    _fields_ = [('A', C.c_void_p), ('B', C.c_void_p), ('C', C.c_void_p), ('bias_grad', C.c_void_p),
+                ('Mc', C.c_int), ('N', C.c_int), ('K', C.c_int), ('lda', C.c_int), ('ldb', C.c_int), ('ldc', C.c_int),
+                ('a_rowmap', C.c_int * 3), ('b_rowmap', C.c_int * 3)]
+
 
 ERRORS = {-1: 'bad shape', -2: 'unsupported dtype', -3: 'insufficient workspace', -4: 'HIP error', -5: 'misaligned pointer/stride'}
 

@@ -82,6 +82,11 @@ def encoder_fwd(enc, image, audio, ik32, ak32, want_f32=False, collect_embs=Fals
 
 def encoder_bwd(enc, t, dxi_b=None, dxa_b=None, dxf_b=None, dxi32=None, dxa32=None, dxf32=None):
     """Gradients w.r.t. the three NORMED outputs (bf16 and/or fp32 parts) -> parameter gradients."""
+    with E.deferred_wgrads():
+        _encoder_bwd(enc, t, dxi_b, dxa_b, dxf_b, dxi32, dxa32, dxf32)
+
+
+def _encoder_bwd(enc, t, dxi_b, dxa_b, dxf_b, dxi32, dxa32, dxf32):
     B = t['B']
     dev = t['x_i'].device
 
@@ -117,10 +122,12 @@ def encoder_bwd(enc, t, dxi_b=None, dxa_b=None, dxf_b=None, dxi32=None, dxa32=No
                                           before_ln1=lambda: main.wait_stream(sf))
             main.wait_stream(sa)
             g_f, g_fb = (dx_f + dxf_a) if sa is not main else dx_f.add_(dxf_a), None
+        E.flush_wgrads()          # every wgrad of this layer (both towers + fusion block) as one grouped GEMM
     E.patch_embed_bwd(enc.image, t['t_pi'], g_i, g_ib)
     E.patch_embed_bwd(enc.audio, t['t_pa'], g_a, g_ab)
     E.gbuf(enc.fusion_tokens).add_(g_f.sum(dim=0, keepdim=True))          # backward of .expand(B, -1, -1)
     E._ready(enc.fusion_tokens)
+    E.join_wgrad_stream(dev)                                               # all parameter gradients final on this stream
 
 
 class _EncoderFn(torch.autograd.Function):
@@ -189,6 +196,7 @@ class _FusionBlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         dx_f, dx_i, dx_a = E.fusion_block_bwd(ctx.fb, ctx.tape, g.contiguous(), None)
+        E.join_wgrad_stream(g.device)
         return (None, dx_f, dx_i, dx_a) + (None,) * ctx.np
 
 
@@ -229,15 +237,17 @@ def avmae_bwd(model, t, g_li, g_la, g_pi=None, g_pa=None):
     dec_i, dec_a = model.decoder('image'), model.decoder('audio')
     main, sa, _ = _streams(t['image'].device)
     sa.wait_stream(main)
-    with torch.cuda.stream(sa):
+    # each decoder's weight gradients are queued and launched as ONE grouped GEMM on that decoder's stream
+    with torch.cuda.stream(sa), E.deferred_wgrads():
         dpa = E.loss_bwd(t['audio'], t['pred_a'], t['am'], t['t_la'], g_la)
         if g_pa is not None:
             dpa = (dpa.float() + g_pa.reshape(dpa.shape)).to(BF16)
         dxa_b, dxf_a = E.decoder_bwd(dec_a, t['t_da'], dpa, t['ak32'], B)
-    dpi = E.loss_bwd(t['image'], t['pred_i'], t['im'], t['t_li'], g_li)
-    if g_pi is not None:
-        dpi = (dpi.float() + g_pi.reshape(dpi.shape)).to(BF16)
-    dxi_b, dxf_i = E.decoder_bwd(dec_i, t['t_di'], dpi, t['ik32'], B)
+    with E.deferred_wgrads():
+        dpi = E.loss_bwd(t['image'], t['pred_i'], t['im'], t['t_li'], g_li)
+        if g_pi is not None:
+            dpi = (dpi.float() + g_pi.reshape(dpi.shape)).to(BF16)
+        dxi_b, dxf_i = E.decoder_bwd(dec_i, t['t_di'], dpi, t['ik32'], B)
     main.wait_stream(sa)
     dxf32 = dxf_i.float() + dxf_a.float()            # both decoders read the same normed fusion tokens
     encoder_bwd(model.encoder, t['t_enc'], dxi_b=dxi_b, dxa_b=dxa_b, dxf32=dxf32)

@@ -45,6 +45,7 @@ struct TNParams {
   int beta;                           // 0: overwrite (only legal with splits == 1), 1: accumulate
   int splits;                         // split of the contraction over blockIdx.y (atomic accumulate)
   float* bias_grad;                   // optional: column sums of A accumulated into [N]
+  int debug_plain_store;              // timing experiments only (variant bit 8): plain stores instead of atomics
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -591,7 +592,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TNParams p) {
 // atomics into the live gradient.
 // ------------------------------------------------------------------------------------------------
 template <int T, int WM_, int WN_>
-__global__ __launch_bounds__(WM_* WN_ * 64) void gemm_tn2_kernel(TNParams p) {
+__device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, const int split_idx) {
   constexpr int NT = WM_ * WN_ * 64, RB = T * 2, CPRW = T / 8;      // 16-byte chunks per tile row
   constexpr int TILE_BYTES = 64 * RB, STAGE_BYTES = 2 * TILE_BYTES;
   constexpr int CH = 64 * CPRW / NT;                                // chunks per thread per operand
@@ -601,11 +602,11 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void gemm_tn2_kernel(TNParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN_, wn = wave % WN_;
   const int tiles_k = (p.K + T - 1) / T;
-  const int bn = blockIdx.x / tiles_k, bk = blockIdx.x % tiles_k;
+  const int bn = tile_idx / tiles_k, bk = tile_idx % tiles_k;
   const int n0 = bn * T, k0 = bk * T;
   const int steps_total = p.Mc >> 6;
   const int steps_per = (steps_total + p.splits - 1) / p.splits;
-  const int s_begin = blockIdx.y * steps_per;
+  const int s_begin = split_idx * steps_per;
   int s_end = s_begin + steps_per; s_end = s_end < steps_total ? s_end : steps_total;
   if (s_begin >= s_end) return;
 
@@ -669,7 +670,9 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void gemm_tn2_kernel(TNParams p) {
   }
 
   const int fr = lane & 15, fg = lane >> 4;
-  const bool atomic = p.splits > 1 || p.beta;
+  // splits > 1: partial sums meet through fp32 atomics; splits == 1: this workgroup owns the tile (plain
+  // read-modify-write when accumulating)
+  const bool atomic = p.splits > 1 && !p.debug_plain_store;
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -682,10 +685,38 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void gemm_tn2_kernel(TNParams p) {
         if (k >= p.K) continue;
         float* c = p.C + (long)n * p.ldc + k;
         if (atomic) unsafeAtomicAdd(c, acc[i][j][r]);
+        else if (p.beta) *c += acc[i][j][r];
         else *c = acc[i][j][r];
       }
-      if (do_bias && fr == 0) unsafeAtomicAdd(p.bias_grad + n, accb[i][r]);
+      if (do_bias && fr == 0) {
+        if (p.splits > 1) unsafeAtomicAdd(p.bias_grad + n, accb[i][r]);
+        else p.bias_grad[n] += accb[i][r];
+      }
     }
+}
+
+template <int T, int WM_, int WN_>
+__global__ __launch_bounds__(WM_* WN_ * 64) void gemm_tn2_kernel(TNParams p) {
+  tn2_body<T, WM_, WN_>(p, blockIdx.x, blockIdx.y);
+}
+
+// grouped launch: up to TN_GROUP_MAX independent weight-gradient problems in ONE grid (the deferred wgrads of a
+// whole layer), each workgroup looks its (problem, tile, split) up from the by-value table
+constexpr int TN_GROUP_MAX = 32;
+struct TNGroup {
+  TNParams prob[TN_GROUP_MAX];
+  int first_block[TN_GROUP_MAX + 1];
+  int count;
+};
+
+template <int T, int WM_, int WN_>
+__global__ __launch_bounds__(WM_* WN_ * 64) void gemm_tn_grouped_kernel(const TNGroup g) {
+  int pi = 0;
+  while (pi + 1 < g.count && (int)blockIdx.x >= g.first_block[pi + 1]) ++pi;
+  const TNParams& p = g.prob[pi];
+  const int local = blockIdx.x - g.first_block[pi];
+  const int tiles = ((p.N + T - 1) / T) * ((p.K + T - 1) / T);
+  tn2_body<T, WM_, WN_>(p, local % tiles, local / tiles);
 }
 
 template <int T, int WM_, int WN_>
@@ -779,6 +810,39 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
   return dav_launch_status();
 }
 
+extern "C" int dav_gemm_tn_grouped_bf16(const DavTnProblem* probs, int count, hipStream_t stream) {
+  if (count <= 0 || count > TN_GROUP_MAX) return DAV_ERR_SHAPE;
+  static TNGroup g;          // host staging; copied by value into the kernel arguments at launch
+  long total_tiles = 0;
+  for (int i = 0; i < count; ++i) {
+    const DavTnProblem& q = probs[i];
+    if (q.Mc <= 0 || (q.Mc & 63) || q.N <= 0 || q.K <= 0 || (q.N & 7) || (q.K & 7) || (q.lda & 7) || (q.ldb & 7)) return DAV_ERR_SHAPE;
+    if (((uintptr_t)q.A | (uintptr_t)q.B) & 15) return DAV_ERR_ALIGN;
+    total_tiles += (long)((q.N + 127) / 128) * ((q.K + 127) / 128);
+  }
+  // aim at ~4 workgroups of 8 waves per CU-slot pair (1024 blocks) but keep >= 8 k-steps of 64 rows per split
+  int first = 0;
+  for (int i = 0; i < count; ++i) {
+    const DavTnProblem& q = probs[i];
+    TNParams& p = g.prob[i];
+    p.A = (const bf16_t*)q.A; p.B = (const bf16_t*)q.B; p.Mc = q.Mc; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = q.ldb;
+    p.amap = RowMap{q.a_rowmap[0], q.a_rowmap[1], q.a_rowmap[2]};
+    p.bmap = RowMap{q.b_rowmap[0], q.b_rowmap[1], q.b_rowmap[2]};
+    p.C = q.C; p.ldc = q.ldc; p.beta = 1; p.bias_grad = q.bias_grad; p.debug_plain_store = 0;
+    const int tiles = ((q.N + 127) / 128) * ((q.K + 127) / 128), steps = q.Mc >> 6;
+    int splits = (int)((1024 + total_tiles - 1) / total_tiles);
+    const int max_splits = steps / 8 > 0 ? steps / 8 : 1;
+    if (splits > max_splits) splits = max_splits;
+    p.splits = splits;
+    g.first_block[i] = first;
+    first += tiles * splits;
+  }
+  g.first_block[count] = first;
+  g.count = count;
+  DAV_LAUNCH((gemm_tn_grouped_kernel<128, 2, 4>), dim3(first), dim3(512), (size_t)2 * 2 * 64 * 128 * 2, stream, g);
+  return dav_launch_status();
+}
+
 extern "C" int dav_gemm_tn_bf16(const void* A, const void* B, int Mc, int N, int K, int lda, int ldb,
                                 const int* a_rowmap, const int* b_rowmap, float* C, int ldc, int beta,
                                 float* bias_grad, int variant, hipStream_t stream) {
@@ -787,13 +851,15 @@ extern "C" int dav_gemm_tn_bf16(const void* A, const void* B, int Mc, int N, int
   TNParams p;
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.Mc = Mc; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb;
   p.amap = mk(a_rowmap); p.bmap = mk(b_rowmap); p.C = C; p.ldc = ldc; p.beta = beta; p.bias_grad = bias_grad;
+  p.debug_plain_store = (variant >> 8) & 1;
+  variant &= ~256;
   const int steps = (Mc + 63) / 64;
   const int cfg = variant >> 4;           // 0 auto, 1 = 128x128 tiles, 2 = 64x64 tiles (benchmark knob)
   if (!(variant & 15) && (Mc & 63) == 0 && (beta || cfg)) {
     const int t128 = ((N + 127) / 128) * ((K + 127) / 128), t64 = ((N + 63) / 64) * ((K + 63) / 64);
     const bool big = cfg ? cfg == 1 : (Mc >= 20000 && t128 >= 48);   // 64x64 tiles win except on the longest contractions
     const int tiles = big ? t128 : t64;
-    int splits = beta ? (768 + tiles - 1) / tiles : 1;
+    int splits = beta ? (768 + tiles - 1) / tiles : 1;      // accumulate mode may split the contraction
     const int max_splits = steps / 6 > 0 ? steps / 6 : 1;      // at least ~6 k-steps of 64 rows per split
     if (splits > max_splits) splits = max_splits;
     p.splits = splits;

@@ -100,11 +100,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LNFwd p) {
   }
 }
 
-// dgamma/dbeta: the 4 waves of a workgroup combine their partial sums in LDS and write ONE partial row
+// 8 waves per workgroup (512 workgroups -> 16 waves/CU in flight).  dgamma/dbeta: the waves of a workgroup combine their partial sums in LDS and write ONE partial row
 // [2*D] per workgroup to the caller's workspace; ln_bwd_reduce_kernel then sums the rows (no same-address
 // atomics, which serialise in L2 when hundreds of workgroups hit the same 2*D words).
 template <int MAXC>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwd p) {
+__global__ __launch_bounds__(512) void ln_bwd_kernel(LNBwd p) {
   extern __shared__ __attribute__((aligned(16))) float lds_red[];   // [2][D]
   const int lane = threadIdx.x & 63;
   const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LNBwd p) {
     }
   }
 
-  if (p.dgamma == nullptr) return;
+  if (p.partial == nullptr) return;
   for (int c = threadIdx.x; c < 2 * p.D; c += blockDim.x) lds_red[c] = 0.f;
   __syncthreads();
 #pragma unroll
@@ -215,9 +215,50 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* partia
   }
 }
 
+// grouped form: up to LN_GROUP_MAX deferred (partial, nrows, D, dgamma, dbeta) reductions in one launch
+constexpr int LN_GROUP_MAX = 64;
+struct LNReduceGroup {
+  const float* partial[LN_GROUP_MAX];
+  float* dgamma[LN_GROUP_MAX];
+  float* dbeta[LN_GROUP_MAX];
+  int nrows[LN_GROUP_MAX], D[LN_GROUP_MAX], first_block[LN_GROUP_MAX + 1];
+  int count;
+};
+
+__global__ __launch_bounds__(1024) void ln_bwd_reduce_grouped_kernel(const LNReduceGroup g) {
+  __shared__ float red[16][65];
+  int pi = 0;
+  while (pi + 1 < g.count && (int)blockIdx.x >= g.first_block[pi + 1]) ++pi;
+  const float* partial = g.partial[pi];
+  const int nrows = g.nrows[pi], D = g.D[pi];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = (blockIdx.x - g.first_block[pi]) * 64 + tx;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < 2 * D) {
+    int r = ty;
+    for (; r + 48 < nrows; r += 64) {
+      s0 += partial[(size_t)r * 2 * D + c];
+      s1 += partial[(size_t)(r + 16) * 2 * D + c];
+      s2 += partial[(size_t)(r + 32) * 2 * D + c];
+      s3 += partial[(size_t)(r + 48) * 2 * D + c];
+    }
+    for (; r < nrows; r += 16) s0 += partial[(size_t)r * 2 * D + c];
+  }
+  red[ty][tx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ty == 0 && c < 2 * D) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += red[i][tx];
+    if (c < D) g.dgamma[pi][c] += s; else g.dbeta[pi][c - D] += s;
+  }
+}
+
+int g_ln_bwd_waves = 4, g_ln_bwd_cap = 512;     // best of tools/ln_bench.py on MI355X; knobs: dav_tune 1 / 2
+
 int ln_bwd_grid(int rows) {
-  int g = (rows + 3) / 4;
-  return g > 512 ? 512 : (g < 1 ? 1 : g);
+  int g = (rows + g_ln_bwd_waves - 1) / g_ln_bwd_waves;
+  return g > g_ln_bwd_cap ? g_ln_bwd_cap : (g < 1 ? 1 : g);
 }
 
 int ln_grid(int rows) {
@@ -243,6 +284,29 @@ extern "C" int dav_layernorm_fwd(const float* x0, long x0_bs, int r0, const floa
   return dav_launch_status();
 }
 
+extern "C" int dav_layernorm_bwd_reduce_grouped(const DavLnReduce* items, int count, hipStream_t stream) {
+  if (count <= 0 || count > LN_GROUP_MAX) return DAV_ERR_SHAPE;
+  static LNReduceGroup g;
+  int first = 0;
+  for (int i = 0; i < count; ++i) {
+    if (items[i].D <= 0 || items[i].rows <= 0) return DAV_ERR_SHAPE;
+    g.partial[i] = (const float*)items[i].workspace; g.dgamma[i] = items[i].dgamma; g.dbeta[i] = items[i].dbeta;
+    g.nrows[i] = ln_bwd_grid(items[i].rows); g.D[i] = items[i].D;
+    g.first_block[i] = first;
+    first += (2 * items[i].D + 63) / 64;
+  }
+  g.first_block[count] = first;
+  g.count = count;
+  DAV_LAUNCH(ln_bwd_reduce_grouped_kernel, dim3(first), dim3(1024), 0, stream, g);
+  return dav_launch_status();
+}
+
+extern "C" int dav_tune(int knob, int value) {
+  if (knob == 1 && (value == 2 || value == 4 || value == 8)) { g_ln_bwd_waves = value; return DAV_OK; }
+  if (knob == 2 && value >= 1 && value <= 4096) { g_ln_bwd_cap = value; return DAV_OK; }
+  return DAV_ERR_SHAPE;
+}
+
 extern "C" size_t dav_layernorm_bwd_workspace_bytes(int rows, int D) {
   return (size_t)ln_bwd_grid(rows) * 2 * D * sizeof(float);
 }
@@ -255,7 +319,8 @@ extern "C" int dav_layernorm_bwd(const float* x0, long x0_bs, int r0, const floa
                                  float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (B <= 0 || D <= 0 || (D & 3) || D > MAXC_LIMIT * 256 || r0 < 0 || r1 < 0 || r0 + r1 <= 0) return DAV_ERR_SHAPE;
   if (!dy_bf16 && !dy_f32) return DAV_ERR_SHAPE;
-  if (dgamma && workspace_bytes < dav_layernorm_bwd_workspace_bytes(B * (r0 + r1), D)) return DAV_ERR_WORKSPACE;
+  if (workspace && workspace_bytes < dav_layernorm_bwd_workspace_bytes(B * (r0 + r1), D)) return DAV_ERR_WORKSPACE;
+  if (dgamma && !workspace) return DAV_ERR_WORKSPACE;
   LNBwd p;
   p.s0 = LNSeg{x0, x0_bs, r0}; p.s1 = LNSeg{x1, x1_bs, r1}; p.B = B; p.D = D;
   p.d0 = LNDst{dx0, dx0_bs, r0, acc0, res0, res0_bs, (bf16_t*)dx0_bf16, dx0_bf_bs};
@@ -266,11 +331,11 @@ extern "C" int dav_layernorm_bwd(const float* x0, long x0_bs, int r0, const floa
   const int grid = ln_bwd_grid(B * (r0 + r1));
   const int nch = (D / 4 + 63) / 64;
   const size_t lds = (size_t)2 * D * sizeof(float);
-  if (nch <= 1) DAV_LAUNCH(ln_bwd_kernel<1>, dim3(grid), dim3(256), lds, stream, p);
-  else if (nch == 2) DAV_LAUNCH(ln_bwd_kernel<2>, dim3(grid), dim3(256), lds, stream, p);
-  else if (nch == 3) DAV_LAUNCH(ln_bwd_kernel<3>, dim3(grid), dim3(256), lds, stream, p);
-  else if (nch == 4) DAV_LAUNCH(ln_bwd_kernel<4>, dim3(grid), dim3(256), lds, stream, p);
-  else DAV_LAUNCH(ln_bwd_kernel<8>, dim3(grid), dim3(256), lds, stream, p);
+  if (nch <= 1) DAV_LAUNCH(ln_bwd_kernel<1>, dim3(grid), dim3(64 * g_ln_bwd_waves), lds, stream, p);
+  else if (nch == 2) DAV_LAUNCH(ln_bwd_kernel<2>, dim3(grid), dim3(64 * g_ln_bwd_waves), lds, stream, p);
+  else if (nch == 3) DAV_LAUNCH(ln_bwd_kernel<3>, dim3(grid), dim3(64 * g_ln_bwd_waves), lds, stream, p);
+  else if (nch == 4) DAV_LAUNCH(ln_bwd_kernel<4>, dim3(grid), dim3(64 * g_ln_bwd_waves), lds, stream, p);
+  else DAV_LAUNCH(ln_bwd_kernel<8>, dim3(grid), dim3(64 * g_ln_bwd_waves), lds, stream, p);
   if (dgamma) DAV_LAUNCH(ln_bwd_reduce_kernel, dim3((2 * D + 63) / 64), dim3(1024), 0, stream, (const float*)workspace, grid, D, dgamma, dbeta);
   return dav_launch_status();
 }

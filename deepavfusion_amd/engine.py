@@ -16,6 +16,7 @@ final through ``set_grad_ready_hook``.
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Dict, List, Optional
 
 import torch
@@ -120,6 +121,84 @@ def _e(shape, dtype, dev):
 
 
 # ------------------------------------------------------------------------------------------------
+# deferred weight gradients: inside `deferred_wgrads()` lin_bwd only records its wgrad problem;
+# `flush_wgrads()` launches everything recorded so far as one grouped GEMM (dav_gemm_tn_grouped_bf16)
+# and then reports the parameters ready.  DAV_GROUPED_WGRAD=0 restores one launch per weight.
+# ------------------------------------------------------------------------------------------------
+_DEFERRED = None
+_DEFERRED_LN = None          # deferred LayerNorm dgamma/dbeta reductions (partial-row workspaces)
+_DEFERRED_LN_READY = []
+
+
+class deferred_wgrads:
+    def __enter__(self):
+        global _DEFERRED, _DEFERRED_LN
+        self.prev = (_DEFERRED, _DEFERRED_LN)
+        on = os.environ.get('DAV_GROUPED_WGRAD', '1') != '0'
+        _DEFERRED = [] if on else None
+        _DEFERRED_LN = [] if on else None
+        return self
+
+    def __exit__(self, *exc):
+        global _DEFERRED, _DEFERRED_LN
+        if exc[0] is None:
+            flush_wgrads()
+        _DEFERRED, _DEFERRED_LN = self.prev
+
+
+def flush_wgrads():
+    """Launch the queued weight-gradient problems on the current stream (their operands must be complete on it)."""
+    if _DEFERRED_LN:
+        items = list(_DEFERRED_LN)
+        del _DEFERRED_LN[:]
+        ops.layernorm_bwd_reduce_grouped(items)
+        for pair in _DEFERRED_LN_READY:
+            _ready(*pair)
+        del _DEFERRED_LN_READY[:]
+    if not _DEFERRED:
+        return
+    probs = list(_DEFERRED)
+    del _DEFERRED[:]
+    # a grouped launch lets ONE workgroup own each output tile (plain read-modify-write), so two problems that
+    # accumulate into the same weight (decoder_embed: patch tokens and fusion tokens) must not share a launch
+    while probs:
+        seen, now, later = set(), [], []
+        for pr in probs:
+            key = pr['C'].data_ptr()
+            (later if key in seen else now).append(pr)
+            seen.add(key)
+        ops.gemm_tn_grouped(now)
+        for pr in now:
+            _ready(*pr['ready'])
+        probs = later
+
+
+# ------------------------------------------------------------------------------------------------
+# weight-gradient stream: wgrad GEMMs depend only on tensors that already exist and nothing in the
+# backward chain waits for them, so they are enqueued on their own stream (a parallel graph branch)
+# and could fill CUs the dgrad chain leaves idle.  Measured slower on MI355X (extra cross-stream edges, L2 thrash),
+# so it is opt-in: DAV_WGRAD_STREAM=1.
+# ------------------------------------------------------------------------------------------------
+_WGRAD_STREAMS = {}
+
+
+def wgrad_stream(dev):
+    if os.environ.get('DAV_WGRAD_STREAM', '0') != '1':      # measured: a loss on MI355X (46.6 vs 38.4 ms/step); off by default
+        return None
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _WGRAD_STREAMS:
+        _WGRAD_STREAMS[key] = torch.cuda.Stream(dev)
+    return _WGRAD_STREAMS[key]
+
+
+def join_wgrad_stream(dev):
+    """Make the current stream wait for every weight-gradient kernel enqueued so far."""
+    sw = _WGRAD_STREAMS.get(dev.index if dev.index is not None else torch.cuda.current_device())
+    if sw is not None:
+        torch.cuda.current_stream(dev).wait_stream(sw)
+
+
+# ------------------------------------------------------------------------------------------------
 # primitives
 # ------------------------------------------------------------------------------------------------
 def ln_fwd(norm, x0, x1, B, eps=None, want_f32=False, want_bf16=True):
@@ -150,8 +229,11 @@ def ln_bwd(norm, x0, x1, B, stats, dy_bf16=None, dy_f32=None, *, dx0=None, acc0=
     ops.layernorm_bwd(x0, r0 * D, r0, x1, r1 * D, r1, B, D, dy_bf16, dy_f32, norm.weight, stats[0], stats[1],
                       dx0, r0 * D, acc0, res0, r0 * D, dx0_bf16, r0 * D,
                       dx1, r1 * D, acc1, res1, r1 * D, dx1_bf16, r1 * D,
-                      gbuf(norm.weight), gbuf(norm.bias))
-    _ready(norm.weight, norm.bias)
+                      gbuf(norm.weight), gbuf(norm.bias), defer=_DEFERRED_LN)
+    if _DEFERRED_LN is None:
+        _ready(norm.weight, norm.bias)
+    else:
+        _DEFERRED_LN_READY.append((norm.weight, norm.bias))
 
 
 def lin_fwd(lin, a, M, *, a_rowmap=None, lda=None, act=0, res=None, res_rowmap=None, out=None, out_bf16=False,
@@ -194,8 +276,24 @@ def lin_bwd(lin, dy, a, M, *, dy_rowmap=None, a_rowmap=None, lda=None, need_dx=T
     gw = gbuf(lin.weight)
     gwv = gw.view(N, -1)
     Cw = gwv if w_col_off == 0 else gwv.view(-1)[w_col_off:]
-    ops.gemm_tn(dy, a, M, N, K, Cw, lda=N, ldb=lda if lda is not None else K, ldc=Kfull, a_rowmap=dy_rowmap,
-                b_rowmap=a_rowmap, beta=1, bias_grad=gbuf(lin.bias) if (use_bias and lin.bias is not None) else None)
+    gb = gbuf(lin.bias) if (use_bias and lin.bias is not None) else None
+    sw = wgrad_stream(dev)
+    if _DEFERRED is not None and M % 64 == 0 and N % 8 == 0 and K % 8 == 0:
+        # weight gradients are off the dependency chain: queue them and launch ONE grouped GEMM per layer
+        _DEFERRED.append(dict(A=dy, B=a, Mc=M, N=N, K=K, C=Cw, lda=N, ldb=lda if lda is not None else K, ldc=Kfull,
+                              a_rowmap=dy_rowmap, b_rowmap=a_rowmap, bias_grad=gb,
+                              ready=(lin.weight, lin.bias) if final else ()))
+        return dx
+    if sw is None:
+        ops.gemm_tn(dy, a, M, N, K, Cw, lda=N, ldb=lda if lda is not None else K, ldc=Kfull, a_rowmap=dy_rowmap,
+                    b_rowmap=a_rowmap, beta=1, bias_grad=gb)
+    else:
+        sw.wait_stream(torch.cuda.current_stream(dev))
+        dy.record_stream(sw)          # keep the operands' memory from being recycled before the side stream read them
+        a.record_stream(sw)
+        with torch.cuda.stream(sw):
+            ops.gemm_tn(dy, a, M, N, K, Cw, lda=N, ldb=lda if lda is not None else K, ldc=Kfull, a_rowmap=dy_rowmap,
+                        b_rowmap=a_rowmap, beta=1, bias_grad=gb)
     if final:
         _ready(lin.weight, lin.bias)
     return dx

@@ -54,6 +54,20 @@ def gemm_tn(A, B, Mc, N, K, C_out, *, lda=None, ldb=None, ldc=None, a_rowmap=Non
                                     _ptr(bias_grad), variant, _stream()), 'dav_gemm_tn_bf16')
 
 
+def gemm_tn_grouped(problems):
+    """problems: list of dicts(A, B, Mc, N, K, C, lda, ldb, ldc, a_rowmap, b_rowmap, bias_grad); see dav_gemm_tn_grouped_bf16."""
+    lib = _lib.load()
+    for i in range(0, len(problems), 32):
+        chunk = problems[i:i + 32]
+        arr = (_lib.DavTnProblem * len(chunk))()
+        for q, d in zip(arr, chunk):
+            q.A, q.B, q.C, q.bias_grad = _ptr(d['A']), _ptr(d['B']), _ptr(d['C']), _ptr(d.get('bias_grad'))
+            q.Mc, q.N, q.K, q.lda, q.ldb, q.ldc = d['Mc'], d['N'], d['K'], d['lda'], d['ldb'], d['ldc']
+            q.a_rowmap[:] = d.get('a_rowmap') or (0, 0, 0)
+            q.b_rowmap[:] = d.get('b_rowmap') or (0, 0, 0)
+        _lib.check(lib.dav_gemm_tn_grouped_bf16(arr, len(chunk), _stream()), 'dav_gemm_tn_grouped_bf16')
+
+
 def attn_fwd(q_ptr, k_ptr, v_ptr, O, LSE, B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, scale):
     lib = _lib.load()
     _lib.check(lib.dav_attn_fwd(q_ptr, k_ptr, v_ptr, _ptr(O), _ptr(LSE), B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs,
@@ -76,17 +90,33 @@ def layernorm_fwd(x0, x0_bs, r0, x1, x1_bs, r1, B, D, gamma, beta, eps, y_bf16, 
 
 def layernorm_bwd(x0, x0_bs, r0, x1, x1_bs, r1, B, D, dy_bf16, dy_f32, gamma, mean, rstd,
                   dx0=None, dx0_bs=0, acc0=0, res0=None, res0_bs=0, dx0_bf16=None, dx0_bf_bs=0,
-                  dx1=None, dx1_bs=0, acc1=0, res1=None, res1_bs=0, dx1_bf16=None, dx1_bf_bs=0, dgamma=None, dbeta=None):
+                  dx1=None, dx1_bs=0, acc1=0, res1=None, res1_bs=0, dx1_bf16=None, dx1_bf_bs=0, dgamma=None, dbeta=None,
+                  defer=None):
+    """``defer``: a list; when given, only the partial dgamma/dbeta rows are produced and
+    (workspace, dgamma, dbeta, rows, D) is appended for a later ``layernorm_bwd_reduce_grouped``."""
     lib = _lib.load()
     ws = None
     if dgamma is not None:
         ws = torch.empty(lib.dav_layernorm_bwd_workspace_bytes(B * (r0 + r1), D) // 4, dtype=F32, device=dgamma.device)
+        if defer is not None:
+            defer.append((ws, dgamma, dbeta, B * (r0 + r1), D))
+            dgamma = dbeta = None
     _lib.check(lib.dav_layernorm_bwd(_ptr(x0), x0_bs, r0, _ptr(x1), x1_bs, r1, B, D, _ptr(dy_bf16), _ptr(dy_f32),
                                      _ptr(gamma), _ptr(mean), _ptr(rstd),
                                      _ptr(dx0), dx0_bs, acc0, _ptr(res0), res0_bs, _ptr(dx0_bf16), dx0_bf_bs,
                                      _ptr(dx1), dx1_bs, acc1, _ptr(res1), res1_bs, _ptr(dx1_bf16), dx1_bf_bs,
                                      _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()),
                'dav_layernorm_bwd')
+
+
+def layernorm_bwd_reduce_grouped(items):
+    lib = _lib.load()
+    for i in range(0, len(items), 64):
+        chunk = items[i:i + 64]
+        arr = (_lib.DavLnReduce * len(chunk))()
+        for q, (ws, dg, db, rows, D) in zip(arr, chunk):
+            q.workspace, q.dgamma, q.dbeta, q.rows, q.D = _ptr(ws), _ptr(dg), _ptr(db), rows, D
+        _lib.check(lib.dav_layernorm_bwd_reduce_grouped(arr, len(chunk), _stream()), 'dav_layernorm_bwd_reduce_grouped')
 
 
 def mask_build(noise: torch.Tensor, len_keep: int):

@@ -156,6 +156,9 @@ class GradReducer:
         view = self.flat.flat_g[lo:hi]
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
+            sw = engine.wgrad_stream(view.device)          # weight gradients are produced on their own stream
+            if sw is not None:
+                self.comm_stream.wait_stream(sw)
             with torch.cuda.stream(self.comm_stream):
                 dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group)
         else:                                     # gloo (CPU tests): no AVG op

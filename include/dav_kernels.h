@@ -38,6 +38,8 @@ extern "C" {
 int dav_abi_version(void);
 /* text of the last HIP error latched by a kernel launch of the calling thread (diagnostics) */
 const char* dav_last_error_string(void);
+/* launch-geometry knobs for tuning experiments (1: LayerNorm-backward waves per workgroup {2,4,8}; 2: its grid cap) */
+int dav_tune(int knob, int value);
 
 /* ---- GEMM --------------------------------------------------------------------------------- */
 /* C[M,N] = epi(alpha * A[M,K] . B[N,K]^T): every nn.Linear forward on the path (timm Attention.qkv/proj,
@@ -62,6 +64,18 @@ int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int K, int lda,
  * variant bit0: scalar LDS reads instead of ds_read_b64_tr_b16. */
 int dav_gemm_tn_bf16(const void* A, const void* B, int Mc, int N, int K, int lda, int ldb, const int* a_rowmap,
                      const int* b_rowmap, float* C, int ldc, int beta, float* bias_grad, int variant, hipStream_t stream);
+
+/* Several weight-gradient problems (C_i[N_i,K_i] += A_i^T . B_i, optional bias_grad_i) in ONE launch — the deferred
+ * wgrads of a whole layer — so that every 128x128 output tile is owned by one workgroup over (most of) its
+ * contraction: no or very few split-K atomics.  count <= 32; every Mc_i % 64 == 0.  Row maps as above
+ * ({0,0,0} = identity).  The table is read on the host during the call only. */
+typedef struct DavTnProblem {
+  const void* A; const void* B;       /* bf16 [Mc, N] (lda), bf16 [Mc, K] (ldb) */
+  float* C; float* bias_grad;         /* fp32 [N, K] (ldc), fp32 [N] or NULL; both accumulated */
+  int Mc, N, K, lda, ldb, ldc;
+  int a_rowmap[3], b_rowmap[3];
+} DavTnProblem;
+int dav_gemm_tn_grouped_bf16(const DavTnProblem* problems, int count, hipStream_t stream);
 
 /* ---- attention ---------------------------------------------------------------------------- */
 /* softmax(scale * Q K^T) V per (batch, head); element (b, n, h, d) of X is X[b*x_bs + n*x_rs + h*dX + d].
@@ -94,6 +108,10 @@ int dav_layernorm_bwd(const float* x0, long x0_bs, int r0, const float* x1, long
                       float* dx1, long dx1_bs, int acc1, const float* res1, long res1_bs, void* dx1_bf16, long dx1_bf_bs,
                       float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, hipStream_t stream);
 size_t dav_layernorm_bwd_workspace_bytes(int rows, int D);   /* rows = B * (r0 + r1) */
+/* Deferred form: call dav_layernorm_bwd with dgamma = dbeta = NULL and a workspace (only the per-workgroup
+ * partial rows are written), then reduce up to 64 such workspaces into their dgamma/dbeta (+=) in ONE launch. */
+typedef struct DavLnReduce { const void* workspace; float* dgamma; float* dbeta; int rows; int D; } DavLnReduce;
+int dav_layernorm_bwd_reduce_grouped(const DavLnReduce* items, int count, hipStream_t stream);
 
 /* ---- masking / gather / scatter ------------------------------------------------------------ */
 /* AVMAE.random_masking (models/avmae.py:120-142) for given noise [N,L]: argsort twice, keep the first

@@ -70,6 +70,30 @@ def test_end_to_end_vs_oracle_and_golden(golden, name):
     assert abs(tot - float(g['grad_norm_total'])) < 5e-3 * float(g['grad_norm_total'])
 
 
+def test_batch64_grouped_wgrad_path_vs_oracle():
+    """B = 64 makes every token count a multiple of 64: the deferred, grouped weight-gradient GEMMs
+    (dav_gemm_tn_grouped_bf16), the LDS-DMA kernels and the grouped LayerNorm reductions are all on the path."""
+    model, sd, cfg, O = _build('micro')
+    image, audio, ni, na = O.synthetic_batch(cfg, 64, seed=77)
+    out = model(image.cuda(), audio.cuda(), torch.from_numpy(ni).cuda(), torch.from_numpy(na).cuda())
+    (out[0] + out[1]).backward()
+    sdo = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in sd.items()}
+    li, la, pi, pa, aux = O.avmae_forward(sdo, cfg, image, audio, ni, na)
+    (li + la).backward()
+    assert abs(float(out[0]) - float(li)) <= LOSS_RTOL * float(li) and abs(float(out[1]) - float(la)) <= LOSS_RTOL * float(la)
+    assert rel(out[2], pi) < ACT_TOL and rel(out[3], pa) < ACT_TOL
+    g_all = sum(float(v.grad.double().norm()) ** 2 for v in sdo.values() if v.grad is not None) ** 0.5
+    rels = []
+    for n, p in model.named_parameters():
+        if not p.requires_grad or n.endswith(ZERO_GRADS):
+            continue
+        ref = sdo[n].grad.double()
+        d = float((p.grad.detach().double().cpu() - ref).norm())
+        rels.append(d / max(float(ref.norm()), 1e-30))
+        assert d <= GRAD_TOL * float(ref.norm()) + 1e-4 * g_all, (n, d, float(ref.norm()))
+    assert np.median(rels) < ACT_TOL
+
+
 def test_random_masking_api_bit_exact(golden):
     g = golden('masking')
     model, *_ = _build('micro')

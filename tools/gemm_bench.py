@@ -45,13 +45,13 @@ def timeit(fn, reps=20):
 def main():
     kind = sys.argv[1] if len(sys.argv) > 1 else 'nt'
     variants = [int(v) for v in sys.argv[2:]] or [0]
-    shapes = NT_SHAPES if kind == 'nt' else TN_SHAPES
+    shapes = NT_SHAPES if kind in ('nt', 'kn') else TN_SHAPES
     tot = {v: 0.0 for v in variants}
     totfl = 0.0
     print(f'{"shape":>22} {"cnt":>4} ' + ' '.join(f'{"v%d us" % v:>9} {"TF":>6}' for v in variants))
     for (M, N, K, cnt) in shapes:
-        A = torch.randn(M, K if kind == 'nt' else N, device=dev).bfloat16()
-        Bm = (torch.randn(N if kind == 'nt' else M, K, device=dev) * 0.05).bfloat16()
+        A = torch.randn(M, K if kind in ('nt', 'kn') else N, device=dev).bfloat16()
+        Bm = (torch.randn(N if kind == 'nt' else (K if kind == 'kn' else M), K if kind != 'kn' else N, device=dev) * 0.05).bfloat16()
         row = f'{M:>7}x{N:>5}x{K:>5} {cnt:>4} '
         fl = 2.0 * M * N * K
         totfl += fl * cnt
@@ -59,6 +59,9 @@ def main():
             if kind == 'nt':
                 C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
                 us = timeit(lambda: ops.gemm_nt(A, Bm, M, N, K, C_out=C, c_bf16=True, variant=v))
+            elif kind == 'kn':
+                C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+                us = timeit(lambda: ops.gemm_nt(A, Bm, M, N, K, ldb=N, C_out=C, c_bf16=True, variant=v | (1 << 12)))
             else:
                 C = torch.zeros(N, K, device=dev)
                 us = timeit(lambda: ops.gemm_tn(A, Bm, M, N, K, C, beta=1, variant=v))

@@ -121,6 +121,21 @@ def gemm_tn():
             C = torch.full((N, K), 7.0, device=dev)
             ops.gemm_tn(A, Bm, Mc, N, K, C, beta=0, variant=variant)
             report(f'gemm_tn {Mc}x{N}x{K} v{variant} store', rel(C, ref), 2e-4)
+    # grouped launch of several problems (deferred wgrads of a layer), incl. bias grads and the split-K path
+    probs, refs = [], []
+    for i, (Mc, N, K) in enumerate([(3136, 768, 768), (3136, 2304, 768), (4032, 768, 3072), (512, 192, 768), (2048, 72, 136), (6080, 3072, 768)]):
+        A, Bm = rnd(Mc, N, dtype=BF16, seed=60 + i), rnd(Mc, K, dtype=BF16, seed=70 + i)
+        C = torch.full((N, K), 0.25, device=dev)
+        bg = torch.full((N,), 0.5, device=dev) if i % 2 == 0 else None
+        probs.append(dict(A=A, B=Bm, Mc=Mc, N=N, K=K, C=C, lda=N, ldb=K, ldc=K, bias_grad=bg))
+        refs.append((C, 0.25 + A.float().t() @ Bm.float(), bg, None if bg is None else 0.5 + A.float().sum(0)))
+    ops.gemm_tn_grouped(probs)
+    for i, (C, rc, bg, rb) in enumerate(refs):
+        report(f'gemm_tn grouped #{i} C', rel(C, rc), 2e-4)
+        if bg is not None:
+            report(f'gemm_tn grouped #{i} bias', rel(bg, rb), 2e-4)
+    ops.gemm_tn_grouped(probs[:2])        # small group -> split-K atomics path
+    report('gemm_tn grouped split acc', rel(refs[0][0], 2 * refs[0][1] - 0.25), 2e-4)
     # row maps + ldc sub-block
     Bsz, rpb, tot, N, K = 3, 5, 9, 64, 128
     Af, Bf = rnd(Bsz * tot, N, dtype=BF16, seed=13), rnd(Bsz * tot, K, dtype=BF16, seed=14)
