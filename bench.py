@@ -89,6 +89,10 @@ def main():
     from deepavfusion_amd.util.flat import FlatAdamW
     from deepavfusion_amd.util.misc import GraphedStep, Trainer
 
+    for kv in os.environ.get('DAV_TUNE', '').split(','):      # e.g. DAV_TUNE=3:0,1:8 (launch-geometry experiments)
+        if ':' in kv:
+            from deepavfusion_amd import _lib
+            _lib.load().dav_tune(int(kv.split(':')[0]), int(kv.split(':')[1]))
     cfg = CONFIGS[a.config]
     B = a.batch or (32 if cfg.embed_dim >= 1024 else 64)
     torch.manual_seed(0)                                   # identical init on every rank (then broadcast anyway)
