@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LNFwd p) {
 // atomics, which serialise in L2 when hundreds of workgroups hit the same 2*D words).
 template <int MAXC>
 __global__ __launch_bounds__(512) void ln_bwd_kernel(LNBwd p) {
-  extern __shared__ __attribute__((aligned(16))) float lds_red[];   // [2][D]
+  extern __shared__ __attribute__((aligned(16))) float lds_red[];   // [waves][2][D]
   const int lane = threadIdx.x & 63;
   const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
   const int R = p.s0.rows + p.s1.rows, rows = p.B * R, nch = p.D >> 2;
@@ -171,21 +171,24 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(LNBwd p) {
   }
 
   if (p.partial == nullptr) return;
-  for (int c = threadIdx.x; c < 2 * p.D; c += blockDim.x) lds_red[c] = 0.f;
-  __syncthreads();
+  // per-wave slices [wave][2][D] written as float4 (conflict-free), then summed over the waves -> one partial row
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  float* rg = lds_red + (size_t)wave * 2 * p.D;
 #pragma unroll
   for (int i = 0; i < MAXC; ++i) {
     const int c = lane + 64 * i;
     if (c < nch) {
-      atomicAdd(lds_red + 4 * c + 0, dg[i].x); atomicAdd(lds_red + 4 * c + 1, dg[i].y);
-      atomicAdd(lds_red + 4 * c + 2, dg[i].z); atomicAdd(lds_red + 4 * c + 3, dg[i].w);
-      atomicAdd(lds_red + p.D + 4 * c + 0, db[i].x); atomicAdd(lds_red + p.D + 4 * c + 1, db[i].y);
-      atomicAdd(lds_red + p.D + 4 * c + 2, db[i].z); atomicAdd(lds_red + p.D + 4 * c + 3, db[i].w);
+      reinterpret_cast<float4*>(rg)[c] = dg[i];
+      reinterpret_cast<float4*>(rg + p.D)[c] = db[i];
     }
   }
   __syncthreads();
   float* part = p.partial + (size_t)blockIdx.x * 2 * p.D;
-  for (int c = threadIdx.x; c < 2 * p.D; c += blockDim.x) part[c] = lds_red[c];
+  for (int c = threadIdx.x; c < 2 * p.D; c += blockDim.x) {
+    float s = 0.f;
+    for (int w = 0; w < nw; ++w) s += lds_red[(size_t)w * 2 * p.D + c];
+    part[c] = s;
+  }
 }
 
 // 64 columns x 16 row-lanes per workgroup: every thread sums its share of the partial rows with 4 independent
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_grouped_kernel(const LNRed
   }
 }
 
-int g_ln_bwd_waves = 4, g_ln_bwd_cap = 512;     // best of tools/ln_bench.py on MI355X; knobs: dav_tune 1 / 2
+int g_ln_bwd_waves = 8, g_ln_bwd_cap = 512;     // best of tools/ln_bench.py on MI355X; knobs: dav_tune 1 / 2
 
 int ln_bwd_grid(int rows) {
   int g = (rows + g_ln_bwd_waves - 1) / g_ln_bwd_waves;
@@ -330,7 +333,7 @@ extern "C" int dav_layernorm_bwd(const float* x0, long x0_bs, int r0, const floa
   p.partial = (float*)workspace;
   const int grid = ln_bwd_grid(B * (r0 + r1));
   const int nch = (D / 4 + 63) / 64;
-  const size_t lds = (size_t)2 * D * sizeof(float);
+  const size_t lds = (size_t)g_ln_bwd_waves * 2 * D * sizeof(float);
   if (nch <= 1) DAV_LAUNCH(ln_bwd_kernel<1>, dim3(grid), dim3(64 * g_ln_bwd_waves), lds, stream, p);
   else if (nch == 2) DAV_LAUNCH(ln_bwd_kernel<2>, dim3(grid), dim3(64 * g_ln_bwd_waves), lds, stream, p);
   else if (nch == 3) DAV_LAUNCH(ln_bwd_kernel<3>, dim3(grid), dim3(64 * g_ln_bwd_waves), lds, stream, p);
