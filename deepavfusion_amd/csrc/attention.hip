@@ -5,7 +5,8 @@
 // registers: scores are produced TRANSPOSED (S^T = K.Q^T on the 16x16x32 bf16 MFMA) so that a
 // lane's four accumulators are four keys of ONE query row -> the row max/sum are a few lane-local
 // ops plus two cross-lane shuffles, and the probabilities feed the second MFMA (O^T = V^T.P^T)
-// straight from registers with no LDS round trip.
+// straight from registers with no LDS round trip.  The V / K / Q / dO tiles are staged ONCE, row-major (16-byte
+// coalesced LDS writes); every transposed operand fragment comes from the transposing ds_read_b64_tr_b16.
 //
 // Covers every attention on the pre-training path through strides only:
 //   * timm Attention inside Block (models/vits.py:32-34, models/avmae.py:53-55,83-85) incl. the
@@ -36,31 +37,26 @@ struct AttnParams {
   int dq_rs, dk_rs, dv_rs;
 };
 
+// 16-byte-slot XOR swizzle of a row-major LDS tile, chosen so that BOTH access patterns are conflict-free:
+//  * ds_read_b128 of 16 consecutive rows at one column slot (its real lane groups are {0-3,12-15,20-27}, ...),
+//  * ds_read_b64_tr_b16 of 8 consecutive rows x 32 bytes (two 16-lane groups of a 32-lane half).
+// 128-byte rows (8 slots, 2 rows per 256-byte bank row): f = 2 * ((row >> 1) & 3)
+//  64-byte rows (4 slots, 4 rows per bank row):           f = (-(row >> 2)) & 3
 template <int RB> __device__ __forceinline__ int row_swz(int row) {
-  return RB == 128 ? ((row >> 1) & 7) : ((row >> 2) & 3);
+  return RB == 128 ? (((row >> 1) & 3) << 1) : ((0 - (row >> 2)) & 3);
 }
 
-// stage `nrows` rows of COLS bf16 (global row stride rs) into a swizzled row-major LDS tile with
-// COLSP columns and nrows_p rows (zero padded); optionally also a transposed copy T[col][row]
-// (row stride t_stride bytes).
-template <int COLS, int COLSP, bool TRANSPOSED_TOO, bool ROWMAJOR = true>
-__device__ __forceinline__ void stage_tile(char* dst, char* dstT, int t_stride, const bf16_t* src, int nrows,
-                                           int nrows_p, int rs, int tid, int nthreads) {
+// stage `nrows` rows of COLS bf16 (global row stride rs) into a swizzled row-major LDS tile with COLSP columns
+// and nrows_p rows (zero padded); 16 bytes per lane, consecutive lanes = consecutive chunks of a row
+template <int COLS, int COLSP>
+__device__ __forceinline__ void stage_tile(char* dst, const bf16_t* src, int nrows, int nrows_p, int rs, int tid, int nthreads) {
   constexpr int CPR = COLSP / 8, RB = COLSP * 2;
   const int total = nrows_p * CPR;
   for (int c = tid; c < total; c += nthreads) {
     const int row = c / CPR, ch = c % CPR;
     uint4 v = uint4{0, 0, 0, 0};
     if (row < nrows && ch * 8 < COLS) v = *reinterpret_cast<const uint4*>(src + (long)row * rs + ch * 8);
-    if (ROWMAJOR) *reinterpret_cast<uint4*>(dst + row * RB + ((ch ^ row_swz<RB>(row)) << 4)) = v;
-    if (TRANSPOSED_TOO && ch * 8 < COLS) {
-      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const bf16_t x = (bf16_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
-        *reinterpret_cast<bf16_t*>(dstT + (ch * 8 + e) * t_stride + row * 2) = x;
-      }
-    }
+    *reinterpret_cast<uint4*>(dst + row * RB + ((ch ^ row_swz<RB>(row)) << 4)) = v;
   }
 }
 
@@ -71,12 +67,20 @@ __device__ __forceinline__ bf16x8 tile_frag(const char* tile, int row, int kk, i
   return *reinterpret_cast<const bf16x8*>(tile + row * RB + (slot << 4));
 }
 
-// fragment of a transposed tile T[col][row]: keys/rows {r0+4g..+3} and {r0+16+4g..+3} of column `col`
-__device__ __forceinline__ bf16x8 tile_frag_t(const char* tileT, int t_stride, int col, int r0, int g) {
-  union { uint2 h[2]; bf16x8 v; } u;
-  const char* base = tileT + col * t_stride + (r0 + 4 * g) * 2;
-  u.h[0] = *reinterpret_cast<const uint2*>(base);
-  u.h[1] = *reinterpret_cast<const uint2*>(base + 32);
+// TRANSPOSED fragment out of the same row-major tile through the hardware transposing LDS read: lane (c = lane & 15,
+// g = lane >> 4) receives column (colbase + c) at rows {r0 + 4g .. +3} and {r0 + 16 + 4g .. +3} — the contraction
+// index order the register-resident P / dS fragments use (see the kernels).
+template <int RB>
+__device__ __forceinline__ bf16x8 tile_frag_tr(const char* tile, int r0, int colbase, int lane) {
+  const int g = lane >> 4, li = lane & 15;
+  union { s16x4 h[2]; bf16x8 v; } u;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = r0 + 16 * h + 4 * g + (li >> 2);
+    const int colb = (colbase + 4 * (li & 3)) * 2;
+    const int addr = row * RB + ((((colb >> 4) ^ row_swz<RB>(row)) << 4) | (colb & 15));
+    u.h[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, tile + addr));
+  }
   return u.v;
 }
 
@@ -102,15 +106,15 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
   constexpr int DQKP = DQK < 32 ? 32 : DQK, KRB = DQKP * 2, KS = DQKP / 32, VC = DV / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int Nkp = (p.Nk + 31) & ~31;
-  const int vt_stride = Nkp * 2 + 16;
-  char* Ks = smem;
-  char* Vt = smem + Nkp * KRB;
+  constexpr int VRB = DV * 2;
+  char* Ks = smem;                 // [Nkp][DQKP]
+  char* Vs = smem + Nkp * KRB;     // [Nkp][DV]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
   const int fr = lane & 15, g = lane >> 4;
 
-  stage_tile<DQK, DQKP, false>(Ks, nullptr, 0, p.K + b * p.k_bs + h * DQK, p.Nk, Nkp, p.k_rs, tid, blockDim.x);
-  stage_tile<DV, DV, true, false>(nullptr, Vt, vt_stride, p.V + b * p.v_bs + h * DV, p.Nk, Nkp, p.v_rs, tid, blockDim.x);
+  stage_tile<DQK, DQKP>(Ks, p.K + b * p.k_bs + h * DQK, p.Nk, Nkp, p.k_rs, tid, blockDim.x);
+  stage_tile<DV, DV>(Vs, p.V + b * p.v_bs + h * DV, p.Nk, Nkp, p.v_rs, tid, blockDim.x);
   __syncthreads();
 
   const int nqt = (p.Nq + 15) >> 4;
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
       for (int c = 0; c < VC; ++c) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) oacc[c][r] *= alpha;
-        oacc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag_t(Vt, vt_stride, c * 16 + fr, k0, g), pf, oacc[c], 0, 0, 0);
+        oacc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag_tr<VRB>(Vs, k0, c * 16, lane), pf, oacc[c], 0, 0, 0);
       }
     }
     lsum += __shfl_xor(lsum, 16, 64);
@@ -192,16 +196,14 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
   constexpr int DQKP = DQK < 32 ? 32 : DQK, KRB = DQKP * 2, KS = DQKP / 32, VRB = DV * 2, VS = DV / 32, QC = DQK / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int Nkp = (p.Nk + 31) & ~31;
-  const int kt_stride = Nkp * 2 + 16;
   char* Ks = smem;                   // [Nkp][DQKP]
   char* Vs = Ks + Nkp * KRB;         // [Nkp][DV]
-  char* Kt = Vs + Nkp * VRB;         // [DQK][Nkp] (+16 B)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
   const int fr = lane & 15, g = lane >> 4;
 
-  stage_tile<DQK, DQKP, true>(Ks, Kt, kt_stride, p.K + b * p.k_bs + h * DQK, p.Nk, Nkp, p.k_rs, tid, blockDim.x);
-  stage_tile<DV, DV, false>(Vs, nullptr, 0, p.V + b * p.v_bs + h * DV, p.Nk, Nkp, p.v_rs, tid, blockDim.x);
+  stage_tile<DQK, DQKP>(Ks, p.K + b * p.k_bs + h * DQK, p.Nk, Nkp, p.k_rs, tid, blockDim.x);
+  stage_tile<DV, DV>(Vs, p.V + b * p.v_bs + h * DV, p.Nk, Nkp, p.v_rs, tid, blockDim.x);
   __syncthreads();
 
   const int nqt = (p.Nq + 15) >> 4;
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
       const bf16x8 dsf = pack8(st[0], st[1]);
 #pragma unroll
       for (int c = 0; c < QC; ++c)
-        dq[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag_t(Kt, kt_stride, c * 16 + fr, k0, g), dsf, dq[c], 0, 0, 0);
+        dq[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag_tr<KRB>(Ks, k0, c * 16, lane), dsf, dq[c], 0, 0, 0);
     }
     if (qok) {
       bf16_t* dqrow = p.dQ + b * p.dq_bs + (long)q * p.dq_rs + h * DQK;
@@ -278,19 +280,16 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
   constexpr int DQKP = DQK < 32 ? 32 : DQK, QRB = DQKP * 2, KS = DQKP / 32, ORB = DV * 2, VS = DV / 32, QC = DQK / 16, VC = DV / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int Nqp = (p.Nq + 31) & ~31;
-  const int t_stride = Nqp * 2 + 16;
   char* Qs = smem;                      // [Nqp][DQKP]
   char* dOs = Qs + Nqp * QRB;           // [Nqp][DV]
-  char* Qt = dOs + Nqp * ORB;           // [DQK][Nqp]
-  char* dOt = Qt + DQK * t_stride;      // [DV][Nqp]
-  float* lse_s = reinterpret_cast<float*>(dOt + DV * t_stride);   // [Nqp]
+  float* lse_s = reinterpret_cast<float*>(dOs + Nqp * ORB);       // [Nqp]
   float* del_s = lse_s + Nqp;                                     // [Nqp]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
   const int fr = lane & 15, g = lane >> 4;
 
-  stage_tile<DQK, DQKP, true>(Qs, Qt, t_stride, p.Q + b * p.q_bs + h * DQK, p.Nq, Nqp, p.q_rs, tid, blockDim.x);
-  stage_tile<DV, DV, true>(dOs, dOt, t_stride, p.dO + b * p.do_bs + h * DV, p.Nq, Nqp, p.do_rs, tid, blockDim.x);
+  stage_tile<DQK, DQKP>(Qs, p.Q + b * p.q_bs + h * DQK, p.Nq, Nqp, p.q_rs, tid, blockDim.x);
+  stage_tile<DV, DV>(dOs, p.dO + b * p.do_bs + h * DV, p.Nq, Nqp, p.do_rs, tid, blockDim.x);
   for (int i = tid; i < Nqp; i += blockDim.x) {
     const long sidx = ((long)b * p.H + h) * p.Nq + i;
     lse_s[i] = i < p.Nq ? p.LSE[sidx] : 1e30f;      // exp(s - 1e30) == 0 for padded query rows
@@ -341,10 +340,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
       const bf16x8 dsf = pack8(dp[0], dp[1]);
 #pragma unroll
       for (int c = 0; c < VC; ++c)
-        dv[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag_t(dOt, t_stride, c * 16 + fr, q0, g), pf, dv[c], 0, 0, 0);
+        dv[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag_tr<ORB>(dOs, q0, c * 16, lane), pf, dv[c], 0, 0, 0);
 #pragma unroll
       for (int c = 0; c < QC; ++c)
-        dk[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag_t(Qt, t_stride, c * 16 + fr, q0, g), dsf, dk[c], 0, 0, 0);
+        dk[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag_tr<QRB>(Qs, q0, c * 16, lane), dsf, dk[c], 0, 0, 0);
     }
     if (kok) {
       bf16_t* dkrow = p.dK + b * p.dk_bs + (long)key * p.dk_rs + h * DQK;
@@ -372,7 +371,7 @@ template <int DQK> constexpr int padqk() { return DQK < 32 ? 32 : DQK; }
 template <int DQK, int DV>
 int launch_fwd(const AttnParams& p, hipStream_t stream) {
   const int Nkp = (p.Nk + 31) & ~31;
-  const size_t lds = (size_t)Nkp * padqk<DQK>() * 2 + (size_t)DV * (Nkp * 2 + 16);
+  const size_t lds = (size_t)Nkp * padqk<DQK>() * 2 + (size_t)Nkp * DV * 2;
   if (lds > 160 * 1024) return DAV_ERR_SHAPE;
   int nw = (p.Nq + 15) / 16; nw = nw > 8 ? 8 : nw; nw = nw < 1 ? 1 : nw;
   auto kern = attn_fwd_kernel<DQK, DV>;
@@ -388,8 +387,8 @@ int launch_fwd(const AttnParams& p, hipStream_t stream) {
 template <int DQK, int DV>
 int launch_bwd(const AttnParams& p, hipStream_t stream) {
   const int Nkp = (p.Nk + 31) & ~31, Nqp = (p.Nq + 31) & ~31;
-  const size_t lds1 = (size_t)Nkp * padqk<DQK>() * 2 + (size_t)Nkp * DV * 2 + (size_t)DQK * (Nkp * 2 + 16);
-  const size_t lds2 = (size_t)Nqp * padqk<DQK>() * 2 + (size_t)Nqp * DV * 2 + (size_t)(DQK + DV) * (Nqp * 2 + 16) + (size_t)Nqp * 8;
+  const size_t lds1 = (size_t)Nkp * padqk<DQK>() * 2 + (size_t)Nkp * DV * 2;
+  const size_t lds2 = (size_t)Nqp * padqk<DQK>() * 2 + (size_t)Nqp * DV * 2 + (size_t)Nqp * 8;
   if (lds1 > 160 * 1024 || lds2 > 160 * 1024) return DAV_ERR_SHAPE;
   int nw1 = (p.Nq + 15) / 16; nw1 = nw1 > 8 ? 8 : nw1; nw1 = nw1 < 1 ? 1 : nw1;
   int nw2 = (p.Nk + 15) / 16; nw2 = nw2 > 8 ? 8 : nw2; nw2 = nw2 < 1 ? 1 : nw2;
