@@ -126,7 +126,8 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) qf[kk] = gfrag(qrow, kk * 32 + 8 * g, kk * 32 + 8 * g < DQK);
 
-    float m = -1e30f, lsum = 0.f;
+    float m = -1e30f, lsum = 0.f;      // m: running max in the log2 domain
+    const float sl2 = p.scale * 1.44269504088896341f;
     f32x4 oacc[VC];
 #pragma unroll
     for (int c = 0; c < VC; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -140,26 +141,38 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
         for (int kk = 0; kk < KS; ++kk)
           st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag<KRB>(Ks, k0 + t * 16 + fr, kk, g), qf[kk], st[t], 0, 0, 0);
       }
+      // scores are kept in the log2 domain (scale * log2(e) folded into one multiply, v_exp_f32 is 2^x);
+      // only the last key tile can hold padded keys
       float mx = -1e30f;
+      if (k0 + 32 > p.Nk) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = k0 + t * 16 + 4 * g + r;
-          st[t][r] = key < p.Nk ? st[t][r] * p.scale : -1e30f;
-          mx = fmaxf(mx, st[t][r]);
-        }
+          for (int r = 0; r < 4; ++r) {
+            const int key = k0 + t * 16 + 4 * g + r;
+            st[t][r] = key < p.Nk ? st[t][r] * sl2 : -1e30f;
+            mx = fmaxf(mx, st[t][r]);
+          }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            st[t][r] *= sl2;
+            mx = fmaxf(mx, st[t][r]);
+          }
+      }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float mn = fmaxf(m, mx);
-      const float alpha = __expf(m - mn);
+      const float alpha = __builtin_amdgcn_exp2f(m - mn);
       m = mn;
       float ps = 0.f;
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          st[t][r] = __expf(st[t][r] - mn);
+          st[t][r] = __builtin_amdgcn_exp2f(st[t][r] - mn);
           ps += st[t][r];
         }
       lsum = lsum * alpha + ps;
@@ -183,7 +196,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
         w.y = pack2bf(oacc[c][2] * inv, oacc[c][3] * inv);
         *reinterpret_cast<uint2*>(orow + c * 16 + 4 * g) = w;
       }
-      if (g == 0 && p.LSE) p.LSE[((long)b * p.H + h) * p.Nq + q] = m + __logf(lsum);
+      if (g == 0 && p.LSE) p.LSE[((long)b * p.H + h) * p.Nq + q] = (m + log2f(lsum)) * 0.69314718055994531f;   // natural-log LSE
     }
   }
 }
@@ -228,7 +241,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
     delta += __shfl_xor(delta, 16, 64);
     delta += __shfl_xor(delta, 32, 64);
     const long sidx = ((long)b * p.H + h) * p.Nq + qc;
-    const float lse = p.LSE[sidx];
+    const float lse2 = p.LSE[sidx] * 1.44269504088896341f;      // log2 domain
+    const float sl2 = p.scale * 1.44269504088896341f;
     if (qok && g == 0) p.Delta[sidx] = delta;
 
     f32x4 dq[QC];
@@ -250,7 +264,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = k0 + t * 16 + 4 * g + r;
-          const float pr = key < p.Nk ? __expf(st[t][r] * p.scale - lse) : 0.f;
+          const float pr = key < p.Nk ? __builtin_amdgcn_exp2f(st[t][r] * sl2 - lse2) : 0.f;
           st[t][r] = pr * (dp[t][r] - delta);     // dS^T
         }
       }
@@ -292,11 +306,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
   stage_tile<DV, DV>(dOs, p.dO + b * p.do_bs + h * DV, p.Nq, Nqp, p.do_rs, tid, blockDim.x);
   for (int i = tid; i < Nqp; i += blockDim.x) {
     const long sidx = ((long)b * p.H + h) * p.Nq + i;
-    lse_s[i] = i < p.Nq ? p.LSE[sidx] : 1e30f;      // exp(s - 1e30) == 0 for padded query rows
+    lse_s[i] = i < p.Nq ? p.LSE[sidx] * 1.44269504088896341f : 1e30f;      // log2 domain; 2^(s - 1e30) == 0 for padded query rows
     del_s[i] = i < p.Nq ? p.Delta[sidx] : 0.f;
   }
   __syncthreads();
 
+  const float sl2 = p.scale * 1.44269504088896341f;
   const int nkt = (p.Nk + 15) >> 4;
   for (int kt = wave; kt < nkt; kt += nw) {
     const int key = kt * 16 + fr;
@@ -331,7 +346,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int qi = q0 + t * 16 + 4 * g + r;
-          const float pr = __expf(s[t][r] * p.scale - lse_s[qi]);
+          const float pr = __builtin_amdgcn_exp2f(s[t][r] * sl2 - lse_s[qi]);
           s[t][r] = pr;                              // P[q][key]
           dp[t][r] = pr * (dp[t][r] - del_s[qi]);    // dS[q][key]
         }

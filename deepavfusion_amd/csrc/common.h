@@ -24,17 +24,15 @@ typedef unsigned short bf16_t;   // raw storage type used in the C ABI
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even fp32 -> bf16 (NaN kept quiet)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
-
+// fp32 -> bf16, round-to-nearest-even, in hardware: v_cvt_pk_bf16_f32 converts and packs two values per instruction
+typedef __attribute__((ext_vector_type(2))) float dav_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 dav_bf16x2;
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  union { dav_bf16x2 v; uint32_t u; } r;
+  r.v = __builtin_convertvector(dav_f32x2{lo, hi}, dav_bf16x2);
+  return r.u;
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
