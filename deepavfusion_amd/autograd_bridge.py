@@ -80,13 +80,14 @@ def encoder_fwd(enc, image, audio, ik32, ak32, want_f32=False, collect_embs=Fals
     return (xi_b, xa_b, xf_b), (xi32, xa32, xf32), embs, tape
 
 
-def encoder_bwd(enc, t, dxi_b=None, dxa_b=None, dxf_b=None, dxi32=None, dxa32=None, dxf32=None):
-    """Gradients w.r.t. the three NORMED outputs (bf16 and/or fp32 parts) -> parameter gradients."""
+def encoder_bwd(enc, t, dxi_b=None, dxa_b=None, dxf_b=None, dxi32=None, dxa32=None, dxf32=None, layer_cb=None):
+    """Gradients w.r.t. the three NORMED outputs (bf16 and/or fp32 parts) -> parameter gradients.
+    ``layer_cb(l)`` is called after layer l's backward (all streams joined, its weight gradients launched)."""
     with E.deferred_wgrads():
-        _encoder_bwd(enc, t, dxi_b, dxa_b, dxf_b, dxi32, dxa32, dxf32)
+        _encoder_bwd(enc, t, dxi_b, dxa_b, dxf_b, dxi32, dxa32, dxf32, layer_cb)
 
 
-def _encoder_bwd(enc, t, dxi_b, dxa_b, dxf_b, dxi32, dxa32, dxf32):
+def _encoder_bwd(enc, t, dxi_b, dxa_b, dxf_b, dxi32, dxa32, dxf32, layer_cb=None):
     B = t['B']
     dev = t['x_i'].device
 
@@ -102,7 +103,7 @@ def _encoder_bwd(enc, t, dxi_b, dxa_b, dxf_b, dxi32, dxa32, dxf32):
     g_f, g_fb = final_norm(enc.fusion_norm, t['x_f'], t['st_f'], dxf_b, dxf32)
     blocks = list(zip(enc.image.blocks, enc.audio.blocks, enc.fusion_blocks))
     main, sa, sf = _streams(dev)
-    for (bi, ba, fb), (ti, ta, tf) in zip(reversed(blocks), reversed(t['layers'])):
+    for l, ((bi, ba, fb), (ti, ta, tf)) in reversed(list(enumerate(zip(blocks, t['layers'])))):
         sa.wait_stream(main)
         sf.wait_stream(main)
         if fb is None:
@@ -123,6 +124,8 @@ def _encoder_bwd(enc, t, dxi_b, dxa_b, dxf_b, dxi32, dxa32, dxf32):
             main.wait_stream(sa)
             g_f, g_fb = (dx_f + dxf_a) if sa is not main else dx_f.add_(dxf_a), None
         E.flush_wgrads()          # every wgrad of this layer (both towers + fusion block) as one grouped GEMM
+        if layer_cb is not None and l > 0:
+            layer_cb(l)
     E.patch_embed_bwd(enc.image, t['t_pi'], g_i, g_ib)
     E.patch_embed_bwd(enc.audio, t['t_pa'], g_a, g_ab)
     E.gbuf(enc.fusion_tokens).add_(g_f.sum(dim=0, keepdim=True))          # backward of .expand(B, -1, -1)
@@ -232,7 +235,7 @@ def avmae_fwd(model, image, audio, noise_i, noise_a):
     return (loss_i, loss_a, pred_i, pred_a), tape, aux
 
 
-def avmae_bwd(model, t, g_li, g_la, g_pi=None, g_pa=None):
+def avmae_bwd(model, t, g_li, g_la, g_pi=None, g_pa=None, layer_cb=None):
     B = t['B']
     dec_i, dec_a = model.decoder('image'), model.decoder('audio')
     main, sa, _ = _streams(t['image'].device)
@@ -250,7 +253,7 @@ def avmae_bwd(model, t, g_li, g_la, g_pi=None, g_pa=None):
         dxi_b, dxf_i = E.decoder_bwd(dec_i, t['t_di'], dpi, t['ik32'], B)
     main.wait_stream(sa)
     dxf32 = dxf_i.float() + dxf_a.float()            # both decoders read the same normed fusion tokens
-    encoder_bwd(model.encoder, t['t_enc'], dxi_b=dxi_b, dxa_b=dxa_b, dxf32=dxf32)
+    encoder_bwd(model.encoder, t['t_enc'], dxi_b=dxi_b, dxa_b=dxa_b, dxf32=dxf32, layer_cb=layer_cb)
 
 
 class _AVMAEFn(torch.autograd.Function):

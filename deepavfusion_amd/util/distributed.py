@@ -165,6 +165,13 @@ class GradReducer:
             dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
             view.div_(self.world)
 
+    def launch_buckets(self, bucket_ids):
+        """All-reduce the given buckets now (their gradients are complete on the current stream): used by the
+        segmented hipGraph step, which learns at capture time which buckets each graph segment completes."""
+        for bi in bucket_ids:
+            if not self._launched[bi]:
+                self._launch(bi)
+
     def finish(self):
         """Launch whatever is still pending (in bucket order) and make the compute stream wait for the reductions."""
         if not self.enabled:

@@ -36,7 +36,8 @@ def get_grad_norm_(parameters, norm_type: float = 2.0) -> torch.Tensor:
 
 
 class Trainer:
-    def __init__(self, model, criterion=None, optimizer=None, accum_iter=1, use_amp=True, distributed=False, bucket_mb=64.0):
+    def __init__(self, model, criterion=None, optimizer=None, accum_iter=1, use_amp=True, distributed=False, bucket_mb=64.0,
+                 first_bucket_mb=8.0):
         self.distributed = distributed
         self.model_without_ddp = model
         self.n_steps = torch.tensor([0])
@@ -44,7 +45,7 @@ class Trainer:
         if self.distributed:
             if self.flat is None:
                 raise RuntimeError('data-parallel training needs FlatAdamW (flat gradient buffer for the RCCL reducer)')
-            model = dist_utils.DataParallel(model, self.flat, bucket_mb=bucket_mb)
+            model = dist_utils.DataParallel(model, self.flat, bucket_mb=bucket_mb, first_bucket_mb=first_bucket_mb)
         self.model = model
         self.criterion = criterion
         self.optimizer = optimizer
@@ -119,13 +120,19 @@ class Trainer:
 
 
 class GraphedStep:
-    """One pre-training step (bf16 weight refresh -> forward -> backward -> grad norm -> AdamW) captured as a
-    single hipGraph and replayed per iteration: ~2000 small kernel launches become one graph launch.
-    With world_size > 1 the graph ends after the backward; the bucketed RCCL all-reduce, the norm and AdamW
-    are enqueued eagerly behind it."""
+    """One pre-training step (forward -> backward -> grad norm -> AdamW) captured in hipGraphs and replayed per
+    iteration: ~1900 kernel launches become a handful of graph launches.
 
-    def __init__(self, trainer: Trainer, image_shape, audio_shape, warmup: int = 2):
+    world_size == 1: one graph holds everything.  world_size > 1 (or ``segments`` > 1): the step is captured as
+    ``segments`` consecutive graphs that share one memory pool — [forward + decoders' backward + the last encoder
+    layers], [middle layers], [first layers] — and after each replayed segment the gradient buckets that segment
+    completed (known from capture time) are all-reduced on the comm stream, i.e. overlapped with the next segment;
+    grad norm + AdamW form a last graph behind the final reduction.  Collectives themselves are never captured."""
+
+    def __init__(self, trainer: Trainer, image_shape, audio_shape, warmup: int = 2, segments: int = 0):
         assert trainer.accum_iter == 1 and isinstance(trainer.optimizer, FlatAdamW)
+        from .. import autograd_bridge as bridge
+        self.bridge = bridge
         self.tr = trainer
         self.model = trainer.model_without_ddp
         self.opt = trainer.optimizer
@@ -134,41 +141,94 @@ class GraphedStep:
         self.audio = torch.zeros(audio_shape, device=dev)
         self.world = dist_utils.get_world_size()
         self.reducer = trainer.model.reducer if trainer.distributed else None
+        if segments <= 0:
+            segments = int(os.environ.get('DAV_SEGMENTS', '0')) or (3 if self.world > 1 else 1)
+        depth = len(self.model.encoder.image.blocks)
+        segments = max(1, min(segments, depth))
+        # layer l ends segment s when l is in `cuts`: backward runs layers depth-1 .. 0
+        self.cuts = sorted({round(depth * (segments - 1 - s) / segments) for s in range(segments - 1)} - {0}, reverse=True)
+        self.n_seg = len(self.cuts) + 1
         saved_hook = engine._GRAD_READY
-        engine.set_grad_ready_hook(None)          # collectives stay outside the graph
+        engine.set_grad_ready_hook(None)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                self._fwd_bwd()
+                self._fwd_bwd(None)
                 self.opt.flat.zero_grad()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+
+        # ---- capture ------------------------------------------------------------------------------------------
+        self.graphs = [torch.cuda.CUDAGraph() for _ in range(self.n_seg)]
+        self.bucket_sched = [[] for _ in range(self.n_seg)]
+        seg = [0]
+        pending = [len(b[2]) for b in self.reducer.buckets] if self.reducer is not None else []
+
+        def on_ready(p):
+            if self.reducer is None:
+                return
+            bi = self.reducer._bucket_of.get(id(p))
+            if bi is not None:
+                pending[bi] -= 1
+                if pending[bi] == 0:
+                    self.bucket_sched[seg[0]].append(bi)
+        engine.set_grad_ready_hook(on_ready)
+
+        def layer_cb(l):
+            if l in self.cuts:
+                self.graphs[seg[0]].capture_end()
+                seg[0] += 1
+                self.graphs[seg[0]].capture_begin(pool=self.graphs[0].pool())
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap):
+            self.graphs[0].capture_begin()
             self.opt.flat.zero_grad()
             engine.refresh_weight_cache(self.model)
-            self.loss_image, self.loss_audio = self._fwd_bwd()
+            self.loss_image, self.loss_audio = self._fwd_bwd(layer_cb)
             if self.world == 1:
                 self.grad_norm = self.opt.flat.grad_norm().clone()
                 self.opt.launch_step()
+            self.graphs[seg[0]].capture_end()
+            self.opt_graph = None
+            if self.world > 1:
+                self.opt_graph = torch.cuda.CUDAGraph()
+                self.opt_graph.capture_begin(pool=self.graphs[0].pool())
+                self.grad_norm = self.opt.flat.grad_norm().clone()
+                self.opt.launch_step()
+                self.opt_graph.capture_end()
+        torch.cuda.current_stream().wait_stream(cap)
+        torch.cuda.synchronize()
+        if self.reducer is not None:          # anything not reported (should not happen) goes with the last segment
+            done = {bi for s in self.bucket_sched for bi in s}
+            self.bucket_sched[-1] += [bi for bi in range(len(self.reducer.buckets)) if bi not in done]
         engine.set_grad_ready_hook(saved_hook)
         self.opt.flat.zero_grad()
 
-    def _fwd_bwd(self):
-        li, la = self.model(self.image, self.audio)[:2]
-        (li + la).backward()
-        return li.detach(), la.detach()
+    def _fwd_bwd(self, layer_cb):
+        """Forward + hand-written backward straight on the engine (no autograd), unit upstream gradients."""
+        B, dev = self.image.shape[0], self.image.device
+        Li, La = self.model.image_gs[0] * self.model.image_gs[1], self.model.audio_gs[0] * self.model.audio_gs[1]
+        noise_i, noise_a = torch.rand(B, Li, device=dev), torch.rand(B, La, device=dev)
+        outs, tape, aux = self.bridge.avmae_fwd(self.model, self.image, self.audio, noise_i, noise_a)
+        one = torch.ones((), device=dev)
+        self.bridge.avmae_bwd(self.model, tape, one, one, layer_cb=layer_cb)
+        return outs[0], outs[1]
 
     def __call__(self, image, audio):
         self.image.copy_(image, non_blocking=True)
         self.audio.copy_(audio, non_blocking=True)
         self.opt.prepare_step()
-        self.graph.replay()
-        if self.world > 1:
-            self.reducer.reduce_all_now()
-            self.grad_norm = self.opt.flat.grad_norm()
-            self.opt.launch_step()
+        if self.reducer is not None:
+            self.reducer.begin_backward()
+        for s, g in enumerate(self.graphs):
+            g.replay()
+            if self.reducer is not None and self.world > 1:
+                self.reducer.launch_buckets(self.bucket_sched[s])      # overlaps the next segment's replay
+        if self.opt_graph is not None:
+            self.reducer.finish()
+            self.opt_graph.replay()
         self.tr.n_steps += 1
         return self.loss_image, self.loss_audio, self.grad_norm
 

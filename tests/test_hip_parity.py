@@ -211,6 +211,41 @@ def test_graphed_step_equals_eager_step():
     assert abs(losses[0][-1] - losses[1][-1]) < 0.15 * losses[0][0]
 
 
+def test_segmented_graph_step_matches_single_graph_and_schedules_every_bucket():
+    """The multi-GPU form of the step (3 graph segments + per-segment gradient buckets) must compute the same step as
+    the single graph, and its capture-time bucket schedule must cover every bucket once, decoders first."""
+    from deepavfusion_amd.util import lr_sched
+    from deepavfusion_amd.util.flat import FlatAdamW
+    from deepavfusion_amd.util.misc import GraphedStep, Trainer
+    finals, losses = [], []
+    for segments, distributed in ((1, False), (2, True)):
+        model, sd, cfg, O = _build('micro')
+        nd = [n for n, p in model.named_parameters() if 'bias' in n or 'norm' in n]
+        groups = lr_sched.param_groups_pretrained(model, 0.05, no_weight_decay_list=nd, image_pt='', audio_pt='')
+        opt = FlatAdamW(groups, lr=1e-3, betas=(0.9, 0.95), model=model)
+        tr = Trainer(model, optimizer=opt, accum_iter=1, distributed=distributed, bucket_mb=0.5, first_bucket_mb=0.25)     # world 1: reducer exists, no collectives
+        image, audio, _, _ = O.structured_batch(cfg, 64, seed=3)
+        gs = GraphedStep(tr, image.shape, audio.shape, segments=segments)
+        assert gs.n_seg == segments
+        if distributed:
+            sched = [bi for seg in gs.bucket_sched for bi in seg]
+            assert sorted(sched) == list(range(len(gs.reducer.buckets))) and len(gs.reducer.buckets) >= 3
+            assert 0 in gs.bucket_sched[0]                       # bucket 0 = decoder parameters, finished in the first segment
+            assert gs.bucket_sched[-1]                           # the last segment completes the remaining buckets
+        run = []
+        for s in range(4):
+            torch.manual_seed(500 + s)
+            li, la, gn = gs(image.cuda(), audio.cuda())
+            run.append((float(li), float(la), float(gn)))
+        losses.append(run)
+        finals.append(opt.flat.flat_p.detach().clone())
+        from deepavfusion_amd import engine
+        engine.set_grad_ready_hook(None)
+    for a, b in zip(*losses):
+        assert abs(a[0] - b[0]) < 2e-3 * abs(a[0]) and abs(a[1] - b[1]) < 2e-3 * abs(a[1]) and abs(a[2] - b[2]) < 2e-2 * abs(a[2]), (a, b)
+    assert rel(finals[1], finals[0]) < 1e-3
+
+
 def test_loss_curve_prefix_matches_reference(golden):
     """First 40 steps of the reference's 1k-step ViT-Tiny curve (tools/gen_golden.py --curve), bf16 HIP vs fp32 reference."""
     try:
