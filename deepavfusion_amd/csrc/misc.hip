@@ -316,11 +316,14 @@ __global__ __launch_bounds__(1024) void sumsq_final_kernel(const float* partial,
 // AdamW over flat buffers.  seg_* describe contiguous segments (param groups laid out back to back):
 // element i belongs to the segment s with seg_end[s-1] <= i < seg_end[s]; hyper[s] = {lr, weight_decay}.
 // step-dependent bias corrections are read from device memory so a captured graph can be replayed.
-__global__ __launch_bounds__(256) void adamw_flat_kernel(float* p, const float* g, float* m, float* v, bf16_t* p_bf16, long n,
+__global__ __launch_bounds__(256) void adamw_flat_kernel(float* p, float* g, float* m, float* v, bf16_t* p_bf16, long n,
                                                          const long* seg_end, const float* hyper, int nseg, float beta1,
-                                                         float beta2, float eps, const float* bias_corr, float grad_scale) {
+                                                         float beta2, float eps, const float* bias_corr, float grad_scale,
+                                                         float* sumsq_out, int zero_grad) {
   constexpr long CHUNK = 256 * 16;        // contiguous elements per workgroup iteration
+  __shared__ float sw[4];
   const float bc1 = bias_corr[0], bc2_sqrt = bias_corr[1];
+  float ss = 0.f;                         // sum of squared (unscaled) gradients seen by this thread
   for (long base = (long)blockIdx.x * CHUNK; base < n; base += (long)gridDim.x * CHUNK) {
     long i = base + threadIdx.x;
     int lo = 0, hi = nseg - 1;            // first segment with seg_end > i
@@ -331,7 +334,9 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* p, const float* 
       if (i >= n) break;
       while (s + 1 < nseg && i >= seg_end[s]) ++s;
       const float lr = hyper[2 * s], wd = hyper[2 * s + 1];
-      const float gi = g[i] * grad_scale;
+      const float graw = g[i];
+      ss += graw * graw;
+      const float gi = graw * grad_scale;
       float pi = p[i];
       const float mi = beta1 * m[i] + (1.f - beta1) * gi;
       const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
@@ -339,7 +344,14 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* p, const float* 
       pi -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
       p[i] = pi; m[i] = mi; v[i] = vi;
       if (p_bf16) p_bf16[i] = f2bf(pi);
+      if (zero_grad) g[i] = 0.f;
     }
+  }
+  if (sumsq_out) {                        // one atomic per workgroup (<= 16384 distinct-time adds on one word)
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(sumsq_out, sw[0] + sw[1] + sw[2] + sw[3]);
   }
 }
 
@@ -459,12 +471,13 @@ extern "C" int dav_l2norm(const float* x, long n, float scale, float* out, void*
   return dav_launch_status();
 }
 
-extern "C" int dav_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, long n, const long* seg_end,
+extern "C" int dav_adamw_flat(float* p, float* g, float* m, float* v, void* p_bf16, long n, const long* seg_end,
                               const float* hyper, int nseg, float beta1, float beta2, float eps, const float* bias_corr,
-                              float grad_scale, hipStream_t stream) {
+                              float grad_scale, float* sumsq_out, int zero_grad, hipStream_t stream) {
   if (n <= 0 || nseg <= 0) return DAV_ERR_SHAPE;
+  if (sumsq_out) HIP_CHECK_RET(hipMemsetAsync(sumsq_out, 0, sizeof(float), stream));
   long g2 = (n + 4095) / 4096; g2 = g2 > 16384 ? 16384 : g2;
   DAV_LAUNCH(adamw_flat_kernel, dim3((int)g2), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, n, seg_end, hyper, nseg,
-                     beta1, beta2, eps, bias_corr, grad_scale);
+                     beta1, beta2, eps, bias_corr, grad_scale, sumsq_out, zero_grad);
   return dav_launch_status();
 }

@@ -198,8 +198,9 @@ def l2norm(x_flat, out, workspace, scale=1.0):
                               workspace.numel() * workspace.element_size(), _stream()), 'dav_l2norm')
 
 
-def adamw_flat(p, g, m, v, p_bf16, seg_end, hyper, nseg, beta1, beta2, eps, bias_corr, grad_scale=1.0):
+def adamw_flat(p, g, m, v, p_bf16, seg_end, hyper, nseg, beta1, beta2, eps, bias_corr, grad_scale=1.0, sumsq_out=None,
+               zero_grad=False):
     lib = _lib.load()
     _lib.check(lib.dav_adamw_flat(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(p_bf16), p.numel(), _ptr(seg_end), _ptr(hyper), nseg,
-                                  float(beta1), float(beta2), float(eps), _ptr(bias_corr), float(grad_scale), _stream()),
-               'dav_adamw_flat')
+                                  float(beta1), float(beta2), float(eps), _ptr(bias_corr), float(grad_scale), _ptr(sumsq_out),
+                                  int(zero_grad), _stream()), 'dav_adamw_flat')

@@ -91,6 +91,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self._bc = torch.ones(2, dtype=torch.float32, device=dev)
         self._gidx = torch.tensor([self._group_of[id(p)] for p in self.flat.params], dtype=torch.long)
         self.step_count = 0
+        self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         for p, o in zip(self.flat.params, self.flat.offsets):    # torch-compatible per-parameter state (views)
             self.state[p] = dict(step=torch.tensor(0.), exp_avg=self.exp_avg[o:o + p.numel()].view(p.shape),
                                  exp_avg_sq=self.exp_avg_sq[o:o + p.numel()].view(p.shape))
@@ -118,12 +119,14 @@ class FlatAdamW(torch.optim.Optimizer):
         for st in self.state.values():
             st['step'] += 1
 
-    def launch_step(self, grad_scale: float = 1.0):
-        """Device side of a step: one kernel over all parameters (capturable)."""
+    def launch_step(self, grad_scale: float = 1.0, fused_norm_and_zero: bool = False):
+        """Device side of a step: one kernel over all parameters (capturable).  With ``fused_norm_and_zero`` the same
+        pass also leaves sum(g^2) in ``self.sumsq`` (grad norm = sqrt) and zeroes the gradients."""
         b1, b2 = self.defaults['betas']
         f = self.flat
         ops.adamw_flat(f.flat_p, f.flat_g, self.exp_avg, self.exp_avg_sq, self.flat_bf16, f.seg_end, self._hyper, len(f.params),
-                       b1, b2, self.defaults['eps'], self._bc, grad_scale)
+                       b1, b2, self.defaults['eps'], self._bc, grad_scale,
+                       sumsq_out=self.sumsq if fused_norm_and_zero else None, zero_grad=fused_norm_and_zero)
         engine.invalidate_weight_cache(f.params)      # fp32 masters changed behind torch's back
 
     @torch.no_grad()

@@ -182,21 +182,21 @@ class GraphedStep:
                 self.graphs[seg[0]].capture_begin(pool=self.graphs[0].pool())
         cap = torch.cuda.Stream()
         cap.wait_stream(torch.cuda.current_stream())
+        self.opt.flat.zero_grad()            # the AdamW pass leaves the gradients zeroed for the next replay
         with torch.cuda.stream(cap):
             self.graphs[0].capture_begin()
-            self.opt.flat.zero_grad()
             engine.refresh_weight_cache(self.model)
             self.loss_image, self.loss_audio = self._fwd_bwd(layer_cb)
             if self.world == 1:
-                self.grad_norm = self.opt.flat.grad_norm().clone()
-                self.opt.launch_step()
+                self.opt.launch_step(fused_norm_and_zero=True)      # AdamW + sum(g^2) + zero_grad in one pass
+                self.grad_norm = self.opt.sumsq.sqrt()
             self.graphs[seg[0]].capture_end()
             self.opt_graph = None
             if self.world > 1:
                 self.opt_graph = torch.cuda.CUDAGraph()
                 self.opt_graph.capture_begin(pool=self.graphs[0].pool())
-                self.grad_norm = self.opt.flat.grad_norm().clone()
-                self.opt.launch_step()
+                self.opt.launch_step(fused_norm_and_zero=True)
+                self.grad_norm = self.opt.sumsq.sqrt()
                 self.opt_graph.capture_end()
         torch.cuda.current_stream().wait_stream(cap)
         torch.cuda.synchronize()

@@ -151,9 +151,13 @@ int dav_cast_transpose_bf16(const float* x, void* y_bf16, int R, int C, hipStrea
 size_t dav_l2norm_workspace_bytes(long n);
 int dav_l2norm(const float* x, long n, float scale, float* out, void* workspace, size_t workspace_bytes, hipStream_t stream);
 /* torch.optim.AdamW(betas=(0.9,0.95)) step (train.py:93) over flat param/grad/state buffers with
- * per-segment {lr, weight_decay}; bias_corr = {1-beta1^t, sqrt(1-beta2^t)} in device memory. */
-int dav_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, long n, const long* seg_end, const float* hyper,
-                   int nseg, float beta1, float beta2, float eps, const float* bias_corr, float grad_scale, hipStream_t stream);
+ * per-segment {lr, weight_decay}; bias_corr = {1-beta1^t, sqrt(1-beta2^t)} in device memory.  The same pass can
+ * (a) accumulate sum(g^2) of the unscaled gradients into *sumsq_out (zeroed first; the grad norm of
+ * util/misc.py:151-163 is its square root), (b) rewrite the bf16 weight mirror p_bf16, (c) zero the gradients
+ * (Trainer.zero_grad) — one trip over the buffers instead of three. */
+int dav_adamw_flat(float* p, float* g, float* m, float* v, void* p_bf16, long n, const long* seg_end, const float* hyper,
+                   int nseg, float beta1, float beta2, float eps, const float* bias_corr, float grad_scale, float* sumsq_out,
+                   int zero_grad, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -349,7 +349,11 @@ def misc_kernels():
         pr.grad = g0 * step
         opt.step()
         bc = torch.tensor([1 - 0.9 ** step, math.sqrt(1 - 0.95 ** step)], device=dev)
-        ops.adamw_flat(p, g0 * step, m, v, pb, seg, hyper, 2, 0.9, 0.95, 1e-8, bc)
+        gcur = (g0 * step).clone()
+        ssq = torch.zeros(1, device=dev)
+        ops.adamw_flat(p, gcur, m, v, pb, seg, hyper, 2, 0.9, 0.95, 1e-8, bc, sumsq_out=ssq, zero_grad=True)
+        report(f'adamw fused sumsq step{step}', abs(float(ssq) - float((g0 * step).double().pow(2).sum())) / float((g0 * step).double().pow(2).sum()), 1e-5)
+        report(f'adamw fused zero_grad step{step}', float(gcur.abs().max()), 0.0)
     report('adamw_flat vs torch.optim.AdamW', rel(p, pr.detach()), 1e-6)
     report('adamw bf16 mirror', rel(pb, p), 4e-3)
 
