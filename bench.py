@@ -78,8 +78,10 @@ def main():
         return 2
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    force_dist = os.environ.get('DAV_FORCE_DIST', '0') == '1'      # test hook: 1-rank RCCL group on a single GPU
+    if world > 1 or force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         torch.distributed.init_process_group(backend='nccl', init_method='env://', world_size=world, rank=rank)
 
     from deepavfusion_amd import ops
@@ -101,7 +103,7 @@ def main():
     groups = lr_sched.param_groups_pretrained(model, 0.05, no_weight_decay_list=nd, image_pt='', audio_pt='')
     lr = 1.5e-4 * B * world / 256                                                              # train.py:32-34
     opt = FlatAdamW(groups, lr=lr, betas=(0.9, 0.95), model=model)
-    trainer = Trainer(model, optimizer=opt, accum_iter=1, use_amp=True, distributed=world > 1)
+    trainer = Trainer(model, optimizer=opt, accum_iter=1, use_amp=True, distributed=world > 1 or force_dist)
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
     image = torch.randn(B, 3, *cfg.image_size, device=dev, generator=g)
@@ -137,7 +139,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_dist:
             torch.distributed.barrier()
             torch.cuda.synchronize()
     sync()
@@ -227,9 +229,12 @@ def main():
         tc = time.perf_counter() - t_start
         result['cpu_baseline'] = {'value': round(Bc * n_done / tc, 3), 'unit': 'AV-pairs/s', 'cores': cores, 'kind': 'port',
                                   'sample': f'{n_done} fp32 oracle steps (fwd+bwd+AdamW) at B={Bc}, same shapes'}
-    print(json.dumps(result))
+    print(json.dumps(result), flush=True)
     return 0
 
 
 if __name__ == '__main__':
-    sys.exit(main())
+    rc = main()
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+    sys.exit(rc)

@@ -109,6 +109,8 @@ class GradReducer:
         self.flat = flat
         self.group = process_group
         self.world = dist.get_world_size(process_group) if is_dist_avail_and_initialized() else 1
+        # test hook: run the collective code path even on a 1-rank group (exercises RCCL + streams on a single GPU)
+        self.force = os.environ.get('DAV_FORCE_DIST', '0') == '1' and is_dist_avail_and_initialized()
         self.buckets = self._make_buckets(flat, int(first_bucket_mb * 2 ** 20 // 4), int(bucket_mb * 2 ** 20 // 4))
         self._bucket_of = {}
         for bi, (lo, hi, plist) in enumerate(self.buckets):
@@ -119,6 +121,16 @@ class GradReducer:
         self.enabled = True
         self.comm_stream = torch.cuda.Stream() if flat.flat_g.is_cuda else None
         self.launch_order: List[int] = []
+        # ReduceOp.AVG is native in RCCL; probe it once and fall back to SUM + scale if this build rejects it
+        self.use_avg = False
+        if (self.world > 1 or self.force) and flat.flat_g.is_cuda:
+            try:
+                probe = torch.ones(8, device=flat.flat_g.device)
+                dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=self.group)
+                torch.cuda.synchronize()
+                self.use_avg = bool(abs(float(probe[0]) - 1.0) < 1e-6)
+            except Exception:
+                self.use_avg = False
 
     @staticmethod
     def _make_buckets(flat, first_elems, cap_elems):
@@ -150,7 +162,7 @@ class GradReducer:
     def _launch(self, bi):
         self._launched[bi] = True
         self.launch_order.append(bi)
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         lo, hi, _ = self.buckets[bi]
         view = self.flat.flat_g[lo:hi]
@@ -160,7 +172,11 @@ class GradReducer:
             if sw is not None:
                 self.comm_stream.wait_stream(sw)
             with torch.cuda.stream(self.comm_stream):
-                dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group)
+                if self.use_avg:
+                    dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group)
+                else:
+                    dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+                    view.mul_(1.0 / self.world)
         else:                                     # gloo (CPU tests): no AVG op
             dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
             view.div_(self.world)
@@ -179,7 +195,7 @@ class GradReducer:
         for bi in range(len(self.buckets)):
             if not self._launched[bi]:
                 self._launch(bi)
-        if self.comm_stream is not None and self.world > 1:
+        if self.comm_stream is not None and (self.world > 1 or self.force):
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 
     def reduce_all_now(self):
@@ -196,7 +212,7 @@ class DataParallel(torch.nn.Module):
         super().__init__()
         self.module = module
         self.reducer = GradReducer(flat, bucket_mb=bucket_mb, first_bucket_mb=first_bucket_mb, process_group=process_group)
-        if self.reducer.world > 1:
+        if self.reducer.world > 1 or self.reducer.force:
             dist.broadcast(flat.flat_p, src=0, group=process_group)           # C2 in SURVEY.md section 2c
             for b in module.buffers():
                 dist.broadcast(b, src=0, group=process_group)

@@ -141,8 +141,9 @@ class GraphedStep:
         self.audio = torch.zeros(audio_shape, device=dev)
         self.world = dist_utils.get_world_size()
         self.reducer = trainer.model.reducer if trainer.distributed else None
+        self.dist_active = self.world > 1 or (self.reducer is not None and self.reducer.force)
         if segments <= 0:
-            segments = int(os.environ.get('DAV_SEGMENTS', '0')) or (3 if self.world > 1 else 1)
+            segments = int(os.environ.get('DAV_SEGMENTS', '0')) or (3 if self.dist_active else 1)
         depth = len(self.model.encoder.image.blocks)
         segments = max(1, min(segments, depth))
         # layer l ends segment s when l is in `cuts`: backward runs layers depth-1 .. 0
@@ -187,12 +188,12 @@ class GraphedStep:
             self.graphs[0].capture_begin()
             engine.refresh_weight_cache(self.model)
             self.loss_image, self.loss_audio = self._fwd_bwd(layer_cb)
-            if self.world == 1:
+            if not self.dist_active:
                 self.opt.launch_step(fused_norm_and_zero=True)      # AdamW + sum(g^2) + zero_grad in one pass
                 self.grad_norm = self.opt.sumsq.sqrt()
             self.graphs[seg[0]].capture_end()
             self.opt_graph = None
-            if self.world > 1:
+            if self.dist_active:
                 self.opt_graph = torch.cuda.CUDAGraph()
                 self.opt_graph.capture_begin(pool=self.graphs[0].pool())
                 self.opt.launch_step(fused_norm_and_zero=True)
@@ -224,7 +225,7 @@ class GraphedStep:
             self.reducer.begin_backward()
         for s, g in enumerate(self.graphs):
             g.replay()
-            if self.reducer is not None and self.world > 1:
+            if self.reducer is not None and self.dist_active:
                 self.reducer.launch_buckets(self.bucket_sched[s])      # overlaps the next segment's replay
         if self.opt_graph is not None:
             self.reducer.finish()
