@@ -234,13 +234,16 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT>
+template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK = 64>
 __global__ __launch_bounds__(WM_* WN_ * 64) void gemm_nt2_kernel(NTParams p) {
   constexpr int NT = WM_ * WN_ * 64;
   constexpr int WTM = BM / WM_, WTN = BN / WN_, FM = WTM / 16, FN = WTN / 16;
-  constexpr int A_CH = BM * 8 / NT, B_CH = BN * 8 / NT, LPT = A_CH + B_CH;
-  constexpr int A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128;
-  static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/threads mismatch");
+  constexpr int ARB = BK * 2, ACPR = BK / 8;               // LDS row bytes / 16-byte chunks per row of A (and NT-mode B) tiles
+  constexpr int A_CH = BM * ACPR / NT, B_CH = BN * ACPR / NT, LPT = A_CH + B_CH;
+  constexpr int A_BYTES = BM * ARB, STAGE_BYTES = (BM + BN) * ARB;
+  static_assert(BM * ACPR % NT == 0 && BN * ACPR % NT == 0, "tile/threads mismatch");
+  static_assert(BK == 64 || BK == 32, "BK");
+  static_assert(!BT || BK == 64, "b_kn mode is built for BK = 64");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -258,31 +261,33 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void gemm_nt2_kernel(NTParams p) {
   int bm, bn;
   {
     const int npan = (tiles_n + 7) >> 3;
-    const int wn = (tiles_n + npan - 1) / npan;
-    const int per = tiles_m * wn;
+    const int wn_ = (tiles_n + npan - 1) / npan;
+    const int per = tiles_m * wn_;
     const int pnl = bid / per, rem = bid - pnl * per;
-    const int wp = (tiles_n - pnl * wn) < wn ? (tiles_n - pnl * wn) : wn;
+    const int wp = (tiles_n - pnl * wn_) < wn_ ? (tiles_n - pnl * wn_) : wn_;
     bm = rem / wp;
-    bn = pnl * wn + rem % wp;
+    bn = pnl * wn_ + rem % wp;
   }
   const int m0 = bm * BM, n0 = bn * BN;
+  // 16-byte-slot XOR swizzle of the row-major tiles: 128-byte rows (BK 64) / 64-byte rows (BK 32)
+  auto rswz = [](int row) { return BK == 64 ? ((row >> 1) & 7) : ((0 - (row >> 2)) & 3); };
 
   const bf16_t* a_src[A_CH];
   const bf16_t* b_src[B_CH];
 #pragma unroll
   for (int i = 0; i < A_CH; ++i) {
-    const int c = tid + NT * i, row = c >> 3, ls = (c & 7) ^ ((row >> 1) & 7);
+    const int c = tid + NT * i, row = c / ACPR, ls = (c % ACPR) ^ rswz(row);
     int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;
     a_src[i] = p.A + map_row(gm, p.amap) * p.lda + ls * 8;
   }
-  // B tile: NT mode = [BN rows][64 k] (128-byte rows, as A); BT mode (B given as [K, N], the dgrad reading W
-  // itself) = [64 k rows][BN cols] (BN*2-byte rows) read back with the transposing ds_read_b64_tr_b16.
+  // B tile: NT mode = [BN rows][BK k] (as A); BT mode (B given as [K, N], the dgrad reading W itself) =
+  // [64 k rows][BN cols] (BN*2-byte rows) read back with the transposing ds_read_b64_tr_b16.
   constexpr int BRB = BN * 2, BCPR = BN / 8;
 #pragma unroll
   for (int i = 0; i < B_CH; ++i) {
     const int c = tid + NT * i;
     if (!BT) {
-      const int row = c >> 3, ls = (c & 7) ^ ((row >> 1) & 7);
+      const int row = c / ACPR, ls = (c % ACPR) ^ rswz(row);
       int gn = n0 + row; gn = gn < p.N ? gn : p.N - 1;
       b_src[i] = p.B + (long)gn * p.ldb + ls * 8;
     } else {
@@ -293,7 +298,7 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void gemm_nt2_kernel(NTParams p) {
     }
   }
   auto dma_tile = [&](int kt) {
-    const int k0 = kt << 6;
+    const int k0 = kt * BK;
     char* st = smem + (kt % STAGES) * STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < A_CH; ++i)
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void gemm_nt2_kernel(NTParams p) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.K >> 6;
+  const int nk = p.K / BK;
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < nk) dma_tile(s);
@@ -327,18 +332,18 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void gemm_nt2_kernel(NTParams p) {
     const char* Ab = smem + (kt % STAGES) * STAGE_BYTES;
     const char* Bb = Ab + A_BYTES;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < BK / 32; ++kk) {
       bf16x8 af[FM], bfr[FN];
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
         const int row = wm * WTM + i * 16 + fr;
-        af[i] = *reinterpret_cast<const bf16x8*>(Ab + row * 128 + (((kk * 4 + fg) ^ ((row >> 1) & 7)) << 4));
+        af[i] = *reinterpret_cast<const bf16x8*>(Ab + row * ARB + (((kk * 4 + fg) ^ rswz(row)) << 4));
       }
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         if (!BT) {
           const int row = wn * WTN + j * 16 + fr;
-          bfr[j] = *reinterpret_cast<const bf16x8*>(Bb + row * 128 + (((kk * 4 + fg) ^ ((row >> 1) & 7)) << 4));
+          bfr[j] = *reinterpret_cast<const bf16x8*>(Bb + row * ARB + (((kk * 4 + fg) ^ rswz(row)) << 4));
         } else {
           bfr[j] = tn2_frag<BRB>(Bb, kk * 32, wn * WTN + j * 16, lane);
         }
@@ -351,76 +356,79 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void gemm_nt2_kernel(NTParams p) {
     }
   }
 
-  // ---- epilogue: registers -> (alpha, bias, activation) -> this wave's LDS patch -> coalesced rows ----
+  // ---- epilogue: 16 tile rows of this wave at a time: registers -> (alpha, bias) -> this wave's small LDS patch
+  //      -> coalesced row segments (16 bytes per lane).  The patch (16 x (WTN + 4) floats per wave) is smaller than
+  //      one ring stage, so the ring alone decides how many workgroups share a CU.
   __syncthreads();                          // all waves finished reading the last stage
-  constexpr int LDW = WTN + 4;              // floats per patch row (+4: 2-way ds_write conflicts only)
-  float* patch = reinterpret_cast<float*>(smem) + wave * (WTM * LDW);
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int n = n0 + wn * WTN + j * 16 + fr;
-      const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) patch[(i * 16 + fg * 4 + r) * LDW + j * 16 + fr] = acc[i][j][r] * p.alpha + bv;
-    }
+  constexpr int LDW = WTN + 4;              // floats per patch row (+4: at most 2-way ds_write conflicts)
+  float* patch = reinterpret_cast<float*>(smem) + wave * (16 * LDW);
   constexpr int CPR = WTN / 4;              // float4 chunks per patch row
   constexpr int RPI = 64 / CPR;             // rows per wave-instruction
   const int cc = lane % CPR, rr = lane / CPR;
   const int n = n0 + wn * WTN + cc * 4;
-  if (n < p.N) {
-#pragma unroll 4
-    for (int it = 0; it < WTM / RPI; ++it) {
-      const int lr = it * RPI + rr;
-      const int m = m0 + wm * WTM + lr;
-      if (m >= p.M) continue;
-      float4 v = *reinterpret_cast<const float4*>(patch + lr * LDW + cc * 4);
-      if (p.c2_mode == 1) {
-        uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
-        *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
-      }
-      if (p.act == 1) {
-        v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w);
-      } else if (p.act == 2) {
-        const uint2 a = *reinterpret_cast<const uint2*>(p.aux + (long)m * p.ldaux + n);
-        v.x *= gelu_grad_f(__uint_as_float(a.x << 16)); v.y *= gelu_grad_f(__uint_as_float(a.x & 0xffff0000u));
-        v.z *= gelu_grad_f(__uint_as_float(a.y << 16)); v.w *= gelu_grad_f(__uint_as_float(a.y & 0xffff0000u));
-      }
-      if (p.c2_mode == 2) {
-        uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
-        *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
-      }
-      if (p.res) {
-        const long rrow = p.res_rows ? (long)p.res_rows[m] : map_row(m, p.rmap);
-        const float4 t = *reinterpret_cast<const float4*>(p.res + rrow * p.ldres + n);
-        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-      }
-      if (p.C) {
-        const long crow = map_row(m, p.cmap);
-        if (p.c_bf16) {
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int nn = n0 + wn * WTN + j * 16 + fr;
+      const float bv = (p.bias && nn < p.N) ? p.bias[nn] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) patch[(fg * 4 + r) * LDW + j * 16 + fr] = acc[i][j][r] * p.alpha + bv;
+    }
+    if (n < p.N && rr < RPI) {
+#pragma unroll
+      for (int it = 0; it < (16 + RPI - 1) / RPI; ++it) {
+        const int lr = it * RPI + rr;
+        const int m = m0 + wm * WTM + i * 16 + lr;
+        if (lr >= 16 || m >= p.M) continue;
+        float4 v = *reinterpret_cast<const float4*>(patch + lr * LDW + cc * 4);
+        if (p.c2_mode == 1) {
           uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
-          *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + crow * p.ldc + n) = w;
-        } else {
-          float4* c = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + crow * p.ldc + n);
-          if (p.beta) { const float4 o = *c; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-          *c = v;
+          *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
         }
-      }
-      if (p.c2_mode == 3) {
-        uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
-        *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
+        if (p.act == 1) {
+          v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w);
+        } else if (p.act == 2) {
+          const uint2 a = *reinterpret_cast<const uint2*>(p.aux + (long)m * p.ldaux + n);
+          v.x *= gelu_grad_f(__uint_as_float(a.x << 16)); v.y *= gelu_grad_f(__uint_as_float(a.x & 0xffff0000u));
+          v.z *= gelu_grad_f(__uint_as_float(a.y << 16)); v.w *= gelu_grad_f(__uint_as_float(a.y & 0xffff0000u));
+        }
+        if (p.c2_mode == 2) {
+          uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
+          *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
+        }
+        if (p.res) {
+          const long rrow = p.res_rows ? (long)p.res_rows[m] : map_row(m, p.rmap);
+          const float4 t = *reinterpret_cast<const float4*>(p.res + rrow * p.ldres + n);
+          v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        if (p.C) {
+          const long crow = map_row(m, p.cmap);
+          if (p.c_bf16) {
+            uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + crow * p.ldc + n) = w;
+          } else {
+            float4* c = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + crow * p.ldc + n);
+            if (p.beta) { const float4 o = *c; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            *c = v;
+          }
+        }
+        if (p.c2_mode == 3) {
+          uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
+          *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
+        }
       }
     }
   }
 }
 
-template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT = false>
+template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT = false, int BK = 64>
 void launch_nt2(const NTParams& p, hipStream_t stream) {
   constexpr int NT = WM_ * WN_ * 64;
-  constexpr size_t ring = (size_t)STAGES * (BM + BN) * 128;
-  constexpr size_t epi = (size_t)WM_ * WN_ * (BM / WM_) * (BN / WN_ + 4) * 4;
+  constexpr size_t ring = (size_t)STAGES * (BM + BN) * BK * 2;
+  constexpr size_t epi = (size_t)WM_ * WN_ * 16 * (BN / WN_ + 4) * 4;
   constexpr size_t lds = ring > epi ? ring : epi;
-  auto kern = gemm_nt2_kernel<BM, BN, WM_, WN_, STAGES, BT>;
+  auto kern = gemm_nt2_kernel<BM, BN, WM_, WN_, STAGES, BT, BK>;
   static bool big = false;
   if (lds > 64 * 1024 && !big) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -789,6 +797,13 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
       case 12: launch_nt2<128, 128, 2, 2, 4>(p, stream); return dav_launch_status();
       case 13: launch_nt2<256, 128, 4, 2, 2>(p, stream); return dav_launch_status();
       case 14: launch_nt2<256, 128, 4, 2, 3>(p, stream); return dav_launch_status();
+      case 15: launch_nt2<128, 128, 2, 2, 2, false, 32>(p, stream); return dav_launch_status();   // 32 KB ring -> 4 WG/CU
+      case 16: launch_nt2<128, 128, 2, 2, 3, false, 32>(p, stream); return dav_launch_status();   // 48 KB -> 3 WG/CU
+      case 17: launch_nt2<128, 128, 2, 2, 4, false, 32>(p, stream); return dav_launch_status();   // 64 KB -> 2 WG/CU
+      case 18: launch_nt2<256, 128, 4, 2, 2, false, 32>(p, stream); return dav_launch_status();   // 48 KB, 8 waves of 64x64
+      case 19: launch_nt2<128, 256, 2, 4, 2, false, 32>(p, stream); return dav_launch_status();   // 48 KB, 8 waves of 64x64
+      case 20: launch_nt2<128, 128, 2, 4, 2, false, 32>(p, stream); return dav_launch_status();   // 8 waves, 32 KB
+      case 21: launch_nt2<128, 128, 2, 4, 3, false, 32>(p, stream); return dav_launch_status();
       default: break;
     }
   }

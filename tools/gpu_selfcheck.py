@@ -70,6 +70,15 @@ def gemm_nt():
             ops.gemm_nt(A, Bm, M, N, K, res=res, ldres=N, C_out=C, beta=1, C2=T, ldc2=N, c2_mode=3, variant=variant)
             report(f'gemm_nt {M}x{N}x{K} v{variant} res+beta', rel(C, ref - bias + res + 0.5), 1e-4)
             report(f'gemm_nt {M}x{N}x{K} v{variant} twin', rel(T, ref - bias + res + 0.5), 6e-3)
+    # every second-generation tile configuration (explicit cfg in variant bits 4-11)
+    for (M, N, K) in [(5184, 2304, 768), (300, 200, 128), (4032, 768, 3072)]:
+        A, Bm = rnd(M, K, dtype=BF16, seed=1), rnd(N, K, dtype=BF16, scale=0.05, seed=2)
+        bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+        ref = A.float() @ Bm.float().t() + bias + res
+        for cfg in (1, 3, 5, 8, 13, 15, 16, 17, 18, 19, 20, 21):
+            C = torch.empty(M, N, device=dev)
+            ops.gemm_nt(A, Bm, M, N, K, bias=bias, res=res, ldres=N, C_out=C, variant=cfg << 4)
+            report(f'gemm_nt {M}x{N}x{K} cfg{cfg}', rel(C, ref), 1e-4)
     # act 2 (multiply by gelu'(aux)) and row maps
     M, N, K = 3 * 7, 128, 64
     Bsz, rpb, tot = 3, 7, 11
