@@ -101,24 +101,37 @@ __device__ __forceinline__ bf16x8 gfrag(const bf16_t* rowptr, int col, bool ok) 
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <int DQK, int DV>
+// CHUNKED = false: all keys of the head resident in LDS, a wave walks over query tiles (the pre-training path's
+// sequences).  CHUNKED = true (long sequences, e.g. the 816-row video blocks): blockIdx.y picks a block of
+// query tiles, one per wave, and the keys stream through LDS in chunks of ATTN_CHUNK rows with the online softmax
+// state carried in registers.
+constexpr int ATTN_CHUNK = 256;
+
+template <int DQK, int DV, bool CHUNKED>
 __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
   constexpr int DQKP = DQK < 32 ? 32 : DQK, KRB = DQKP * 2, KS = DQKP / 32, VC = DV / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int Nkp = (p.Nk + 31) & ~31;
+  const int CH = CHUNKED ? ATTN_CHUNK : Nkp;      // key rows resident at a time
   constexpr int VRB = DV * 2;
-  char* Ks = smem;                 // [Nkp][DQKP]
-  char* Vs = smem + Nkp * KRB;     // [Nkp][DV]
+  char* Ks = smem;                 // [CH][DQKP]
+  char* Vs = smem + CH * KRB;      // [CH][DV]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
   const int fr = lane & 15, g = lane >> 4;
+  const bf16_t* Kg = p.K + b * p.k_bs + h * DQK;
+  const bf16_t* Vg = p.V + b * p.v_bs + h * DV;
 
-  stage_tile<DQK, DQKP>(Ks, p.K + b * p.k_bs + h * DQK, p.Nk, Nkp, p.k_rs, tid, blockDim.x);
-  stage_tile<DV, DV>(Vs, p.V + b * p.v_bs + h * DV, p.Nk, Nkp, p.v_rs, tid, blockDim.x);
-  __syncthreads();
+  if (!CHUNKED) {
+    stage_tile<DQK, DQKP>(Ks, Kg, p.Nk, Nkp, p.k_rs, tid, blockDim.x);
+    stage_tile<DV, DV>(Vs, Vg, p.Nk, Nkp, p.v_rs, tid, blockDim.x);
+    __syncthreads();
+  }
 
   const int nqt = (p.Nq + 15) >> 4;
-  for (int qt = wave; qt < nqt; qt += nw) {
+  // chunked: exactly one (possibly out-of-range, then fully masked-off) tile per wave so that every wave reaches
+  // the chunk barriers
+  for (int qt = CHUNKED ? blockIdx.y * nw + wave : wave; CHUNKED ? qt >= 0 : qt < nqt; qt = CHUNKED ? -1 : qt + nw) {
     const int q = qt * 16 + fr;
     const bool qok = q < p.Nq;
     const bf16_t* qrow = p.Q + b * p.q_bs + (long)(qok ? q : p.Nq - 1) * p.q_rs + h * DQK;
@@ -132,14 +145,24 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
     for (int c = 0; c < VC; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int k0 = 0; k0 < Nkp; k0 += 32) {
+    for (int c0 = 0; c0 < Nkp; c0 += CH) {
+    if (CHUNKED) {
+      const int rows = p.Nk - c0 < CH ? p.Nk - c0 : CH, rows_p = Nkp - c0 < CH ? Nkp - c0 : CH;
+      __syncthreads();                 // every wave is done with the previous chunk
+      stage_tile<DQK, DQKP>(Ks, Kg + (long)c0 * p.k_rs, rows, rows_p, p.k_rs, tid, blockDim.x);
+      stage_tile<DV, DV>(Vs, Vg + (long)c0 * p.v_rs, rows, rows_p, p.v_rs, tid, blockDim.x);
+      __syncthreads();
+    }
+    const int cend = c0 + CH < Nkp ? c0 + CH : Nkp;
+    for (int k0 = c0; k0 < cend; k0 += 32) {
+      const int kl = k0 - c0;          // row of this key step inside the resident chunk
       f32x4 st[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk)
-          st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag<KRB>(Ks, k0 + t * 16 + fr, kk, g), qf[kk], st[t], 0, 0, 0);
+          st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag<KRB>(Ks, kl + t * 16 + fr, kk, g), qf[kk], st[t], 0, 0, 0);
       }
       // scores are kept in the log2 domain (scale * log2(e) folded into one multiply, v_exp_f32 is 2^x);
       // only the last key tile can hold padded keys
@@ -181,8 +204,9 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
       for (int c = 0; c < VC; ++c) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) oacc[c][r] *= alpha;
-        oacc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag_tr<VRB>(Vs, k0, c * 16, lane), pf, oacc[c], 0, 0, 0);
+        oacc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag_tr<VRB>(Vs, kl, c * 16, lane), pf, oacc[c], 0, 0, 0);
       }
+    }
     }
     lsum += __shfl_xor(lsum, 16, 64);
     lsum += __shfl_xor(lsum, 32, 64);
@@ -204,23 +228,28 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
 // ------------------------------------------------------------------------------------------------
 // backward, part 1: dQ (waves own query tiles) + delta
 // ------------------------------------------------------------------------------------------------
-template <int DQK, int DV>
+template <int DQK, int DV, bool CHUNKED>
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
   constexpr int DQKP = DQK < 32 ? 32 : DQK, KRB = DQKP * 2, KS = DQKP / 32, VRB = DV * 2, VS = DV / 32, QC = DQK / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int Nkp = (p.Nk + 31) & ~31;
-  char* Ks = smem;                   // [Nkp][DQKP]
-  char* Vs = Ks + Nkp * KRB;         // [Nkp][DV]
+  const int CH = CHUNKED ? ATTN_CHUNK : Nkp;
+  char* Ks = smem;                   // [CH][DQKP]
+  char* Vs = Ks + CH * KRB;          // [CH][DV]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
   const int fr = lane & 15, g = lane >> 4;
+  const bf16_t* Kg = p.K + b * p.k_bs + h * DQK;
+  const bf16_t* Vg = p.V + b * p.v_bs + h * DV;
 
-  stage_tile<DQK, DQKP>(Ks, p.K + b * p.k_bs + h * DQK, p.Nk, Nkp, p.k_rs, tid, blockDim.x);
-  stage_tile<DV, DV>(Vs, p.V + b * p.v_bs + h * DV, p.Nk, Nkp, p.v_rs, tid, blockDim.x);
-  __syncthreads();
+  if (!CHUNKED) {
+    stage_tile<DQK, DQKP>(Ks, Kg, p.Nk, Nkp, p.k_rs, tid, blockDim.x);
+    stage_tile<DV, DV>(Vs, Vg, p.Nk, Nkp, p.v_rs, tid, blockDim.x);
+    __syncthreads();
+  }
 
   const int nqt = (p.Nq + 15) >> 4;
-  for (int qt = wave; qt < nqt; qt += nw) {
+  for (int qt = CHUNKED ? blockIdx.y * nw + wave : wave; CHUNKED ? qt >= 0 : qt < nqt; qt = CHUNKED ? -1 : qt + nw) {
     const int q = qt * 16 + fr;
     const bool qok = q < p.Nq;
     const int qc = qok ? q : p.Nq - 1;
@@ -249,7 +278,17 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
     for (int c = 0; c < QC; ++c) dq[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int k0 = 0; k0 < Nkp; k0 += 32) {
+    for (int c0 = 0; c0 < Nkp; c0 += CH) {
+    if (CHUNKED) {
+      const int rows = p.Nk - c0 < CH ? p.Nk - c0 : CH, rows_p = Nkp - c0 < CH ? Nkp - c0 : CH;
+      __syncthreads();
+      stage_tile<DQK, DQKP>(Ks, Kg + (long)c0 * p.k_rs, rows, rows_p, p.k_rs, tid, blockDim.x);
+      stage_tile<DV, DV>(Vs, Vg + (long)c0 * p.v_rs, rows, rows_p, p.v_rs, tid, blockDim.x);
+      __syncthreads();
+    }
+    const int cend = c0 + CH < Nkp ? c0 + CH : Nkp;
+    for (int k0 = c0; k0 < cend; k0 += 32) {
+      const int kl = k0 - c0;
       f32x4 st[2], dp[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -257,10 +296,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
         dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk)
-          st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag<KRB>(Ks, k0 + t * 16 + fr, kk, g), qf[kk], st[t], 0, 0, 0);
+          st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag<KRB>(Ks, kl + t * 16 + fr, kk, g), qf[kk], st[t], 0, 0, 0);
 #pragma unroll
         for (int kk = 0; kk < VS; ++kk)
-          dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag<VRB>(Vs, k0 + t * 16 + fr, kk, g), dof[kk], dp[t], 0, 0, 0);
+          dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag<VRB>(Vs, kl + t * 16 + fr, kk, g), dof[kk], dp[t], 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = k0 + t * 16 + 4 * g + r;
@@ -271,7 +310,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
       const bf16x8 dsf = pack8(st[0], st[1]);
 #pragma unroll
       for (int c = 0; c < QC; ++c)
-        dq[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag_tr<KRB>(Ks, k0, c * 16, lane), dsf, dq[c], 0, 0, 0);
+        dq[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag_tr<KRB>(Ks, kl, c * 16, lane), dsf, dq[c], 0, 0, 0);
+    }
     }
     if (qok) {
       bf16_t* dqrow = p.dQ + b * p.dq_bs + (long)q * p.dq_rs + h * DQK;
@@ -289,31 +329,40 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
 // ------------------------------------------------------------------------------------------------
 // backward, part 2: dK, dV (waves own key tiles)
 // ------------------------------------------------------------------------------------------------
-template <int DQK, int DV>
+template <int DQK, int DV, bool CHUNKED>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
   constexpr int DQKP = DQK < 32 ? 32 : DQK, QRB = DQKP * 2, KS = DQKP / 32, ORB = DV * 2, VS = DV / 32, QC = DQK / 16, VC = DV / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int Nqp = (p.Nq + 31) & ~31;
-  char* Qs = smem;                      // [Nqp][DQKP]
-  char* dOs = Qs + Nqp * QRB;           // [Nqp][DV]
-  float* lse_s = reinterpret_cast<float*>(dOs + Nqp * ORB);       // [Nqp]
-  float* del_s = lse_s + Nqp;                                     // [Nqp]
+  const int CH = CHUNKED ? ATTN_CHUNK : Nqp;     // query rows resident at a time
+  char* Qs = smem;                      // [CH][DQKP]
+  char* dOs = Qs + CH * QRB;            // [CH][DV]
+  float* lse_s = reinterpret_cast<float*>(dOs + CH * ORB);        // [CH]
+  float* del_s = lse_s + CH;                                      // [CH]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
   const int fr = lane & 15, g = lane >> 4;
+  const bf16_t* Qg = p.Q + b * p.q_bs + h * DQK;
+  const bf16_t* dOg = p.dO + b * p.do_bs + h * DV;
 
-  stage_tile<DQK, DQKP>(Qs, p.Q + b * p.q_bs + h * DQK, p.Nq, Nqp, p.q_rs, tid, blockDim.x);
-  stage_tile<DV, DV>(dOs, p.dO + b * p.do_bs + h * DV, p.Nq, Nqp, p.do_rs, tid, blockDim.x);
-  for (int i = tid; i < Nqp; i += blockDim.x) {
-    const long sidx = ((long)b * p.H + h) * p.Nq + i;
-    lse_s[i] = i < p.Nq ? p.LSE[sidx] * 1.44269504088896341f : 1e30f;      // log2 domain; 2^(s - 1e30) == 0 for padded query rows
-    del_s[i] = i < p.Nq ? p.Delta[sidx] : 0.f;
+  auto stage_q = [&](int c0) {
+    const int rows = p.Nq - c0 < CH ? p.Nq - c0 : CH, rows_p = Nqp - c0 < CH ? Nqp - c0 : CH;
+    stage_tile<DQK, DQKP>(Qs, Qg + (long)c0 * p.q_rs, rows, rows_p, p.q_rs, tid, blockDim.x);
+    stage_tile<DV, DV>(dOs, dOg + (long)c0 * p.do_rs, rows, rows_p, p.do_rs, tid, blockDim.x);
+    for (int i = tid; i < rows_p; i += blockDim.x) {
+      const long sidx = ((long)b * p.H + h) * p.Nq + c0 + i;
+      lse_s[i] = i < rows ? p.LSE[sidx] * 1.44269504088896341f : 1e30f;      // log2 domain; 2^(s - 1e30) == 0 for padded query rows
+      del_s[i] = i < rows ? p.Delta[sidx] : 0.f;
+    }
+  };
+  if (!CHUNKED) {
+    stage_q(0);
+    __syncthreads();
   }
-  __syncthreads();
 
   const float sl2 = p.scale * 1.44269504088896341f;
   const int nkt = (p.Nk + 15) >> 4;
-  for (int kt = wave; kt < nkt; kt += nw) {
+  for (int kt = CHUNKED ? blockIdx.y * nw + wave : wave; CHUNKED ? kt >= 0 : kt < nkt; kt = CHUNKED ? -1 : kt + nw) {
     const int key = kt * 16 + fr;
     const bool kok = key < p.Nk;
     const int kc = kok ? key : p.Nk - 1;
@@ -331,7 +380,15 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll
     for (int c = 0; c < VC; ++c) dv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int q0 = 0; q0 < Nqp; q0 += 32) {
+    for (int c0 = 0; c0 < Nqp; c0 += CH) {
+    if (CHUNKED) {
+      __syncthreads();
+      stage_q(c0);
+      __syncthreads();
+    }
+    const int cend = c0 + CH < Nqp ? c0 + CH : Nqp;
+    for (int qa = c0; qa < cend; qa += 32) {
+      const int q0 = qa - c0;            // row inside the resident chunk
       f32x4 s[2], dp[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -360,6 +417,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
       for (int c = 0; c < QC; ++c)
         dk[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag_tr<QRB>(Qs, q0, c * 16, lane), dsf, dk[c], 0, 0, 0);
     }
+    }
     if (kok) {
       bf16_t* dkrow = p.dK + b * p.dk_bs + (long)key * p.dk_rs + h * DQK;
       bf16_t* dvrow = p.dV + b * p.dv_bs + (long)key * p.dv_rs + h * DV;
@@ -383,43 +441,72 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
 
 template <int DQK> constexpr int padqk() { return DQK < 32 ? 32 : DQK; }
 
+// resident-in-LDS variant up to this many bytes (2 workgroups per CU), chunked beyond
+constexpr size_t ATTN_RESIDENT_MAX = 80 * 1024;
+
+template <typename K>
+int raise_lds_cap(K kern, size_t lds, bool& done) {
+  if (lds > 64 * 1024 && !done) {      // once per kernel (160 KiB on gfx950)
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done = true;
+  }
+  return 0;
+}
+
+inline int waves_for(int rows) { int nw = (rows + 15) / 16; return nw > 8 ? 8 : (nw < 1 ? 1 : nw); }
+
 template <int DQK, int DV>
 int launch_fwd(const AttnParams& p, hipStream_t stream) {
   const int Nkp = (p.Nk + 31) & ~31;
-  const size_t lds = (size_t)Nkp * padqk<DQK>() * 2 + (size_t)Nkp * DV * 2;
-  if (lds > 160 * 1024) return DAV_ERR_SHAPE;
-  int nw = (p.Nq + 15) / 16; nw = nw > 8 ? 8 : nw; nw = nw < 1 ? 1 : nw;
-  auto kern = attn_fwd_kernel<DQK, DV>;
-  static bool big_lds = false;     // raise the dynamic-LDS cap once per kernel (160 KiB on gfx950)
-  if (lds > 64 * 1024 && !big_lds) {
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    big_lds = true;
+  const size_t row = (size_t)padqk<DQK>() * 2 + (size_t)DV * 2;
+  const size_t lds = Nkp * row;
+  const int nw = waves_for(p.Nq);
+  if (lds <= ATTN_RESIDENT_MAX) {
+    auto kern = attn_fwd_kernel<DQK, DV, false>;
+    static bool big = false;
+    if (int rc = raise_lds_cap(kern, lds, big)) return rc;
+    DAV_LAUNCH(kern, dim3(p.B * p.H), dim3(nw * 64), lds, stream, p);
+  } else {
+    auto kern = attn_fwd_kernel<DQK, DV, true>;
+    static bool big = false;
+    const size_t ldc = ATTN_CHUNK * row;
+    if (int rc = raise_lds_cap(kern, ldc, big)) return rc;
+    DAV_LAUNCH(kern, dim3(p.B * p.H, (p.Nq + nw * 16 - 1) / (nw * 16)), dim3(nw * 64), ldc, stream, p);
   }
-  DAV_LAUNCH(kern, dim3(p.B * p.H), dim3(nw * 64), lds, stream, p);
   return dav_launch_status();
 }
 
 template <int DQK, int DV>
 int launch_bwd(const AttnParams& p, hipStream_t stream) {
   const int Nkp = (p.Nk + 31) & ~31, Nqp = (p.Nq + 31) & ~31;
-  const size_t lds1 = (size_t)Nkp * padqk<DQK>() * 2 + (size_t)Nkp * DV * 2;
-  const size_t lds2 = (size_t)Nqp * padqk<DQK>() * 2 + (size_t)Nqp * DV * 2 + (size_t)Nqp * 8;
-  if (lds1 > 160 * 1024 || lds2 > 160 * 1024) return DAV_ERR_SHAPE;
-  int nw1 = (p.Nq + 15) / 16; nw1 = nw1 > 8 ? 8 : nw1; nw1 = nw1 < 1 ? 1 : nw1;
-  int nw2 = (p.Nk + 15) / 16; nw2 = nw2 > 8 ? 8 : nw2; nw2 = nw2 < 1 ? 1 : nw2;
-  auto k1 = attn_bwd_dq_kernel<DQK, DV>;
-  auto k2 = attn_bwd_dkv_kernel<DQK, DV>;
-  static bool big1 = false, big2 = false;
-  if (lds1 > 64 * 1024 && !big1) {
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    big1 = true;
+  const size_t row = (size_t)padqk<DQK>() * 2 + (size_t)DV * 2;
+  const size_t lds1 = Nkp * row, lds2 = Nqp * (row + 8);
+  const int nw1 = waves_for(p.Nq), nw2 = waves_for(p.Nk);
+  // dQ first: it also writes Delta, which the dK/dV kernel reads
+  if (lds1 <= ATTN_RESIDENT_MAX) {
+    auto k1 = attn_bwd_dq_kernel<DQK, DV, false>;
+    static bool big = false;
+    if (int rc = raise_lds_cap(k1, lds1, big)) return rc;
+    DAV_LAUNCH(k1, dim3(p.B * p.H), dim3(nw1 * 64), lds1, stream, p);
+  } else {
+    auto k1 = attn_bwd_dq_kernel<DQK, DV, true>;
+    static bool big = false;
+    const size_t ldc = ATTN_CHUNK * row;
+    if (int rc = raise_lds_cap(k1, ldc, big)) return rc;
+    DAV_LAUNCH(k1, dim3(p.B * p.H, (p.Nq + nw1 * 16 - 1) / (nw1 * 16)), dim3(nw1 * 64), ldc, stream, p);
   }
-  if (lds2 > 64 * 1024 && !big2) {
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    big2 = true;
+  if (lds2 <= ATTN_RESIDENT_MAX) {
+    auto k2 = attn_bwd_dkv_kernel<DQK, DV, false>;
+    static bool big = false;
+    if (int rc = raise_lds_cap(k2, lds2, big)) return rc;
+    DAV_LAUNCH(k2, dim3(p.B * p.H), dim3(nw2 * 64), lds2, stream, p);
+  } else {
+    auto k2 = attn_bwd_dkv_kernel<DQK, DV, true>;
+    static bool big = false;
+    const size_t ldc = ATTN_CHUNK * (row + 8);
+    if (int rc = raise_lds_cap(k2, ldc, big)) return rc;
+    DAV_LAUNCH(k2, dim3(p.B * p.H, (p.Nk + nw2 * 16 - 1) / (nw2 * 16)), dim3(nw2 * 64), ldc, stream, p);
   }
-  DAV_LAUNCH(k1, dim3(p.B * p.H), dim3(nw1 * 64), lds1, stream, p);
-  DAV_LAUNCH(k2, dim3(p.B * p.H), dim3(nw2 * 64), lds2, stream, p);
   return dav_launch_status();
 }
 

@@ -166,10 +166,15 @@ def ref_attn(q, k, v, scale):
 def attention():
     for (B, H, Nq, Nk, dqk, dv, off) in [(2, 3, 49, 81, 64, 64, 32), (3, 2, 8, 49, 64, 64, 0), (2, 16, 228, 228, 32, 32, 0),
                                         (2, 2, 352, 352, 32, 32, 0), (2, 12, 16, 64, 16, 64, 0), (3, 2, 4, 6, 16, 64, 0),
-                                        (2, 2, 5, 13, 64, 64, 8), (1, 1, 1, 1, 32, 32, 0), (2, 12, 63, 95, 64, 64, 32)]:
+                                        (2, 2, 5, 13, 64, 64, 8), (1, 1, 1, 1, 32, 32, 0), (2, 12, 63, 95, 64, 64, 32),
+                                        # long sequences: keys / queries stream through LDS in chunks
+                                        (2, 3, 784, 816, 64, 64, 32), (2, 2, 352, 352, 64, 64, 0), (1, 2, 100, 1000, 64, 64, 0),
+                                        (1, 2, 1000, 40, 64, 64, 0), (2, 2, 1300, 1300, 32, 32, 0), (1, 3, 17, 530, 16, 64, 0),
+                                        (1, 2, 257, 257, 64, 64, 0)]:
         scale = 0.125 if dqk == 16 else dqk ** -0.5
         # fused layout when dqk == dv: buffer [B, Nk, 3, H, d]; queries are rows off.. of the same buffer
-        if dqk == dv:
+        fused = dqk == dv and Nq <= Nk
+        if fused:
             buf = rnd(B, Nk, 3, H, dqk, dtype=BF16, seed=21)
             assert Nq + off == Nk or off == 0
             qo = off if Nq + off == Nk else 0
@@ -195,7 +200,7 @@ def attention():
         report(tag + ' lse', rel(LSE, lse_ref), 1e-4)
         dO = rnd(B * Nq, H * dv, dtype=BF16, seed=25)
         ref.backward(dO.view(B, Nq, H, dv).permute(0, 2, 1, 3).float())
-        if dqk == dv:
+        if fused:
             dbuf = torch.zeros_like(buf)
             dqt = (dbuf, qt[1]); dkt = (dbuf, kt[1]); dvt = (dbuf, vt[1])
         else:
@@ -204,7 +209,7 @@ def attention():
         Delta = torch.empty_like(LSE)
         ops.attn_bwd(p(qt), p(kt), p(vt), O, dO, LSE, Delta, p(dqt), p(dkt), p(dvt), B, H, Nq, Nk, dqk, dv, *strides,
                      Nq * H * dv, H * dv, Nq * H * dv, H * dv, *strides, scale)
-        if dqk == dv:
+        if fused:
             gq = dbuf[:, qo:qo + Nq, 0].permute(0, 2, 1, 3); gk = dbuf[:, :, 1].permute(0, 2, 1, 3); gv = dbuf[:, :, 2].permute(0, 2, 1, 3)
         else:
             gq, gk, gv = dqb.permute(0, 2, 1, 3), dkb.permute(0, 2, 1, 3), dvb.permute(0, 2, 1, 3)
