@@ -18,6 +18,8 @@
 #include "common.h"
 #include "dav_kernels.h"
 
+int dav_attn_qt = 0;      // dav_tune knob 3: 0 = auto, 1 / 2 = query tiles per wave in the forward kernel
+
 namespace {
 
 struct AttnParams {
@@ -107,7 +109,18 @@ __device__ __forceinline__ bf16x8 gfrag(const bf16_t* rowptr, int col, bool ok) 
 // state carried in registers.
 constexpr int ATTN_CHUNK = 256;
 
-template <int DQK, int DV, bool CHUNKED>
+// cross-lane max over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) with the gfx950 row/half swaps
+// instead of two LDS-pipe ds_bpermute round trips
+__device__ __forceinline__ float rows_max(float x) {
+  const unsigned u = __float_as_uint(x);
+  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);     // {x.r0,x.r0,x.r2,x.r2}, {x.r1,x.r1,x.r3,x.r3}
+  const float y = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const unsigned v = __float_as_uint(y);
+  auto c = __builtin_amdgcn_permlane32_swap(v, v, false, false);     // {y.lo,y.lo}, {y.hi,y.hi}
+  return fmaxf(__uint_as_float(c[0]), __uint_as_float(c[1]));
+}
+
+template <int DQK, int DV, bool CHUNKED, int QT>
 __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
   constexpr int DQKP = DQK < 32 ? 32 : DQK, KRB = DQKP * 2, KS = DQKP / 32, VC = DV / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -129,98 +142,120 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
   }
 
   const int nqt = (p.Nq + 15) >> 4;
-  // chunked: exactly one (possibly out-of-range, then fully masked-off) tile per wave so that every wave reaches
-  // the chunk barriers
-  for (int qt = CHUNKED ? blockIdx.y * nw + wave : wave; CHUNKED ? qt >= 0 : qt < nqt; qt = CHUNKED ? -1 : qt + nw) {
-    const int q = qt * 16 + fr;
-    const bool qok = q < p.Nq;
-    const bf16_t* qrow = p.Q + b * p.q_bs + (long)(qok ? q : p.Nq - 1) * p.q_rs + h * DQK;
-    bf16x8 qf[KS];
+  const float sl2 = p.scale * 1.44269504088896341f;
+  // A wave works on QT query tiles at once (independent softmax chains for the scheduler to interleave; every K / V
+  // fragment read from LDS feeds QT MFMAs).  Chunked: exactly one (possibly out-of-range, then fully masked-off)
+  // group per wave so that every wave reaches the chunk barriers.
+  for (int qt = (CHUNKED ? blockIdx.y * nw + wave : wave) * QT; CHUNKED ? qt >= 0 : qt < nqt; qt = CHUNKED ? -1 : qt + nw * QT) {
+    bool qok[QT];
+    bf16x8 qf[QT][KS];
+    float m[QT], lsum[QT];             // m: reference max in the log2 domain
+    f32x4 oacc[QT][VC];
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) qf[kk] = gfrag(qrow, kk * 32 + 8 * g, kk * 32 + 8 * g < DQK);
-
-    float m = -1e30f, lsum = 0.f;      // m: running max in the log2 domain
-    const float sl2 = p.scale * 1.44269504088896341f;
-    f32x4 oacc[VC];
+    for (int u = 0; u < QT; ++u) {
+      const int q = (qt + u) * 16 + fr;
+      qok[u] = q < p.Nq;
+      const bf16_t* qrow = p.Q + b * p.q_bs + (long)(qok[u] ? q : p.Nq - 1) * p.q_rs + h * DQK;
 #pragma unroll
-    for (int c = 0; c < VC; ++c) oacc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int kk = 0; kk < KS; ++kk) qf[u][kk] = gfrag(qrow, kk * 32 + 8 * g, kk * 32 + 8 * g < DQK);
+      m[u] = -1e30f; lsum[u] = 0.f;
+#pragma unroll
+      for (int c = 0; c < VC; ++c) oacc[u][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     for (int c0 = 0; c0 < Nkp; c0 += CH) {
-    if (CHUNKED) {
-      const int rows = p.Nk - c0 < CH ? p.Nk - c0 : CH, rows_p = Nkp - c0 < CH ? Nkp - c0 : CH;
-      __syncthreads();                 // every wave is done with the previous chunk
-      stage_tile<DQK, DQKP>(Ks, Kg + (long)c0 * p.k_rs, rows, rows_p, p.k_rs, tid, blockDim.x);
-      stage_tile<DV, DV>(Vs, Vg + (long)c0 * p.v_rs, rows, rows_p, p.v_rs, tid, blockDim.x);
-      __syncthreads();
-    }
-    const int cend = c0 + CH < Nkp ? c0 + CH : Nkp;
-    for (int k0 = c0; k0 < cend; k0 += 32) {
-      const int kl = k0 - c0;          // row of this key step inside the resident chunk
-      f32x4 st[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk)
-          st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag<KRB>(Ks, kl + t * 16 + fr, kk, g), qf[kk], st[t], 0, 0, 0);
+      if (CHUNKED) {
+        const int rows = p.Nk - c0 < CH ? p.Nk - c0 : CH, rows_p = Nkp - c0 < CH ? Nkp - c0 : CH;
+        __syncthreads();                 // every wave is done with the previous chunk
+        stage_tile<DQK, DQKP>(Ks, Kg + (long)c0 * p.k_rs, rows, rows_p, p.k_rs, tid, blockDim.x);
+        stage_tile<DV, DV>(Vs, Vg + (long)c0 * p.v_rs, rows, rows_p, p.v_rs, tid, blockDim.x);
+        __syncthreads();
       }
-      // scores are kept in the log2 domain (scale * log2(e) folded into one multiply, v_exp_f32 is 2^x);
-      // only the last key tile can hold padded keys
-      float mx = -1e30f;
-      if (k0 + 32 > p.Nk) {
+      const int cend = c0 + CH < Nkp ? c0 + CH : Nkp;
+      for (int k0 = c0; k0 < cend; k0 += 32) {
+        const char* Kst = Ks + (k0 - c0) * KRB;    // this key step's 32 rows inside the resident chunk
+        const char* Vst = Vs + (k0 - c0) * VRB;
+        bf16x8 kf[2][KS];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = k0 + t * 16 + 4 * g + r;
-            st[t][r] = key < p.Nk ? st[t][r] * sl2 : -1e30f;
-            mx = fmaxf(mx, st[t][r]);
+          for (int kk = 0; kk < KS; ++kk) kf[t][kk] = tile_frag<KRB>(Kst, t * 16 + fr, kk, g);
+        f32x4 st[QT][2];
+#pragma unroll
+        for (int u = 0; u < QT; ++u)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            st[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+              st[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][kk], qf[u][kk], st[u][t], 0, 0, 0);
           }
-      } else {
+        // only the last key tile can hold padded keys
+        if (k0 + 32 > p.Nk) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+          for (int u = 0; u < QT; ++u)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            st[t][r] *= sl2;
-            mx = fmaxf(mx, st[t][r]);
-          }
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mn = fmaxf(m, mx);
-      const float alpha = __builtin_amdgcn_exp2f(m - mn);
-      m = mn;
-      float ps = 0.f;
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          st[t][r] = __builtin_amdgcn_exp2f(st[t][r] - mn);
-          ps += st[t][r];
+              for (int r = 0; r < 4; ++r)
+                if (k0 + t * 16 + 4 * g + r >= p.Nk) st[u][t][r] = -1e30f;
         }
-      lsum = lsum * alpha + ps;
-      const bf16x8 pf = pack8(st[0], st[1]);
+        bf16x8 pf[QT];
 #pragma unroll
-      for (int c = 0; c < VC; ++c) {
+        for (int u = 0; u < QT; ++u) {
+          float mx = fmaxf(fmaxf(fmaxf(st[u][0][0], st[u][0][1]), fmaxf(st[u][0][2], st[u][0][3])),
+                           fmaxf(fmaxf(st[u][1][0], st[u][1][1]), fmaxf(st[u][1][2], st[u][1][3])));
+          mx = rows_max(mx) * sl2;       // log2 domain (scale * log2(e) > 0 commutes with max)
+          // deferred rescale: keep the reference max while no row's tile max exceeds it by more than 2^8 — the
+          // probabilities then stay <= 256 (bf16 keeps its relative precision), O and the row sum need no multiply
+          if (!__all(mx - m[u] <= 8.f)) {
+            const float mn = fmaxf(m[u], mx);
+            const float alpha = __builtin_amdgcn_exp2f(m[u] - mn);
+            m[u] = mn;
+            lsum[u] *= alpha;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) oacc[c][r] *= alpha;
-        oacc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag_tr<VRB>(Vs, kl, c * 16, lane), pf, oacc[c], 0, 0, 0);
+            for (int c = 0; c < VC; ++c)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) oacc[u][c][r] *= alpha;
+          }
+          float ps = 0.f;
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              st[u][t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[u][t][r], sl2, -m[u]));    // v_exp_f32 is 2^x
+              ps += st[u][t][r];
+            }
+          lsum[u] += ps;
+          pf[u] = pack8(st[u][0], st[u][1]);
+        }
+#pragma unroll
+        for (int c = 0; c < VC; ++c) {
+          const bf16x8 vf = tile_frag_tr<VRB>(Vst, 0, c * 16, lane);
+#pragma unroll
+          for (int u = 0; u < QT; ++u)
+            oacc[u][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[u], oacc[u][c], 0, 0, 0);
+        }
       }
     }
-    }
-    lsum += __shfl_xor(lsum, 16, 64);
-    lsum += __shfl_xor(lsum, 32, 64);
-    const float inv = 1.f / lsum;
-    if (qok) {
-      bf16_t* orow = p.O + b * p.o_bs + (long)q * p.o_rs + h * DV;
 #pragma unroll
-      for (int c = 0; c < VC; ++c) {
-        uint2 w;
-        w.x = pack2bf(oacc[c][0] * inv, oacc[c][1] * inv);
-        w.y = pack2bf(oacc[c][2] * inv, oacc[c][3] * inv);
-        *reinterpret_cast<uint2*>(orow + c * 16 + 4 * g) = w;
+    for (int u = 0; u < QT; ++u) {
+      float l = lsum[u];
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+      const float inv = 1.f / l;
+      const int q = (qt + u) * 16 + fr;
+      if (qok[u]) {
+        bf16_t* orow = p.O + b * p.o_bs + (long)q * p.o_rs + h * DV;
+#pragma unroll
+        for (int c = 0; c < VC; ++c) {
+          uint2 w;
+          w.x = pack2bf(oacc[u][c][0] * inv, oacc[u][c][1] * inv);
+          w.y = pack2bf(oacc[u][c][2] * inv, oacc[u][c][3] * inv);
+          *reinterpret_cast<uint2*>(orow + c * 16 + 4 * g) = w;
+        }
+        if (g == 0 && p.LSE) p.LSE[((long)b * p.H + h) * p.Nq + q] = (m[u] + log2f(l)) * 0.69314718055994531f;   // natural-log LSE
       }
-      if (g == 0 && p.LSE) p.LSE[((long)b * p.H + h) * p.Nq + q] = (m + log2f(lsum)) * 0.69314718055994531f;   // natural-log LSE
     }
   }
 }
@@ -288,7 +323,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
     }
     const int cend = c0 + CH < Nkp ? c0 + CH : Nkp;
     for (int k0 = c0; k0 < cend; k0 += 32) {
-      const int kl = k0 - c0;
+      const char* Kst = Ks + (k0 - c0) * KRB;
+      const char* Vst = Vs + (k0 - c0) * VRB;
       f32x4 st[2], dp[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -296,10 +332,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
         dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk)
-          st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag<KRB>(Ks, kl + t * 16 + fr, kk, g), qf[kk], st[t], 0, 0, 0);
+          st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag<KRB>(Kst, t * 16 + fr, kk, g), qf[kk], st[t], 0, 0, 0);
 #pragma unroll
         for (int kk = 0; kk < VS; ++kk)
-          dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag<VRB>(Vs, kl + t * 16 + fr, kk, g), dof[kk], dp[t], 0, 0, 0);
+          dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag<VRB>(Vst, t * 16 + fr, kk, g), dof[kk], dp[t], 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = k0 + t * 16 + 4 * g + r;
@@ -310,7 +346,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
       const bf16x8 dsf = pack8(st[0], st[1]);
 #pragma unroll
       for (int c = 0; c < QC; ++c)
-        dq[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag_tr<KRB>(Ks, kl, c * 16, lane), dsf, dq[c], 0, 0, 0);
+        dq[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag_tr<KRB>(Kst, 0, c * 16, lane), dsf, dq[c], 0, 0, 0);
     }
     }
     if (qok) {
@@ -389,6 +425,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
     const int cend = c0 + CH < Nqp ? c0 + CH : Nqp;
     for (int qa = c0; qa < cend; qa += 32) {
       const int q0 = qa - c0;            // row inside the resident chunk
+      const char* Qst = Qs + q0 * QRB;
+      const char* dOst = dOs + q0 * ORB;
       f32x4 s[2], dp[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -396,10 +434,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
         dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk)
-          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag<QRB>(Qs, q0 + t * 16 + fr, kk, g), kf[kk], s[t], 0, 0, 0);
+          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag<QRB>(Qst, t * 16 + fr, kk, g), kf[kk], s[t], 0, 0, 0);
 #pragma unroll
         for (int kk = 0; kk < VS; ++kk)
-          dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag<ORB>(dOs, q0 + t * 16 + fr, kk, g), vf[kk], dp[t], 0, 0, 0);
+          dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag<ORB>(dOst, t * 16 + fr, kk, g), vf[kk], dp[t], 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int qi = q0 + t * 16 + 4 * g + r;
@@ -412,10 +450,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
       const bf16x8 dsf = pack8(dp[0], dp[1]);
 #pragma unroll
       for (int c = 0; c < VC; ++c)
-        dv[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag_tr<ORB>(dOs, q0, c * 16, lane), pf, dv[c], 0, 0, 0);
+        dv[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag_tr<ORB>(dOst, 0, c * 16, lane), pf, dv[c], 0, 0, 0);
 #pragma unroll
       for (int c = 0; c < QC; ++c)
-        dk[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag_tr<QRB>(Qs, q0, c * 16, lane), dsf, dk[c], 0, 0, 0);
+        dk[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag_tr<QRB>(Qst, 0, c * 16, lane), dsf, dk[c], 0, 0, 0);
     }
     }
     if (kok) {
@@ -444,10 +482,11 @@ template <int DQK> constexpr int padqk() { return DQK < 32 ? 32 : DQK; }
 // resident-in-LDS variant up to this many bytes (2 workgroups per CU), chunked beyond
 constexpr size_t ATTN_RESIDENT_MAX = 80 * 1024;
 
-template <typename K>
-int raise_lds_cap(K kern, size_t lds, bool& done) {
-  if (lds > 64 * 1024 && !done) {      // once per kernel (160 KiB on gfx950)
-    HIP_CHECK_RET(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+template <auto KERN>
+int raise_lds_cap(size_t lds) {
+  static bool done = false;            // once per kernel (160 KiB on gfx950)
+  if (lds > 64 * 1024 && !done) {
+    HIP_CHECK_RET(hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done = true;
   }
   return 0;
@@ -460,18 +499,20 @@ int launch_fwd(const AttnParams& p, hipStream_t stream) {
   const int Nkp = (p.Nk + 31) & ~31;
   const size_t row = (size_t)padqk<DQK>() * 2 + (size_t)DV * 2;
   const size_t lds = Nkp * row;
-  const int nw = waves_for(p.Nq);
+  const bool two = dav_attn_qt == 2 || (dav_attn_qt == 0 && p.Nq >= 1024);      // two query tiles per wave
+  const int nw = waves_for(two ? (p.Nq + 1) / 2 : p.Nq);
   if (lds <= ATTN_RESIDENT_MAX) {
-    auto kern = attn_fwd_kernel<DQK, DV, false>;
-    static bool big = false;
-    if (int rc = raise_lds_cap(kern, lds, big)) return rc;
+    auto kern = two ? attn_fwd_kernel<DQK, DV, false, 2> : attn_fwd_kernel<DQK, DV, false, 1>;
+    if (int rc = raise_lds_cap<attn_fwd_kernel<DQK, DV, false, 1>>(lds)) return rc;
+    if (int rc = raise_lds_cap<attn_fwd_kernel<DQK, DV, false, 2>>(lds)) return rc;
     DAV_LAUNCH(kern, dim3(p.B * p.H), dim3(nw * 64), lds, stream, p);
   } else {
-    auto kern = attn_fwd_kernel<DQK, DV, true>;
-    static bool big = false;
+    auto kern = two ? attn_fwd_kernel<DQK, DV, true, 2> : attn_fwd_kernel<DQK, DV, true, 1>;
     const size_t ldc = ATTN_CHUNK * row;
-    if (int rc = raise_lds_cap(kern, ldc, big)) return rc;
-    DAV_LAUNCH(kern, dim3(p.B * p.H, (p.Nq + nw * 16 - 1) / (nw * 16)), dim3(nw * 64), ldc, stream, p);
+    if (int rc = raise_lds_cap<attn_fwd_kernel<DQK, DV, true, 1>>(ldc)) return rc;
+    if (int rc = raise_lds_cap<attn_fwd_kernel<DQK, DV, true, 2>>(ldc)) return rc;
+    const int rows_wg = nw * 16 * (two ? 2 : 1);
+    DAV_LAUNCH(kern, dim3(p.B * p.H, (p.Nq + rows_wg - 1) / rows_wg), dim3(nw * 64), ldc, stream, p);
   }
   return dav_launch_status();
 }
@@ -485,26 +526,22 @@ int launch_bwd(const AttnParams& p, hipStream_t stream) {
   // dQ first: it also writes Delta, which the dK/dV kernel reads
   if (lds1 <= ATTN_RESIDENT_MAX) {
     auto k1 = attn_bwd_dq_kernel<DQK, DV, false>;
-    static bool big = false;
-    if (int rc = raise_lds_cap(k1, lds1, big)) return rc;
+    if (int rc = raise_lds_cap<attn_bwd_dq_kernel<DQK, DV, false>>(lds1)) return rc;
     DAV_LAUNCH(k1, dim3(p.B * p.H), dim3(nw1 * 64), lds1, stream, p);
   } else {
     auto k1 = attn_bwd_dq_kernel<DQK, DV, true>;
-    static bool big = false;
     const size_t ldc = ATTN_CHUNK * row;
-    if (int rc = raise_lds_cap(k1, ldc, big)) return rc;
+    if (int rc = raise_lds_cap<attn_bwd_dq_kernel<DQK, DV, true>>(ldc)) return rc;
     DAV_LAUNCH(k1, dim3(p.B * p.H, (p.Nq + nw1 * 16 - 1) / (nw1 * 16)), dim3(nw1 * 64), ldc, stream, p);
   }
   if (lds2 <= ATTN_RESIDENT_MAX) {
     auto k2 = attn_bwd_dkv_kernel<DQK, DV, false>;
-    static bool big = false;
-    if (int rc = raise_lds_cap(k2, lds2, big)) return rc;
+    if (int rc = raise_lds_cap<attn_bwd_dkv_kernel<DQK, DV, false>>(lds2)) return rc;
     DAV_LAUNCH(k2, dim3(p.B * p.H), dim3(nw2 * 64), lds2, stream, p);
   } else {
     auto k2 = attn_bwd_dkv_kernel<DQK, DV, true>;
-    static bool big = false;
     const size_t ldc = ATTN_CHUNK * (row + 8);
-    if (int rc = raise_lds_cap(k2, ldc, big)) return rc;
+    if (int rc = raise_lds_cap<attn_bwd_dkv_kernel<DQK, DV, true>>(ldc)) return rc;
     DAV_LAUNCH(k2, dim3(p.B * p.H, (p.Nk + nw2 * 16 - 1) / (nw2 * 16)), dim3(nw2 * 64), ldc, stream, p);
   }
   return dav_launch_status();

@@ -304,7 +304,10 @@ extern "C" int dav_layernorm_bwd_reduce_grouped(const DavLnReduce* items, int co
   return dav_launch_status();
 }
 
+extern int dav_attn_qt;      // attention.hip
+
 extern "C" int dav_tune(int knob, int value) {
+  if (knob == 3 && value >= 0 && value <= 2) { dav_attn_qt = value; return DAV_OK; }
   if (knob == 1 && (value == 2 || value == 4 || value == 8)) { g_ln_bwd_waves = value; return DAV_OK; }
   if (knob == 2 && value >= 1 && value <= 4096) { g_ln_bwd_cap = value; return DAV_OK; }
   return DAV_ERR_SHAPE;

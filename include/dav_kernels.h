@@ -38,7 +38,8 @@ extern "C" {
 int dav_abi_version(void);
 /* text of the last HIP error latched by a kernel launch of the calling thread (diagnostics) */
 const char* dav_last_error_string(void);
-/* launch-geometry knobs for tuning experiments (1: LayerNorm-backward waves per workgroup {2,4,8}; 2: its grid cap) */
+/* launch-geometry knobs for tuning experiments (1: LayerNorm-backward waves per workgroup {2,4,8}; 2: its grid cap;
+ * 3: query tiles per wave of the attention forward, 0 = automatic, 1, 2) */
 int dav_tune(int knob, int value);
 
 /* ---- GEMM --------------------------------------------------------------------------------- */

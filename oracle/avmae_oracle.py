@@ -67,6 +67,36 @@ class PathConfig:
         return (self.audio_size[0] // self.patch, self.audio_size[1] // self.patch)
 
 
+@dataclass
+class VideoConfig:
+    """Shapes of one ``VideoEarlyFusion`` instance (BASELINE.json configs[4]): ctor arguments of
+    ``models/video_earlyfusion.py:10-27`` + the factory constants of ``models/video_vits.py:246-345``
+    (patch (2,16,16), norm eps 1e-6) and ``models/video_earlyfusion.py:134-171``."""
+    embed_dim: int = 768
+    depth: int = 12
+    num_heads: int = 12
+    mlp_ratio: float = 4.0
+    patch: int = 16
+    video_size: Tuple[int, int, int] = (8, 224, 224)
+    video_patch: Tuple[int, int, int] = (2, 16, 16)
+    audio_size: Tuple[int, int] = (128, 192)
+    fusion_tkns: Tuple[int, int, int] = (16, 8, 8)
+    fusion_layers: Tuple[int, ...] = field(default_factory=lambda: tuple(range(12)))
+    fusion_mlp_ratio: float = 1.0
+    fusion_attn_ratio: float = 0.25
+    fusion_num_heads: int = 12
+    enc_eps: float = 1e-6      # models/video_vits.py:135 / models/vits.py:125
+    fus_eps: float = 1e-5      # nn.LayerNorm default: models/video_earlyfusion.py:50,54
+
+    @property
+    def video_grid(self):
+        return tuple(s // p for s, p in zip(self.video_size, self.video_patch))
+
+    @property
+    def audio_grid(self):
+        return (self.audio_size[0] // self.patch, self.audio_size[1] // self.patch)
+
+
 # --------------------------------------------------------------------------- #
 # util/pos_embed.py
 # --------------------------------------------------------------------------- #
@@ -196,6 +226,26 @@ def prepare_patch_tokens(x: Tensor, sd, name: str, patch: int, ids_keep: Optiona
     return t
 
 
+def patch_embed3d(x: Tensor, sd: Dict[str, Tensor], name: str, patch: Tuple[int, int, int]) -> Tensor:
+    """util/pos_embed.py:123-146 — Conv3d(kernel=stride=patch) -> flatten(2).transpose(1,2), restated as
+    unfold + matmul: token = (gt*gH + gy)*gW + gx, feature = ((c*pt + dt)*ph + py)*pw + px."""
+    B, C, T, H, W = x.shape
+    pt, ph, pw = patch
+    gt, gh, gw = T // pt, H // ph, W // pw
+    w = sd[name + '.proj.weight'].reshape(-1, C * pt * ph * pw)
+    cols = x.reshape(B, C, gt, pt, gh, ph, gw, pw).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B, gt * gh * gw, C * pt * ph * pw)
+    return cols @ w.t() + sd[name + '.proj.bias']
+
+
+def video_prepare_patch_tokens(x: Tensor, sd, name: str, patch: Tuple[int, int, int], ids_keep: Optional[Tensor]) -> Tensor:
+    """models/video_vits.py:218-239 with use_cls_token=False: the gather comes BEFORE the pos-embed add
+    (:229-232), so kept-token subsets only broadcast when len(ids_keep) == num_patches."""
+    t = patch_embed3d(x, sd, name + '.patch_embed', patch)
+    if ids_keep is not None:
+        t = t.gather(1, ids_keep.unsqueeze(-1).expand(-1, -1, t.shape[-1]))
+    return t + sd[name + '.pos_embed']
+
+
 # --------------------------------------------------------------------------- #
 # models/fusion_blocks.py
 # --------------------------------------------------------------------------- #
@@ -247,36 +297,52 @@ def fusion_block_factorized(xmm: Tensor, xv: Tensor, xa: Tensor, sd, name: str, 
 # --------------------------------------------------------------------------- #
 # models/deepavfusion.py
 # --------------------------------------------------------------------------- #
+def _early_fusion_layers(sd, cfg, x_v: Tensor, x_a: Tensor, prefix: str, vis: str, return_embs: bool):
+    """The layer loop shared by models/deepavfusion.py:96-118 and models/video_earlyfusion.py:107-131
+    (``vis`` = 'image' / 'video'; the video Block in 'joint_all' mode is the timm pre-LN block,
+    models/video_vits.py:46-47,94)."""
+    B = x_v.shape[0]
+    x_f = sd[prefix + 'fusion_tokens'].expand(B, -1, -1)
+    nF = x_f.shape[1]
+    embs = []
+    for l in range(cfg.depth):
+        if l not in cfg.fusion_layers:
+            x_v = timm_block(x_v, sd, f'{prefix}{vis}.blocks.{l}', cfg.num_heads, cfg.enc_eps)
+            x_a = timm_block(x_a, sd, f'{prefix}audio.blocks.{l}', cfg.num_heads, cfg.enc_eps)
+        else:
+            # fusion tokens are context rows whose own outputs are dropped (:104-105);
+            # the fusion block reads the layer's INPUT x_v / x_a (:106-107)
+            n_v = timm_block(torch.cat((x_f, x_v), 1), sd, f'{prefix}{vis}.blocks.{l}', cfg.num_heads, cfg.enc_eps)[:, nF:]
+            n_a = timm_block(torch.cat((x_f, x_a), 1), sd, f'{prefix}audio.blocks.{l}', cfg.num_heads, cfg.enc_eps)[:, nF:]
+            x_f = fusion_block_factorized(x_f, x_v, x_a, sd, f'{prefix}fusion_blocks.{l}', cfg.fusion_num_heads,
+                                          cfg.fusion_tkns, cfg.fus_eps)
+            x_v, x_a = n_v, n_a
+        if return_embs:
+            embs.append((x_v, x_a, x_f))
+    x_v = layer_norm(x_v, sd, f'{prefix}{vis}.norm', cfg.enc_eps)
+    x_a = layer_norm(x_a, sd, prefix + 'audio.norm', cfg.enc_eps)
+    x_f = layer_norm(x_f, sd, prefix + 'fusion_norm', cfg.fus_eps)
+    if return_embs:
+        return x_v, x_a, x_f, embs
+    return x_v, x_a, x_f
+
+
 def deepavfusion_forward(sd, cfg: PathConfig, image: Tensor, audio: Tensor,
                          image_ids_keep: Optional[Tensor] = None, audio_ids_keep: Optional[Tensor] = None,
                          prefix: str = '', return_embs: bool = False):
     """models/deepavfusion.py:88-118 (factorized_mmi arch)."""
-    B = image.shape[0]
     x_i = prepare_patch_tokens(image, sd, prefix + 'image', cfg.patch, image_ids_keep)
     x_a = prepare_patch_tokens(audio, sd, prefix + 'audio', cfg.patch, audio_ids_keep)
-    x_f = sd[prefix + 'fusion_tokens'].expand(B, -1, -1)
-    nI, nA, nF = x_i.shape[1], x_a.shape[1], x_f.shape[1]
-    embs = []
-    for l in range(cfg.depth):
-        if l not in cfg.fusion_layers:
-            x_i = timm_block(x_i, sd, f'{prefix}image.blocks.{l}', cfg.num_heads, cfg.enc_eps)
-            x_a = timm_block(x_a, sd, f'{prefix}audio.blocks.{l}', cfg.num_heads, cfg.enc_eps)
-        else:
-            # fusion tokens are context rows whose own outputs are dropped (:104-105);
-            # the fusion block reads the layer's INPUT x_i / x_a (:106-107)
-            n_i = timm_block(torch.cat((x_f, x_i), 1), sd, f'{prefix}image.blocks.{l}', cfg.num_heads, cfg.enc_eps)[:, nF:]
-            n_a = timm_block(torch.cat((x_f, x_a), 1), sd, f'{prefix}audio.blocks.{l}', cfg.num_heads, cfg.enc_eps)[:, nF:]
-            x_f = fusion_block_factorized(x_f, x_i, x_a, sd, f'{prefix}fusion_blocks.{l}', cfg.fusion_num_heads,
-                                          cfg.fusion_tkns, cfg.fus_eps)
-            x_i, x_a = n_i, n_a
-        if return_embs:
-            embs.append((x_i, x_a, x_f))
-    x_i = layer_norm(x_i, sd, prefix + 'image.norm', cfg.enc_eps)
-    x_a = layer_norm(x_a, sd, prefix + 'audio.norm', cfg.enc_eps)
-    x_f = layer_norm(x_f, sd, prefix + 'fusion_norm', cfg.fus_eps)
-    if return_embs:
-        return x_i, x_a, x_f, embs
-    return x_i, x_a, x_f
+    return _early_fusion_layers(sd, cfg, x_i, x_a, prefix, 'image', return_embs)
+
+
+def video_earlyfusion_forward(sd, cfg: VideoConfig, video: Tensor, audio: Tensor,
+                              video_ids_keep: Optional[Tensor] = None, audio_ids_keep: Optional[Tensor] = None,
+                              prefix: str = '', return_embs: bool = False):
+    """models/video_earlyfusion.py:95-131: video [B,3,T,H,W], audio [B,1,n_mels,frames]."""
+    x_v = video_prepare_patch_tokens(video, sd, prefix + 'video', cfg.video_patch, video_ids_keep)
+    x_a = prepare_patch_tokens(audio, sd, prefix + 'audio', cfg.patch, audio_ids_keep)
+    return _early_fusion_layers(sd, cfg, x_v, x_a, prefix, 'video', return_embs)
 
 
 # --------------------------------------------------------------------------- #
@@ -356,24 +422,23 @@ def _block_shapes(prefix: str, dim: int, hidden: int):
     }
 
 
-def state_shapes(cfg: PathConfig) -> Dict[str, Tuple[int, ...]]:
-    """Names and shapes of ``AVMAE(DeepAVFusion(...)).state_dict()``."""
-    D, p = cfg.embed_dim, cfg.patch
-    s: Dict[str, Tuple[int, ...]] = {}
-    for mod, grid, cin in (('image', cfg.image_grid, 3), ('audio', cfg.audio_grid, 1)):
-        pre = f'encoder.{mod}'
-        s[f'{pre}.pos_embed'] = (1, grid[0] * grid[1], D)
-        s[f'{pre}.patch_embed.proj.weight'] = (D, cin, p, p)
-        s[f'{pre}.patch_embed.proj.bias'] = (D,)
-        for l in range(cfg.depth):
-            s.update(_block_shapes(f'{pre}.blocks.{l}', D, int(D * cfg.mlp_ratio)))
-        s[f'{pre}.norm.weight'] = (D,)
-        s[f'{pre}.norm.bias'] = (D,)
-    s['encoder.fusion_tokens'] = (1, sum(cfg.fusion_tkns), D)
+def _tower_shapes(s, pre, n_patches, conv_shape, D, depth, mlp_ratio):
+    s[f'{pre}.pos_embed'] = (1, n_patches, D)
+    s[f'{pre}.patch_embed.proj.weight'] = conv_shape
+    s[f'{pre}.patch_embed.proj.bias'] = (D,)
+    for l in range(depth):
+        s.update(_block_shapes(f'{pre}.blocks.{l}', D, int(D * mlp_ratio)))
+    s[f'{pre}.norm.weight'] = (D,)
+    s[f'{pre}.norm.bias'] = (D,)
+
+
+def _fusion_shapes(s, enc, cfg):
+    D = cfg.embed_dim
+    s[f'{enc}fusion_tokens'] = (1, sum(cfg.fusion_tkns), D)
     Da = int(D * cfg.fusion_attn_ratio)
     Hf = int(D * cfg.fusion_mlp_ratio)
     for l in cfg.fusion_layers:
-        pre = f'encoder.fusion_blocks.{l}'
+        pre = f'{enc}fusion_blocks.{l}'
         for n in ('norm1_mm', 'norm1_aud', 'norm1_img', 'norm2'):
             s[f'{pre}.{n}.weight'] = (D,)
             s[f'{pre}.{n}.bias'] = (D,)
@@ -387,8 +452,31 @@ def state_shapes(cfg: PathConfig) -> Dict[str, Tuple[int, ...]]:
         s[f'{pre}.attn.proj.weight'] = (D, D); s[f'{pre}.attn.proj.bias'] = (D,)
         s[f'{pre}.mlp.fc1.weight'] = (Hf, D); s[f'{pre}.mlp.fc1.bias'] = (Hf,)
         s[f'{pre}.mlp.fc2.weight'] = (D, Hf); s[f'{pre}.mlp.fc2.bias'] = (D,)
-    s['encoder.fusion_norm.weight'] = (D,)
-    s['encoder.fusion_norm.bias'] = (D,)
+    s[f'{enc}fusion_norm.weight'] = (D,)
+    s[f'{enc}fusion_norm.bias'] = (D,)
+
+
+def video_state_shapes(cfg: VideoConfig) -> Dict[str, Tuple[int, ...]]:
+    """Names and shapes of ``VideoEarlyFusion(...).state_dict()`` (models/video_earlyfusion.py:29-54)."""
+    D, p = cfg.embed_dim, cfg.patch
+    s: Dict[str, Tuple[int, ...]] = {}
+    gv, ga = cfg.video_grid, cfg.audio_grid
+    _tower_shapes(s, 'video', gv[0] * gv[1] * gv[2], (D, 3) + tuple(cfg.video_patch), D, cfg.depth, cfg.mlp_ratio)
+    _tower_shapes(s, 'audio', ga[0] * ga[1], (D, 1, p, p), D, cfg.depth, cfg.mlp_ratio)
+    _fusion_shapes(s, '', cfg)
+    return s
+
+
+def state_shapes(cfg) -> Dict[str, Tuple[int, ...]]:
+    """Names and shapes of ``AVMAE(DeepAVFusion(...)).state_dict()``; for a VideoConfig those
+    of ``VideoEarlyFusion``."""
+    if isinstance(cfg, VideoConfig):
+        return video_state_shapes(cfg)
+    D, p = cfg.embed_dim, cfg.patch
+    s: Dict[str, Tuple[int, ...]] = {}
+    for mod, grid, cin in (('image', cfg.image_grid, 3), ('audio', cfg.audio_grid, 1)):
+        _tower_shapes(s, f'encoder.{mod}', grid[0] * grid[1], (D, cin, p, p), D, cfg.depth, cfg.mlp_ratio)
+    _fusion_shapes(s, 'encoder.', cfg)
     Dd = cfg.decoder_dim
     for mod, grid, cin in (('image', cfg.image_grid, 3), ('audio', cfg.audio_grid, 1)):
         pre = f'{mod}_decoder_'
@@ -402,7 +490,8 @@ def state_shapes(cfg: PathConfig) -> Dict[str, Tuple[int, ...]]:
     return s
 
 
-FROZEN = ('encoder.image.pos_embed', 'encoder.audio.pos_embed')   # models/vits.py:29
+FROZEN = ('encoder.image.pos_embed', 'encoder.audio.pos_embed',   # models/vits.py:29
+          'video.pos_embed', 'audio.pos_embed')                    # models/video_vits.py:148 (pos_trainable=False)
 
 
 def closed_form_state(cfg: PathConfig, seed: int = 0) -> Dict[str, Tensor]:
@@ -413,7 +502,9 @@ def closed_form_state(cfg: PathConfig, seed: int = 0) -> Dict[str, Tensor]:
     sd: Dict[str, Tensor] = {}
     for name, shape in state_shapes(cfg).items():
         rs = np.random.RandomState((zlib.crc32(name.encode()) + 7919 * seed) & 0x7FFFFFFF)
-        if name in FROZEN:
+        if name == 'video.pos_embed':
+            arr = sincos_3d(shape[-1], cfg.video_grid)[None]
+        elif name in FROZEN:
             grid = cfg.image_grid if '.image.' in name else cfg.audio_grid
             arr = sincos_2d(shape[-1], grid)[None]
         elif name.endswith('decoder_pos_embed'):
@@ -444,6 +535,15 @@ def synthetic_batch(cfg: PathConfig, B: int, seed: int = 1234):
     noise_i = (noise_i + 0.5) / noise_i.size
     noise_a = (noise_a + 0.5) / noise_a.size
     return torch.from_numpy(image), torch.from_numpy(audio), noise_i, noise_a
+
+
+def synthetic_video_batch(cfg: VideoConfig, B: int, seed: int = 1234):
+    """Clip [B,3,T,H,W] ~ N(0,1) + log-mel [B,1,n_mels,frames] in about [-7, 4] (the ``__main__`` probe of
+    models/video_earlyfusion.py:174-186 uses randn for both)."""
+    rs = np.random.RandomState(seed)
+    video = rs.standard_normal((B, 3) + tuple(cfg.video_size)).astype(np.float32)
+    audio = np.clip(rs.standard_normal((B, 1) + tuple(cfg.audio_size)) * 2.0 - 3.0, -7, 4).astype(np.float32)
+    return torch.from_numpy(video), torch.from_numpy(audio)
 
 
 def structured_batch(cfg: PathConfig, B: int, seed: int):

@@ -4,9 +4,10 @@ TEST INFRASTRUCTURE (see oracle/__init__.py).  ``micro`` is a parity-only shape
 whose head widths (64 encoder / 32 decoder / 16 fusion q-k) match what the HIP
 attention kernels are specialised for; ``tiny`` is BASELINE.json configs[0];
 ``base`` is configs[1] (the bench workload); ``base_as`` configs[2]; ``large``
-configs[3].
+configs[3]; ``video_base`` configs[4] (``video_efav_base`` on an 8-frame clip + 3 s audio),
+``video_micro`` its parity-only miniature.
 """
-from .avmae_oracle import PathConfig
+from .avmae_oracle import PathConfig, VideoConfig
 
 CONFIGS = {
     'micro': PathConfig(embed_dim=128, depth=2, num_heads=2, image_size=(64, 64), audio_size=(32, 112),
@@ -19,4 +20,7 @@ CONFIGS = {
     'base_m75': PathConfig(audio_mask_ratio=0.75),
     'base_as': PathConfig(fusion_mlp_ratio=4.0, fusion_attn_ratio=1.0),
     'large': PathConfig(embed_dim=1024, depth=24, num_heads=16, fusion_layers=tuple(range(24)), fusion_num_heads=16),
+    'video_micro': VideoConfig(embed_dim=128, depth=2, num_heads=2, video_size=(4, 48, 32), audio_size=(32, 48),
+                               fusion_tkns=(4, 3, 2), fusion_layers=(0, 1), fusion_num_heads=2),
+    'video_base': VideoConfig(),
 }

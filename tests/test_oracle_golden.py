@@ -175,6 +175,39 @@ def test_end_to_end(golden, name):
     assert abs(total - float(g['grad_norm_total'])) < 1e-4 * float(g['grad_norm_total'])
 
 
+def probe_weights(shapes, seed):
+    rs = np.random.RandomState(seed)
+    return [torch.from_numpy(rs.standard_normal(tuple(s)).astype(np.float32)) for s in shapes]
+
+
+def test_video_earlyfusion(golden):
+    """BASELINE configs[4] family: models/video_earlyfusion.py:95-131 through the reference."""
+    g = golden('e2e_video_micro')
+    cfg = CONFIGS['video_micro']
+    assert np.allclose(O.sincos_3d(cfg.embed_dim, cfg.video_grid), g['video_pos_embed_init'][0], atol=1e-6)   # H != W grid
+    sd = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in O.closed_form_state(cfg, 0).items()}
+    video, audio = O.synthetic_video_batch(cfg, int(g['B']), seed=int(g['seed']))
+    xv, xa, xf, embs = O.video_earlyfusion_forward(sd, cfg, video, audio, return_embs=True)
+    close(xv.detach().numpy(), g['x_video'], rtol=5e-5)
+    close(xa.detach().numpy(), g['x_audio'], rtol=5e-5)
+    close(xf.detach().numpy(), g['x_fusion'], rtol=5e-5)
+    close(embs[-1][0].detach().numpy()[:, ::2, ::5], g['emb_last_video_sub'], rtol=5e-5)
+    close(embs[0][2].detach().numpy(), g['emb_first_fusion'], rtol=5e-5)
+    assert abs(float(xv.sum() + xa.sum() + xf.sum()) - float(g['loss_sum'])) < 1e-3
+    w = probe_weights([xv.shape, xa.shape, xf.shape], int(g['seed']) + 1)
+    loss = (xv * w[0]).sum() + (xa * w[1]).sum() + (xf * w[2]).sum()
+    assert abs(float(loss) - float(g['loss_probe'])) < 1e-4 * abs(float(g['loss_probe']))
+    loss.backward()
+    norms = dict(zip(g['grad_names'].tolist(), g['grad_norms'].tolist()))
+    assert set(norms) == {k for k, v in sd.items() if v.requires_grad}
+    for k, ref in norms.items():
+        got = float(sd[k].grad.double().norm())
+        assert abs(got - ref) <= 2e-4 * max(ref, 1e-6) + 1e-6, (k, got, ref)
+    for k in g.files:
+        if k.startswith('grad.'):
+            close(sd[k[5:]].grad.numpy(), g[k], rtol=1e-4)
+
+
 def test_lr_schedule_and_param_groups(golden):
     g = golden('lr_groups')
     cfg = CONFIGS['micro']

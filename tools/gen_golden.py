@@ -339,6 +339,56 @@ def gen_curve(steps=1000, B=2):
                         steps_per_epoch=np.int64(steps_per_epoch), warmup_epochs=np.int64(1))
 
 
+def probe_weights(shapes, seed):
+    """Fixed output weights so that the probe loss sum_i <w_i, out_i> has well-conditioned gradients
+    (the plain sum of LayerNorm outputs used by models/video_earlyfusion.py:185 is nearly gradient-free)."""
+    rs = np.random.RandomState(seed)
+    return [torch.from_numpy(rs.standard_normal(s).astype(np.float32)) for s in shapes]
+
+
+def gen_video(name, B, seed):
+    """BASELINE configs[4] family: VideoEarlyFusion forward + backward (models/video_earlyfusion.py:95-131)."""
+    from models import video_vits                                 # reference
+    from models.video_earlyfusion import VideoEarlyFusion         # reference
+    cfg = CONFIGS[name]
+    video_vits.video_vit_micro = lambda pretrained=None, **kw: video_vits.VideoViTEncoder(
+        patch_size=(2, 16, 16), embed_dim=128, depth=2, num_heads=2, mlp_ratio=4, **kw)
+    arch = {'video_micro': ('video_vit_micro', 'vit_micro'), 'video_base': ('video_vit_base', 'vit_base')}[name]
+    model = VideoEarlyFusion(video_arch=arch[0], video_pretrained='', video_size=cfg.video_size,
+                             audio_arch=arch[1], audio_pretrained='', audio_size=cfg.audio_size,
+                             fusion_layers='all', num_fusion_tkns=cfg.fusion_tkns, fusion_mlp_ratio=cfg.fusion_mlp_ratio,
+                             fusion_attn_ratio=cfg.fusion_attn_ratio, fusion_num_heads=cfg.fusion_num_heads)
+    out = {'video_pos_embed_init': model.video.pos_embed.detach().numpy().copy(),      # the reference's own 3-D table
+           'B': np.int64(B), 'seed': np.int64(seed)}
+    sd = O.closed_form_state(cfg, seed=0)
+    model.load_state_dict(sd, strict=True)          # pins the state-dict contract (names + shapes)
+    video, audio = O.synthetic_video_batch(cfg, B, seed=seed)
+    xv, xa, xf = model(video, audio)
+    w = probe_weights([xv.shape, xa.shape, xf.shape], seed + 1)
+    loss = (xv * w[0]).sum() + (xa * w[1]).sum() + (xf * w[2]).sum()
+    loss.backward()
+    out.update(x_video=xv.detach().numpy(), x_audio=xa.detach().numpy(), x_fusion=xf.detach().numpy(),
+               loss_sum=np.float64((xv.sum() + xa.sum() + xf.sum()).item()),        # the reference probe's loss (:185)
+               loss_probe=np.float64(loss.item()))
+    names, norms = [], []
+    for n, p in model.named_parameters():
+        if p.grad is not None:
+            names.append(n)
+            norms.append(float(p.grad.double().norm()))
+    out['grad_names'] = np.array(names)
+    out['grad_norms'] = np.array(norms, dtype=np.float64)
+    for n in ('fusion_tokens', 'video.patch_embed.proj.weight', 'video.blocks.0.attn.qkv.bias', 'audio.patch_embed.proj.bias',
+              'fusion_blocks.1.attn.k.weight', 'video.norm.weight'):
+        out['grad.' + n] = dict(model.named_parameters())[n].grad.numpy().copy()
+    # embeddings per layer (return_embs=True) of a second call pin that surface too
+    with torch.no_grad():
+        embs = model(video, audio, return_embs=True)[3]
+    out['emb_last_video_sub'] = embs[-1][0].numpy()[:, ::2, ::5].copy()
+    out['emb_first_fusion'] = embs[0][2].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, f'e2e_{name}.npz'), **out)
+    print(f'video[{name}] loss_sum={float(out["loss_sum"]):.6f} loss_probe={float(out["loss_probe"]):.6f}')
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--curve', action='store_true')
@@ -349,7 +399,8 @@ if __name__ == '__main__':
     torch.manual_seed(0)
     jobs = {'masking': gen_masking, 'posembed': gen_posembed, 'ops': gen_ops,
             'e2e_micro': lambda: gen_e2e('micro', 3, 21, True), 'e2e_tiny': lambda: gen_e2e('tiny', 2, 22, False),
-            'lr': gen_lr_and_groups, 'trainer': gen_trainer_steps}
+            'lr': gen_lr_and_groups, 'trainer': gen_trainer_steps,
+            'video_micro': lambda: gen_video('video_micro', 2, 31)}
     if a.curve:
         jobs = {'curve': gen_curve}
     for k, f in jobs.items():
