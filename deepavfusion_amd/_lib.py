@@ -36,6 +36,7 @@ SIGNATURES = {
     'dav_layernorm_bwd_reduce_grouped': [_p, _i, _p],
     'dav_mask_build': [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p],
     'dav_patch_gather': [_p, _i, _i, _i, _i, _p, _i, _p, _p],
+    'dav_patch_gather3d': [_p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p],
     'dav_unshuffle_fwd': [_p, _p, _p, _p, _i, _i, _i, _i, _p, _l, _i, _p],
     'dav_rows_gather_cast': [_p, _l, _i, _p, _i, _i, _i, _p, _p],
     'dav_unshuffle_bwd_reduce': [_p, _l, _i, _p, _i, _i, _i, _i, _p, _p, _p],

@@ -42,18 +42,25 @@ def _ids32(ids):
     return None if ids is None else ids.to(torch.int32).contiguous()
 
 
+def _vis(enc):
+    """The visual tower: ``.image`` of DeepAVFusion (models/deepavfusion.py:20) or ``.video`` of VideoEarlyFusion
+    (models/video_earlyfusion.py:32) — the layer loop is the same."""
+    return enc.video if hasattr(enc, 'video') else enc.image
+
+
 # ------------------------------------------------------------------------------------------------
 # encoder (models/deepavfusion.py:88-118)
 # ------------------------------------------------------------------------------------------------
 def encoder_fwd(enc, image, audio, ik32, ak32, want_f32=False, collect_embs=False):
     B = image.shape[0]
-    x_i, t_pi = E.patch_embed_fwd(enc.image, image, ik32)
+    vis = _vis(enc)
+    x_i, t_pi = E.patch_embed_fwd(vis, image, ik32)
     x_a, t_pa = E.patch_embed_fwd(enc.audio, audio, ak32)
-    x_f = enc.fusion_tokens.detach().expand(B, -1, -1).contiguous()
-    Hi, Ha, Hf = enc.image.num_heads, enc.audio.num_heads, enc.fusion_num_heads
+    x_f = enc.fusion_tokens.detach().expand(B, -1, -1).clone(memory_format=torch.contiguous_format)   # never an alias of the parameter (B == 1)
+    Hi, Ha, Hf = vis.num_heads, enc.audio.num_heads, enc.fusion_num_heads
     layers, embs = [], []
     main, sa, sf = _streams(image.device)
-    for l, (bi, ba, fb) in enumerate(zip(enc.image.blocks, enc.audio.blocks, enc.fusion_blocks)):
+    for l, (bi, ba, fb) in enumerate(zip(vis.blocks, enc.audio.blocks, enc.fusion_blocks)):
         sa.wait_stream(main)
         sf.wait_stream(main)
         if fb is None:
@@ -73,7 +80,7 @@ def encoder_fwd(enc, image, audio, ik32, ak32, want_f32=False, collect_embs=Fals
         layers.append((ti, ta, tf))
         if collect_embs:
             embs.append((x_i, x_a, x_f))
-    xi_b, xi32, st_i = E.ln_fwd(enc.image.norm, None, x_i, B, want_f32=want_f32)
+    xi_b, xi32, st_i = E.ln_fwd(vis.norm, None, x_i, B, want_f32=want_f32)
     xa_b, xa32, st_a = E.ln_fwd(enc.audio.norm, None, x_a, B, want_f32=want_f32)
     xf_b, xf32, st_f = E.ln_fwd(enc.fusion_norm, None, x_f, B, want_f32=want_f32)
     tape = dict(t_pi=t_pi, t_pa=t_pa, layers=layers, x_i=x_i, x_a=x_a, x_f=x_f, st_i=st_i, st_a=st_a, st_f=st_f, B=B)
@@ -90,6 +97,7 @@ def encoder_bwd(enc, t, dxi_b=None, dxa_b=None, dxf_b=None, dxi32=None, dxa32=No
 def _encoder_bwd(enc, t, dxi_b, dxa_b, dxf_b, dxi32, dxa32, dxf32, layer_cb=None):
     B = t['B']
     dev = t['x_i'].device
+    vis = _vis(enc)
 
     def final_norm(norm, x, st, dy_b, dy32):
         g = torch.empty_like(x)
@@ -98,10 +106,10 @@ def _encoder_bwd(enc, t, dxi_b, dxa_b, dxf_b, dxi32, dxa32, dxf32, layer_cb=None
             return g.zero_(), gb.zero_()
         E.ln_bwd(norm, None, x, B, st, dy_bf16=dy_b, dy_f32=dy32, dx1=g, dx1_bf16=gb)
         return g, gb
-    g_i, g_ib = final_norm(enc.image.norm, t['x_i'], t['st_i'], dxi_b, dxi32)
+    g_i, g_ib = final_norm(vis.norm, t['x_i'], t['st_i'], dxi_b, dxi32)
     g_a, g_ab = final_norm(enc.audio.norm, t['x_a'], t['st_a'], dxa_b, dxa32)
     g_f, g_fb = final_norm(enc.fusion_norm, t['x_f'], t['st_f'], dxf_b, dxf32)
-    blocks = list(zip(enc.image.blocks, enc.audio.blocks, enc.fusion_blocks))
+    blocks = list(zip(vis.blocks, enc.audio.blocks, enc.fusion_blocks))
     main, sa, sf = _streams(dev)
     for l, ((bi, ba, fb), (ti, ta, tf)) in reversed(list(enumerate(zip(blocks, t['layers'])))):
         sa.wait_stream(main)
@@ -126,7 +134,7 @@ def _encoder_bwd(enc, t, dxi_b, dxa_b, dxf_b, dxi32, dxa32, dxf32, layer_cb=None
         E.flush_wgrads()          # every wgrad of this layer (both towers + fusion block) as one grouped GEMM
         if layer_cb is not None and l > 0:
             layer_cb(l)
-    E.patch_embed_bwd(enc.image, t['t_pi'], g_i, g_ib)
+    E.patch_embed_bwd(vis, t['t_pi'], g_i, g_ib)
     E.patch_embed_bwd(enc.audio, t['t_pa'], g_a, g_ab)
     E.gbuf(enc.fusion_tokens).add_(g_f.sum(dim=0, keepdim=True))          # backward of .expand(B, -1, -1)
     E._ready(enc.fusion_tokens)

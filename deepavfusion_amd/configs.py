@@ -36,6 +36,33 @@ class PathConfig:
         return (self.audio_size[0] // self.patch, self.audio_size[1] // self.patch)
 
 
+@dataclass
+class VideoConfig:
+    """``video_efav_*`` (models/video_earlyfusion.py:134-171): BASELINE.json configs[4] is ``video_efav_base`` on an
+    8-frame 224x224 clip with 3 s of audio ((128, 192) log-mel), batch 16."""
+    embed_dim: int = 768
+    depth: int = 12
+    num_heads: int = 12
+    mlp_ratio: float = 4.0
+    patch: int = 16
+    video_size: Tuple[int, int, int] = (8, 224, 224)
+    video_patch: Tuple[int, int, int] = (2, 16, 16)
+    audio_size: Tuple[int, int] = (128, 192)
+    fusion_tkns: Tuple[int, int, int] = (16, 8, 8)
+    fusion_layers: Tuple[int, ...] = field(default_factory=lambda: tuple(range(12)))
+    fusion_mlp_ratio: float = 1.0
+    fusion_attn_ratio: float = 0.25
+    fusion_num_heads: int = 12
+
+    @property
+    def video_grid(self):
+        return tuple(s // p for s, p in zip(self.video_size, self.video_patch))
+
+    @property
+    def audio_grid(self):
+        return (self.audio_size[0] // self.patch, self.audio_size[1] // self.patch)
+
+
 CONFIGS = {
     # parity-only micro shape (head widths 64 / 32 / 16 like the real models)
     'micro': PathConfig(embed_dim=128, depth=2, num_heads=2, image_size=(64, 64), audio_size=(32, 112), fusion_tkns=(4, 3, 2),
@@ -49,4 +76,8 @@ CONFIGS = {
     'base_as': PathConfig(fusion_mlp_ratio=4.0, fusion_attn_ratio=1.0),
     # configs[3]: ViT-L
     'large': PathConfig(embed_dim=1024, depth=24, num_heads=16, fusion_layers=tuple(range(24)), fusion_num_heads=16),
+    # configs[4]: video early fusion (temporal-token stress: 784 + 32 rows per clip)
+    'video_micro': VideoConfig(embed_dim=128, depth=2, num_heads=2, video_size=(4, 48, 32), audio_size=(32, 48),
+                               fusion_tkns=(4, 3, 2), fusion_layers=(0, 1), fusion_num_heads=2),
+    'video_base': VideoConfig(),
 }

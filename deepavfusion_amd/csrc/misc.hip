@@ -54,22 +54,25 @@ __global__ __launch_bounds__(1024) void mask_build_kernel(const float* noise, in
 // kept-patch gather (timm PatchEmbed im2row restricted to ids_keep; models/vits.py:93,100):
 // A[b*nk + t, c*256 + py*16 + px] = bf16(img[b, c, gy*16+py, gx*16+px]);  patch = 16 fixed.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void patch_gather_kernel(const float* img, int B, int C, int H, int W, const int* ids,
-                                                           int nk, bf16_t* A) {
+__global__ __launch_bounds__(256) void patch_gather_kernel(const float* img, int B, int C, int T, int PT, int H, int W,
+                                                           const int* ids, int nk, bf16_t* A) {
+  // img [B, C, T, H, W] (T = PT = 1 for images); patch (PT, 16, 16); token = (gt*gH + gy)*gW + gx;
+  // A[row, ((c*PT + dt)*16 + py)*16 + px] — the flattening of the Conv2d / Conv3d weight
   const int lane = threadIdx.x & 63;
   const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
-  const int gW = W >> 4, rows = B * nk, K = C * 256;
+  const int gW = W >> 4, gH = H >> 4, rows = B * nk, K = C * PT * 256;
   for (int row = gw; row < rows; row += nwaves) {
     const int b = row / nk, t = row % nk;
     const int pidx = ids ? ids[row] : t;
-    const int gy = pidx / gW, gx = pidx % gW;
-    for (int ch = lane; ch < C * 32; ch += 64) {          // chunk = 8 consecutive px of one patch row
-      const int c = ch >> 5, py = (ch >> 1) & 15, half = ch & 1;
-      const float* src = img + (((long)b * C + c) * H + gy * 16 + py) * W + gx * 16 + half * 8;
+    const int gx = pidx % gW, gy = (pidx / gW) % gH, gt = pidx / (gW * gH);
+    for (int ch = lane; ch < C * PT * 32; ch += 64) {     // chunk = 8 consecutive px of one patch row
+      const int cd = ch >> 5, py = (ch >> 1) & 15, half = ch & 1;
+      const int c = cd / PT, dt = cd % PT;
+      const float* src = img + ((((long)b * C + c) * T + gt * PT + dt) * H + gy * 16 + py) * W + gx * 16 + half * 8;
       const float4 a = reinterpret_cast<const float4*>(src)[0], d = reinterpret_cast<const float4*>(src)[1];
       uint4 w;
       w.x = pack2bf(a.x, a.y); w.y = pack2bf(a.z, a.w); w.z = pack2bf(d.x, d.y); w.w = pack2bf(d.z, d.w);
-      *reinterpret_cast<uint4*>(A + (long)row * K + c * 256 + py * 16 + half * 8) = w;
+      *reinterpret_cast<uint4*>(A + (long)row * K + cd * 256 + py * 16 + half * 8) = w;
     }
   }
 }
@@ -376,8 +379,16 @@ extern "C" int dav_mask_build(const float* noise, int N, int L, int len_keep, in
 extern "C" int dav_patch_gather(const float* img, int B, int C, int H, int W, const int* ids_keep32, int nk, void* A,
                                 hipStream_t stream) {
   if (B <= 0 || C <= 0 || (H & 15) || (W & 15) || nk <= 0) return DAV_ERR_SHAPE;
-  DAV_LAUNCH(patch_gather_kernel, dim3(wave_grid((long)B * nk)), dim3(256), 0, stream, img, B, C, H, W, ids_keep32,
+  DAV_LAUNCH(patch_gather_kernel, dim3(wave_grid((long)B * nk)), dim3(256), 0, stream, img, B, C, 1, 1, H, W, ids_keep32,
                      nk, (bf16_t*)A);
+  return dav_launch_status();
+}
+
+extern "C" int dav_patch_gather3d(const float* video, int B, int C, int T, int H, int W, int pt, const int* ids_keep32,
+                                  int nk, void* A, hipStream_t stream) {
+  if (B <= 0 || C <= 0 || pt <= 0 || T <= 0 || (T % pt) || (H & 15) || (W & 15) || nk <= 0) return DAV_ERR_SHAPE;
+  DAV_LAUNCH(patch_gather_kernel, dim3(wave_grid((long)B * nk)), dim3(256), 0, stream, video, B, C, T, pt, H, W,
+                     ids_keep32, nk, (bf16_t*)A);
   return dav_launch_status();
 }
 

@@ -489,8 +489,11 @@ def fusion_block_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
     ops.pair_reduce(dKp, B, nv, na, Da, dkv_p, dka_p)
     ops.pair_reduce(dVp, B, nv, na, D, dvv_p, dva_p)
     # d(xv_out) = g1[rows v] + dkv_p Wk[:, :D] + dvv_p Wv[:, :D]   (fp32 accumulate, bf16 twin on the last GEMM)
-    dxvo = g1.view(B, nF, D)[:, nmm:nmm + nv].contiguous().view(B * nv, D)
-    dxao = g1.view(B, nF, D)[:, nmm + nv:].contiguous().view(B * na, D)
+    # copies (clone, not .contiguous(): at B == 1 the slices are already contiguous VIEWS of g1, and the GEMMs below
+    # accumulate into them while g1 is still needed by the norm1_mm backward)
+    cf = torch.contiguous_format
+    dxvo = g1.view(B, nF, D)[:, nmm:nmm + nv].clone(memory_format=cf).view(B * nv, D)
+    dxao = g1.view(B, nF, D)[:, nmm + nv:].clone(memory_format=cf).view(B * na, D)
     dxvo_b, dxao_b = _e((B * nv, D), BF16, dev), _e((B * na, D), BF16, dev)
     lin_bwd(at.k, dkv_p, t['xvo_b'], B * nv, k=D, dx=dxvo, dx_beta=1, final=False)
     lin_bwd(at.v, dvv_p, t['xvo_b'], B * nv, k=D, dx=dxvo, dx_beta=1, dx_C2=dxvo_b, dx_c2_mode=3, final=False)
@@ -518,18 +521,26 @@ def fusion_block_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
 # patch embedding of the kept patches (timm PatchEmbed + pos_embed + gather; models/vits.py:91-100)
 # ------------------------------------------------------------------------------------------------
 def patch_embed_fwd(vit, img, ids_keep32):
-    B, C, H, W = img.shape
+    """Images [B,C,H,W] (timm PatchEmbed + models/vits.py:93-100: pos-embed added BEFORE the gather) and clips
+    [B,C,T,H,W] (PatchEmbed3D + models/video_vits.py:229-232: gathered tokens + pos_embed in natural order, which
+    only broadcasts when every patch is kept)."""
+    B, C = img.shape[:2]
     pe = vit.patch_embed
     L = pe.num_patches
     nk = ids_keep32.shape[1] if ids_keep32 is not None else L
     D = vit.embed_dim
-    K = C * 256
+    clip = img.dim() == 5
+    pt = pe.patch_size[0] if clip else 1
+    if clip and nk != L:
+        raise RuntimeError(f'The size of tensor a ({nk}) must match the size of tensor b ({L}) at non-singleton dimension 1')
+    K = C * pt * 256
     A = _e((B * nk, K), BF16, img.device)
-    ops.patch_gather(img, ids_keep32, nk, A)
+    ops.patch_gather(img, ids_keep32, nk, A, pt)
     Wb = wcache(pe.proj.weight)
     tok = _e((B, nk, D), F32, img.device)
+    pos_by_id = ids_keep32 is not None and not clip
     ops.gemm_nt(A, Wb, B * nk, D, K, bias=pe.proj.bias, res=vit.pos_embed, ldres=D,
-                res_rows=ids_keep32, res_rowmap=None if ids_keep32 is not None else (L, 0, 0), C_out=tok)
+                res_rows=ids_keep32 if pos_by_id else None, res_rowmap=None if pos_by_id else (L, 0, 0), C_out=tok)
     return tok, dict(A=A, nk=nk)
 
 

@@ -134,8 +134,14 @@ def mask_build(noise: torch.Tensor, len_keep: int):
     return ids_keep, mask, ids_restore, ids_keep32, ids_restore32
 
 
-def patch_gather(img, ids_keep32, nk, out):
+def patch_gather(img, ids_keep32, nk, out, pt=1):
+    """img [B,C,H,W] with 16x16 patches, or a clip [B,C,T,H,W] with (pt,16,16) tubelets."""
     lib = _lib.load()
+    if img.dim() == 5:
+        B, Cc, T, H, W = img.shape
+        _lib.check(lib.dav_patch_gather3d(_ptr(img), B, Cc, T, H, W, pt, _ptr(ids_keep32), nk, _ptr(out), _stream()),
+                   'dav_patch_gather3d')
+        return
     B, Cc, H, W = img.shape
     _lib.check(lib.dav_patch_gather(_ptr(img), B, Cc, H, W, _ptr(ids_keep32), nk, _ptr(out), _stream()), 'dav_patch_gather')
 

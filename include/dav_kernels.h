@@ -122,6 +122,10 @@ int dav_mask_build(const float* noise, int N, int L, int len_keep, int64_t* ids_
 /* im2row of the kept 16x16 patches only (timm PatchEmbed + the gather of models/vits.py:100):
  * A[b*nk+t, c*256+py*16+px] bf16; ids NULL = all patches in order. */
 int dav_patch_gather(const float* img, int B, int C, int H, int W, const int* ids_keep32, int nk, void* A_bf16, hipStream_t stream);
+/* the same for clips [B,C,T,H,W] and (pt,16,16) tubelets (PatchEmbed3D, util/pos_embed.py:123-146, used by
+ * models/video_vits.py:218-220): token = (gt*gH + gy)*gW + gx, A[b*nk+t, ((c*pt + dt)*16 + py)*16 + px] */
+int dav_patch_gather3d(const float* video, int B, int C, int T, int H, int W, int pt, const int* ids_keep32, int nk,
+                       void* A_bf16, hipStream_t stream);
 /* models/avmae.py:161-165: out[b, off+r] = (restore[b,r] < nk ? emb[b*nk+restore[b,r]] : mask_token) + pos[r] */
 int dav_unshuffle_fwd(const float* emb, const float* mask_token, const float* pos, const int* ids_restore32, int B, int L, int nk,
                       int D, float* out, long out_bs, int out_row_off, hipStream_t stream);

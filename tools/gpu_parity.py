@@ -11,7 +11,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from deepavfusion_amd.build_model import build_avmae            # noqa: E402
+from deepavfusion_amd.build_model import build_avmae, build_video_earlyfusion            # noqa: E402
+from deepavfusion_amd.configs import CONFIGS as PCONFIGS         # noqa: E402
 from oracle import avmae_oracle as O                            # noqa: E402
 from oracle.configs import CONFIGS                              # noqa: E402
 
@@ -73,6 +74,51 @@ def run(name, B, seed):
             print(f'   vs golden: loss_image ref={float(g["loss_image"]):.6f} loss_audio ref={float(g["loss_audio"]):.6f}')
 
 
+def run_video(name, B, seed, **over):
+    """VideoEarlyFusion (BASELINE configs[4] family) forward + backward under the fixtures' probe loss."""
+    import dataclasses
+    cfg = dataclasses.replace(CONFIGS[name], **over)
+    sd = O.closed_form_state(cfg, 0)
+    model = build_video_earlyfusion(dataclasses.replace(PCONFIGS[name], **over)).to(dev)
+    model.load_state_dict(sd, strict=True)
+    video, audio = O.synthetic_video_batch(cfg, B, seed=seed)
+    t0 = time.time()
+    sdo = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in sd.items()}
+    xv, xa, xf = O.video_earlyfusion_forward(sdo, cfg, video, audio)
+    rs = np.random.RandomState(seed + 1)
+    w = [torch.from_numpy(rs.standard_normal(tuple(t.shape)).astype(np.float32)) for t in (xv, xa, xf)]
+    loss = (xv * w[0]).sum() + (xa * w[1]).sum() + (xf * w[2]).sum()
+    loss.backward()
+    t_or = time.time() - t0
+    model.zero_grad()
+    ov, oa, of = model(video.to(dev), audio.to(dev))
+    lh = (ov * w[0].to(dev)).sum() + (oa * w[1].to(dev)).sum() + (of * w[2].to(dev)).sum()
+    lh.backward()
+    torch.cuda.synchronize()
+    print(f'[{name} B={B}] oracle {t_or:.1f}s  probe loss hip={float(lh):.5f} ref={float(loss):.5f}')
+    print(f'   x_video rel {rel(ov, xv):.3e}  x_audio rel {rel(oa, xa):.3e}  x_fusion rel {rel(of, xf):.3e}')
+    worst = []
+    for n, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        if p.grad is None:
+            print('   MISSING grad', n)
+            continue
+        worst.append((rel(p.grad, sdo[n].grad), n, float(sdo[n].grad.norm())))
+    worst.sort(reverse=True)
+    for e, n, gn in worst[:12]:
+        print(f'      {e:.3e}  |g|={gn:.3e}  {n}')
+    print(f'   median grad rel-L2 {sorted(w_[0] for w_ in worst)[len(worst) // 2]:.3e} over {len(worst)} tensors')
+    if os.environ.get('DAV_PARITY_ALL'):
+        import re
+        groups = {}
+        for e, n, gn in worst:
+            key = re.sub(r'\.\d+\.', '.N.', n)
+            groups.setdefault(key, []).append(e)
+        for k, v in sorted(groups.items()):
+            print(f'      {k:50s} min {min(v):.2e} max {max(v):.2e}')
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['micro', 'tiny']
     for w in which:
@@ -82,3 +128,9 @@ if __name__ == '__main__':
             run('tiny', 2, 22)
         elif w == 'base_b2':
             run('base', 2, 23)
+        elif w == 'video_micro':
+            run_video('video_micro', 2, 31)
+        elif w == 'video_base':
+            run_video('video_base', 1, 33)
+        elif w == 'video_long':       # micro widths on the full 784-token clip
+            run_video('video_micro', int(os.environ.get('B', 1)), 34, video_size=(8, 224, 224), audio_size=(128, 192))

@@ -163,6 +163,24 @@ def ref_attn(q, k, v, scale):
 
 
 @check
+def patch_gather3d():
+    for (B, C, T, H, W, pt) in [(2, 3, 4, 48, 32, 2), (1, 3, 8, 64, 64, 2), (2, 1, 3, 32, 48, 1)]:
+        x = rnd(B, C, T, H, W, seed=91)
+        gt, gh, gw = T // pt, H // 16, W // 16
+        L = gt * gh * gw
+        cols = x.view(B, C, gt, pt, gh, 16, gw, 16).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B, L, C * pt * 256)
+        A = torch.empty(B * L, C * pt * 256, device=dev, dtype=BF16)
+        ops.patch_gather(x, None, L, A, pt)
+        report(f'patch_gather3d all {B}x{C}x{T}x{H}x{W}', rel(A.view(B, L, -1), cols.to(BF16)), 1e-6)
+        nk = max(1, L // 3)
+        ids = torch.stack([torch.randperm(L, device=dev)[:nk] for _ in range(B)]).to(torch.int32)
+        A2 = torch.empty(B * nk, C * pt * 256, device=dev, dtype=BF16)
+        ops.patch_gather(x, ids, nk, A2, pt)
+        ref = torch.gather(cols, 1, ids.long().unsqueeze(-1).expand(-1, -1, cols.shape[-1]))
+        report(f'patch_gather3d kept {B}x{C}x{T}x{H}x{W}', rel(A2.view(B, nk, -1), ref.to(BF16)), 1e-6)
+
+
+@check
 def attention():
     for (B, H, Nq, Nk, dqk, dv, off) in [(2, 3, 49, 81, 64, 64, 32), (3, 2, 8, 49, 64, 64, 0), (2, 16, 228, 228, 32, 32, 0),
                                         (2, 2, 352, 352, 32, 32, 0), (2, 12, 16, 64, 16, 64, 0), (3, 2, 4, 6, 16, 64, 0),
@@ -375,7 +393,7 @@ def misc_kernels():
 def main():
     flt = sys.argv[1] if len(sys.argv) > 1 else ''
     print('device:', torch.cuda.get_device_name(0), flush=True)
-    for fn in (gemm_nt, gemm_tn, attention, layernorm, masking, misc_kernels):
+    for fn in (gemm_nt, gemm_tn, attention, layernorm, masking, misc_kernels, patch_gather3d):
         if flt in fn.__name__:
             fn()
     bad = [r for r in RESULTS if not r[3]]
