@@ -49,10 +49,37 @@ def test_state_dict_contract_matches_reference_shapes():
         sd = m.state_dict()
         assert set(sd) == set(shapes)
         assert all(tuple(v.shape) == tuple(shapes[k]) for k, v in sd.items())
-        assert [n for n, p in m.named_parameters() if not p.requires_grad] == list(O.FROZEN)
+        assert [n for n, p in m.named_parameters() if not p.requires_grad] == [n for n in O.FROZEN if n.startswith('encoder.')]
         m.load_state_dict(O.closed_form_state(OC[name], 0), strict=True)
+    assert list(CONFIGS) == list(OC)
     for a, b in zip(CONFIGS.values(), OC.values()):
-        assert (a.embed_dim, a.depth, a.fusion_tkns, a.decoder_dim, a.audio_mask_ratio) == (b.embed_dim, b.depth, b.fusion_tkns, b.decoder_dim, b.audio_mask_ratio)
+        assert (a.embed_dim, a.depth, a.fusion_tkns, a.audio_size) == (b.embed_dim, b.depth, b.fusion_tkns, b.audio_size)
+        if hasattr(a, 'decoder_dim'):
+            assert (a.decoder_dim, a.audio_mask_ratio, a.image_size) == (b.decoder_dim, b.audio_mask_ratio, b.image_size)
+        else:
+            assert (a.video_size, a.video_patch) == (b.video_size, b.video_patch)
+
+
+def test_video_state_dict_contract_and_pos_table(golden):
+    """VideoEarlyFusion (configs[4]): names/shapes as pinned by the strict load into the reference
+    (tools/gen_golden.py gen_video), the 3-D sin-cos table equals the reference's own initial buffer."""
+    from deepavfusion_amd.build_model import build_video_earlyfusion
+    from deepavfusion_amd.configs import CONFIGS
+    from oracle import avmae_oracle as O
+    from oracle.configs import CONFIGS as OC
+    g = golden('e2e_video_micro')
+    m = build_video_earlyfusion(CONFIGS['video_micro'])
+    shapes = O.state_shapes(OC['video_micro'])
+    sd = m.state_dict()
+    assert set(sd) == set(shapes) and all(tuple(v.shape) == tuple(shapes[k]) for k, v in sd.items())
+    assert set(g['grad_names'].tolist()) == {n for n, p in m.named_parameters() if p.requires_grad}
+    assert [n for n, p in m.named_parameters() if not p.requires_grad] == ['video.pos_embed', 'audio.pos_embed']
+    assert np.allclose(sd['video.pos_embed'].numpy(), g['video_pos_embed_init'], atol=1e-6)
+    m.load_state_dict(O.closed_form_state(OC['video_micro'], 0), strict=True)
+    ids = m.params_layer_ids()
+    # as in the reference, the frozen pos-embeds are not listed (models/video_vits.py:185-192)
+    assert len([p for p, _ in ids if p is not None]) == len([p for p in m.parameters() if p.requires_grad])
+    assert max(l for _, l in ids) == OC['video_micro'].depth + 1
 
 
 def test_sincos_tables(golden):
