@@ -68,6 +68,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='eager kernel launches instead of hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true', help='skip the dominant-kernel replay (clean per-step profiles)')
+    ap.add_argument('--roofline-only', action='store_true',
+                    help='one eager step (to record the launch mix) + 20 replays of the dominant kernel: the run profiled for profiles/*roofline*')
     a = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -119,7 +121,7 @@ def main():
             return orig(A, Bm, M, N, K, **kw)
         ops.gemm_nt = logged
 
-    if a.no_graph:
+    if a.no_graph or a.roofline_only:
         def step():
             li, la = trainer.model(image, audio)[:2]
             trainer.step(li + la)
@@ -131,9 +133,11 @@ def main():
     if rank == 0:
         from deepavfusion_amd import ops as _o
         _o.gemm_nt = orig
-        n_per_pass = len(gemm_log) // (1 if a.no_graph else 3)     # GraphedStep: 2 warm-up passes + 1 capture pass
+        n_per_pass = len(gemm_log) // (1 if (a.no_graph or a.roofline_only) else 3)     # GraphedStep: 2 warm-up passes + 1 capture pass
         gemm_log = gemm_log[-n_per_pass:]
 
+    if a.roofline_only:
+        a.warmup, a.steps, a.no_cpu_baseline = 0, 1, True
     for _ in range(a.warmup):
         step()
 
@@ -166,12 +170,15 @@ def main():
         'data': 'synthetic',
         'config': {'workload': f'AVMAE(DeepAVFusion {a.config}) fwd+bwd+allreduce+AdamW, B={B}/GPU, 224x224 RGB + (128,640) log-mel, '
                                f'masks {cfg.image_mask_ratio}/{cfg.audio_mask_ratio}, fusion attn_ratio {cfg.fusion_attn_ratio} mlp_ratio {cfg.fusion_mlp_ratio}',
-                   'global_batch': B * world, 'parallelism': f'dp{world}', 'graph': not a.no_graph},
+                   'global_batch': B * world, 'parallelism': f'dp{world}', 'graph': not (a.no_graph or a.roofline_only)},
         'pairs_per_s_per_gpu': round(pairs_per_s / world, 2),
         'loss': round(loss, 5),
         'step_necessary_gflop_per_pair': round(flops_pair / 1e9, 1),
         'step_mfma_frac': round(flops_pair * pairs_per_s / world / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
     }
+
+    if a.roofline_only:
+        result['note'] = 'roofline-only run: value/ms_per_step are ONE eager step, not the metric; see roofline'
 
     # ---- roofline of the dominant kernel (gemm_nt_kernel<128,128>): replay this step's launch mix --------------
     # the launches the library's dispatch (gemm.hip: nt_auto_config) sends to the 128x128 / 8-wave kernel
@@ -190,7 +197,7 @@ def main():
         replay()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
-        reps = 5
+        reps = 20 if a.roofline_only else 5
         e0.record()                     # torch's current stream == the stream ops.* launch on
         for _ in range(reps):
             replay()
