@@ -122,11 +122,11 @@ __device__ __forceinline__ float rows_max(float x) {
 
 template <int DQK, int DV, bool CHUNKED, int QT>
 __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
-  constexpr int DQKP = DQK < 32 ? 32 : DQK, KRB = DQKP * 2, KS = DQKP / 32, VC = DV / 16;
+  constexpr int DQKP = DQK < 32 ? 32 : DQK, KRB = DQKP * 2, KS = DQKP / 32, VC = DV / 16, DVP = DV < 32 ? 32 : DV;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int Nkp = (p.Nk + 31) & ~31;
   const int CH = CHUNKED ? ATTN_CHUNK : Nkp;      // key rows resident at a time
-  constexpr int VRB = DV * 2;
+  constexpr int VRB = DVP * 2;         // value rows are zero-padded to 32 columns in LDS like narrow q/k rows
   char* Ks = smem;                 // [CH][DQKP]
   char* Vs = smem + CH * KRB;      // [CH][DV]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
 
   if (!CHUNKED) {
     stage_tile<DQK, DQKP>(Ks, Kg, p.Nk, Nkp, p.k_rs, tid, blockDim.x);
-    stage_tile<DV, DV>(Vs, Vg, p.Nk, Nkp, p.v_rs, tid, blockDim.x);
+    stage_tile<DV, DVP>(Vs, Vg, p.Nk, Nkp, p.v_rs, tid, blockDim.x);
     __syncthreads();
   }
 
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
         const int rows = p.Nk - c0 < CH ? p.Nk - c0 : CH, rows_p = Nkp - c0 < CH ? Nkp - c0 : CH;
         __syncthreads();                 // every wave is done with the previous chunk
         stage_tile<DQK, DQKP>(Ks, Kg + (long)c0 * p.k_rs, rows, rows_p, p.k_rs, tid, blockDim.x);
-        stage_tile<DV, DV>(Vs, Vg + (long)c0 * p.v_rs, rows, rows_p, p.v_rs, tid, blockDim.x);
+        stage_tile<DV, DVP>(Vs, Vg + (long)c0 * p.v_rs, rows, rows_p, p.v_rs, tid, blockDim.x);
         __syncthreads();
       }
       const int cend = c0 + CH < Nkp ? c0 + CH : Nkp;
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
 // ------------------------------------------------------------------------------------------------
 template <int DQK, int DV, bool CHUNKED>
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
-  constexpr int DQKP = DQK < 32 ? 32 : DQK, KRB = DQKP * 2, KS = DQKP / 32, VRB = DV * 2, VS = DV / 32, QC = DQK / 16;
+  constexpr int DQKP = DQK < 32 ? 32 : DQK, KRB = DQKP * 2, KS = DQKP / 32, DVP = DV < 32 ? 32 : DV, VRB = DVP * 2, VS = DVP / 32, QC = DQK / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int Nkp = (p.Nk + 31) & ~31;
   const int CH = CHUNKED ? ATTN_CHUNK : Nkp;
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
 
   if (!CHUNKED) {
     stage_tile<DQK, DQKP>(Ks, Kg, p.Nk, Nkp, p.k_rs, tid, blockDim.x);
-    stage_tile<DV, DV>(Vs, Vg, p.Nk, Nkp, p.v_rs, tid, blockDim.x);
+    stage_tile<DV, DVP>(Vs, Vg, p.Nk, Nkp, p.v_rs, tid, blockDim.x);
     __syncthreads();
   }
 
@@ -297,8 +297,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
     float delta = 0.f;
 #pragma unroll
     for (int kk = 0; kk < VS; ++kk) {
-      dof[kk] = gfrag(dorow, kk * 32 + 8 * g, true);
-      const bf16x8 of = gfrag(orow, kk * 32 + 8 * g, true);
+      dof[kk] = gfrag(dorow, kk * 32 + 8 * g, kk * 32 + 8 * g < DV);
+      const bf16x8 of = gfrag(orow, kk * 32 + 8 * g, kk * 32 + 8 * g < DV);
 #pragma unroll
       for (int e = 0; e < 8; ++e) delta += (float)dof[kk][e] * (float)of[e];
     }
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
       const int rows = p.Nk - c0 < CH ? p.Nk - c0 : CH, rows_p = Nkp - c0 < CH ? Nkp - c0 : CH;
       __syncthreads();
       stage_tile<DQK, DQKP>(Ks, Kg + (long)c0 * p.k_rs, rows, rows_p, p.k_rs, tid, blockDim.x);
-      stage_tile<DV, DV>(Vs, Vg + (long)c0 * p.v_rs, rows, rows_p, p.v_rs, tid, blockDim.x);
+      stage_tile<DV, DVP>(Vs, Vg + (long)c0 * p.v_rs, rows, rows_p, p.v_rs, tid, blockDim.x);
       __syncthreads();
     }
     const int cend = c0 + CH < Nkp ? c0 + CH : Nkp;
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
 // ------------------------------------------------------------------------------------------------
 template <int DQK, int DV, bool CHUNKED>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
-  constexpr int DQKP = DQK < 32 ? 32 : DQK, QRB = DQKP * 2, KS = DQKP / 32, ORB = DV * 2, VS = DV / 32, QC = DQK / 16, VC = DV / 16;
+  constexpr int DQKP = DQK < 32 ? 32 : DQK, QRB = DQKP * 2, KS = DQKP / 32, DVP = DV < 32 ? 32 : DV, ORB = DVP * 2, VS = DVP / 32, QC = DQK / 16, VC = DV / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int Nqp = (p.Nq + 31) & ~31;
   const int CH = CHUNKED ? ATTN_CHUNK : Nqp;     // query rows resident at a time
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
   auto stage_q = [&](int c0) {
     const int rows = p.Nq - c0 < CH ? p.Nq - c0 : CH, rows_p = Nqp - c0 < CH ? Nqp - c0 : CH;
     stage_tile<DQK, DQKP>(Qs, Qg + (long)c0 * p.q_rs, rows, rows_p, p.q_rs, tid, blockDim.x);
-    stage_tile<DV, DV>(dOs, dOg + (long)c0 * p.do_rs, rows, rows_p, p.do_rs, tid, blockDim.x);
+    stage_tile<DV, DVP>(dOs, dOg + (long)c0 * p.do_rs, rows, rows_p, p.do_rs, tid, blockDim.x);
     for (int i = tid; i < rows_p; i += blockDim.x) {
       const long sidx = ((long)b * p.H + h) * p.Nq + c0 + i;
       lse_s[i] = i < rows ? p.LSE[sidx] * 1.44269504088896341f : 1e30f;      // log2 domain; 2^(s - 1e30) == 0 for padded query rows
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) kf[kk] = gfrag(krow, kk * 32 + 8 * g, kk * 32 + 8 * g < DQK);
 #pragma unroll
-    for (int kk = 0; kk < VS; ++kk) vf[kk] = gfrag(vrow, kk * 32 + 8 * g, true);
+    for (int kk = 0; kk < VS; ++kk) vf[kk] = gfrag(vrow, kk * 32 + 8 * g, kk * 32 + 8 * g < DV);
 
     f32x4 dk[QC], dv[VC];
 #pragma unroll
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
   }
 }
 
-template <int DQK> constexpr int padqk() { return DQK < 32 ? 32 : DQK; }
+template <int DQK> constexpr int padqk() { return DQK < 32 ? 32 : DQK; }      // LDS columns of a q/k (or v/dO) row
 
 // resident-in-LDS variant up to this many bytes (2 workgroups per CU), chunked beyond
 constexpr size_t ATTN_RESIDENT_MAX = 80 * 1024;
@@ -497,7 +497,7 @@ inline int waves_for(int rows) { int nw = (rows + 15) / 16; return nw > 8 ? 8 : 
 template <int DQK, int DV>
 int launch_fwd(const AttnParams& p, hipStream_t stream) {
   const int Nkp = (p.Nk + 31) & ~31;
-  const size_t row = (size_t)padqk<DQK>() * 2 + (size_t)DV * 2;
+  const size_t row = (size_t)padqk<DQK>() * 2 + (size_t)padqk<DV>() * 2;
   const size_t lds = Nkp * row;
   const bool two = dav_attn_qt == 2 || (dav_attn_qt == 0 && p.Nq >= 1024);      // two query tiles per wave
   const int nw = waves_for(two ? (p.Nq + 1) / 2 : p.Nq);
@@ -520,7 +520,7 @@ int launch_fwd(const AttnParams& p, hipStream_t stream) {
 template <int DQK, int DV>
 int launch_bwd(const AttnParams& p, hipStream_t stream) {
   const int Nkp = (p.Nk + 31) & ~31, Nqp = (p.Nq + 31) & ~31;
-  const size_t row = (size_t)padqk<DQK>() * 2 + (size_t)DV * 2;
+  const size_t row = (size_t)padqk<DQK>() * 2 + (size_t)padqk<DV>() * 2;
   const size_t lds1 = Nkp * row, lds2 = Nqp * (row + 8);
   const int nw1 = waves_for(p.Nq), nw2 = waves_for(p.Nk);
   // dQ first: it also writes Delta, which the dK/dV kernel reads
@@ -572,6 +572,7 @@ extern "C" int dav_attn_fwd(const void* Q, const void* K, const void* V, void* O
   if (dqk == 64 && dv == 64) return launch_fwd<64, 64>(p, stream);
   if (dqk == 32 && dv == 32) return launch_fwd<32, 32>(p, stream);
   if (dqk == 16 && dv == 64) return launch_fwd<16, 64>(p, stream);
+  if (dqk == 16 && dv == 16) return launch_fwd<16, 16>(p, stream);
   return DAV_ERR_SHAPE;
 }
 
@@ -593,5 +594,6 @@ extern "C" int dav_attn_bwd(const void* Q, const void* K, const void* V, const v
   if (dqk == 64 && dv == 64) return launch_bwd<64, 64>(p, stream);
   if (dqk == 32 && dv == 32) return launch_bwd<32, 32>(p, stream);
   if (dqk == 16 && dv == 64) return launch_bwd<16, 64>(p, stream);
+  if (dqk == 16 && dv == 16) return launch_bwd<16, 16>(p, stream);
   return DAV_ERR_SHAPE;
 }

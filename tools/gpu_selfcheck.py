@@ -188,7 +188,9 @@ def attention():
                                         # long sequences: keys / queries stream through LDS in chunks
                                         (2, 3, 784, 816, 64, 64, 32), (2, 2, 352, 352, 64, 64, 0), (1, 2, 100, 1000, 64, 64, 0),
                                         (1, 2, 1000, 40, 64, 64, 0), (2, 2, 1300, 1300, 32, 32, 0), (1, 3, 17, 530, 16, 64, 0),
-                                        (1, 2, 257, 257, 64, 64, 0)]:
+                                        (1, 2, 257, 257, 64, 64, 0),
+                                        # q/k/v head width 16 (token / dense_mmi fusion archs at attn_ratio 0.25)
+                                        (2, 12, 32, 112, 16, 16, 0), (1, 3, 32, 3087, 16, 16, 0), (2, 2, 9, 20, 16, 16, 0)]:
         scale = 0.125 if dqk == 16 else dqk ** -0.5
         # fused layout when dqk == dv: buffer [B, Nk, 3, H, d]; queries are rows off.. of the same buffer
         fused = dqk == dv and Nq <= Nk
