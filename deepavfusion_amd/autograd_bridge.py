@@ -200,7 +200,7 @@ class _FusionBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, fb, xmm, xv, xa, *params):
         ctx.set_materialize_grads(False)
-        out, tape = E.fusion_block_fwd(fb, xmm, xv, xa, fb.num_heads, fb.fusion_tkns)
+        out, tape = E.fusion_block_fwd(fb, xmm, xv, xa, fb.num_heads, getattr(fb, 'fusion_tkns', None))
         ctx.fb, ctx.tape, ctx.np = fb, tape, len(params)
         return out
 

@@ -13,7 +13,7 @@ def build_avmae(cfg):
     layers = 'all' if tuple(cfg.fusion_layers) == tuple(range(cfg.depth)) else '-'.join(str(l) for l in cfg.fusion_layers)
     enc = DeepAVFusion(image_arch=arch, image_pretrained='', image_size=tuple(cfg.image_size),
                        audio_arch=arch, audio_pretrained='', audio_size=tuple(cfg.audio_size),
-                       fusion_arch='factorized_mmi', fusion_layers=layers, num_fusion_tkns=tuple(cfg.fusion_tkns),
+                       fusion_arch=getattr(cfg, 'fusion_arch', 'factorized_mmi'), fusion_layers=layers, num_fusion_tkns=tuple(cfg.fusion_tkns),
                        fusion_mlp_ratio=cfg.fusion_mlp_ratio, fusion_attn_ratio=cfg.fusion_attn_ratio,
                        fusion_num_heads=cfg.fusion_num_heads)
     return AVMAE(enc, enc.embed_dim,

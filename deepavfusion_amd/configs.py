@@ -18,6 +18,7 @@ class PathConfig:
     fusion_mlp_ratio: float = 1.0
     fusion_attn_ratio: float = 0.25
     fusion_num_heads: int = 12
+    fusion_arch: str = 'factorized_mmi'                 # models/deepavfusion.py:11, 28-35
     decoder_dim: int = 512
     decoder_depth: int = 8
     decoder_heads: int = 16
@@ -67,11 +68,17 @@ CONFIGS = {
     # parity-only micro shape (head widths 64 / 32 / 16 like the real models)
     'micro': PathConfig(embed_dim=128, depth=2, num_heads=2, image_size=(64, 64), audio_size=(32, 112), fusion_tkns=(4, 3, 2),
                         fusion_layers=(0, 1), fusion_num_heads=2, decoder_dim=64, decoder_depth=2, decoder_heads=2),
+    'micro_token': PathConfig(embed_dim=128, depth=2, num_heads=2, image_size=(64, 64), audio_size=(32, 112), fusion_tkns=(4, 3, 2),
+                              fusion_layers=(0, 1), fusion_num_heads=2, decoder_dim=64, decoder_depth=2, decoder_heads=2, fusion_arch='token'),
+    'micro_dense': PathConfig(embed_dim=128, depth=2, num_heads=2, image_size=(64, 64), audio_size=(32, 112), fusion_tkns=(4, 3, 2),
+                              fusion_layers=(0, 1), fusion_num_heads=2, decoder_dim=64, decoder_depth=2, decoder_heads=2, fusion_arch='dense_mmi'),
     # BASELINE.json configs[0]: ViT-Tiny, 64x64 image + 2 s audio
     'tiny': PathConfig(embed_dim=192, depth=12, num_heads=3, image_size=(64, 64), audio_size=(128, 128), fusion_num_heads=3),
     # configs[1] (bench workload): ViT-B, README VGGSound recipe (attn_ratio 0.25, mlp_ratio 1.0), 10 s audio
     'base': PathConfig(),
     'base_m75': PathConfig(audio_mask_ratio=0.75),
+    'base_token': PathConfig(fusion_arch='token'),
+    'base_dense': PathConfig(fusion_arch='dense_mmi'),      # 63 x 49 = 3087 (audio, image) pairs per sample
     # configs[2]: AudioSet-style fusion widths
     'base_as': PathConfig(fusion_mlp_ratio=4.0, fusion_attn_ratio=1.0),
     # configs[3]: ViT-L

@@ -413,7 +413,7 @@ def _cross_bwd(ca, c, do, xq_b, q_rowmap, nq, xkv_b, nk, B, D, heads, dxq_out, d
     return lin_bwd(ca.kv, dkv, xkv_b, B * nk)
 
 
-def fusion_block_fwd(fb, x_f, x_i, x_a, heads, tkns):
+def _factorized_fwd(fb, x_f, x_i, x_a, heads, tkns):
     B, nF, D = x_f.shape
     nI, nA = x_i.shape[1], x_a.shape[1]
     nmm, nv, na = tkns
@@ -457,7 +457,7 @@ def fusion_block_fwd(fb, x_f, x_i, x_a, heads, tkns):
     return out, tape
 
 
-def fusion_block_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
+def _factorized_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
     """g fp32 [B,nF,D] grad of the block output.  Returns (dx_f fp32 + bf16 twin, dx_i, dx_a);
     dx_i / dx_a are freshly STORED (fp32 [B,n,D]) unless buffers are passed."""
     x_f, x_i, x_a, heads = t['x_f'], t['x_i'], t['x_a'], t['heads']
@@ -515,6 +515,167 @@ def fusion_block_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
     dx_f = _e((B, nF, D), F32, dev)
     ln_bwd(fb.norm1_mm, None, x_f, B, t['st_mm'], dy_bf16=dxmm_b, dy_f32=g1, dx1=dx_f)
     return dx_f, dx_i, dx_a
+
+
+# ------------------------------------------------------------------------------------------------
+# the two alternative fusion blocks behind fusion_arch (models/fusion_blocks.py:89-213).  Arguments are POSITIONAL as
+# the encoder passes them — (x_fusion, x_image, x_audio), models/deepavfusion.py:106 — and the reference's swapped
+# parameter names are reproduced:
+#   token     : norm1_img normalises the 3rd argument (audio), norm1_aud the 2nd (image); keys = [audio rows | image rows]
+#   dense_mmi : norms in order; inside the attention pairs are (audio_i, image_j), p = i*nI + j, features [audio || image]
+# Both share the norm-then-residual form and the norm2 + MLP tail of the factorised block.
+# ------------------------------------------------------------------------------------------------
+def _alt_tail_fwd(fb, xmm1, B, nF, D, dev):
+    h2, _, st2 = ln_fwd(fb.norm2, None, xmm1, B)
+    Hd = fb.mlp.fc1.weight.shape[0]
+    z = _e((B * nF, Hd), BF16, dev)
+    u = lin_fwd(fb.mlp.fc1, h2, B * nF, act=1, out_bf16=True, C2=z, c2_mode=1)
+    out = lin_fwd(fb.mlp.fc2, u, B * nF, res=xmm1).view(B, nF, D)
+    return out, dict(h2=h2, st2=st2, z=z, u=u, xmm1=xmm1)
+
+
+def _alt_tail_bwd(fb, tt, g, gb, B, nF, D, dev):
+    """-> (g1 fp32 [B,nF,D], g1b bf16): gradient at xmm1 (the attention residual output)."""
+    if gb is None:
+        gb = to_bf16(g)
+    dz = lin_bwd(fb.mlp.fc2, gb, tt['u'], B * nF, gelu_aux=tt['z'])
+    dh2 = lin_bwd(fb.mlp.fc1, dz, tt['h2'], B * nF)
+    g1 = _e((B, nF, D), F32, dev)
+    g1b = _e((B * nF, D), BF16, dev)
+    ln_bwd(fb.norm2, None, tt['xmm1'], B, tt['st2'], dy_bf16=dh2, dx1=g1, res1=g, dx1_bf16=g1b)
+    return g1, g1b
+
+
+def _token_fwd(fb, x_f, x_2, x_3, heads):
+    B, nF, D = x_f.shape
+    n2, n3 = x_2.shape[1], x_3.shape[1]
+    dev, at = x_f.device, fb.attn
+    Da = at.q.weight.shape[0]
+    hd = Da // heads
+    xmm_b, xmm32, st_mm = ln_fwd(fb.norm1_mm, None, x_f, B, want_f32=True)
+    x3_b, _, st_3 = ln_fwd(fb.norm1_img, None, x_3, B)          # "xv" = 3rd argument (:135-136)
+    x2_b, _, st_2 = ln_fwd(fb.norm1_aud, None, x_2, B)          # "xa" = 2nd argument
+    nS = n3 + n2                                                 # cat(xv, xa) (:106): 3rd-argument rows first
+    kv = _e((B * nS, 2 * Da), BF16, dev)
+    lin_fwd(at.kv, x3_b, B * n3, out=kv, c_rowmap=(n3, nS, 0))
+    lin_fwd(at.kv, x2_b, B * n2, out=kv, c_rowmap=(n2, nS, n3))
+    q = lin_fwd(at.q, xmm_b, B * nF, out_bf16=True)
+    o, lse = attention_fwd((q, 0), (kv, 0), (kv, Da), B, heads, nF, nS, hd, hd, hd ** -0.5,
+                           nF * Da, Da, nS * 2 * Da, 2 * Da, nS * 2 * Da, 2 * Da, dev)
+    xmm1 = lin_fwd(at.proj, o, B * nF, res=xmm32).view(B, nF, D)
+    out, tt = _alt_tail_fwd(fb, xmm1, B, nF, D, dev)
+    tt.update(arch='token', x_f=x_f, x_2=x_2, x_3=x_3, xmm_b=xmm_b, st_mm=st_mm, x2_b=x2_b, st_2=st_2, x3_b=x3_b, st_3=st_3,
+              kv=kv, q=q, o=o, lse=lse, heads=heads)
+    return out, tt
+
+
+def _token_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
+    x_f, x_2, x_3, heads = t['x_f'], t['x_2'], t['x_3'], t['heads']
+    B, nF, D = x_f.shape
+    n2, n3 = x_2.shape[1], x_3.shape[1]
+    nS = n3 + n2
+    dev, at = x_f.device, fb.attn
+    Da = at.q.weight.shape[0]
+    hd = Da // heads
+    g1, g1b = _alt_tail_bwd(fb, t, g, gb, B, nF, D, dev)
+    do = lin_bwd(at.proj, g1b, t['o'], B * nF)
+    dq, dkv = _e((B * nF, Da), BF16, dev), _e((B * nS, 2 * Da), BF16, dev)
+    attention_bwd((t['q'], 0), (t['kv'], 0), (t['kv'], Da), t['o'], do, t['lse'], (dq, 0), (dkv, 0), (dkv, Da),
+                  B, heads, nF, nS, hd, hd, hd ** -0.5, nF * Da, Da, nS * 2 * Da, 2 * Da, nS * 2 * Da, 2 * Da,
+                  nF * Da, Da, nS * 2 * Da, 2 * Da, nS * 2 * Da, 2 * Da)
+    dxmm_b = lin_bwd(at.q, dq, t['xmm_b'], B * nF)
+    dx3_b = lin_bwd(at.kv, dkv, t['x3_b'], B * n3, dy_rowmap=(n3, nS, 0), final=False)
+    dx2_b = lin_bwd(at.kv, dkv, t['x2_b'], B * n2, dy_rowmap=(n2, nS, n3))
+    acc_2, acc_3 = (1 if dx_i is not None else 0), (1 if dx_a is not None else 0)
+    if dx_i is None:
+        dx_i = _e((B, n2, D), F32, dev)
+    if dx_a is None:
+        dx_a = _e((B, n3, D), F32, dev)
+    ln_bwd(fb.norm1_aud, None, x_2, B, t['st_2'], dy_bf16=dx2_b, dx1=dx_i, acc1=acc_2)
+    ln_bwd(fb.norm1_img, None, x_3, B, t['st_3'], dy_bf16=dx3_b, dx1=dx_a, acc1=acc_3)
+    dx_f = _e((B, nF, D), F32, dev)
+    ln_bwd(fb.norm1_mm, None, x_f, B, t['st_mm'], dy_bf16=dxmm_b, dy_f32=g1, dx1=dx_f)
+    return dx_f, dx_i, dx_a
+
+
+def _dense_fwd(fb, x_f, x_i, x_a, heads):
+    B, nF, D = x_f.shape
+    nI, nA = x_i.shape[1], x_a.shape[1]
+    dev, at = x_f.device, fb.attn
+    Da = at.q.weight.shape[0]
+    hd = Da // heads
+    xmm_b, xmm32, st_mm = ln_fwd(fb.norm1_mm, None, x_f, B, want_f32=True)
+    xi_b, _, st_i = ln_fwd(fb.norm1_img, None, x_i, B)
+    xa_b, _, st_a = ln_fwd(fb.norm1_aud, None, x_a, B)
+    # Linear(cat(audio_i, image_j)) = W[:, :D] audio_i + W[:, D:] image_j + b: two small GEMMs + a broadcast add
+    # instead of the [B, nA*nI, 2D] pair tensor of models/fusion_blocks.py:171-174
+    pa = lin_fwd(at.kv, xa_b, B * nA, k=D)                                   # fp32 [B*nA, 2Da]
+    pi = lin_fwd(at.kv, xi_b, B * nI, k=D, w_col_off=D, use_bias=False)
+    P = nA * nI
+    KV = _e((B * P, 2 * Da), BF16, dev)
+    ops.pair_expand(pa, pi, B, nA, nI, 2 * Da, KV)
+    q = lin_fwd(at.q, xmm_b, B * nF, out_bf16=True)
+    scale = (D // heads) ** -0.5                                  # from the FULL dim (:157-158)
+    o, lse = attention_fwd((q, 0), (KV, 0), (KV, Da), B, heads, nF, P, hd, hd, scale,
+                           nF * Da, Da, P * 2 * Da, 2 * Da, P * 2 * Da, 2 * Da, dev)
+    xmm1 = lin_fwd(at.proj, o, B * nF, res=xmm32).view(B, nF, D)
+    out, tt = _alt_tail_fwd(fb, xmm1, B, nF, D, dev)
+    tt.update(arch='dense_mmi', x_f=x_f, x_i=x_i, x_a=x_a, xmm_b=xmm_b, st_mm=st_mm, xi_b=xi_b, st_i=st_i, xa_b=xa_b, st_a=st_a,
+              KV=KV, q=q, o=o, lse=lse, heads=heads)
+    return out, tt
+
+
+def _dense_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
+    x_f, x_i, x_a, heads = t['x_f'], t['x_i'], t['x_a'], t['heads']
+    B, nF, D = x_f.shape
+    nI, nA = x_i.shape[1], x_a.shape[1]
+    P = nA * nI
+    dev, at = x_f.device, fb.attn
+    Da = at.q.weight.shape[0]
+    hd = Da // heads
+    g1, g1b = _alt_tail_bwd(fb, t, g, gb, B, nF, D, dev)
+    do = lin_bwd(at.proj, g1b, t['o'], B * nF)
+    dq, dKV = _e((B * nF, Da), BF16, dev), _e((B * P, 2 * Da), BF16, dev)
+    scale = (D // heads) ** -0.5
+    attention_bwd((t['q'], 0), (t['KV'], 0), (t['KV'], Da), t['o'], do, t['lse'], (dq, 0), (dKV, 0), (dKV, Da),
+                  B, heads, nF, P, hd, hd, scale, nF * Da, Da, P * 2 * Da, 2 * Da, P * 2 * Da, 2 * Da,
+                  nF * Da, Da, P * 2 * Da, 2 * Da, P * 2 * Da, 2 * Da)
+    dxmm_b = lin_bwd(at.q, dq, t['xmm_b'], B * nF)
+    dpa, dpi = _e((B * nA, 2 * Da), BF16, dev), _e((B * nI, 2 * Da), BF16, dev)
+    ops.pair_reduce(dKV, B, nA, nI, 2 * Da, dpa, dpi)
+    dxa_b = lin_bwd(at.kv, dpa, t['xa_b'], B * nA, k=D, final=False)
+    dxi_b = lin_bwd(at.kv, dpi, t['xi_b'], B * nI, k=D, w_col_off=D, use_bias=False)
+    acc_i, acc_a = (1 if dx_i is not None else 0), (1 if dx_a is not None else 0)
+    if dx_i is None:
+        dx_i = _e((B, nI, D), F32, dev)
+    if dx_a is None:
+        dx_a = _e((B, nA, D), F32, dev)
+    ln_bwd(fb.norm1_img, None, x_i, B, t['st_i'], dy_bf16=dxi_b, dx1=dx_i, acc1=acc_i)
+    ln_bwd(fb.norm1_aud, None, x_a, B, t['st_a'], dy_bf16=dxa_b, dx1=dx_a, acc1=acc_a)
+    dx_f = _e((B, nF, D), F32, dev)
+    ln_bwd(fb.norm1_mm, None, x_f, B, t['st_mm'], dy_bf16=dxmm_b, dy_f32=g1, dx1=dx_f)
+    return dx_f, dx_i, dx_a
+
+
+def fusion_block_fwd(fb, x_f, x_i, x_a, heads, tkns):
+    """Dispatch on the block's architecture (models/deepavfusion.py:28-35); x_i / x_a = the 2nd / 3rd positional
+    argument of the reference call ``blk_fusion(x_fusion, x_image, x_audio)``."""
+    arch = getattr(fb, 'arch', 'factorized_mmi')
+    if arch == 'token':
+        return _token_fwd(fb, x_f, x_i, x_a, heads)
+    if arch == 'dense_mmi':
+        return _dense_fwd(fb, x_f, x_i, x_a, heads)
+    return _factorized_fwd(fb, x_f, x_i, x_a, heads, tkns)
+
+
+def fusion_block_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
+    """g fp32 [B,nF,D] grad of the block output -> (dx_f, dx_i, dx_a), gradients of the three positional inputs."""
+    arch = t.get('arch', 'factorized_mmi')
+    if arch == 'token':
+        return _token_bwd(fb, t, g, gb, dx_i=dx_i, dx_a=dx_a)
+    if arch == 'dense_mmi':
+        return _dense_bwd(fb, t, g, gb, dx_i=dx_i, dx_a=dx_a)
+    return _factorized_bwd(fb, t, g, gb, dx_i=dx_i, dx_a=dx_a)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -11,8 +11,8 @@ from .vits import init_linear_and_norm
 class DeepAVFusion(nn.Module):
     """Same ctor signature / attributes / state-dict keys as models/deepavfusion.py:6-54.
 
-    Only ``fusion_arch='factorized_mmi'`` (the default and every BASELINE configuration) is on the
-    MI355X path; ``token`` / ``dense_mmi`` are listed as "next" in SURVEY.md section 8(f).
+    ``fusion_arch`` selects the block as models/deepavfusion.py:28-35 does: 'factorized_mmi' (default, every BASELINE
+    configuration), 'token' (FusionBlock_LocalAVTokens) or 'dense_mmi' (FusionBlock_DenseAVInteractions).
     """
     def __init__(self, image_arch='vit_base', image_pretrained=True, image_size=(224, 224),
                  audio_arch='vit_base', audio_pretrained=True, audio_size=(128, 192),
@@ -28,9 +28,14 @@ class DeepAVFusion(nn.Module):
         self.num_fusion = tuple(num_fusion_tkns)
         self.fusion_num_heads = fusion_num_heads
         self.fusion_tokens = nn.Parameter(torch.zeros(1, sum(num_fusion_tkns), self.embed_dim))
-        if fusion_arch != 'factorized_mmi':
-            raise NotImplementedError(f"fusion_arch={fusion_arch!r}: only 'factorized_mmi' runs on the gfx950 path")
-        make_block = partial(fusion_blocks.FusionBlock_FactorizedAVInteractions, fusion_tkns=num_fusion_tkns)
+        if fusion_arch == 'token':
+            make_block = fusion_blocks.FusionBlock_LocalAVTokens
+        elif fusion_arch == 'dense_mmi':
+            make_block = fusion_blocks.FusionBlock_DenseAVInteractions
+        elif fusion_arch == 'factorized_mmi':
+            make_block = partial(fusion_blocks.FusionBlock_FactorizedAVInteractions, fusion_tkns=num_fusion_tkns)
+        else:
+            make_block = None                            # as in the reference: unknown arch -> no fusion blocks at all
         depth = max(len(self.image.blocks), len(self.audio.blocks))
         if fusion_layers == 'all':                       # models/deepavfusion.py:38-45
             layers = set(range(depth))
@@ -42,7 +47,7 @@ class DeepAVFusion(nn.Module):
             layers = {int(l) for l in str(fusion_layers).split('-')}
         self.fusion_blocks = nn.ModuleList([
             make_block(dim=self.embed_dim, num_heads=fusion_num_heads, attn_ratio=fusion_attn_ratio,
-                       mlp_ratio=fusion_mlp_ratio, qkv_bias=True, norm_layer=nn.LayerNorm) if i in layers else None
+                       mlp_ratio=fusion_mlp_ratio, qkv_bias=True, norm_layer=nn.LayerNorm) if (i in layers and make_block is not None) else None
             for i in range(depth)])
         self.fusion_norm = nn.LayerNorm(self.embed_dim)
         self.initialize_weights()

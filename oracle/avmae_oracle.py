@@ -46,6 +46,7 @@ class PathConfig:
     fusion_mlp_ratio: float = 1.0
     fusion_attn_ratio: float = 0.25
     fusion_num_heads: int = 12
+    fusion_arch: str = 'factorized_mmi'     # 'token' | 'dense_mmi' | 'factorized_mmi' (models/deepavfusion.py:28-35)
     decoder_dim: int = 512
     decoder_depth: int = 8
     decoder_heads: int = 16
@@ -294,6 +295,59 @@ def fusion_block_factorized(xmm: Tensor, xv: Tensor, xa: Tensor, sd, name: str, 
     return xmm
 
 
+def local_av_attention(xmm: Tensor, xv: Tensor, xa: Tensor, sd, name: str, heads: int) -> Tensor:
+    """CrossAttention_LocalAVTokens.forward, models/fusion_blocks.py:103-117: fusion tokens attend to
+    cat(xv, xa); q/k/v all of width Da = dim*dim_ratio, scale (Da/heads)^-0.5 (:93-95)."""
+    B, nmm, _ = xmm.shape
+    Da = sd[name + '.q.weight'].shape[0]
+    hd = Da // heads
+    src = torch.cat((xv, xa), dim=1)
+    q = linear(xmm, sd, name + '.q').reshape(B, nmm, heads, hd).permute(0, 2, 1, 3)
+    kv = linear(src, sd, name + '.kv').reshape(B, src.shape[1], 2, heads, hd).permute(2, 0, 3, 1, 4)
+    o = softmax_attention(q, kv[0], kv[1], hd ** -0.5)
+    return linear(o.transpose(1, 2).reshape(B, nmm, Da), sd, name + '.proj')
+
+
+def fusion_block_token(x_f: Tensor, x_image: Tensor, x_audio: Tensor, sd, name: str, heads: int, eps: float) -> Tensor:
+    """FusionBlock_LocalAVTokens, models/fusion_blocks.py:120-145, as CALLED by models/deepavfusion.py:106
+    ``blk_fusion(x_fusion, x_image, x_audio)`` against the signature ``forward(self, xmm, xa, xv)`` (:135):
+    xa := x_image, xv := x_audio, so norm1_img normalises the AUDIO tokens and norm1_aud the IMAGE tokens (:136),
+    and the key/value sequence is cat(normed audio, normed image) (:106 of fusion_blocks)."""
+    xmm = layer_norm(x_f, sd, name + '.norm1_mm', eps)
+    xv = layer_norm(x_audio, sd, name + '.norm1_img', eps)
+    xa = layer_norm(x_image, sd, name + '.norm1_aud', eps)
+    xmm = xmm + local_av_attention(xmm, xv, xa, sd, name + '.attn', heads)
+    return xmm + timm_mlp(layer_norm(xmm, sd, name + '.norm2', eps), sd, name + '.mlp')
+
+
+def dense_av_attention(xmm: Tensor, first: Tensor, second: Tensor, sd, name: str, heads: int) -> Tensor:
+    """CrossAttention_DenseAVInteractions.forward(self, xmm, xa, xv), models/fusion_blocks.py:168-188, with
+    ``first`` bound to its ``xa`` and ``second`` to its ``xv``: pairs p = i*na + j carry [xv[i] || xa[j]] =
+    [second[i] || first[j]] (:171-174); k/v width Da, scale (dim/heads)^-0.5 from the FULL dim (:157-158)."""
+    B, nmm, C = xmm.shape
+    Da = sd[name + '.q.weight'].shape[0]
+    hd = Da // heads
+    nv, na = second.shape[1], first.shape[1]
+    pairs = torch.cat((second[:, :, None, :].expand(B, nv, na, C), first[:, None, :, :].expand(B, nv, na, C)), dim=3)
+    pairs = pairs.reshape(B, nv * na, 2 * C)
+    q = linear(xmm, sd, name + '.q').reshape(B, nmm, heads, hd).permute(0, 2, 1, 3)
+    kv = linear(pairs, sd, name + '.kv').reshape(B, nv * na, 2, heads, hd).permute(2, 0, 3, 1, 4)
+    o = softmax_attention(q, kv[0], kv[1], (C // heads) ** -0.5)
+    return linear(o.transpose(1, 2).reshape(B, nmm, Da), sd, name + '.proj')
+
+
+def fusion_block_dense(x_f: Tensor, x_image: Tensor, x_audio: Tensor, sd, name: str, heads: int, eps: float) -> Tensor:
+    """FusionBlock_DenseAVInteractions, models/fusion_blocks.py:191-213: forward(xmm, xv, xa) takes the call of
+    models/deepavfusion.py:106 in order, but passes ``self.attn(xmm, xv, xa)`` (:206) to a forward declared
+    ``(xmm, xa, xv)`` (:168) — inside the attention the image tokens play "xa" and the audio tokens "xv", i.e.
+    pairs are (audio_i, image_j)."""
+    xmm = layer_norm(x_f, sd, name + '.norm1_mm', eps)
+    xv = layer_norm(x_image, sd, name + '.norm1_img', eps)
+    xa = layer_norm(x_audio, sd, name + '.norm1_aud', eps)
+    xmm = xmm + dense_av_attention(xmm, xv, xa, sd, name + '.attn', heads)
+    return xmm + timm_mlp(layer_norm(xmm, sd, name + '.norm2', eps), sd, name + '.mlp')
+
+
 # --------------------------------------------------------------------------- #
 # models/deepavfusion.py
 # --------------------------------------------------------------------------- #
@@ -314,8 +368,14 @@ def _early_fusion_layers(sd, cfg, x_v: Tensor, x_a: Tensor, prefix: str, vis: st
             # the fusion block reads the layer's INPUT x_v / x_a (:106-107)
             n_v = timm_block(torch.cat((x_f, x_v), 1), sd, f'{prefix}{vis}.blocks.{l}', cfg.num_heads, cfg.enc_eps)[:, nF:]
             n_a = timm_block(torch.cat((x_f, x_a), 1), sd, f'{prefix}audio.blocks.{l}', cfg.num_heads, cfg.enc_eps)[:, nF:]
-            x_f = fusion_block_factorized(x_f, x_v, x_a, sd, f'{prefix}fusion_blocks.{l}', cfg.fusion_num_heads,
-                                          cfg.fusion_tkns, cfg.fus_eps)
+            arch = getattr(cfg, 'fusion_arch', 'factorized_mmi')
+            if arch == 'token':
+                x_f = fusion_block_token(x_f, x_v, x_a, sd, f'{prefix}fusion_blocks.{l}', cfg.fusion_num_heads, cfg.fus_eps)
+            elif arch == 'dense_mmi':
+                x_f = fusion_block_dense(x_f, x_v, x_a, sd, f'{prefix}fusion_blocks.{l}', cfg.fusion_num_heads, cfg.fus_eps)
+            else:
+                x_f = fusion_block_factorized(x_f, x_v, x_a, sd, f'{prefix}fusion_blocks.{l}', cfg.fusion_num_heads,
+                                              cfg.fusion_tkns, cfg.fus_eps)
             x_v, x_a = n_v, n_a
         if return_embs:
             embs.append((x_v, x_a, x_f))
@@ -442,14 +502,21 @@ def _fusion_shapes(s, enc, cfg):
         for n in ('norm1_mm', 'norm1_aud', 'norm1_img', 'norm2'):
             s[f'{pre}.{n}.weight'] = (D,)
             s[f'{pre}.{n}.bias'] = (D,)
-        for ca in ('attn_v', 'attn_a'):
-            s[f'{pre}.attn.{ca}.q.weight'] = (D, D); s[f'{pre}.attn.{ca}.q.bias'] = (D,)
-            s[f'{pre}.attn.{ca}.kv.weight'] = (2 * D, D); s[f'{pre}.attn.{ca}.kv.bias'] = (2 * D,)
-            s[f'{pre}.attn.{ca}.proj.weight'] = (D, D); s[f'{pre}.attn.{ca}.proj.bias'] = (D,)
-        s[f'{pre}.attn.q.weight'] = (Da, D); s[f'{pre}.attn.q.bias'] = (Da,)
-        s[f'{pre}.attn.k.weight'] = (Da, 2 * D); s[f'{pre}.attn.k.bias'] = (Da,)
-        s[f'{pre}.attn.v.weight'] = (D, 2 * D); s[f'{pre}.attn.v.bias'] = (D,)
-        s[f'{pre}.attn.proj.weight'] = (D, D); s[f'{pre}.attn.proj.bias'] = (D,)
+        arch = getattr(cfg, 'fusion_arch', 'factorized_mmi')
+        if arch in ('token', 'dense_mmi'):          # models/fusion_blocks.py:97-101 / :160-164
+            kin = D if arch == 'token' else 2 * D
+            s[f'{pre}.attn.q.weight'] = (Da, D); s[f'{pre}.attn.q.bias'] = (Da,)
+            s[f'{pre}.attn.kv.weight'] = (2 * Da, kin); s[f'{pre}.attn.kv.bias'] = (2 * Da,)
+            s[f'{pre}.attn.proj.weight'] = (D, Da); s[f'{pre}.attn.proj.bias'] = (D,)
+        else:
+            for ca in ('attn_v', 'attn_a'):
+                s[f'{pre}.attn.{ca}.q.weight'] = (D, D); s[f'{pre}.attn.{ca}.q.bias'] = (D,)
+                s[f'{pre}.attn.{ca}.kv.weight'] = (2 * D, D); s[f'{pre}.attn.{ca}.kv.bias'] = (2 * D,)
+                s[f'{pre}.attn.{ca}.proj.weight'] = (D, D); s[f'{pre}.attn.{ca}.proj.bias'] = (D,)
+            s[f'{pre}.attn.q.weight'] = (Da, D); s[f'{pre}.attn.q.bias'] = (Da,)
+            s[f'{pre}.attn.k.weight'] = (Da, 2 * D); s[f'{pre}.attn.k.bias'] = (Da,)
+            s[f'{pre}.attn.v.weight'] = (D, 2 * D); s[f'{pre}.attn.v.bias'] = (D,)
+            s[f'{pre}.attn.proj.weight'] = (D, D); s[f'{pre}.attn.proj.bias'] = (D,)
         s[f'{pre}.mlp.fc1.weight'] = (Hf, D); s[f'{pre}.mlp.fc1.bias'] = (Hf,)
         s[f'{pre}.mlp.fc2.weight'] = (D, Hf); s[f'{pre}.mlp.fc2.bias'] = (D,)
     s[f'{enc}fusion_norm.weight'] = (D,)

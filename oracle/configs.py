@@ -13,11 +13,20 @@ CONFIGS = {
     'micro': PathConfig(embed_dim=128, depth=2, num_heads=2, image_size=(64, 64), audio_size=(32, 112),
                         fusion_tkns=(4, 3, 2), fusion_layers=(0, 1), fusion_mlp_ratio=1.0, fusion_attn_ratio=0.25,
                         fusion_num_heads=2, decoder_dim=64, decoder_depth=2, decoder_heads=2),
+    # the two non-default fusion archs at the micro shape
+    'micro_token': PathConfig(embed_dim=128, depth=2, num_heads=2, image_size=(64, 64), audio_size=(32, 112),
+                              fusion_tkns=(4, 3, 2), fusion_layers=(0, 1), fusion_num_heads=2, decoder_dim=64, decoder_depth=2,
+                              decoder_heads=2, fusion_arch='token'),
+    'micro_dense': PathConfig(embed_dim=128, depth=2, num_heads=2, image_size=(64, 64), audio_size=(32, 112),
+                              fusion_tkns=(4, 3, 2), fusion_layers=(0, 1), fusion_num_heads=2, decoder_dim=64, decoder_depth=2,
+                              decoder_heads=2, fusion_arch='dense_mmi'),
     'tiny': PathConfig(embed_dim=192, depth=12, num_heads=3, image_size=(64, 64), audio_size=(128, 128),
                        fusion_tkns=(16, 8, 8), fusion_layers=tuple(range(12)), fusion_mlp_ratio=1.0,
                        fusion_attn_ratio=0.25, fusion_num_heads=3),
     'base': PathConfig(),
     'base_m75': PathConfig(audio_mask_ratio=0.75),
+    'base_token': PathConfig(fusion_arch='token'),
+    'base_dense': PathConfig(fusion_arch='dense_mmi'),      # 63 x 49 = 3087 (audio, image) pairs per sample
     'base_as': PathConfig(fusion_mlp_ratio=4.0, fusion_attn_ratio=1.0),
     'large': PathConfig(embed_dim=1024, depth=24, num_heads=16, fusion_layers=tuple(range(24)), fusion_num_heads=16),
     'video_micro': VideoConfig(embed_dim=128, depth=2, num_heads=2, video_size=(4, 48, 32), audio_size=(32, 48),

@@ -29,10 +29,10 @@ def _build(name):
 
 
 # gradients whose true value is exactly zero (softmax shift invariance): pure rounding noise on both sides
-ZERO_GRADS = ('attn.k.bias',)
+ZERO_GRADS = ('attn.k.bias',)      # factorised block; the kv.bias of the token / dense blocks has a live v half
 
 
-@pytest.mark.parametrize('name', ['micro', 'tiny'])
+@pytest.mark.parametrize('name', ['micro', 'tiny', 'micro_token', 'micro_dense'])
 def test_end_to_end_vs_oracle_and_golden(golden, name):
     g = golden(f'e2e_{name}')
     model, sd, cfg, O = _build(name)

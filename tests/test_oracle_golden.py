@@ -147,7 +147,7 @@ def test_patchify_and_loss(golden):
             close(p.grad.numpy(), g[f'loss.{mod}.{norm}.gpred'])
 
 
-@pytest.mark.parametrize('name', ['micro', 'tiny'])
+@pytest.mark.parametrize('name', ['micro', 'tiny', 'micro_token', 'micro_dense'])
 def test_end_to_end(golden, name):
     g = golden(f'e2e_{name}')
     cfg = CONFIGS[name]

@@ -46,7 +46,7 @@ def register_archs():
     vits.vit_tiny = mk(192, 12, 3)
 
 
-ARCH_OF = {'micro': 'vit_micro', 'tiny': 'vit_tiny', 'base': 'vit_base'}
+ARCH_OF = {'micro': 'vit_micro', 'micro_token': 'vit_micro', 'micro_dense': 'vit_micro', 'tiny': 'vit_tiny', 'base': 'vit_base'}
 
 
 def build_reference(name):
@@ -54,7 +54,7 @@ def build_reference(name):
     enc = DeepAVFusion(
         image_arch=ARCH_OF[name], image_pretrained='', image_size=cfg.image_size,
         audio_arch=ARCH_OF[name], audio_pretrained='', audio_size=cfg.audio_size,
-        fusion_arch='factorized_mmi', fusion_layers='all', num_fusion_tkns=cfg.fusion_tkns,
+        fusion_arch=cfg.fusion_arch, fusion_layers='all', num_fusion_tkns=cfg.fusion_tkns,
         fusion_mlp_ratio=cfg.fusion_mlp_ratio, fusion_attn_ratio=cfg.fusion_attn_ratio,
         fusion_num_heads=cfg.fusion_num_heads)
     model = AVMAE(enc, enc.embed_dim,
@@ -240,8 +240,9 @@ def gen_e2e(name, B, seed, keep_preds):
     out['grad_norms'] = np.array(norms, dtype=np.float64)
     out['grad_norm_total'] = np.float64(ref_misc.get_grad_norm_(model.parameters()).item())   # util/misc.py:151-163
     # a few full gradients
+    fk = 'encoder.fusion_blocks.0.attn.k.weight' if cfg.fusion_arch == 'factorized_mmi' else 'encoder.fusion_blocks.0.attn.kv.weight'
     for n in ('encoder.fusion_tokens', 'image_decoder_mask_token', 'encoder.image.patch_embed.proj.bias',
-              'encoder.fusion_blocks.0.attn.k.weight', 'encoder.audio.blocks.0.attn.qkv.bias'):
+              fk, 'encoder.audio.blocks.0.attn.qkv.bias'):
         out['grad.' + n] = dict(model.named_parameters())[n].grad.numpy().copy()
     np.savez_compressed(os.path.join(OUT, f'e2e_{name}.npz'), **out)
     print(f'e2e[{name}] loss_image={float(li):.6f} loss_audio={float(la):.6f} gnorm={float(out["grad_norm_total"]):.6f}')
@@ -400,7 +401,9 @@ if __name__ == '__main__':
     jobs = {'masking': gen_masking, 'posembed': gen_posembed, 'ops': gen_ops,
             'e2e_micro': lambda: gen_e2e('micro', 3, 21, True), 'e2e_tiny': lambda: gen_e2e('tiny', 2, 22, False),
             'lr': gen_lr_and_groups, 'trainer': gen_trainer_steps,
-            'video_micro': lambda: gen_video('video_micro', 2, 31)}
+            'video_micro': lambda: gen_video('video_micro', 2, 31),
+            'e2e_micro_token': lambda: gen_e2e('micro_token', 3, 23, False),
+            'e2e_micro_dense': lambda: gen_e2e('micro_dense', 3, 24, False)}
     if a.curve:
         jobs = {'curve': gen_curve}
     for k, f in jobs.items():
