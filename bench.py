@@ -236,6 +236,12 @@ def main():
         tc = time.perf_counter() - t_start
         result['cpu_baseline'] = {'value': round(Bc * n_done / tc, 3), 'unit': 'AV-pairs/s', 'cores': cores, 'kind': 'port',
                                   'sample': f'{n_done} fp32 oracle steps (fwd+bwd+AdamW) at B={Bc}, same shapes'}
+    try:                                    # RCCL's version banner sits in C stdio's buffer: push it out BEFORE the JSON line
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stderr.flush()
     print(json.dumps(result), flush=True)
     return 0
 
