@@ -234,6 +234,75 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Epilogue shared by the NT kernels: 16 tile rows of a wave at a time: registers -> (alpha, bias) -> the wave's small LDS
+// patch -> coalesced row segments (16 bytes per lane).  The patch (16 x (WTN + 4) floats per wave) is smaller than one
+// ring stage, so the ring alone decides how many workgroups share a CU.
+template <int FM, int FN, int WTM, int WTN>
+__device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4 (&acc)[FM][FN], char* patch_base, int m0, int n0, int wave,
+                                            int wm, int wn, int lane) {
+  const int fr = lane & 15, fg = lane >> 4;
+  constexpr int LDW = WTN + 4;              // floats per patch row (+4: at most 2-way ds_write conflicts)
+  float* patch = reinterpret_cast<float*>(patch_base) + wave * (16 * LDW);
+  constexpr int CPR = WTN / 4;              // float4 chunks per patch row
+  constexpr int RPI = 64 / CPR;             // rows per wave-instruction
+  const int cc = lane % CPR, rr = lane / CPR;
+  const int n = n0 + wn * WTN + cc * 4;
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int nn = n0 + wn * WTN + j * 16 + fr;
+      const float bv = (p.bias && nn < p.N) ? p.bias[nn] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) patch[(fg * 4 + r) * LDW + j * 16 + fr] = acc[i][j][r] * p.alpha + bv;
+    }
+    if (n < p.N && rr < RPI) {
+#pragma unroll
+      for (int it = 0; it < (16 + RPI - 1) / RPI; ++it) {
+        const int lr = it * RPI + rr;
+        const int m = m0 + wm * WTM + i * 16 + lr;
+        if (lr >= 16 || m >= p.M) continue;
+        float4 v = *reinterpret_cast<const float4*>(patch + lr * LDW + cc * 4);
+        if (p.c2_mode == 1) {
+          uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
+          *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
+        }
+        if (p.act == 1) {
+          v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w);
+        } else if (p.act == 2) {
+          const uint2 a = *reinterpret_cast<const uint2*>(p.aux + (long)m * p.ldaux + n);
+          v.x *= gelu_grad_f(__uint_as_float(a.x << 16)); v.y *= gelu_grad_f(__uint_as_float(a.x & 0xffff0000u));
+          v.z *= gelu_grad_f(__uint_as_float(a.y << 16)); v.w *= gelu_grad_f(__uint_as_float(a.y & 0xffff0000u));
+        }
+        if (p.c2_mode == 2) {
+          uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
+          *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
+        }
+        if (p.res) {
+          const long rrow = p.res_rows ? (long)p.res_rows[m] : map_row(m, p.rmap);
+          const float4 t = *reinterpret_cast<const float4*>(p.res + rrow * p.ldres + n);
+          v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        if (p.C) {
+          const long crow = map_row(m, p.cmap);
+          if (p.c_bf16) {
+            uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + crow * p.ldc + n) = w;
+          } else {
+            float4* c = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + crow * p.ldc + n);
+            if (p.beta) { const float4 o = *c; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            *c = v;
+          }
+        }
+        if (p.c2_mode == 3) {
+          uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
+          *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
+        }
+      }
+    }
+  }
+}
+
 template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK = 64>
 __global__ __launch_bounds__(WM_* WN_ * 64) void gemm_nt2_kernel(NTParams p) {
   constexpr int NT = WM_ * WN_ * 64;
@@ -356,70 +425,8 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void gemm_nt2_kernel(NTParams p) {
     }
   }
 
-  // ---- epilogue: 16 tile rows of this wave at a time: registers -> (alpha, bias) -> this wave's small LDS patch
-  //      -> coalesced row segments (16 bytes per lane).  The patch (16 x (WTN + 4) floats per wave) is smaller than
-  //      one ring stage, so the ring alone decides how many workgroups share a CU.
   __syncthreads();                          // all waves finished reading the last stage
-  constexpr int LDW = WTN + 4;              // floats per patch row (+4: at most 2-way ds_write conflicts)
-  float* patch = reinterpret_cast<float*>(smem) + wave * (16 * LDW);
-  constexpr int CPR = WTN / 4;              // float4 chunks per patch row
-  constexpr int RPI = 64 / CPR;             // rows per wave-instruction
-  const int cc = lane % CPR, rr = lane / CPR;
-  const int n = n0 + wn * WTN + cc * 4;
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int nn = n0 + wn * WTN + j * 16 + fr;
-      const float bv = (p.bias && nn < p.N) ? p.bias[nn] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) patch[(fg * 4 + r) * LDW + j * 16 + fr] = acc[i][j][r] * p.alpha + bv;
-    }
-    if (n < p.N && rr < RPI) {
-#pragma unroll
-      for (int it = 0; it < (16 + RPI - 1) / RPI; ++it) {
-        const int lr = it * RPI + rr;
-        const int m = m0 + wm * WTM + i * 16 + lr;
-        if (lr >= 16 || m >= p.M) continue;
-        float4 v = *reinterpret_cast<const float4*>(patch + lr * LDW + cc * 4);
-        if (p.c2_mode == 1) {
-          uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
-          *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
-        }
-        if (p.act == 1) {
-          v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w);
-        } else if (p.act == 2) {
-          const uint2 a = *reinterpret_cast<const uint2*>(p.aux + (long)m * p.ldaux + n);
-          v.x *= gelu_grad_f(__uint_as_float(a.x << 16)); v.y *= gelu_grad_f(__uint_as_float(a.x & 0xffff0000u));
-          v.z *= gelu_grad_f(__uint_as_float(a.y << 16)); v.w *= gelu_grad_f(__uint_as_float(a.y & 0xffff0000u));
-        }
-        if (p.c2_mode == 2) {
-          uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
-          *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
-        }
-        if (p.res) {
-          const long rrow = p.res_rows ? (long)p.res_rows[m] : map_row(m, p.rmap);
-          const float4 t = *reinterpret_cast<const float4*>(p.res + rrow * p.ldres + n);
-          v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-        }
-        if (p.C) {
-          const long crow = map_row(m, p.cmap);
-          if (p.c_bf16) {
-            uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
-            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + crow * p.ldc + n) = w;
-          } else {
-            float4* c = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + crow * p.ldc + n);
-            if (p.beta) { const float4 o = *c; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-            *c = v;
-          }
-        }
-        if (p.c2_mode == 3) {
-          uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
-          *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
-        }
-      }
-    }
-  }
+  nt_epilogue<FM, FN, WTM, WTN>(p, acc, smem, m0, n0, wave, wm, wn, lane);
 }
 
 template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT = false, int BK = 64>
