@@ -130,6 +130,26 @@ class FlatAdamW(torch.optim.Optimizer):
         engine.invalidate_weight_cache(f.params)      # fp32 masters changed behind torch's back
 
     @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        """Accepts what ``torch.optim.AdamW.state_dict()`` produces for the same parameter groups (the 'optimizer' entry
+        of a reference checkpoint, util/misc.py:251-262) as well as this class's own ``state_dict()`` — they are the same
+        format.  The loaded moments are copied into the flat buffers and the per-parameter state becomes views again."""
+        super().load_state_dict(state_dict)
+        steps = []
+        for p, o in zip(self.flat.params, self.flat.offsets):
+            st, n = self.state.get(p, {}), p.numel()
+            for key, flat in (('exp_avg', self.exp_avg), ('exp_avg_sq', self.exp_avg_sq)):
+                if key in st:
+                    flat[o:o + n].copy_(st[key].reshape(-1).to(flat.device, torch.float32))
+                else:
+                    flat[o:o + n].zero_()
+            step = float(st['step']) if 'step' in st else 0.0
+            steps.append(int(step))
+            self.state[p] = dict(step=torch.tensor(step), exp_avg=self.exp_avg[o:o + n].view(p.shape),
+                                 exp_avg_sq=self.exp_avg_sq[o:o + n].view(p.shape))
+        self.step_count = max(steps) if steps else 0
+
+    @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0):
         self.prepare_step()
         self.launch_step(grad_scale)

@@ -235,8 +235,13 @@ class GraphedStep:
 
 
 class CheckpointManager:
-    """util/misc.py:222-309: rank-0 ``checkpoint_latest.pth`` (+ numbered every save_freq) holding
-    {'state_dict', 'optimizer', 'n_steps', 'epoch'}; ``resume()`` restores them and returns the start epoch."""
+    """util/misc.py:222-309, same file format: ``checkpoint_latest.pth`` (+ ``checkpoint_best.pth``, + numbered every
+    save_freq) = {'state_dict': model.state_dict(), 'optimizer': <torch AdamW format>, 'n_steps', 'scaler', 'epoch', ...};
+    ``resume()`` -> (start_epoch, metrics).  A checkpoint written by the reference resumes here and vice versa: the
+    optimizer entry is the torch format (FlatAdamW.state_dict / load_state_dict), and because this path trains in bf16
+    without loss scaling a neutral GradScaler state is written under 'scaler' for the reference's resume loop."""
+
+    NEUTRAL_SCALER = {'scale': 1.0, 'growth_factor': 2.0, 'backoff_factor': 0.5, 'growth_interval': 2000, '_growth_tracker': 0}
 
     def __init__(self, modules, ckpt_dir, epochs, save_freq=None):
         self.modules, self.ckpt_dir, self.epochs, self.save_freq = modules, ckpt_dir, epochs, save_freq
@@ -244,47 +249,56 @@ class CheckpointManager:
         if self.rank == 0:
             os.makedirs(ckpt_dir, exist_ok=True)
 
-    def _state(self):
-        out = {}
-        for k, m in self.modules.items():
-            if isinstance(m, torch.Tensor):
-                out[k] = m.clone().cpu()
-            elif isinstance(m, FlatAdamW):
-                out[k] = dict(step_count=m.step_count, exp_avg=m.exp_avg.cpu(), exp_avg_sq=m.exp_avg_sq.cpu(),
-                              param_groups=[{kk: vv for kk, vv in g.items() if kk != 'params'} for g in m.param_groups])
-            else:
-                out[k] = copy.deepcopy({kk: (vv.cpu() if isinstance(vv, torch.Tensor) else vv) for kk, vv in m.state_dict().items()})
-        return out
+    def map_location(self, state, device):
+        if isinstance(state, dict):
+            return {k: self.map_location(v, device) for k, v in state.items()}
+        if isinstance(state, (list, tuple)):
+            return type(state)(self.map_location(v, device) for v in state)
+        if isinstance(state, torch.Tensor):
+            return state.detach().to(device, copy=True)
+        return state
 
-    def checkpoint(self, epoch, save_dict=None):
+    def create_state_dict(self, save_dict=None):
+        state = {}
+        for k, m in self.modules.items():
+            if m is None:
+                state[k] = None
+            elif isinstance(m, torch.Tensor):
+                state[k] = m.detach().clone().cpu()
+            else:
+                state[k] = self.map_location(m.state_dict(), 'cpu')
+        state.setdefault('scaler', dict(self.NEUTRAL_SCALER))
+        if save_dict is not None:
+            state.update(save_dict)
+        return state
+
+    def checkpoint(self, epoch, save_dict=None, is_best=False):
         if self.rank != 0:
             return
-        state = self._state()
-        state.update(save_dict or {})
-        path = os.path.join(self.ckpt_dir, 'checkpoint_latest.pth')
-        torch.save(state, path)
-        if self.save_freq and (epoch % self.save_freq == 0 or epoch == self.epochs):
+        state = self.create_state_dict(save_dict)
+        torch.save(state, os.path.join(self.ckpt_dir, 'checkpoint_latest.pth'))
+        if is_best:
+            torch.save(state, os.path.join(self.ckpt_dir, 'checkpoint_best.pth'))
+        if self.save_freq is not None and (epoch % self.save_freq == 0 or epoch == self.epochs):
             torch.save(state, os.path.join(self.ckpt_dir, f'checkpoint_{epoch:04d}.pth'))
 
     def resume(self):
         path = os.path.join(self.ckpt_dir, 'checkpoint_latest.pth')
+        start_epoch, metrics = 0, {}
         if not os.path.isfile(path):
-            return (0,)
+            return start_epoch, metrics
         ckpt = torch.load(path, map_location='cpu')
         for k, m in self.modules.items():
-            if k not in ckpt:
+            if m is None:
                 continue
             if isinstance(m, torch.Tensor):
-                m.copy_(ckpt[k])
-            elif isinstance(m, FlatAdamW):
-                m.step_count = ckpt[k]['step_count']
-                m.exp_avg.copy_(ckpt[k]['exp_avg'])
-                m.exp_avg_sq.copy_(ckpt[k]['exp_avg_sq'])
-                m.sync_bf16()
+                m.data[:] = ckpt[k].data
             else:
                 m.load_state_dict(ckpt[k])
+        start_epoch = ckpt['epoch']
+        metrics = {k: v for k, v in ckpt.items() if k not in set(self.modules.keys()) and k not in ('epoch', 'scaler')}
         engine.invalidate_weight_cache(self.modules['state_dict'].parameters())
         for m in self.modules.values():
             if isinstance(m, FlatAdamW):
-                m.sync_bf16()
-        return (ckpt.get('epoch', 0),)
+                m.sync_bf16()                # fp32 masters were overwritten in place: refresh the bf16 mirror the GEMMs read
+        return start_epoch, metrics

@@ -374,3 +374,79 @@ def test_loss_curve_prefix_matches_reference(golden):
         tr.step(li + la)
         ref = g['loss_image'][s] + g['loss_audio'][s]
         assert abs(float(li + la) - ref) < 0.01 * ref, (s, float(li + la), ref)          # +-1 %
+
+
+def test_checkpoint_round_trip_and_reference_format(tmp_path):
+    """util/misc.py:222-309 file format.  (1) two steps, save, resume into a fresh model + optimizer: identical
+    parameters, moments and next-step result.  (2) a checkpoint laid out the way the reference writes it — state_dict +
+    the state_dict() of a plain torch.optim.AdamW over the same parameter groups + n_steps / scaler / epoch — resumes,
+    and the next FlatAdamW step equals torch's AdamW step on the same gradients."""
+    from deepavfusion_amd.util import lr_sched
+    from deepavfusion_amd.util.flat import FlatAdamW
+    from deepavfusion_amd.util.misc import CheckpointManager, Trainer
+
+    def make():
+        model, sd, cfg, O = _build('micro')
+        nd = [n for n, p in model.named_parameters() if 'bias' in n or 'norm' in n]
+        groups = lr_sched.param_groups_pretrained(model, 0.05, no_weight_decay_list=nd, image_pt='', audio_pt='')
+        opt = FlatAdamW(groups, lr=1e-3, betas=(0.9, 0.95), model=model)
+        return model, opt, Trainer(model, optimizer=opt, accum_iter=1), cfg, O
+
+    def one_step(tr, image, audio, seed):
+        torch.manual_seed(seed)
+        li, la = tr.model(image, audio)[:2]
+        tr.step(li + la)
+        return float(li) + float(la)
+
+    model, opt, tr, cfg, O = make()
+    image, audio, _, _ = O.structured_batch(cfg, 4, seed=5)
+    image, audio = image.cuda(), audio.cuda()
+    for s in range(2):
+        one_step(tr, image, audio, 100 + s)
+    d1 = str(tmp_path / 'a')
+    CheckpointManager(tr.module_dict(), d1, epochs=10).checkpoint(3, {'epoch': 3, 'best': 0.5}, is_best=True)
+    import os
+    assert os.path.isfile(os.path.join(d1, 'checkpoint_latest.pth')) and os.path.isfile(os.path.join(d1, 'checkpoint_best.pth'))
+    ck = torch.load(os.path.join(d1, 'checkpoint_latest.pth'), map_location='cpu')
+    assert set(ck) == {'state_dict', 'n_steps', 'optimizer', 'scaler', 'epoch', 'best'}
+    assert set(ck['optimizer']) == {'state', 'param_groups'} and set(ck['optimizer']['state'][0]) == {'step', 'exp_avg', 'exp_avg_sq'}
+    model2, opt2, tr2, _, _ = make()
+    start, metrics = CheckpointManager(tr2.module_dict(), d1, epochs=10).resume()
+    assert start == 3 and metrics == {'best': 0.5} and int(tr2.n_steps) == 2 and opt2.step_count == 2
+    assert torch.equal(opt2.flat.flat_p, opt.flat.flat_p) and torch.equal(opt2.exp_avg, opt.exp_avg) and torch.equal(opt2.exp_avg_sq, opt.exp_avg_sq)
+    l1, l2 = one_step(tr, image, audio, 200), one_step(tr2, image, audio, 200)
+    assert l1 == l2 and torch.equal(opt2.flat.flat_p, opt.flat.flat_p)
+
+    # (2) reference-style checkpoint built with torch.optim.AdamW on CPU copies of the same parameter groups
+    model3, opt3, tr3, _, _ = make()
+    cpu_params = {id(p): p.detach().cpu().clone().requires_grad_(True) for p in model3.parameters() if p.requires_grad}
+    tgroups = [{**{k: v for k, v in g.items() if k != 'params'}, 'params': [cpu_params[id(p)] for p in g['params']]} for g in opt3.param_groups]
+    topt = torch.optim.AdamW(tgroups, lr=1e-3, betas=(0.9, 0.95))
+    gen = torch.Generator().manual_seed(9)
+    for q in cpu_params.values():
+        q.grad = torch.randn(q.shape, generator=gen) * 1e-2
+    topt.step()                                                      # gives every parameter a state (step 1)
+    ref_ckpt = {'state_dict': {k: v.detach().cpu().clone() for k, v in model3.state_dict().items()}, 'n_steps': torch.tensor([7]),
+                'optimizer': topt.state_dict(), 'scaler': {'scale': 65536.0, 'growth_factor': 2.0, 'backoff_factor': 0.5,
+                                                           'growth_interval': 2000, '_growth_tracker': 3}, 'epoch': 5}
+    for (n, p) in model3.named_parameters():                          # the reference file holds the post-step weights
+        if p.requires_grad:
+            ref_ckpt['state_dict'][n] = cpu_params[id(p)].detach().clone()
+    d2 = str(tmp_path / 'b')
+    os.makedirs(d2)
+    torch.save(ref_ckpt, os.path.join(d2, 'checkpoint_latest.pth'))
+    start, _ = CheckpointManager(tr3.module_dict(), d2, epochs=10).resume()
+    assert start == 5 and int(tr3.n_steps) == 7 and opt3.step_count == 1
+    for p in model3.parameters():
+        if p.requires_grad:
+            assert torch.equal(p.detach().cpu(), cpu_params[id(p)].detach())
+    # same gradients on both sides -> same second step
+    for p in model3.parameters():
+        if p.requires_grad:
+            g = torch.randn(p.shape, generator=gen) * 1e-2
+            cpu_params[id(p)].grad = g.clone()
+            p.grad.copy_(g)
+    topt.step()
+    opt3.step()
+    worst = max(float((p.detach().cpu() - cpu_params[id(p)].detach()).abs().max()) for p in model3.parameters() if p.requires_grad)
+    assert worst < 2e-6, worst
