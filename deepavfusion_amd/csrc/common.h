@@ -46,12 +46,22 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // exact (erf) GELU and its derivative, as nn.GELU() default
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_grad_f(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+// Exact (erf) GELU and its derivative from ONE exponential: erf through Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7,
+// far inside the bf16 the results are stored in) — erf(|x|) = 1 - poly(t) e^{-x^2}, t = 1 / (1 + p|x|); with x = z / sqrt(2)
+// the same e^{-z^2/2} is the Gaussian density of the derivative.  Phi is formed without cancellation on either side:
+// z < 0: Phi = 0.5 poly e,  z >= 0: Phi = 1 - 0.5 poly e.   gelu = z Phi,  gelu' = Phi + z pdf(z).
+__device__ __forceinline__ void gelu_pair_f(float z, float& u, float& d) {
+  const float az = fabsf(z);
+  const float e = __expf(-0.5f * z * z);
+  const float t = __frcp_rn(1.0f + 0.3275911f * 0.70710678118654752f * az);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float half_tail = 0.5f * poly * e;                  // 0.5 * erfc(|z| / sqrt 2)
+  const float cdf = z < 0.f ? half_tail : 1.0f - half_tail;
+  u = z * cdf;
+  d = cdf + z * (0.39894228040143268f * e);
 }
+__device__ __forceinline__ float gelu_f(float x) { float u, d; gelu_pair_f(x, u, d); return u; }
+__device__ __forceinline__ float gelu_grad_f(float x) { float u, d; gelu_pair_f(x, u, d); return d; }
 
 #define HIP_CHECK_RET(expr)                    \
   do {                                         \

@@ -188,8 +188,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTParams p) {
         float v = acc[i][j][r] * p.alpha;
         if (p.bias) v += p.bias[n];
         if (p.c2_mode == 1) p.C2[(long)m * p.ldc2 + n] = f2bf(v);
-        if (p.act == 1) v = gelu_f(v);
-        else if (p.act == 2) v *= gelu_grad_f(bf2f(p.aux[(long)m * p.ldaux + n]));
+        if (p.act == 1) {
+          float u, d;
+          gelu_pair_f(v, u, d);
+          if (p.c2_mode == 4) p.C2[(long)m * p.ldc2 + n] = f2bf(d);
+          v = u;
+        } else if (p.act == 2) {
+          v *= gelu_grad_f(bf2f(p.aux[(long)m * p.ldaux + n]));
+        } else if (p.act == 3) {
+          v *= bf2f(p.aux[(long)m * p.ldaux + n]);
+        }
         if (p.c2_mode == 2) p.C2[(long)m * p.ldc2 + n] = f2bf(v);
         if (p.res) v += p.res[rrow * p.ldres + n];
         if (p.C) {
@@ -268,11 +276,20 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4 (&acc)[FM][
           *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
         }
         if (p.act == 1) {
-          v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w);
+          float4 d;
+          gelu_pair_f(v.x, v.x, d.x); gelu_pair_f(v.y, v.y, d.y); gelu_pair_f(v.z, v.z, d.z); gelu_pair_f(v.w, v.w, d.w);
+          if (p.c2_mode == 4) {          // bf16 twin = GELU'(pre-activation): the fc2 input gradient only multiplies by it
+            uint2 w; w.x = pack2bf(d.x, d.y); w.y = pack2bf(d.z, d.w);
+            *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
+          }
         } else if (p.act == 2) {
           const uint2 a = *reinterpret_cast<const uint2*>(p.aux + (long)m * p.ldaux + n);
           v.x *= gelu_grad_f(__uint_as_float(a.x << 16)); v.y *= gelu_grad_f(__uint_as_float(a.x & 0xffff0000u));
           v.z *= gelu_grad_f(__uint_as_float(a.y << 16)); v.w *= gelu_grad_f(__uint_as_float(a.y & 0xffff0000u));
+        } else if (p.act == 3) {
+          const uint2 a = *reinterpret_cast<const uint2*>(p.aux + (long)m * p.ldaux + n);
+          v.x *= __uint_as_float(a.x << 16); v.y *= __uint_as_float(a.x & 0xffff0000u);
+          v.z *= __uint_as_float(a.y << 16); v.w *= __uint_as_float(a.y & 0xffff0000u);
         }
         if (p.c2_mode == 2) {
           uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
@@ -766,7 +783,9 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
   if (((uintptr_t)A | (uintptr_t)B) & 15) return DAV_ERR_ALIGN;
   if (beta && c_is_bf16) return DAV_ERR_DTYPE;
   if (!C && !C2) return DAV_ERR_SHAPE;
-  if (C2 && (c2_mode < 1 || c2_mode > 3)) return DAV_ERR_SHAPE;
+  if (C2 && (c2_mode < 1 || c2_mode > 4)) return DAV_ERR_SHAPE;
+  if (C2 && c2_mode == 4 && act != 1) return DAV_ERR_SHAPE;
+  if ((act == 2 || act == 3) && !aux) return DAV_ERR_SHAPE;
   NTParams p;
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb;
   p.amap = mk(a_rowmap); p.bias = bias; p.act = act; p.aux = (const bf16_t*)aux; p.ldaux = ldaux;

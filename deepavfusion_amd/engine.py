@@ -270,7 +270,7 @@ def lin_bwd(lin, dy, a, M, *, dy_rowmap=None, a_rowmap=None, lda=None, need_dx=T
         else:
             WT = wcache_t(lin.weight)
             Bt, ldb, variant = (WT if w_col_off == 0 else WT[w_col_off:]), N, 0
-        ops.gemm_nt(dy, Bt, M, K, N, lda=N, ldb=ldb, a_rowmap=dy_rowmap, act=2 if gelu_aux is not None else 0,
+        ops.gemm_nt(dy, Bt, M, K, N, lda=N, ldb=ldb, a_rowmap=dy_rowmap, act=3 if gelu_aux is not None else 0,
                     aux=gelu_aux, ldaux=K, C_out=dx, ldc=K, c_bf16=dx.dtype == BF16, c_rowmap=dx_rowmap, beta=dx_beta,
                     C2=dx_C2, ldc2=K, c2_mode=dx_c2_mode, variant=variant)
     gw = gbuf(lin.weight)
@@ -340,7 +340,7 @@ def block_fwd(blk, x_mod, x_fus, heads, eps):
     h2, _, st2 = ln_fwd(blk.norm2, None, x1, B, eps)
     Hd = blk.mlp.fc1.weight.shape[0]
     z = _e((Mq, Hd), BF16, dev)
-    u = lin_fwd(blk.mlp.fc1, h2, Mq, act=1, out_bf16=True, C2=z, c2_mode=1)
+    u = lin_fwd(blk.mlp.fc1, h2, Mq, act=1, out_bf16=True, C2=z, c2_mode=4)
     x2 = lin_fwd(blk.mlp.fc2, u, Mq, res=x1).view(B, n, D)
     tape = dict(x_mod=x_mod, x_fus=x_fus, h1=h1, st1=st1, qkv=qkv, o=o, lse=lse, x1=x1, h2=h2, st2=st2, z=z, u=u,
                 heads=heads, nF=nF)
@@ -449,7 +449,7 @@ def _factorized_fwd(fb, x_f, x_i, x_a, heads, tkns):
     h2, _, st2 = ln_fwd(fb.norm2, None, xmm1, B)
     Hd = fb.mlp.fc1.weight.shape[0]
     z = _e((B * nF, Hd), BF16, dev)
-    u = lin_fwd(fb.mlp.fc1, h2, B * nF, act=1, out_bf16=True, C2=z, c2_mode=1)
+    u = lin_fwd(fb.mlp.fc1, h2, B * nF, act=1, out_bf16=True, C2=z, c2_mode=4)
     out = lin_fwd(fb.mlp.fc2, u, B * nF, res=xmm1).view(B, nF, D)
     tape = dict(x_f=x_f, x_i=x_i, x_a=x_a, xmm_b=xmm_b, st_mm=st_mm, xv_b=xv_b, st_v=st_v, xa_b=xa_b, st_a=st_a, cv=cv, ca=ca,
                 xvo_b=xvo_b, xao_b=xao_b, Kp=Kp, Vp=Vp, q2=q2, o2=o2, lse2=lse2, xmm1=xmm1, h2=h2, st2=st2, z=z, u=u,
@@ -529,7 +529,7 @@ def _alt_tail_fwd(fb, xmm1, B, nF, D, dev):
     h2, _, st2 = ln_fwd(fb.norm2, None, xmm1, B)
     Hd = fb.mlp.fc1.weight.shape[0]
     z = _e((B * nF, Hd), BF16, dev)
-    u = lin_fwd(fb.mlp.fc1, h2, B * nF, act=1, out_bf16=True, C2=z, c2_mode=1)
+    u = lin_fwd(fb.mlp.fc1, h2, B * nF, act=1, out_bf16=True, C2=z, c2_mode=4)
     out = lin_fwd(fb.mlp.fc2, u, B * nF, res=xmm1).view(B, nF, D)
     return out, dict(h2=h2, st2=st2, z=z, u=u, xmm1=xmm1)
 

@@ -47,8 +47,9 @@ int dav_tune(int knob, int value);
  * Mlp.fc1/fc2; models/fusion_blocks.py:41-44 q/kv/proj, :227-232 q/k/v/proj; models/avmae.py:31,59
  * decoder_embed, :60,88 decoder_pred; the patch-embed conv of models/vits.py:27 as a GEMM over
  * gathered patches) and, with B = W^T, their input gradients.
- * epilogue order: v = alpha*acc + bias[n]; [C2 mode 1]; act 1 = exact GELU, act 2 = v *= GELU'(aux[m,n])
- * (fc1 backward); [C2 mode 2]; + fp32 residual (row map or explicit row list: the block residual adds
+ * epilogue order: v = alpha*acc + bias[n]; [C2 mode 1]; act 1 = exact (erf) GELU [C2 mode 4: the twin is GELU'(v)
+ * of the pre-activation v], act 2 = v *= GELU'(aux[m,n]), act 3 = v *= aux[m,n] (fc1 backward, with aux = the pre-activation
+ * or the mode-4 twin of the forward); [C2 mode 2]; + fp32 residual (row map or explicit row list: the block residual adds
  * and "+ pos_embed[ids_keep]"); beta != 0 adds the old fp32 C; store C (fp32 or bf16, through
  * c_rowmap; may be NULL); [C2 mode 3].  C2 is a dense bf16 [M, ldc2] twin for the next GEMM.
  * variant bit12: B is given as [K, N] row-major (ldb = row stride; K % 64 == 0, N % 8 == 0) — the dgrad reads

@@ -64,6 +64,17 @@ def gemm_nt():
             ops.gemm_nt(A, Bm, M, N, K, bias=bias, act=1, C_out=U, c_bf16=True, C2=Z, ldc2=N, c2_mode=1, variant=variant)
             report(f'gemm_nt {M}x{N}x{K} v{variant} gelu', rel(U, torch.nn.functional.gelu(ref)), 6e-3)
             report(f'gemm_nt {M}x{N}x{K} v{variant} preact', rel(Z, ref), 6e-3)
+            # gelu fp32 out (the erf approximation itself: |err| <= 1.5e-7) + GELU' twin; then the multiply-only backward form
+            U32 = torch.empty(M, N, device=dev)
+            D = torch.empty(M, N, device=dev, dtype=BF16)
+            ops.gemm_nt(A, Bm, M, N, K, bias=bias, act=1, C_out=U32, C2=D, ldc2=N, c2_mode=4, variant=variant)
+            xg = ref.clone().requires_grad_(True)
+            torch.nn.functional.gelu(xg).sum().backward()
+            report(f'gemm_nt {M}x{N}x{K} v{variant} gelu32', float((U32 - torch.nn.functional.gelu(ref)).abs().max()), 2e-5)
+            report(f"gemm_nt {M}x{N}x{K} v{variant} gelu'twin", float((D.float() - xg.grad).abs().max()), 5e-3)
+            G = torch.empty(M, N, device=dev)
+            ops.gemm_nt(A, Bm, M, N, K, act=3, aux=D, ldaux=N, C_out=G, variant=variant)
+            report(f'gemm_nt {M}x{N}x{K} v{variant} act3', rel(G, (ref - bias) * D.float()), 1e-4)
             # residual + beta accumulate + bf16 twin of the final value
             C = torch.full((M, N), 0.5, device=dev)
             T = torch.empty(M, N, device=dev, dtype=BF16)
