@@ -261,6 +261,8 @@ def avmae_bwd(model, t, g_li, g_la, g_pi=None, g_pa=None, layer_cb=None):
         dxi_b, dxf_i = E.decoder_bwd(dec_i, t['t_di'], dpi, t['ik32'], B)
     main.wait_stream(sa)
     dxf32 = dxf_i.float() + dxf_a.float()            # both decoders read the same normed fusion tokens
+    if layer_cb is not None:
+        layer_cb(len(model.encoder.fusion_blocks))    # both decoders' backward done (streams joined): a legal graph cut
     encoder_bwd(model.encoder, t['t_enc'], dxi_b=dxi_b, dxa_b=dxa_b, dxf32=dxf32, layer_cb=layer_cb)
 
 

@@ -124,8 +124,8 @@ class GraphedStep:
     iteration: ~1900 kernel launches become a handful of graph launches.
 
     world_size == 1: one graph holds everything.  world_size > 1 (or ``segments`` > 1): the step is captured as
-    ``segments`` consecutive graphs that share one memory pool — [forward + decoders' backward + the last encoder
-    layers], [middle layers], [first layers] — and after each replayed segment the gradient buckets that segment
+    ``segments`` consecutive graphs that share one memory pool — [forward + decoders' backward], then equal groups of
+    encoder layers, last to first — and after each replayed segment the gradient buckets that segment
     completed (known from capture time) are all-reduced on the comm stream, i.e. overlapped with the next segment;
     grad norm + AdamW form a last graph behind the final reduction.  Collectives themselves are never captured."""
 
@@ -143,11 +143,19 @@ class GraphedStep:
         self.reducer = trainer.model.reducer if trainer.distributed else None
         self.dist_active = self.world > 1 or (self.reducer is not None and self.reducer.force)
         if segments <= 0:
-            segments = int(os.environ.get('DAV_SEGMENTS', '0')) or (3 if self.dist_active else 1)
+            segments = int(os.environ.get('DAV_SEGMENTS', '0')) or (5 if self.dist_active else 1)
         depth = len(self.model.encoder.image.blocks)
-        segments = max(1, min(segments, depth))
-        # layer l ends segment s when l is in `cuts`: backward runs layers depth-1 .. 0
-        self.cuts = sorted({round(depth * (segments - 1 - s) / segments) for s in range(segments - 1)} - {0}, reverse=True)
+        segments = max(1, min(segments, depth + 1))
+        # The backward runs: both decoders, then encoder layers depth-1 .. 0.  A segment ends after "layer" l when l is in
+        # `cuts`; l == depth stands for "after the decoders".  That is always the first cut: the decoders' gradients
+        # (a sixth of the bytes) start their all-reduce while the whole encoder backward is still ahead; the remaining cuts
+        # leave quadratically fewer layers behind them (depth 12, 5 segments: layers 11..7 | 6..3 | 2..1 | 0), so the last
+        # reduction — the only one nothing is left to overlap with — is one layer's worth of bytes.
+        self.cuts = []
+        if segments >= 2:
+            enc_parts = segments - 1
+            self.cuts = sorted({depth} | ({round(depth * ((enc_parts - s) / enc_parts) ** 2) for s in range(1, enc_parts)} - {0, depth}),
+                               reverse=True)
         self.n_seg = len(self.cuts) + 1
         saved_hook = engine._GRAD_READY
         engine.set_grad_ready_hook(None)

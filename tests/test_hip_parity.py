@@ -415,7 +415,9 @@ def test_checkpoint_round_trip_and_reference_format(tmp_path):
     assert start == 3 and metrics == {'best': 0.5} and int(tr2.n_steps) == 2 and opt2.step_count == 2
     assert torch.equal(opt2.flat.flat_p, opt.flat.flat_p) and torch.equal(opt2.exp_avg, opt.exp_avg) and torch.equal(opt2.exp_avg_sq, opt.exp_avg_sq)
     l1, l2 = one_step(tr, image, audio, 200), one_step(tr2, image, audio, 200)
-    assert l1 == l2 and torch.equal(opt2.flat.flat_p, opt.flat.flat_p)
+    # identical forward; the weight gradients of token counts that are not multiples of 64 meet through split-K fp32
+    # atomics (summation order varies run to run), so the stepped parameters agree to rounding, not bit for bit
+    assert l1 == l2 and torch.allclose(opt2.flat.flat_p, opt.flat.flat_p, rtol=1e-5, atol=1e-6)
 
     # (2) reference-style checkpoint built with torch.optim.AdamW on CPU copies of the same parameter groups
     model3, opt3, tr3, _, _ = make()
