@@ -11,7 +11,7 @@ Parity status
 * Everything the reference itself owns on this path (``models/deepavfusion.py``,
   ``models/fusion_blocks.py``, ``models/avmae.py``, ``models/vits.py``,
   ``util/pos_embed.py``, ``util/lr_sched.py``, ``util/misc.py`` grad-norm /
-  step semantics) is PINNED: ``tools/gen_golden.py`` imports those files from
+  step semantics) is PINNED: ``tests/golden/gen_golden.py`` imports those files from
   ``/root/reference`` in the build container and stores their outputs as
   fixtures under ``tests/golden/``; ``tests/test_oracle_golden.py`` checks this
   restatement against them.

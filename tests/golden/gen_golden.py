@@ -4,11 +4,11 @@
 Runs only in the build container (needs /root/reference).  The reference's own
 Python files are imported unmodified from /root/reference; the two missing
 third-party imports (timm==0.9.2, wandb) are satisfied by the stand-ins in
-tools/ref_shim (see its README).  Fixtures are DATA only: inputs are produced
+tests/golden/ref_shim (see its README).  Fixtures are DATA only: inputs are produced
 by seeded closed-form generators that live in oracle/avmae_oracle.py, expected
 outputs are what the reference computed.
 
-    python tools/gen_golden.py [--curve]      # --curve adds the 1k-step loss curve (~5 min)
+    python tests/golden/gen_golden.py [--curve]      # --curve adds the 1k-step loss curve (~5 min)
 """
 import argparse
 import os
@@ -19,8 +19,9 @@ import numpy as np
 import torch
 from torch import nn
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, 'tools', 'ref_shim'))
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(HERE, 'ref_shim'))
 sys.path.insert(0, '/root/reference')
 sys.path.insert(0, ROOT)
 

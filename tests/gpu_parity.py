@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end parity of the HIP path against the CPU oracle (and the committed golden fixtures),
 printing per-tensor errors.  Diagnostic companion of tests/test_hip_parity.py.
-Usage: python tools/gpu_parity.py [micro|tiny|base_b2] ..."""
+Usage: python tests/gpu_parity.py [micro|tiny|base_b2] ..."""
 import os
 import sys
 import time

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run every HIP kernel against a torch fp32 reference on the GPU box and print the errors.
-Diagnostic companion of tests/ (never aborts on the first failure).  Usage: python tools/gpu_selfcheck.py [filter]"""
+Diagnostic companion of tests/ (never aborts on the first failure).  Usage: python tests/gpu_selfcheck.py [filter]"""
 import math
 import os
 import sys

@@ -36,6 +36,17 @@ def test_product_never_imports_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(dirpath, f)).read()
                 assert 'oracle' not in src, f'{f} mentions the oracle'
+    # outside the package only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/
+    import re
+    pat = re.compile(r'^\s*(from|import)\s+oracle\b', re.M)
+    for d in ('tools', 'configs'):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, d)):
+            for f in files:
+                if f.endswith('.py'):
+                    assert not pat.search(open(os.path.join(dirpath, f)).read()), f'{d}/{f} imports the oracle'
+    assert not pat.search(open(os.path.join(ROOT, 'train.py')).read())
+    bench = open(os.path.join(ROOT, 'bench.py')).read()
+    assert len(pat.findall(bench)) == 2 and bench.index('from oracle') > bench.index('CPU baseline')
 
 
 def test_state_dict_contract_matches_reference_shapes():
@@ -45,7 +56,7 @@ def test_state_dict_contract_matches_reference_shapes():
     from oracle.configs import CONFIGS as OC
     for name in ('micro', 'tiny'):
         m = build_avmae(CONFIGS[name])
-        shapes = O.state_shapes(OC[name])           # pinned by strict load into the reference (tools/gen_golden.py)
+        shapes = O.state_shapes(OC[name])           # pinned by strict load into the reference (tests/golden/gen_golden.py)
         sd = m.state_dict()
         assert set(sd) == set(shapes)
         assert all(tuple(v.shape) == tuple(shapes[k]) for k, v in sd.items())
@@ -62,7 +73,7 @@ def test_state_dict_contract_matches_reference_shapes():
 
 def test_video_state_dict_contract_and_pos_table(golden):
     """VideoEarlyFusion (configs[4]): names/shapes as pinned by the strict load into the reference
-    (tools/gen_golden.py gen_video), the 3-D sin-cos table equals the reference's own initial buffer."""
+    (tests/golden/gen_golden.py gen_video), the 3-D sin-cos table equals the reference's own initial buffer."""
     from deepavfusion_amd.build_model import build_video_earlyfusion
     from deepavfusion_amd.configs import CONFIGS
     from oracle import avmae_oracle as O

@@ -1,12 +1,12 @@
 """GPU: every HIP kernel, called through the C ABI, against a torch fp32 reference of the same op
-(tolerances are in tools/gpu_selfcheck.py next to each check; index work is bit-exact)."""
+(tolerances are in tests/gpu_selfcheck.py next to each check; index work is bit-exact)."""
 import os
 import sys
 
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, 'tools'))
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 pytestmark = pytest.mark.gpu
 

@@ -348,7 +348,7 @@ def test_segmented_graph_step_matches_single_graph_and_schedules_every_bucket():
 
 
 def test_loss_curve_prefix_matches_reference(golden):
-    """First 40 steps of the reference's 1k-step ViT-Tiny curve (tools/gen_golden.py --curve), bf16 HIP vs fp32 reference."""
+    """First 40 steps of the reference's 1k-step ViT-Tiny curve (tests/golden/gen_golden.py --curve), bf16 HIP vs fp32 reference."""
     try:
         g = golden('curve_tiny')
     except FileNotFoundError:

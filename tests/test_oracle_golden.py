@@ -1,5 +1,5 @@
 """CPU: pin the oracle (oracle/) against fixtures produced by the reference itself
-(tools/gen_golden.py imported /root/reference in the build container)."""
+(tests/golden/gen_golden.py imported /root/reference in the build container)."""
 import numpy as np
 import pytest
 import torch
