@@ -114,6 +114,12 @@ def _encoder_bwd(enc, t, dxi_b, dxa_b, dxf_b, dxi32, dxa32, dxf32, layer_cb=None
     for l, ((bi, ba, fb), (ti, ta, tf)) in reversed(list(enumerate(zip(blocks, t['layers'])))):
         sa.wait_stream(main)
         sf.wait_stream(main)
+        # Memory lifetime across streams: the gradients entering this layer were allocated on one stream (main for the
+        # final norms, the fusion / audio stream further down) and are READ by kernels of another.  Dropping the last
+        # reference hands the block back to the allocating stream's pool at once, and a later allocation on THAT stream
+        # could overwrite it while the reader (concurrent in the captured graph) has not run yet.  So everything consumed
+        # here stays referenced until all three streams have re-joined.
+        hold = (g_i, g_ib, g_a, g_ab, g_f, g_fb)
         if fb is None:
             with torch.cuda.stream(sa):
                 g_a, g_ab, _ = E.block_bwd(ba, ta, g_a, g_ab)
@@ -130,7 +136,9 @@ def _encoder_bwd(enc, t, dxi_b, dxa_b, dxf_b, dxi32, dxa32, dxf32, layer_cb=None
             g_i, g_ib, dx_f = E.block_bwd(bi, ti, g_i, g_ib, dx_fus=dx_f, dx_fus_acc=1, dx_mod=dx_i, dx_mod_acc=1,
                                           before_ln1=lambda: main.wait_stream(sf))
             main.wait_stream(sa)
+            main.wait_stream(sf)
             g_f, g_fb = (dx_f + dxf_a) if sa is not main else dx_f.add_(dxf_a), None
+        del hold
         E.flush_wgrads()          # every wgrad of this layer (both towers + fusion block) as one grouped GEMM
         if layer_cb is not None and l > 0:
             layer_cb(l)

@@ -452,3 +452,18 @@ def test_checkpoint_round_trip_and_reference_format(tmp_path):
     opt3.step()
     worst = max(float((p.detach().cpu() - cpu_params[id(p)].detach()).abs().max()) for p in model3.parameters() if p.requires_grad)
     assert worst < 2e-6, worst
+
+
+def test_captured_step_repeats_bit_for_bit_across_replays():
+    """Race screen: in the captured step the three branches of a layer really run concurrently (eager launches barely
+    overlap), so a missing stream dependency or a buffer recycled while another stream still reads it shows up as
+    replay-to-replay differences in the gradients.  Fixed data + fixed masking noise, 200 replays, every parameter
+    gradient must repeat (tests/graph_race_probe.py prints the offenders)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'tests', 'graph_race_probe.py'), 'micro', '200', '64'],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert '200 replays, 0 deviation events' in out.stdout, out.stdout[-3000:]
