@@ -128,6 +128,8 @@ if __name__ == '__main__':
             run('tiny', 2, 22)
         elif w == 'base_b2':
             run('base', 2, 23)
+        elif w == 'base_b64':          # the bench workload at full size (the oracle needs a few minutes of host time)
+            run('base', 64, 26)
         elif w in ('base_token', 'base_dense'):
             run(w, 2, 25)
         elif w == 'video_micro':

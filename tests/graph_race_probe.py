@@ -82,6 +82,14 @@ for it in range(replays):
             dd = float((gcur[o:o + n] - ref[o:o + n]).norm())
             if dd > 1e-5 * rn + 1e-9:
                 events.append((it, names[id(p)], dd / (rn + 1e-20)))
+# the captured graph against an eager pass over the same inputs (same kernels, launches serialised by the host)
+gref = ref.clone()
+opt.flat.zero_grad()
+le = fwd_bwd()
+torch.cuda.synchronize()
+ge = opt.flat.flat_g
+worst = max(float((ge[o:o + p.numel()] - gref[o:o + p.numel()]).norm() / (gref[o:o + p.numel()].norm() + 1e-20)) for p, o in offs)
+print(f'graph vs eager: loss {lref} vs {(float(le[0]), float(le[1]))}, worst per-tensor gradient rel diff {worst:.2e}')
 print(f'{name} B={B}: {replays} replays, {len(events)} deviation events')
 seen = {}
 for it, n, d in events:
