@@ -853,7 +853,7 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
 
 extern "C" int dav_gemm_tn_grouped_bf16(const DavTnProblem* probs, int count, hipStream_t stream) {
   if (count <= 0 || count > TN_GROUP_MAX) return DAV_ERR_SHAPE;
-  static TNGroup g;          // host staging; copied by value into the kernel arguments at launch
+  static thread_local TNGroup g;   // host staging (one per calling thread); copied by value into the kernel arguments at launch
   long total_tiles = 0;
   for (int i = 0; i < count; ++i) {
     const DavTnProblem& q = probs[i];

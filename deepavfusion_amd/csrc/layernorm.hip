@@ -289,7 +289,7 @@ extern "C" int dav_layernorm_fwd(const float* x0, long x0_bs, int r0, const floa
 
 extern "C" int dav_layernorm_bwd_reduce_grouped(const DavLnReduce* items, int count, hipStream_t stream) {
   if (count <= 0 || count > LN_GROUP_MAX) return DAV_ERR_SHAPE;
-  static LNReduceGroup g;
+  static thread_local LNReduceGroup g;   // host staging, one per calling thread (the library is re-entrant across threads)
   int first = 0;
   for (int i = 0; i < count; ++i) {
     if (items[i].D <= 0 || items[i].rows <= 0) return DAV_ERR_SHAPE;
