@@ -830,6 +830,7 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
       case 19: launch_nt2<128, 256, 2, 4, 2, false, 32>(p, stream); return dav_launch_status();   // 48 KB, 8 waves of 64x64
       case 20: launch_nt2<128, 128, 2, 4, 2, false, 32>(p, stream); return dav_launch_status();   // 8 waves, 32 KB
       case 21: launch_nt2<128, 128, 2, 4, 3, false, 32>(p, stream); return dav_launch_status();
+      case 22: launch_nt2<128, 128, 2, 4, 4, false, 32>(p, stream); return dav_launch_status();   // 64 KB, 1.5 steps of lookahead
       default: break;
     }
   }
