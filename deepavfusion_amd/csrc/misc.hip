@@ -319,35 +319,49 @@ __global__ __launch_bounds__(1024) void sumsq_final_kernel(const float* partial,
 // AdamW over flat buffers.  seg_* describe contiguous segments (param groups laid out back to back):
 // element i belongs to the segment s with seg_end[s-1] <= i < seg_end[s]; hyper[s] = {lr, weight_decay}.
 // step-dependent bias corrections are read from device memory so a captured graph can be replayed.
+// Segments start on 64-element boundaries (FlatParams.ALIGN), so a lane's 4 consecutive elements share one segment and
+// every access is a 16-byte one; n is a multiple of 4.
 __global__ __launch_bounds__(256) void adamw_flat_kernel(float* p, float* g, float* m, float* v, bf16_t* p_bf16, long n,
                                                          const long* seg_end, const float* hyper, int nseg, float beta1,
                                                          float beta2, float eps, const float* bias_corr, float grad_scale,
                                                          float* sumsq_out, int zero_grad) {
-  constexpr long CHUNK = 256 * 16;        // contiguous elements per workgroup iteration
+  constexpr long CHUNK = 256 * 4 * 4;     // contiguous elements per workgroup iteration: 4 float4 per lane
   __shared__ float sw[4];
   const float bc1 = bias_corr[0], bc2_sqrt = bias_corr[1];
+  const float ob1 = 1.f - beta1, ob2 = 1.f - beta2;
   float ss = 0.f;                         // sum of squared (unscaled) gradients seen by this thread
   for (long base = (long)blockIdx.x * CHUNK; base < n; base += (long)gridDim.x * CHUNK) {
-    long i = base + threadIdx.x;
+    long i = base + threadIdx.x * 4;
     int lo = 0, hi = nseg - 1;            // first segment with seg_end > i
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (i >= seg_end[mid]) lo = mid + 1; else hi = mid; }
     int s = lo;
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it, i += 256) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it, i += 1024) {
       if (i >= n) break;
       while (s + 1 < nseg && i >= seg_end[s]) ++s;
       const float lr = hyper[2 * s], wd = hyper[2 * s + 1];
-      const float graw = g[i];
-      ss += graw * graw;
-      const float gi = graw * grad_scale;
-      float pi = p[i];
-      const float mi = beta1 * m[i] + (1.f - beta1) * gi;
-      const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
-      pi *= 1.f - lr * wd;
-      pi -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
-      p[i] = pi; m[i] = mi; v[i] = vi;
-      if (p_bf16) p_bf16[i] = f2bf(pi);
-      if (zero_grad) g[i] = 0.f;
+      const float decay = 1.f - lr * wd, step = lr / bc1;
+      const float4 gr = *reinterpret_cast<const float4*>(g + i);
+      float4 pi = *reinterpret_cast<const float4*>(p + i);
+      float4 mi = *reinterpret_cast<const float4*>(m + i);
+      float4 vi = *reinterpret_cast<const float4*>(v + i);
+      ss += gr.x * gr.x + gr.y * gr.y + gr.z * gr.z + gr.w * gr.w;
+      const float gx = gr.x * grad_scale, gy = gr.y * grad_scale, gz = gr.z * grad_scale, gw = gr.w * grad_scale;
+      mi.x = beta1 * mi.x + ob1 * gx; mi.y = beta1 * mi.y + ob1 * gy; mi.z = beta1 * mi.z + ob1 * gz; mi.w = beta1 * mi.w + ob1 * gw;
+      vi.x = beta2 * vi.x + ob2 * gx * gx; vi.y = beta2 * vi.y + ob2 * gy * gy;
+      vi.z = beta2 * vi.z + ob2 * gz * gz; vi.w = beta2 * vi.w + ob2 * gw * gw;
+      pi.x = pi.x * decay - step * mi.x / (sqrtf(vi.x) / bc2_sqrt + eps);
+      pi.y = pi.y * decay - step * mi.y / (sqrtf(vi.y) / bc2_sqrt + eps);
+      pi.z = pi.z * decay - step * mi.z / (sqrtf(vi.z) / bc2_sqrt + eps);
+      pi.w = pi.w * decay - step * mi.w / (sqrtf(vi.w) / bc2_sqrt + eps);
+      *reinterpret_cast<float4*>(p + i) = pi;
+      *reinterpret_cast<float4*>(m + i) = mi;
+      *reinterpret_cast<float4*>(v + i) = vi;
+      if (p_bf16) {
+        uint2 w; w.x = pack2bf(pi.x, pi.y); w.y = pack2bf(pi.z, pi.w);
+        *reinterpret_cast<uint2*>(p_bf16 + i) = w;
+      }
+      if (zero_grad) *reinterpret_cast<float4*>(g + i) = float4{0.f, 0.f, 0.f, 0.f};
     }
   }
   if (sumsq_out) {                        // one atomic per workgroup (<= 16384 distinct-time adds on one word)
@@ -485,7 +499,8 @@ extern "C" int dav_l2norm(const float* x, long n, float scale, float* out, void*
 extern "C" int dav_adamw_flat(float* p, float* g, float* m, float* v, void* p_bf16, long n, const long* seg_end,
                               const float* hyper, int nseg, float beta1, float beta2, float eps, const float* bias_corr,
                               float grad_scale, float* sumsq_out, int zero_grad, hipStream_t stream) {
-  if (n <= 0 || nseg <= 0) return DAV_ERR_SHAPE;
+  if (n <= 0 || nseg <= 0 || (n & 3)) return DAV_ERR_SHAPE;
+  if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15 || ((uintptr_t)p_bf16 & 7)) return DAV_ERR_ALIGN;
   if (sumsq_out) HIP_CHECK_RET(hipMemsetAsync(sumsq_out, 0, sizeof(float), stream));
   long g2 = (n + 4095) / 4096; g2 = g2 > 16384 ? 16384 : g2;
   DAV_LAUNCH(adamw_flat_kernel, dim3((int)g2), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, n, seg_end, hyper, nseg,

@@ -160,7 +160,8 @@ int dav_l2norm(const float* x, long n, float scale, float* out, void* workspace,
  * per-segment {lr, weight_decay}; bias_corr = {1-beta1^t, sqrt(1-beta2^t)} in device memory.  The same pass can
  * (a) accumulate sum(g^2) of the unscaled gradients into *sumsq_out (zeroed first; the grad norm of
  * util/misc.py:151-163 is its square root), (b) rewrite the bf16 weight mirror p_bf16, (c) zero the gradients
- * (Trainer.zero_grad) — one trip over the buffers instead of three. */
+ * (Trainer.zero_grad) — one trip over the buffers instead of three.  All accesses are 16-byte ones: the buffers must be
+ * 16-byte aligned (p_bf16 8-byte), n and every seg_end a multiple of 4 (FlatParams aligns segments to 64 elements). */
 int dav_adamw_flat(float* p, float* g, float* m, float* v, void* p_bf16, long n, const long* seg_end, const float* hyper,
                    int nseg, float beta1, float beta2, float eps, const float* bias_corr, float grad_scale, float* sumsq_out,
                    int zero_grad, hipStream_t stream);

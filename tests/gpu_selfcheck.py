@@ -382,7 +382,7 @@ def misc_kernels():
     out, ws = torch.empty(1, device=dev), torch.empty(1024, device=dev)
     ops.l2norm(flat, out, ws, 0.5)
     report('l2norm', abs(float(out) - 0.5 * float(flat.double().norm())) / float(flat.double().norm()), 1e-6)
-    n = 100003
+    n = 100036                    # the flat buffers' contract: length and segment boundaries multiples of 4, 16-byte aligned
     p0, g0 = rnd(n, seed=53), rnd(n, seed=54)
     pr = p0.clone().requires_grad_(True)
     opt = torch.optim.AdamW([{'params': [pr], 'weight_decay': 0.05}], lr=1e-2, betas=(0.9, 0.95))
