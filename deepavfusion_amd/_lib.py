@@ -39,6 +39,8 @@ SIGNATURES = {
     'dav_patch_gather3d': [_p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p],
     'dav_unshuffle_fwd': [_p, _p, _p, _p, _i, _i, _i, _i, _p, _l, _i, _p],
     'dav_rows_gather_cast': [_p, _l, _i, _p, _i, _i, _i, _p, _p],
+    'dav_rows_axpy': [_p, _p, _p, _i, _i, _i, _p, _p],
+    'dav_rows_scale_cast': [_p, _p, _i, _i, _i, _p, _p],
     'dav_unshuffle_bwd_reduce': [_p, _l, _i, _p, _i, _i, _i, _i, _p, _p, _p],
     'dav_patch_mse_fwd': [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
     'dav_patch_mse_bwd': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p],

@@ -42,6 +42,26 @@ def _ids32(ids):
     return None if ids is None else ids.to(torch.int32).contiguous()
 
 
+def drop_path_scales(owner, blk, B, dev, tag):
+    """Per-sample DropPath scales of the two residual branches of ``blk`` — (s_attn, s_mlp), each fp32 [B] with values
+    0 or 1/keep (timm DropPath, scale_by_keep) — or None when the block has no DropPath or the model is in eval mode.
+    ``owner._drop_path_sampler(tag, branch, B)`` (a 0/1 keep mask) replaces the Bernoulli draw when set: parity tests
+    inject the masks, the two RNG streams can never match."""
+    p = getattr(blk, 'drop_path_prob', 0.0)
+    if p <= 0.0 or not owner.training:
+        return None
+    keep = 1.0 - p
+    sampler = getattr(owner, '_drop_path_sampler', None)
+
+    def one(branch):
+        if sampler is not None:
+            m = sampler(tag, branch, B).to(device=dev, dtype=F32)
+        else:
+            m = torch.empty(B, device=dev, dtype=F32).bernoulli_(keep)
+        return m / keep if keep > 0.0 else m
+    return one(0), one(1)
+
+
 def _vis(enc):
     """The visual tower: ``.image`` of DeepAVFusion (models/deepavfusion.py:20) or ``.video`` of VideoEarlyFusion
     (models/video_earlyfusion.py:32) — the layer loop is the same."""
@@ -64,16 +84,20 @@ def encoder_fwd(enc, image, audio, ik32, ak32, want_f32=False, collect_embs=Fals
         sa.wait_stream(main)
         sf.wait_stream(main)
         if fb is None:
+            dpi, dpa = drop_path_scales(enc, bi, B, image.device, f'visual.{l}'), drop_path_scales(enc, ba, B, image.device, f'audio.{l}')
             with torch.cuda.stream(sa):
-                x_a, ta = E.block_fwd(ba, x_a, None, Ha, ba.norm1.eps)
-            x_i, ti = E.block_fwd(bi, x_i, None, Hi, bi.norm1.eps)
+                x_a, ta = E.block_fwd(ba, x_a, None, Ha, ba.norm1.eps, dpa)
+            x_i, ti = E.block_fwd(bi, x_i, None, Hi, bi.norm1.eps, dpi)
             tf = None
         else:
+            # the reference draws in call order: visual block (attn, mlp), audio block, fusion block (:104-106)
+            dpi, dpa = drop_path_scales(enc, bi, B, image.device, f'visual.{l}'), drop_path_scales(enc, ba, B, image.device, f'audio.{l}')
+            dpf = drop_path_scales(enc, fb, B, image.device, f'fusion.{l}')
             with torch.cuda.stream(sa):
-                n_a, ta = E.block_fwd(ba, x_a, x_f, Ha, ba.norm1.eps)
+                n_a, ta = E.block_fwd(ba, x_a, x_f, Ha, ba.norm1.eps, dpa)
             with torch.cuda.stream(sf):
-                n_f, tf = E.fusion_block_fwd(fb, x_f, x_i, x_a, Hf, enc.num_fusion)  # reads the layer INPUT x_i / x_a (:106-107)
-            n_i, ti = E.block_fwd(bi, x_i, x_f, Hi, bi.norm1.eps)
+                n_f, tf = E.fusion_block_fwd(fb, x_f, x_i, x_a, Hf, enc.num_fusion, dpf)  # reads the layer INPUT x_i / x_a (:106-107)
+            n_i, ti = E.block_fwd(bi, x_i, x_f, Hi, bi.norm1.eps, dpi)
             x_i, x_a, x_f = n_i, n_a, n_f
         main.wait_stream(sa)
         main.wait_stream(sf)
@@ -208,7 +232,8 @@ class _FusionBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, fb, xmm, xv, xa, *params):
         ctx.set_materialize_grads(False)
-        out, tape = E.fusion_block_fwd(fb, xmm, xv, xa, fb.num_heads, getattr(fb, 'fusion_tkns', None))
+        out, tape = E.fusion_block_fwd(fb, xmm, xv, xa, fb.num_heads, getattr(fb, 'fusion_tkns', None),
+                                       drop_path_scales(fb, fb, xmm.shape[0], xmm.device, 'fusion'))
         ctx.fb, ctx.tape, ctx.np = fb, tape, len(params)
         return out
 

@@ -118,6 +118,43 @@ __global__ __launch_bounds__(256) void rows_gather_cast_kernel(const float* x, l
   }
 }
 
+// DropPath (stochastic depth, timm DropPath as used at models/vits.py:32-34 and models/fusion_blocks.py:69,78-79,130,199,
+// 278): per-sample scale s[b] in {0, 1/keep}.  out[b, r] = res[b, r] + s[b] * y[b, r]  (fp32, rows of D; out may alias res)
+__global__ __launch_bounds__(256) void rows_axpy_kernel(const float* res, const float* y, const float* scale, int B, int rows,
+                                                        int D, float* out) {
+  const int lane = threadIdx.x & 63;
+  const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int nch = D >> 2;
+  for (int row = gw; row < B * rows; row += nwaves) {
+    const float sb = scale[row / rows];
+    const float4* r4 = reinterpret_cast<const float4*>(res + (long)row * D);
+    const float4* y4 = reinterpret_cast<const float4*>(y + (long)row * D);
+    float4* o4 = reinterpret_cast<float4*>(out + (long)row * D);
+    for (int c = lane; c < nch; c += 64) {
+      const float4 a = r4[c], b = y4[c];
+      o4[c] = float4{a.x + sb * b.x, a.y + sb * b.y, a.z + sb * b.z, a.w + sb * b.w};
+    }
+  }
+}
+
+// its backward on the branch side: out_bf16[b, r] = bf16(s[b] * g[b, r])  (the residual side passes g through unchanged)
+__global__ __launch_bounds__(256) void rows_scale_cast_kernel(const float* g, const float* scale, int B, int rows, int D,
+                                                              bf16_t* out) {
+  const int lane = threadIdx.x & 63;
+  const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int nch = D >> 2;
+  for (int row = gw; row < B * rows; row += nwaves) {
+    const float sb = scale[row / rows];
+    const float4* g4 = reinterpret_cast<const float4*>(g + (long)row * D);
+    uint2* o = reinterpret_cast<uint2*>(out + (long)row * D);
+    for (int c = lane; c < nch; c += 64) {
+      const float4 a = g4[c];
+      uint2 w; w.x = pack2bf(sb * a.x, sb * a.y); w.y = pack2bf(sb * a.z, sb * a.w);
+      o[c] = w;
+    }
+  }
+}
+
 // batch reductions of the un-shuffle backward: dpos[r] += sum_b dx[b, off+r];  dmask_token += sum over masked rows
 __global__ __launch_bounds__(256) void unshuffle_bwd_reduce_kernel(const float* dx, long dx_bs, int row_off, const int* restore,
                                                                    int B, int L, int nk, int D, float* dpos, float* dmask_token) {
@@ -419,6 +456,21 @@ extern "C" int dav_rows_gather_cast(const float* x, long x_bs, int row_off, cons
   if (B <= 0 || n <= 0 || (D & 3)) return DAV_ERR_SHAPE;
   DAV_LAUNCH(rows_gather_cast_kernel, dim3(wave_grid((long)B * n)), dim3(256), 0, stream, x, x_bs, row_off, ids32, B, n,
                      D, (bf16_t*)out);
+  return dav_launch_status();
+}
+
+extern "C" int dav_rows_axpy(const float* res, const float* y, const float* scale, int B, int rows, int D, float* out,
+                             hipStream_t stream) {
+  if (B <= 0 || rows <= 0 || D <= 0 || (D & 3)) return DAV_ERR_SHAPE;
+  DAV_LAUNCH(rows_axpy_kernel, dim3(wave_grid((long)B * rows)), dim3(256), 0, stream, res, y, scale, B, rows, D, out);
+  return dav_launch_status();
+}
+
+extern "C" int dav_rows_scale_cast(const float* g, const float* scale, int B, int rows, int D, void* out_bf16,
+                                   hipStream_t stream) {
+  if (B <= 0 || rows <= 0 || D <= 0 || (D & 3)) return DAV_ERR_SHAPE;
+  DAV_LAUNCH(rows_scale_cast_kernel, dim3(wave_grid((long)B * rows)), dim3(256), 0, stream, g, scale, B, rows, D,
+                     (bf16_t*)out_bf16);
   return dav_launch_status();
 }
 

@@ -325,9 +325,21 @@ def to_bf16(x):
 # ------------------------------------------------------------------------------------------------
 # timm Block (pre-LN) with optional fusion-token context rows
 # ------------------------------------------------------------------------------------------------
-def block_fwd(blk, x_mod, x_fus, heads, eps):
+def _res_add(lin, a, M, res, B, rows, D, scale, **kw):
+    """res + [scale[b] *] lin(a): fused into the GEMM epilogue, or — with a DropPath scale — GEMM to a temporary followed
+    by the per-sample scaled add (timm DropPath: x + drop_path(branch(x)))."""
+    if scale is None:
+        return lin_fwd(lin, a, M, res=res, **kw)
+    y = lin_fwd(lin, a, M, **kw)
+    out = _e((M, D), F32, a.device)
+    ops.rows_axpy(res, y, scale, B, rows, D, out)
+    return out
+
+
+def block_fwd(blk, x_mod, x_fus, heads, eps, dp=None):
     """x_mod fp32 [B,n,D]; x_fus fp32 [B,nF,D] or None (context rows: keys/values only —
-    models/deepavfusion.py:104-105).  Returns (x_out fp32 [B,n,D], tape)."""
+    models/deepavfusion.py:104-105).  ``dp`` = (s_attn, s_mlp): per-sample DropPath scales (fp32 [B], 0 or 1/keep) of the
+    two residual branches, None when inactive.  Returns (x_out fp32 [B,n,D], tape)."""
     B, n, D = x_mod.shape
     nF = x_fus.shape[1] if x_fus is not None else 0
     R, hd, dev = nF + n, D // heads, x_mod.device
@@ -336,14 +348,14 @@ def block_fwd(blk, x_mod, x_fus, heads, eps):
     qkv = lin_fwd(blk.attn.qkv, h1, M, out_bf16=True)                                       # [B*R, 3D]
     o, lse = attention_fwd((qkv, nF * 3 * D), (qkv, D), (qkv, 2 * D), B, heads, n, R, hd, hd, hd ** -0.5,
                            R * 3 * D, 3 * D, R * 3 * D, 3 * D, R * 3 * D, 3 * D, dev)
-    x1 = lin_fwd(blk.attn.proj, o, Mq, res=x_mod).view(B, n, D)
+    x1 = _res_add(blk.attn.proj, o, Mq, x_mod, B, n, D, None if dp is None else dp[0]).view(B, n, D)
     h2, _, st2 = ln_fwd(blk.norm2, None, x1, B, eps)
     Hd = blk.mlp.fc1.weight.shape[0]
     z = _e((Mq, Hd), BF16, dev)
     u = lin_fwd(blk.mlp.fc1, h2, Mq, act=1, out_bf16=True, C2=z, c2_mode=4)
-    x2 = lin_fwd(blk.mlp.fc2, u, Mq, res=x1).view(B, n, D)
+    x2 = _res_add(blk.mlp.fc2, u, Mq, x1, B, n, D, None if dp is None else dp[1]).view(B, n, D)
     tape = dict(x_mod=x_mod, x_fus=x_fus, h1=h1, st1=st1, qkv=qkv, o=o, lse=lse, x1=x1, h2=h2, st2=st2, z=z, u=u,
-                heads=heads, nF=nF)
+                heads=heads, nF=nF, dp=dp)
     return x2, tape
 
 
@@ -354,13 +366,19 @@ def block_bwd(blk, t, g2, g2b, *, dx_fus=None, dx_fus_acc=0, dx_mod=None, dx_mod
     B, n, D = x_mod.shape
     R, hd, dev = nF + n, D // heads, x_mod.device
     M, Mq = B * R, B * n
-    if g2b is None:
+    dp = t.get('dp')
+    if dp is not None:                      # the branch sees s[b] * g, the residual path g itself
+        g2b = _e((Mq, D), BF16, dev)
+        ops.rows_scale_cast(g2, dp[1], B, n, D, g2b)
+    elif g2b is None:
         g2b = to_bf16(g2)
     dz = lin_bwd(blk.mlp.fc2, g2b, t['u'], Mq, gelu_aux=t['z'])                              # [Mq, Hd] bf16 (already * GELU')
     dh2 = lin_bwd(blk.mlp.fc1, dz, t['h2'], Mq)
     g1 = _e((B, n, D), F32, dev)
     g1b = _e((Mq, D), BF16, dev)
     ln_bwd(blk.norm2, None, t['x1'], B, t['st2'], dy_bf16=dh2, dx1=g1, res1=g2, dx1_bf16=g1b)
+    if dp is not None:
+        ops.rows_scale_cast(g1, dp[0], B, n, D, g1b)
     do = lin_bwd(blk.attn.proj, g1b, t['o'], Mq)
     dqkv = torch.zeros((M, 3 * D), dtype=BF16, device=dev) if nF > 0 else _e((M, 3 * D), BF16, dev)
     qkv = t['qkv']
@@ -413,7 +431,7 @@ def _cross_bwd(ca, c, do, xq_b, q_rowmap, nq, xkv_b, nk, B, D, heads, dxq_out, d
     return lin_bwd(ca.kv, dkv, xkv_b, B * nk)
 
 
-def _factorized_fwd(fb, x_f, x_i, x_a, heads, tkns):
+def _factorized_fwd(fb, x_f, x_i, x_a, heads, tkns, dp=None):
     B, nF, D = x_f.shape
     nI, nA = x_i.shape[1], x_a.shape[1]
     nmm, nv, na = tkns
@@ -430,8 +448,10 @@ def _factorized_fwd(fb, x_f, x_i, x_a, heads, tkns):
     # proj of the two aggregations: fp32 result lands in its rows of xmm1 (+ normed-xmm residual),
     # bf16 twin of the pre-residual value feeds the pair projections
     xvo_b, xao_b = _e((B * nv, D), BF16, dev), _e((B * na, D), BF16, dev)
-    lin_fwd(at.attn_v.proj, cv['o'], B * nv, res=xmm32, res_rowmap=rmv, out=xmm1, c_rowmap=rmv, C2=xvo_b, c2_mode=2)
-    lin_fwd(at.attn_a.proj, ca['o'], B * na, res=xmm32, res_rowmap=rma, out=xmm1, c_rowmap=rma, C2=xao_b, c2_mode=2)
+    # with DropPath the three projections land WITHOUT the residual; it is added below with the per-sample scale
+    r32 = xmm32 if dp is None else None
+    lin_fwd(at.attn_v.proj, cv['o'], B * nv, res=r32, res_rowmap=rmv, out=xmm1, c_rowmap=rmv, C2=xvo_b, c2_mode=2)
+    lin_fwd(at.attn_a.proj, ca['o'], B * na, res=r32, res_rowmap=rma, out=xmm1, c_rowmap=rma, C2=xao_b, c2_mode=2)
     # all (v, a) pairs: Linear(cat(xv_i, xa_j)) = W[:, :D] xv_i + W[:, D:] xa_j + b  (never materialised)
     kv_p = lin_fwd(at.k, xvo_b, B * nv, k=D)
     ka_p = lin_fwd(at.k, xao_b, B * na, k=D, w_col_off=D, use_bias=False)
@@ -445,13 +465,15 @@ def _factorized_fwd(fb, x_f, x_i, x_a, heads, tkns):
     scale = (D // heads) ** -0.5                                                             # NOT (Da/heads)^-0.5 (:220-222)
     o2, lse2 = attention_fwd((q2, 0), (Kp, 0), (Vp, 0), B, heads, nmm, P, Da // heads, D // heads, scale,
                              nmm * Da, Da, P * Da, Da, P * D, D, dev)
-    lin_fwd(at.proj, o2, B * nmm, res=xmm32, res_rowmap=rm2, out=xmm1, c_rowmap=rm2)
+    lin_fwd(at.proj, o2, B * nmm, res=r32, res_rowmap=rm2, out=xmm1, c_rowmap=rm2)
+    if dp is not None:
+        ops.rows_axpy(xmm32, xmm1, dp[0], B, nF, D, xmm1)               # xmm + s[b] * attn(xmm, xv, xa)
     h2, _, st2 = ln_fwd(fb.norm2, None, xmm1, B)
     Hd = fb.mlp.fc1.weight.shape[0]
     z = _e((B * nF, Hd), BF16, dev)
     u = lin_fwd(fb.mlp.fc1, h2, B * nF, act=1, out_bf16=True, C2=z, c2_mode=4)
-    out = lin_fwd(fb.mlp.fc2, u, B * nF, res=xmm1).view(B, nF, D)
-    tape = dict(x_f=x_f, x_i=x_i, x_a=x_a, xmm_b=xmm_b, st_mm=st_mm, xv_b=xv_b, st_v=st_v, xa_b=xa_b, st_a=st_a, cv=cv, ca=ca,
+    out = _res_add(fb.mlp.fc2, u, B * nF, xmm1, B, nF, D, None if dp is None else dp[1]).view(B, nF, D)
+    tape = dict(dp=dp, x_f=x_f, x_i=x_i, x_a=x_a, xmm_b=xmm_b, st_mm=st_mm, xv_b=xv_b, st_v=st_v, xa_b=xa_b, st_a=st_a, cv=cv, ca=ca,
                 xvo_b=xvo_b, xao_b=xao_b, Kp=Kp, Vp=Vp, q2=q2, o2=o2, lse2=lse2, xmm1=xmm1, h2=h2, st2=st2, z=z, u=u,
                 heads=heads, tkns=tkns)
     return out, tape
@@ -468,13 +490,24 @@ def _factorized_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
     Da = at.q.weight.shape[0]
     P = nv * na
     rm2, rmv, rma = (nmm, nF, 0), (nv, nF, nmm), (na, nF, nmm + nv)
-    if gb is None:
+    dp = t.get('dp')
+    if dp is not None:
+        gb = _e((B * nF, D), BF16, dev)
+        ops.rows_scale_cast(g, dp[1], B, nF, D, gb)
+    elif gb is None:
         gb = to_bf16(g)
     dz = lin_bwd(fb.mlp.fc2, gb, t['u'], B * nF, gelu_aux=t['z'])
     dh2 = lin_bwd(fb.mlp.fc1, dz, t['h2'], B * nF)
     g1 = _e((B, nF, D), F32, dev)
     g1b = _e((B * nF, D), BF16, dev)
     ln_bwd(fb.norm2, None, t['xmm1'], B, t['st2'], dy_bf16=dh2, dx1=g1, res1=g, dx1_bf16=g1b)
+    # g1 = gradient at xmm1: unchanged it is the residual-path gradient of the normed xmm (norm1_mm backward below);
+    # the attention branch sees it scaled per sample when DropPath is on
+    gy = g1
+    if dp is not None:
+        gy = _e((B, nF, D), F32, dev)
+        ops.rows_axpy(torch.zeros_like(g1), g1, dp[0], B, nF, D, gy)
+        ops.rows_scale_cast(g1, dp[0], B, nF, D, g1b)
     # d(normed xmm) from the three projections of its row groups lands in one bf16 buffer
     dxmm_b = _e((B * nF, D), BF16, dev)
     # --- pair attention branch (rows [0, nmm)) ---
@@ -492,8 +525,8 @@ def _factorized_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
     # copies (clone, not .contiguous(): at B == 1 the slices are already contiguous VIEWS of g1, and the GEMMs below
     # accumulate into them while g1 is still needed by the norm1_mm backward)
     cf = torch.contiguous_format
-    dxvo = g1.view(B, nF, D)[:, nmm:nmm + nv].clone(memory_format=cf).view(B * nv, D)
-    dxao = g1.view(B, nF, D)[:, nmm + nv:].clone(memory_format=cf).view(B * na, D)
+    dxvo = gy.view(B, nF, D)[:, nmm:nmm + nv].clone(memory_format=cf).view(B * nv, D)
+    dxao = gy.view(B, nF, D)[:, nmm + nv:].clone(memory_format=cf).view(B * na, D)
     dxvo_b, dxao_b = _e((B * nv, D), BF16, dev), _e((B * na, D), BF16, dev)
     lin_bwd(at.k, dkv_p, t['xvo_b'], B * nv, k=D, dx=dxvo, dx_beta=1, final=False)
     lin_bwd(at.v, dvv_p, t['xvo_b'], B * nv, k=D, dx=dxvo, dx_beta=1, dx_C2=dxvo_b, dx_c2_mode=3, final=False)
@@ -525,28 +558,35 @@ def _factorized_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
 #   dense_mmi : norms in order; inside the attention pairs are (audio_i, image_j), p = i*nI + j, features [audio || image]
 # Both share the norm-then-residual form and the norm2 + MLP tail of the factorised block.
 # ------------------------------------------------------------------------------------------------
-def _alt_tail_fwd(fb, xmm1, B, nF, D, dev):
+def _alt_tail_fwd(fb, xmm1, B, nF, D, dev, dp=None):
     h2, _, st2 = ln_fwd(fb.norm2, None, xmm1, B)
     Hd = fb.mlp.fc1.weight.shape[0]
     z = _e((B * nF, Hd), BF16, dev)
     u = lin_fwd(fb.mlp.fc1, h2, B * nF, act=1, out_bf16=True, C2=z, c2_mode=4)
-    out = lin_fwd(fb.mlp.fc2, u, B * nF, res=xmm1).view(B, nF, D)
-    return out, dict(h2=h2, st2=st2, z=z, u=u, xmm1=xmm1)
+    out = _res_add(fb.mlp.fc2, u, B * nF, xmm1, B, nF, D, None if dp is None else dp[1]).view(B, nF, D)
+    return out, dict(h2=h2, st2=st2, z=z, u=u, xmm1=xmm1, dp=dp)
 
 
 def _alt_tail_bwd(fb, tt, g, gb, B, nF, D, dev):
-    """-> (g1 fp32 [B,nF,D], g1b bf16): gradient at xmm1 (the attention residual output)."""
-    if gb is None:
+    """-> (g1 fp32 [B,nF,D], g1b bf16): gradient at xmm1 (the attention residual output); with DropPath g1b is the
+    gradient of the attention BRANCH (scaled per sample), g1 stays the residual-path gradient."""
+    dp = tt.get('dp')
+    if dp is not None:
+        gb = _e((B * nF, D), BF16, dev)
+        ops.rows_scale_cast(g, dp[1], B, nF, D, gb)
+    elif gb is None:
         gb = to_bf16(g)
     dz = lin_bwd(fb.mlp.fc2, gb, tt['u'], B * nF, gelu_aux=tt['z'])
     dh2 = lin_bwd(fb.mlp.fc1, dz, tt['h2'], B * nF)
     g1 = _e((B, nF, D), F32, dev)
     g1b = _e((B * nF, D), BF16, dev)
     ln_bwd(fb.norm2, None, tt['xmm1'], B, tt['st2'], dy_bf16=dh2, dx1=g1, res1=g, dx1_bf16=g1b)
+    if dp is not None:
+        ops.rows_scale_cast(g1, dp[0], B, nF, D, g1b)
     return g1, g1b
 
 
-def _token_fwd(fb, x_f, x_2, x_3, heads):
+def _token_fwd(fb, x_f, x_2, x_3, heads, dp=None):
     B, nF, D = x_f.shape
     n2, n3 = x_2.shape[1], x_3.shape[1]
     dev, at = x_f.device, fb.attn
@@ -562,8 +602,8 @@ def _token_fwd(fb, x_f, x_2, x_3, heads):
     q = lin_fwd(at.q, xmm_b, B * nF, out_bf16=True)
     o, lse = attention_fwd((q, 0), (kv, 0), (kv, Da), B, heads, nF, nS, hd, hd, hd ** -0.5,
                            nF * Da, Da, nS * 2 * Da, 2 * Da, nS * 2 * Da, 2 * Da, dev)
-    xmm1 = lin_fwd(at.proj, o, B * nF, res=xmm32).view(B, nF, D)
-    out, tt = _alt_tail_fwd(fb, xmm1, B, nF, D, dev)
+    xmm1 = _res_add(at.proj, o, B * nF, xmm32, B, nF, D, None if dp is None else dp[0]).view(B, nF, D)
+    out, tt = _alt_tail_fwd(fb, xmm1, B, nF, D, dev, dp)
     tt.update(arch='token', x_f=x_f, x_2=x_2, x_3=x_3, xmm_b=xmm_b, st_mm=st_mm, x2_b=x2_b, st_2=st_2, x3_b=x3_b, st_3=st_3,
               kv=kv, q=q, o=o, lse=lse, heads=heads)
     return out, tt
@@ -598,7 +638,7 @@ def _token_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
     return dx_f, dx_i, dx_a
 
 
-def _dense_fwd(fb, x_f, x_i, x_a, heads):
+def _dense_fwd(fb, x_f, x_i, x_a, heads, dp=None):
     B, nF, D = x_f.shape
     nI, nA = x_i.shape[1], x_a.shape[1]
     dev, at = x_f.device, fb.attn
@@ -618,8 +658,8 @@ def _dense_fwd(fb, x_f, x_i, x_a, heads):
     scale = (D // heads) ** -0.5                                  # from the FULL dim (:157-158)
     o, lse = attention_fwd((q, 0), (KV, 0), (KV, Da), B, heads, nF, P, hd, hd, scale,
                            nF * Da, Da, P * 2 * Da, 2 * Da, P * 2 * Da, 2 * Da, dev)
-    xmm1 = lin_fwd(at.proj, o, B * nF, res=xmm32).view(B, nF, D)
-    out, tt = _alt_tail_fwd(fb, xmm1, B, nF, D, dev)
+    xmm1 = _res_add(at.proj, o, B * nF, xmm32, B, nF, D, None if dp is None else dp[0]).view(B, nF, D)
+    out, tt = _alt_tail_fwd(fb, xmm1, B, nF, D, dev, dp)
     tt.update(arch='dense_mmi', x_f=x_f, x_i=x_i, x_a=x_a, xmm_b=xmm_b, st_mm=st_mm, xi_b=xi_b, st_i=st_i, xa_b=xa_b, st_a=st_a,
               KV=KV, q=q, o=o, lse=lse, heads=heads)
     return out, tt
@@ -657,15 +697,15 @@ def _dense_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
     return dx_f, dx_i, dx_a
 
 
-def fusion_block_fwd(fb, x_f, x_i, x_a, heads, tkns):
+def fusion_block_fwd(fb, x_f, x_i, x_a, heads, tkns, dp=None):
     """Dispatch on the block's architecture (models/deepavfusion.py:28-35); x_i / x_a = the 2nd / 3rd positional
     argument of the reference call ``blk_fusion(x_fusion, x_image, x_audio)``."""
     arch = getattr(fb, 'arch', 'factorized_mmi')
     if arch == 'token':
-        return _token_fwd(fb, x_f, x_i, x_a, heads)
+        return _token_fwd(fb, x_f, x_i, x_a, heads, dp)
     if arch == 'dense_mmi':
-        return _dense_fwd(fb, x_f, x_i, x_a, heads)
-    return _factorized_fwd(fb, x_f, x_i, x_a, heads, tkns)
+        return _dense_fwd(fb, x_f, x_i, x_a, heads, dp)
+    return _factorized_fwd(fb, x_f, x_i, x_a, heads, tkns, dp)
 
 
 def fusion_block_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):

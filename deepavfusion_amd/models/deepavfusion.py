@@ -47,7 +47,8 @@ class DeepAVFusion(nn.Module):
             layers = {int(l) for l in str(fusion_layers).split('-')}
         self.fusion_blocks = nn.ModuleList([
             make_block(dim=self.embed_dim, num_heads=fusion_num_heads, attn_ratio=fusion_attn_ratio,
-                       mlp_ratio=fusion_mlp_ratio, qkv_bias=True, norm_layer=nn.LayerNorm) if (i in layers and make_block is not None) else None
+                       mlp_ratio=fusion_mlp_ratio, qkv_bias=True, drop=drop, attn_drop=attn_drop, drop_path=drop_path,
+                       norm_layer=nn.LayerNorm) if (i in layers and make_block is not None) else None
             for i in range(depth)])
         self.fusion_norm = nn.LayerNorm(self.embed_dim)
         self.initialize_weights()

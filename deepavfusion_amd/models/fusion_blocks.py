@@ -40,8 +40,9 @@ class FusionBlock_FactorizedAVInteractions(nn.Module):
     def __init__(self, dim, num_heads, attn_ratio=0.25, mlp_ratio=4., qkv_bias=False, fusion_tkns=(8, 4, 4), drop=0.,
                  attn_drop=0., drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm):
         super().__init__()
-        if drop or attn_drop or drop_path:
-            raise NotImplementedError('dropout / drop-path are fine-tuning options outside the pre-training path')
+        if drop or attn_drop:
+            raise NotImplementedError('attention / projection dropout is not on the gfx950 path (drop_path is)')
+        self.drop_path_prob = float(drop_path)        # one DropPath module called on both branches (models/fusion_blocks.py:278)
         self.num_heads, self.fusion_tkns = num_heads, tuple(fusion_tkns)
         self.norm1_mm = norm_layer(dim)
         self.norm1_aud = norm_layer(dim)
@@ -89,8 +90,9 @@ class _FusionBlockAlt(nn.Module):
     def __init__(self, dim, num_heads, attn_ratio=0.25, mlp_ratio=4., qkv_bias=False, drop=0., attn_drop=0., drop_path=0.,
                  act_layer=nn.GELU, norm_layer=nn.LayerNorm):
         super().__init__()
-        if drop or attn_drop or drop_path:
-            raise NotImplementedError('dropout / drop-path are fine-tuning options outside the pre-training path')
+        if drop or attn_drop:
+            raise NotImplementedError('attention / projection dropout is not on the gfx950 path (drop_path is)')
+        self.drop_path_prob = float(drop_path)
         self.num_heads = num_heads
         self.norm1_mm = norm_layer(dim)
         self.norm1_aud = norm_layer(dim)

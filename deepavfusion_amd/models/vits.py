@@ -55,13 +55,14 @@ class Mlp(nn.Module):
 
 
 class Block(nn.Module):
-    """Parameter holder of timm's pre-LN Block (no LayerScale / drop-path at pre-training)."""
+    """Parameter holder of timm's pre-LN Block (no LayerScale; DropPath on both residual branches when drop_path > 0)."""
     def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=True, norm_layer=nn.LayerNorm, drop_path=0., attn_drop=0.,
                  proj_drop=0.):
         super().__init__()
-        if drop_path or attn_drop or proj_drop:
-            raise NotImplementedError('dropout / drop-path are fine-tuning options outside the pre-training path')
+        if attn_drop or proj_drop:
+            raise NotImplementedError('attention / projection dropout is not on the gfx950 path (drop_path is)')
         self.num_heads = num_heads
+        self.drop_path_prob = float(drop_path)        # timm DropPath on both residual branches (training mode only)
         self.norm1 = norm_layer(dim)
         self.attn = Attention(dim, num_heads, qkv_bias)
         self.norm2 = norm_layer(dim)

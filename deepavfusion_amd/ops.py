@@ -210,3 +210,15 @@ def adamw_flat(p, g, m, v, p_bf16, seg_end, hyper, nseg, beta1, beta2, eps, bias
     _lib.check(lib.dav_adamw_flat(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(p_bf16), p.numel(), _ptr(seg_end), _ptr(hyper), nseg,
                                   float(beta1), float(beta2), float(eps), _ptr(bias_corr), float(grad_scale), _ptr(sumsq_out),
                                   int(zero_grad), _stream()), 'dav_adamw_flat')
+
+
+def rows_axpy(res, y, scale, B, rows, D, out):
+    """out[b, r] = res[b, r] + scale[b] * y[b, r]  (fp32 rows of D; DropPath forward)."""
+    lib = _lib.load()
+    _lib.check(lib.dav_rows_axpy(_ptr(res), _ptr(y), _ptr(scale), B, rows, D, _ptr(out), _stream()), 'dav_rows_axpy')
+
+
+def rows_scale_cast(g, scale, B, rows, D, out_bf16):
+    """out_bf16[b, r] = bf16(scale[b] * g[b, r])  (DropPath backward, branch side)."""
+    lib = _lib.load()
+    _lib.check(lib.dav_rows_scale_cast(_ptr(g), _ptr(scale), B, rows, D, _ptr(out_bf16), _stream()), 'dav_rows_scale_cast')

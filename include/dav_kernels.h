@@ -133,6 +133,11 @@ int dav_unshuffle_fwd(const float* emb, const float* mask_token, const float* po
 /* out[b*n+t] = bf16(x[b, row_off + (ids ? ids[b*n+t] : t)]) — backward of the gather / of x[:, nF:] slices */
 int dav_rows_gather_cast(const float* x, long x_bs, int row_off, const int* ids32, int B, int n, int D, void* out_bf16,
                          hipStream_t stream);
+/* DropPath (timm; models/vits.py:32-34, models/fusion_blocks.py:69,130,199,278 when drop_path > 0 — fine-tuning) with a
+ * per-sample scale s[b] in {0, 1/keep}: forward out[b,r,:] = res[b,r,:] + s[b]*y[b,r,:] (fp32; out may alias res); backward of
+ * the branch side out_bf16[b,r,:] = bf16(s[b]*g[b,r,:]) (the residual side passes g through unchanged). */
+int dav_rows_axpy(const float* res, const float* y, const float* scale, int B, int rows, int D, float* out, hipStream_t stream);
+int dav_rows_scale_cast(const float* g, const float* scale, int B, int rows, int D, void* out_bf16, hipStream_t stream);
 /* dpos[r] += sum_b dx[b, off+r]; dmask_token += sum over masked (b, r) */
 int dav_unshuffle_bwd_reduce(const float* dx, long dx_bs, int row_off, const int* ids_restore32, int B, int L, int nk, int D,
                              float* dpos, float* dmask_token, hipStream_t stream);

@@ -209,10 +209,15 @@ def timm_mlp(x: Tensor, sd, name: str) -> Tensor:
     return linear(F.gelu(linear(x, sd, name + '.fc1')), sd, name + '.fc2')   # exact erf GELU
 
 
-def timm_block(x: Tensor, sd, name: str, heads: int, eps: float) -> Tensor:
-    """Pre-LN block, no LayerScale / drop-path at pre-training."""
-    x = x + timm_attention(layer_norm(x, sd, name + '.norm1', eps), sd, name + '.attn', heads)
-    x = x + timm_mlp(layer_norm(x, sd, name + '.norm2', eps), sd, name + '.mlp')
+def _dp(branch: Tensor, s: Optional[Tensor]) -> Tensor:
+    """timm DropPath with the per-sample scale s[b] in {0, 1/keep} already drawn (None = inactive)."""
+    return branch if s is None else branch * s.view(-1, *([1] * (branch.ndim - 1)))
+
+
+def timm_block(x: Tensor, sd, name: str, heads: int, eps: float, dp=None) -> Tensor:
+    """Pre-LN block, no LayerScale; ``dp`` = (s_attn, s_mlp) DropPath scales of drop_path1 / drop_path2 (fine-tuning)."""
+    x = x + _dp(timm_attention(layer_norm(x, sd, name + '.norm1', eps), sd, name + '.attn', heads), None if dp is None else dp[0])
+    x = x + _dp(timm_mlp(layer_norm(x, sd, name + '.norm2', eps), sd, name + '.mlp'), None if dp is None else dp[1])
     return x
 
 
@@ -284,14 +289,14 @@ def factorized_attention(xmm: Tensor, xv: Tensor, xa: Tensor, sd, name: str, hea
 
 
 def fusion_block_factorized(xmm: Tensor, xv: Tensor, xa: Tensor, sd, name: str, heads: int,
-                            tkns: Sequence[int], eps: float) -> Tensor:
+                            tkns: Sequence[int], eps: float, dp=None) -> Tensor:
     """models/fusion_blocks.py:280-289 — norm-THEN-residual: the residual base
     is the normed xmm (:281-283)."""
     xmm = layer_norm(xmm, sd, name + '.norm1_mm', eps)
     xv = layer_norm(xv, sd, name + '.norm1_img', eps)
     xa = layer_norm(xa, sd, name + '.norm1_aud', eps)
-    xmm = xmm + factorized_attention(xmm, xv, xa, sd, name + '.attn', heads, tkns)
-    xmm = xmm + timm_mlp(layer_norm(xmm, sd, name + '.norm2', eps), sd, name + '.mlp')
+    xmm = xmm + _dp(factorized_attention(xmm, xv, xa, sd, name + '.attn', heads, tkns), None if dp is None else dp[0])
+    xmm = xmm + _dp(timm_mlp(layer_norm(xmm, sd, name + '.norm2', eps), sd, name + '.mlp'), None if dp is None else dp[1])
     return xmm
 
 
@@ -308,7 +313,7 @@ def local_av_attention(xmm: Tensor, xv: Tensor, xa: Tensor, sd, name: str, heads
     return linear(o.transpose(1, 2).reshape(B, nmm, Da), sd, name + '.proj')
 
 
-def fusion_block_token(x_f: Tensor, x_image: Tensor, x_audio: Tensor, sd, name: str, heads: int, eps: float) -> Tensor:
+def fusion_block_token(x_f: Tensor, x_image: Tensor, x_audio: Tensor, sd, name: str, heads: int, eps: float, dp=None) -> Tensor:
     """FusionBlock_LocalAVTokens, models/fusion_blocks.py:120-145, as CALLED by models/deepavfusion.py:106
     ``blk_fusion(x_fusion, x_image, x_audio)`` against the signature ``forward(self, xmm, xa, xv)`` (:135):
     xa := x_image, xv := x_audio, so norm1_img normalises the AUDIO tokens and norm1_aud the IMAGE tokens (:136),
@@ -316,8 +321,8 @@ def fusion_block_token(x_f: Tensor, x_image: Tensor, x_audio: Tensor, sd, name: 
     xmm = layer_norm(x_f, sd, name + '.norm1_mm', eps)
     xv = layer_norm(x_audio, sd, name + '.norm1_img', eps)
     xa = layer_norm(x_image, sd, name + '.norm1_aud', eps)
-    xmm = xmm + local_av_attention(xmm, xv, xa, sd, name + '.attn', heads)
-    return xmm + timm_mlp(layer_norm(xmm, sd, name + '.norm2', eps), sd, name + '.mlp')
+    xmm = xmm + _dp(local_av_attention(xmm, xv, xa, sd, name + '.attn', heads), None if dp is None else dp[0])
+    return xmm + _dp(timm_mlp(layer_norm(xmm, sd, name + '.norm2', eps), sd, name + '.mlp'), None if dp is None else dp[1])
 
 
 def dense_av_attention(xmm: Tensor, first: Tensor, second: Tensor, sd, name: str, heads: int) -> Tensor:
@@ -336,7 +341,7 @@ def dense_av_attention(xmm: Tensor, first: Tensor, second: Tensor, sd, name: str
     return linear(o.transpose(1, 2).reshape(B, nmm, Da), sd, name + '.proj')
 
 
-def fusion_block_dense(x_f: Tensor, x_image: Tensor, x_audio: Tensor, sd, name: str, heads: int, eps: float) -> Tensor:
+def fusion_block_dense(x_f: Tensor, x_image: Tensor, x_audio: Tensor, sd, name: str, heads: int, eps: float, dp=None) -> Tensor:
     """FusionBlock_DenseAVInteractions, models/fusion_blocks.py:191-213: forward(xmm, xv, xa) takes the call of
     models/deepavfusion.py:106 in order, but passes ``self.attn(xmm, xv, xa)`` (:206) to a forward declared
     ``(xmm, xa, xv)`` (:168) — inside the attention the image tokens play "xa" and the audio tokens "xv", i.e.
@@ -344,14 +349,14 @@ def fusion_block_dense(x_f: Tensor, x_image: Tensor, x_audio: Tensor, sd, name: 
     xmm = layer_norm(x_f, sd, name + '.norm1_mm', eps)
     xv = layer_norm(x_image, sd, name + '.norm1_img', eps)
     xa = layer_norm(x_audio, sd, name + '.norm1_aud', eps)
-    xmm = xmm + dense_av_attention(xmm, xv, xa, sd, name + '.attn', heads)
-    return xmm + timm_mlp(layer_norm(xmm, sd, name + '.norm2', eps), sd, name + '.mlp')
+    xmm = xmm + _dp(dense_av_attention(xmm, xv, xa, sd, name + '.attn', heads), None if dp is None else dp[0])
+    return xmm + _dp(timm_mlp(layer_norm(xmm, sd, name + '.norm2', eps), sd, name + '.mlp'), None if dp is None else dp[1])
 
 
 # --------------------------------------------------------------------------- #
 # models/deepavfusion.py
 # --------------------------------------------------------------------------- #
-def _early_fusion_layers(sd, cfg, x_v: Tensor, x_a: Tensor, prefix: str, vis: str, return_embs: bool):
+def _early_fusion_layers(sd, cfg, x_v: Tensor, x_a: Tensor, prefix: str, vis: str, return_embs: bool, drop=None):
     """The layer loop shared by models/deepavfusion.py:96-118 and models/video_earlyfusion.py:107-131
     (``vis`` = 'image' / 'video'; the video Block in 'joint_all' mode is the timm pre-LN block,
     models/video_vits.py:46-47,94)."""
@@ -359,23 +364,24 @@ def _early_fusion_layers(sd, cfg, x_v: Tensor, x_a: Tensor, prefix: str, vis: st
     x_f = sd[prefix + 'fusion_tokens'].expand(B, -1, -1)
     nF = x_f.shape[1]
     embs = []
+    dpo = (lambda tag: None) if drop is None else (lambda tag: drop.get(tag))     # drop: {'visual.l' | 'audio.l' | 'fusion.l': (s_attn, s_mlp)}
     for l in range(cfg.depth):
         if l not in cfg.fusion_layers:
-            x_v = timm_block(x_v, sd, f'{prefix}{vis}.blocks.{l}', cfg.num_heads, cfg.enc_eps)
-            x_a = timm_block(x_a, sd, f'{prefix}audio.blocks.{l}', cfg.num_heads, cfg.enc_eps)
+            x_v = timm_block(x_v, sd, f'{prefix}{vis}.blocks.{l}', cfg.num_heads, cfg.enc_eps, dpo(f'visual.{l}'))
+            x_a = timm_block(x_a, sd, f'{prefix}audio.blocks.{l}', cfg.num_heads, cfg.enc_eps, dpo(f'audio.{l}'))
         else:
             # fusion tokens are context rows whose own outputs are dropped (:104-105);
             # the fusion block reads the layer's INPUT x_v / x_a (:106-107)
-            n_v = timm_block(torch.cat((x_f, x_v), 1), sd, f'{prefix}{vis}.blocks.{l}', cfg.num_heads, cfg.enc_eps)[:, nF:]
-            n_a = timm_block(torch.cat((x_f, x_a), 1), sd, f'{prefix}audio.blocks.{l}', cfg.num_heads, cfg.enc_eps)[:, nF:]
+            n_v = timm_block(torch.cat((x_f, x_v), 1), sd, f'{prefix}{vis}.blocks.{l}', cfg.num_heads, cfg.enc_eps, dpo(f'visual.{l}'))[:, nF:]
+            n_a = timm_block(torch.cat((x_f, x_a), 1), sd, f'{prefix}audio.blocks.{l}', cfg.num_heads, cfg.enc_eps, dpo(f'audio.{l}'))[:, nF:]
             arch = getattr(cfg, 'fusion_arch', 'factorized_mmi')
             if arch == 'token':
-                x_f = fusion_block_token(x_f, x_v, x_a, sd, f'{prefix}fusion_blocks.{l}', cfg.fusion_num_heads, cfg.fus_eps)
+                x_f = fusion_block_token(x_f, x_v, x_a, sd, f'{prefix}fusion_blocks.{l}', cfg.fusion_num_heads, cfg.fus_eps, dpo(f'fusion.{l}'))
             elif arch == 'dense_mmi':
-                x_f = fusion_block_dense(x_f, x_v, x_a, sd, f'{prefix}fusion_blocks.{l}', cfg.fusion_num_heads, cfg.fus_eps)
+                x_f = fusion_block_dense(x_f, x_v, x_a, sd, f'{prefix}fusion_blocks.{l}', cfg.fusion_num_heads, cfg.fus_eps, dpo(f'fusion.{l}'))
             else:
                 x_f = fusion_block_factorized(x_f, x_v, x_a, sd, f'{prefix}fusion_blocks.{l}', cfg.fusion_num_heads,
-                                              cfg.fusion_tkns, cfg.fus_eps)
+                                              cfg.fusion_tkns, cfg.fus_eps, dpo(f'fusion.{l}'))
             x_v, x_a = n_v, n_a
         if return_embs:
             embs.append((x_v, x_a, x_f))
@@ -389,11 +395,12 @@ def _early_fusion_layers(sd, cfg, x_v: Tensor, x_a: Tensor, prefix: str, vis: st
 
 def deepavfusion_forward(sd, cfg: PathConfig, image: Tensor, audio: Tensor,
                          image_ids_keep: Optional[Tensor] = None, audio_ids_keep: Optional[Tensor] = None,
-                         prefix: str = '', return_embs: bool = False):
-    """models/deepavfusion.py:88-118 (factorized_mmi arch)."""
+                         prefix: str = '', return_embs: bool = False, drop=None):
+    """models/deepavfusion.py:88-118.  ``drop``: DropPath scales per block (training with drop_path > 0), see
+    _early_fusion_layers."""
     x_i = prepare_patch_tokens(image, sd, prefix + 'image', cfg.patch, image_ids_keep)
     x_a = prepare_patch_tokens(audio, sd, prefix + 'audio', cfg.patch, audio_ids_keep)
-    return _early_fusion_layers(sd, cfg, x_i, x_a, prefix, 'image', return_embs)
+    return _early_fusion_layers(sd, cfg, x_i, x_a, prefix, 'image', return_embs, drop)
 
 
 def video_earlyfusion_forward(sd, cfg: VideoConfig, video: Tensor, audio: Tensor,

@@ -391,6 +391,55 @@ def gen_video(name, B, seed):
     print(f'video[{name}] loss_sum={float(out["loss_sum"]):.6f} loss_probe={float(out["loss_probe"]):.6f}')
 
 
+def gen_droppath(B=4, seed=41, p=0.25):
+    """DeepAVFusion in TRAINING mode with drop_path > 0 (the fine-tuning setting, configs/finetune.yaml:47): the
+    Bernoulli draws of every DropPath are replaced, in call order, by masks stored in the fixture."""
+    cfg = CONFIGS['micro']
+    enc = DeepAVFusion(image_arch='vit_micro', image_pretrained='', image_size=cfg.image_size,
+                       audio_arch='vit_micro', audio_pretrained='', audio_size=cfg.audio_size,
+                       fusion_arch='factorized_mmi', fusion_layers='all', num_fusion_tkns=cfg.fusion_tkns,
+                       fusion_mlp_ratio=cfg.fusion_mlp_ratio, fusion_attn_ratio=cfg.fusion_attn_ratio,
+                       fusion_num_heads=cfg.fusion_num_heads, drop_path=p)
+    sd = {k[len('encoder.'):]: v for k, v in O.closed_form_state(cfg, seed=0).items() if k.startswith('encoder.')}
+    enc.load_state_dict(sd, strict=True)
+    enc.train()
+    image, audio, ni, na = O.synthetic_batch(cfg, B, seed=seed)
+    ik = torch.from_numpy(O.random_masking_from_noise(ni, cfg.image_mask_ratio)[0])
+    ak = torch.from_numpy(O.random_masking_from_noise(na, cfg.audio_mask_ratio)[0])
+    rs = np.random.RandomState(seed + 2)
+    masks = (rs.uniform(size=(cfg.depth * 6, B)) < (1 - p)).astype(np.float32)      # call order: per layer visual(2), audio(2), fusion(2)
+    masks[0, :] = [1, 0, 1, 1][:B]                                                   # make sure both outcomes occur early
+    calls = [0]
+    real = torch.Tensor.bernoulli_
+
+    def fake(self, prob=0.5, *a, **k):
+        m = torch.from_numpy(masks[calls[0]]).view(self.shape)
+        calls[0] += 1
+        return self.copy_(m)
+    torch.Tensor.bernoulli_ = fake
+    try:
+        xi, xa, xf = enc(image, audio, ik, ak)
+    finally:
+        torch.Tensor.bernoulli_ = real
+    assert calls[0] == cfg.depth * 6, calls[0]
+    w = probe_weights([xi.shape, xa.shape, xf.shape], seed + 1)
+    loss = (xi * w[0]).sum() + (xa * w[1]).sum() + (xf * w[2]).sum()
+    loss.backward()
+    out = {'B': np.int64(B), 'seed': np.int64(seed), 'p': np.float64(p), 'masks': masks, 'x_image': xi.detach().numpy(),
+           'x_audio': xa.detach().numpy(), 'x_fusion': xf.detach().numpy(), 'loss_probe': np.float64(loss.item())}
+    names, norms = [], []
+    for n, q in enc.named_parameters():
+        if q.grad is not None:
+            names.append(n)
+            norms.append(float(q.grad.double().norm()))
+    out['grad_names'] = np.array(names)
+    out['grad_norms'] = np.array(norms, dtype=np.float64)
+    for n in ('fusion_tokens', 'image.blocks.0.mlp.fc2.weight', 'audio.blocks.1.attn.proj.bias', 'fusion_blocks.0.attn.attn_v.q.weight'):
+        out['grad.' + n] = dict(enc.named_parameters())[n].grad.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, 'droppath_micro.npz'), **out)
+    print(f'droppath loss_probe={float(loss):.6f}, kept {masks.mean():.2f}')
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--curve', action='store_true')
@@ -403,6 +452,7 @@ if __name__ == '__main__':
             'e2e_micro': lambda: gen_e2e('micro', 3, 21, True), 'e2e_tiny': lambda: gen_e2e('tiny', 2, 22, False),
             'lr': gen_lr_and_groups, 'trainer': gen_trainer_steps,
             'video_micro': lambda: gen_video('video_micro', 2, 31),
+            'droppath': gen_droppath,
             'e2e_micro_token': lambda: gen_e2e('micro_token', 3, 23, False),
             'e2e_micro_dense': lambda: gen_e2e('micro_dense', 3, 24, False)}
     if a.curve:

@@ -370,6 +370,19 @@ def misc_kernels():
     d4 = d.float().view(B, nv, na, Wd)
     report('pair_reduce v', rel(dPv, d4.sum(2).reshape(-1, Wd)), 4e-3)
     report('pair_reduce a', rel(dPa, d4.sum(1).reshape(-1, Wd)), 4e-3)
+    # DropPath row kernels
+    Bq, rq, Dq = 5, 7, 192
+    res, yb, sc = rnd(Bq * rq, Dq, seed=61), rnd(Bq * rq, Dq, seed=62), torch.tensor([0., 1.25, 1.25, 0., 1.25], device=dev)
+    outp = torch.empty_like(res)
+    ops.rows_axpy(res, yb, sc, Bq, rq, Dq, outp)
+    refp = res + yb * sc.repeat_interleave(rq)[:, None]
+    report('rows_axpy', rel(outp, refp), 1e-6)
+    ops.rows_axpy(res, yb, sc, Bq, rq, Dq, yb)                      # in place over y
+    report('rows_axpy in place', rel(yb, refp), 1e-6)
+    gq = rnd(Bq * rq, Dq, seed=63)
+    ob = torch.empty(Bq * rq, Dq, device=dev, dtype=BF16)
+    ops.rows_scale_cast(gq, sc, Bq, rq, Dq, ob)
+    report('rows_scale_cast exact', float((ob != (gq * sc.repeat_interleave(rq)[:, None]).to(BF16)).sum()), 0.0)
     # casts / norm / adamw
     x = rnd(1000, 77, seed=51)
     y = torch.empty(1000, 77, device=dev, dtype=BF16)

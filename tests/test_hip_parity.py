@@ -195,6 +195,58 @@ def test_video_long_sequences_vs_oracle():
     _check_video_grads(model, sdo)
 
 
+def test_drop_path_training_mode_vs_oracle_and_golden(golden):
+    """drop_path > 0 in training mode (fine-tuning constructor surface): per-sample scaled residual
+    branches forward, scaled branch gradients backward, masks injected through the sampler hook."""
+    from deepavfusion_amd.models.deepavfusion import DeepAVFusion
+    from oracle import avmae_oracle as O
+    from oracle.configs import CONFIGS as OC
+    g = golden('droppath_micro')
+    cfg = OC['micro']
+    B, p = int(g['B']), float(g['p'])
+    enc = DeepAVFusion(image_arch='vit_micro', image_pretrained='', image_size=cfg.image_size, audio_arch='vit_micro',
+                       audio_pretrained='', audio_size=cfg.audio_size, num_fusion_tkns=cfg.fusion_tkns,
+                       fusion_num_heads=cfg.fusion_num_heads, drop_path=p).cuda()
+    full = O.closed_form_state(cfg, 0)
+    esd = {k[len('encoder.'):]: v for k, v in full.items() if k.startswith('encoder.')}
+    enc.load_state_dict(esd, strict=True)
+    image, audio, ni, na = O.synthetic_batch(cfg, B, seed=int(g['seed']))
+    ik = torch.from_numpy(O.random_masking_from_noise(ni, cfg.image_mask_ratio)[0])
+    ak = torch.from_numpy(O.random_masking_from_noise(na, cfg.audio_mask_ratio)[0])
+    masks = torch.from_numpy(g['masks'])
+    order = {'visual': 0, 'audio': 1, 'fusion': 2}
+    enc._drop_path_sampler = lambda tag, branch, n: masks[6 * int(tag.split('.')[1]) + 2 * order[tag.split('.')[0]] + branch]
+    enc.train()
+    xi, xa, xf = enc(image.cuda(), audio.cuda(), ik.cuda(), ak.cuda())
+    for got, key in ((xi, 'x_image'), (xa, 'x_audio'), (xf, 'x_fusion')):
+        assert rel(got, g[key]) < ACT_TOL, key
+    w, loss = _probe((xi, xa, xf), int(g['seed']) + 1)
+    # the probe is a random-signed sum (heavy cancellation): bound its error by the size of the summed terms
+    terms = float(sum(((t.detach().cpu() * wi) ** 2).sum() for t, wi in zip((xi, xa, xf), w)) ** 0.5)
+    assert abs(float(loss) - float(g['loss_probe'])) <= ACT_TOL * terms
+    loss.backward()
+    keep = 1.0 - p
+    drop = {f'{t}.{l}': (masks[6 * l + 2 * j] / keep, masks[6 * l + 2 * j + 1] / keep)
+            for l in range(cfg.depth) for j, t in enumerate(('visual', 'audio', 'fusion'))}
+    sdo = {k: v.clone().requires_grad_(('encoder.' + k) not in O.FROZEN) for k, v in esd.items()}
+    ov = O.deepavfusion_forward(sdo, cfg, image, audio, ik, ak, drop=drop)
+    sum((t * wi).sum() for t, wi in zip(ov, w)).backward()
+    _check_video_grads(enc, sdo)
+    # eval mode ignores drop_path
+    enc.eval()
+    with torch.no_grad():
+        xe = enc(image.cuda(), audio.cuda(), ik.cuda(), ak.cuda())[0]
+    assert rel(xe, O.deepavfusion_forward(esd, cfg, image, audio, ik, ak)[0]) < ACT_TOL
+    # and the default sampler draws Bernoulli(keep) scales
+    enc._drop_path_sampler = None
+    enc.train()
+    from deepavfusion_amd.autograd_bridge import drop_path_scales
+    torch.manual_seed(0)
+    s = torch.stack([drop_path_scales(enc, enc.image.blocks[0], 4096, torch.device('cuda'), 'visual.0')[0] for _ in range(4)])
+    vals = s.unique().tolist()
+    assert all(v == 0.0 or abs(v - 1.0 / keep) < 1e-6 for v in vals) and abs(float((s > 0).float().mean()) - keep) < 0.03
+
+
 def test_random_masking_api_bit_exact(golden):
     g = golden('masking')
     model, *_ = _build('micro')

@@ -208,6 +208,46 @@ def test_video_earlyfusion(golden):
             close(sd[k[5:]].grad.numpy(), g[k], rtol=1e-4)
 
 
+def drop_scales_from_fixture(g, depth):
+    """masks are stored in the reference's call order: per layer visual (attn, mlp), audio (attn, mlp), fusion (attn, mlp)."""
+    keep = 1.0 - float(g['p'])
+    m = torch.from_numpy(g['masks']) / keep
+    drop = {}
+    for l in range(depth):
+        for j, tag in enumerate(('visual', 'audio', 'fusion')):
+            drop[f'{tag}.{l}'] = (m[6 * l + 2 * j], m[6 * l + 2 * j + 1])
+    return drop
+
+
+def test_drop_path_training_mode(golden):
+    """DeepAVFusion(drop_path=0.25).train() through the reference with injected DropPath masks (fine-tuning setting)."""
+    g = golden('droppath_micro')
+    cfg = CONFIGS['micro']
+    full = O.closed_form_state(cfg, 0)
+    sd = {k[len('encoder.'):]: v.clone().requires_grad_(k not in O.FROZEN) for k, v in full.items() if k.startswith('encoder.')}
+    image, audio, ni, na = O.synthetic_batch(cfg, int(g['B']), seed=int(g['seed']))
+    ik = torch.from_numpy(O.random_masking_from_noise(ni, cfg.image_mask_ratio)[0])
+    ak = torch.from_numpy(O.random_masking_from_noise(na, cfg.audio_mask_ratio)[0])
+    xi, xa, xf = O.deepavfusion_forward(sd, cfg, image, audio, ik, ak, drop=drop_scales_from_fixture(g, cfg.depth))
+    close(xi.detach().numpy(), g['x_image'], rtol=5e-5)
+    close(xa.detach().numpy(), g['x_audio'], rtol=5e-5)
+    close(xf.detach().numpy(), g['x_fusion'], rtol=5e-5)
+    w = probe_weights([xi.shape, xa.shape, xf.shape], int(g['seed']) + 1)
+    loss = (xi * w[0]).sum() + (xa * w[1]).sum() + (xf * w[2]).sum()
+    assert abs(float(loss) - float(g['loss_probe'])) < 1e-4 * abs(float(g['loss_probe']))
+    loss.backward()
+    norms = dict(zip(g['grad_names'].tolist(), g['grad_norms'].tolist()))
+    for k, ref in norms.items():
+        got = float(sd[k].grad.double().norm())
+        assert abs(got - ref) <= 2e-4 * max(ref, 1e-6) + 1e-6, (k, got, ref)
+    for k in g.files:
+        if k.startswith('grad.'):
+            close(sd[k[5:]].grad.numpy(), g[k], rtol=1e-4)
+    # without the scales the result is a different one (the masks do drop samples)
+    xi0 = O.deepavfusion_forward(sd, cfg, image, audio, ik, ak)[0]
+    assert float((xi0 - xi).abs().max()) > 1e-2
+
+
 def test_lr_schedule_and_param_groups(golden):
     g = golden('lr_groups')
     cfg = CONFIGS['micro']
