@@ -46,6 +46,7 @@ class Trainer:
             if self.flat is None:
                 raise RuntimeError('data-parallel training needs FlatAdamW (flat gradient buffer for the RCCL reducer)')
             model = dist_utils.DataParallel(model, self.flat, bucket_mb=bucket_mb, first_bucket_mb=first_bucket_mb)
+            optimizer.sync_bf16()        # rank 0's fp32 weights were just broadcast: re-derive the bf16 mirror the GEMMs read
         self.model = model
         self.criterion = criterion
         self.optimizer = optimizer

@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _setup(distributed):
+def _setup(distributed, perturb=0.0):
     from deepavfusion_amd.build_model import build_avmae
     from deepavfusion_amd.configs import CONFIGS
     from deepavfusion_amd.util import lr_sched
@@ -33,6 +33,11 @@ def _setup(distributed):
     from oracle.configs import CONFIGS as OC
     model = build_avmae(CONFIGS['micro']).cuda()
     model.load_state_dict(O.closed_form_state(OC['micro'], 0), strict=True)
+    if perturb:                                  # a rank that was initialised differently: the wrapper must fix that
+        with torch.no_grad():
+            for q in model.parameters():
+                if q.requires_grad:
+                    q.add_(perturb * torch.randn_like(q))
     nd = [n for n, p in model.named_parameters() if 'bias' in n or 'norm' in n]
     groups = lr_sched.param_groups_pretrained(model, 0.05, no_weight_decay_list=nd, image_pt='', audio_pt='')
     opt = FlatAdamW(groups, lr=1e-3, betas=(0.9, 0.95), model=model)
@@ -48,7 +53,7 @@ def _worker(rank, world, port, outdir):
     torch.cuda.set_device(0)
     from deepavfusion_amd.util.misc import GraphedStep
     # ---- eager data-parallel steps on this rank's shard of the batch (masking noise injected) -----------------------
-    model, opt, tr, cfg, O = _setup(True)
+    model, opt, tr, cfg, O = _setup(True, perturb=0.05 * rank)        # rank 1 starts from different weights
     assert len(tr.model.reducer.buckets) >= 3            # (AVG natively or SUM + scale, whichever this backend offers)
     image, audio, ni, na = O.synthetic_batch(cfg, world * B_PER, seed=11)
     sl = slice(rank * B_PER, (rank + 1) * B_PER)
