@@ -85,9 +85,7 @@ class FlatAdamW(torch.optim.Optimizer):
             for p in g['params']:
                 self._group_of[id(p)] = gi
         n = len(self.flat.params)
-        self._hyper_host = torch.zeros(n, 2, dtype=torch.float32).pin_memory()
         self._hyper = torch.zeros(n, 2, dtype=torch.float32, device=dev)
-        self._bc_host = torch.zeros(2, dtype=torch.float32).pin_memory()
         self._bc = torch.ones(2, dtype=torch.float32, device=dev)
         self._gidx = torch.tensor([self._group_of[id(p)] for p in self.flat.params], dtype=torch.long)
         self.step_count = 0
@@ -105,17 +103,23 @@ class FlatAdamW(torch.optim.Optimizer):
         engine.invalidate_weight_cache(self.flat.params)
 
     def prepare_step(self):
-        """Host side of a step (kept outside hipGraph capture): bump t, upload per-tensor {lr, wd} and bias corrections."""
+        """Host side of a step (kept outside hipGraph capture): bump t, upload per-tensor {lr, wd} and bias corrections.
+        The staging tensors are FRESH pinned allocations every step: the host may be many replayed steps ahead of the GPU,
+        and a reused staging buffer would be overwritten with a later step's values before this step's asynchronous copy
+        has run (torch's pinned-memory allocator recycles a block only after the copy that read it has completed)."""
         self.step_count += 1
         lrs = torch.tensor([g['lr'] for g in self.param_groups], dtype=torch.float32)
         wds = torch.tensor([g['weight_decay'] for g in self.param_groups], dtype=torch.float32)
-        self._hyper_host[:, 0] = lrs[self._gidx]
-        self._hyper_host[:, 1] = wds[self._gidx]
+        pin = self._hyper.is_cuda
+        hyper = torch.empty(self._hyper.shape, dtype=torch.float32, pin_memory=pin)
+        hyper[:, 0] = lrs[self._gidx]
+        hyper[:, 1] = wds[self._gidx]
         b1, b2 = self.defaults['betas']
-        self._bc_host[0] = 1 - b1 ** self.step_count
-        self._bc_host[1] = math.sqrt(1 - b2 ** self.step_count)
-        self._hyper.copy_(self._hyper_host, non_blocking=True)
-        self._bc.copy_(self._bc_host, non_blocking=True)
+        bc = torch.empty(2, dtype=torch.float32, pin_memory=pin)
+        bc[0] = 1 - b1 ** self.step_count
+        bc[1] = math.sqrt(1 - b2 ** self.step_count)
+        self._hyper.copy_(hyper, non_blocking=True)
+        self._bc.copy_(bc, non_blocking=True)
         for st in self.state.values():
             st['step'] += 1
 

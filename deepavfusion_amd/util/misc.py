@@ -195,6 +195,9 @@ class GraphedStep:
         self.opt.flat.zero_grad()            # the AdamW pass leaves the gradients zeroed for the next replay
         with torch.cuda.stream(cap):
             self.graphs[0].capture_begin()
+            # every derived bf16 copy (casts of un-mirrored weights, TRANSPOSED copies) must be re-derived INSIDE the graph:
+            # copies left over from the warm-up passes would otherwise be read, stale, by every replay
+            engine.invalidate_weight_cache(self.model.parameters())
             engine.refresh_weight_cache(self.model)
             self.loss_image, self.loss_audio = self._fwd_bwd(layer_cb)
             if not self.dist_active:

@@ -56,6 +56,7 @@ cap.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(cap):
     graph.capture_begin()
     opt.flat.zero_grad()
+    engine.invalidate_weight_cache(model.parameters())
     engine.refresh_weight_cache(model)
     li, la = fwd_bwd()
     graph.capture_end()

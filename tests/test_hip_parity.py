@@ -519,3 +519,41 @@ def test_captured_step_repeats_bit_for_bit_across_replays():
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert '200 replays, 0 deviation events' in out.stdout, out.stdout[-3000:]
+
+
+def test_graphed_steps_without_host_sync_use_their_own_hyperparameters():
+    """The host runs far ahead of the GPU when captured steps are replayed back to back (train.py only synchronises at
+    its log lines): every step must still see ITS learning rate and bias corrections, not those of a later step.  The
+    loss trajectory under a per-step lr schedule is compared with a run that synchronises after every step (parameters
+    themselves are no criterion: Adam turns the rounding noise of exactly-zero gradients, e.g. key biases, into
+    lr-sized steps of random sign)."""
+    from deepavfusion_amd.util import lr_sched
+    from deepavfusion_amd.util.flat import FlatAdamW
+    from deepavfusion_amd.util.misc import GraphedStep, Trainer
+    logs = []
+    for sync_every_step in (True, False):
+        model, sd, cfg, O = _build('micro')
+        nd = [n for n, p in model.named_parameters() if 'bias' in n or 'norm' in n]
+        groups = lr_sched.param_groups_pretrained(model, 0.05, no_weight_decay_list=nd, image_pt='', audio_pt='')
+        opt = FlatAdamW(groups, lr=1e-3, betas=(0.9, 0.95), model=model)
+        tr = Trainer(model, optimizer=opt, accum_iter=1)
+        image, audio, _, _ = O.structured_batch(cfg, 64, seed=3)
+        image, audio = image.cuda(), audio.cuda()
+        gs = GraphedStep(tr, image.shape, audio.shape)
+        big = torch.zeros(64 << 20, device='cuda')
+        trace = torch.zeros(12, device='cuda')
+        for s in range(12):
+            for g in opt.param_groups:
+                g['lr'] = 2e-3 * (1 + s) if s % 2 == 0 else 1e-4          # a schedule that changes a lot from step to step
+            if not sync_every_step and s == 0:
+                for _ in range(60):                           # keep the GPU busy so that the host gets ahead of it (no RNG use)
+                    big.add_(1.0)
+            torch.manual_seed(700 + s)
+            li, la, _ = gs(image, audio)
+            trace[s].copy_(li + la)                           # stream-ordered read of the graph's output, no host sync
+            if sync_every_step:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        logs.append(trace.cpu())
+    assert float(logs[0][0]) > float(logs[0][-1])             # it trains
+    assert torch.allclose(logs[0], logs[1], rtol=2e-4), (logs[0], logs[1])

@@ -103,6 +103,7 @@ def main():
         cap.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(cap):
             graph.capture_begin()
+            engine.invalidate_weight_cache(model.parameters())
             engine.refresh_weight_cache(model)
             loss_t = fwd_bwd()
             opt.launch_step(fused_norm_and_zero=True)
