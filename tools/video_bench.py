@@ -53,6 +53,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', default='video_base')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--race', type=int, default=0, help='race screen: capture forward+backward only, replay N times, gradients must repeat')
     a = ap.parse_args()
     dev = torch.device('cuda', 0)
     from deepavfusion_amd import autograd_bridge as bridge
@@ -86,6 +87,37 @@ def main():
         opt.launch_step(fused_norm_and_zero=True)
         return loss
 
+    if a.race:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                opt.flat.zero_grad()
+                fwd_bwd()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap):
+            graph.capture_begin()
+            opt.flat.zero_grad()
+            engine.invalidate_weight_cache(model.parameters())
+            engine.refresh_weight_cache(model)
+            fwd_bwd()
+            graph.capture_end()
+        torch.cuda.current_stream().wait_stream(cap)
+        ref, bad = None, 0
+        for it in range(a.race):
+            graph.replay()
+            torch.cuda.synchronize()
+            g_ = opt.flat.flat_g.clone()
+            if ref is None:
+                ref = g_
+            elif float((g_ - ref).abs().max()) > 1e-5 * float(ref.abs().max()):
+                bad += 1
+        print(f'race screen {a.config} B={B}: {a.race} replays, {bad} deviating')
+        return
     opt.flat.zero_grad()
     if a.no_graph:
         step = eager_step
