@@ -118,6 +118,7 @@ class GradReducer:
                 self._bucket_of[id(p)] = bi
         self._pending = [len(b[2]) for b in self.buckets]
         self._launched = [False] * len(self.buckets)
+        self._streams = [set() for _ in self.buckets]      # streams on which a bucket's gradients were finished
         self.enabled = True
         self.comm_stream = torch.cuda.Stream() if flat.flat_g.is_cuda else None
         self.launch_order: List[int] = []
@@ -148,6 +149,7 @@ class GradReducer:
     def begin_backward(self):
         self._pending = [len(b[2]) for b in self.buckets]
         self._launched = [False] * len(self.buckets)
+        self._streams = [set() for _ in self.buckets]
         self.launch_order = []
 
     def grad_ready(self, p):
@@ -155,6 +157,10 @@ class GradReducer:
         bi = self._bucket_of.get(id(p))
         if bi is None or not self.enabled:
             return
+        if self.comm_stream is not None:
+            # the engine finishes gradients on several streams (towers / decoders run on their own): the reduction has
+            # to wait for every one of them, not only for the stream of the parameter that happens to report last
+            self._streams[bi].add(torch.cuda.current_stream())
         self._pending[bi] -= 1
         if self._pending[bi] == 0 and not self._launched[bi]:
             self._launch(bi)
@@ -168,6 +174,8 @@ class GradReducer:
         view = self.flat.flat_g[lo:hi]
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
+            for st in self._streams[bi]:
+                self.comm_stream.wait_stream(st)
             sw = engine.wgrad_stream(view.device)          # weight gradients are produced on their own stream
             if sw is not None:
                 self.comm_stream.wait_stream(sw)
