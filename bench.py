@@ -67,7 +67,9 @@ def main():
     ap.add_argument('--config', default='base')
     ap.add_argument('--no-graph', action='store_true', help='eager kernel launches instead of hipGraph replay')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-threads', type=int, default=0, help='host threads for the cpu_baseline leg (0 = all cores; 1 = scalar figure)')
+    ap.add_argument('--cpu-threads', type=int, default=0,
+                    help='host threads for the cpu_baseline leg (0 = min(16, cores): more threads oversubscribe these matmuls — '
+                         '128 threads are 7x slower than 16 on the MI355X host; 1 = scalar figure)')
     ap.add_argument('--no-roofline', action='store_true', help='skip the dominant-kernel replay (clean per-step profiles)')
     ap.add_argument('--roofline-only', action='store_true',
                     help='one eager step (to record the launch mix) + 20 replays of the dominant kernel: the run profiled for profiles/*roofline*')
@@ -224,13 +226,12 @@ def main():
         ocfg = OC[a.config]
         sd = {k: v.detach().float().cpu().clone().requires_grad_(k not in O.FROZEN) for k, v in model.state_dict().items()}
         optc = torch.optim.AdamW([p for p in sd.values() if p.requires_grad], lr=1e-4, betas=(0.9, 0.95))
-        if a.cpu_threads > 0:
-            torch.set_num_threads(a.cpu_threads)
+        torch.set_num_threads(a.cpu_threads if a.cpu_threads > 0 else min(16, os.cpu_count() or 16))
         cores = torch.get_num_threads()
-        Bc = 4 if cores > 1 else 1
+        Bc = 8 if cores > 1 else 1
         im, au, ni, na = O.synthetic_batch(ocfg, Bc, seed=7)
         n_done, t_start = 0, time.perf_counter()
-        while n_done < 4 and (time.perf_counter() - t_start < 12.0 or n_done < 1):
+        while n_done < 6 and (time.perf_counter() - t_start < 15.0 or n_done < 1):
             li, la = O.avmae_forward(sd, ocfg, im, au, ni, na)[:2]
             (li + la).backward()
             optc.step()
