@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""Randomised shape fuzz of the C-ABI kernels against torch fp32 references (companion of tests/gpu_selfcheck.py, which uses
+fixed shape lists).  Usage: python tests/gpu_fuzz.py [seed] [n_gemm] [n_attn] [n_ln]"""
+import os
+import random
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from deepavfusion_amd import ops   # noqa: E402
+
+dev = torch.device('cuda')
+BF16, F32 = torch.bfloat16, torch.float32
+FAILS = []
+
+
+def rel(a, b):
+    """relative L2 error; where the reference is (numerically) zero — e.g. dq / dk of a softmax over ONE key — the error
+    is taken relative to unit scale instead"""
+    a, b = a.detach().double().flatten(), b.detach().double().flatten()
+    nb = float(b.norm())
+    return float((a - b).norm() / (nb if nb > 1e-6 * max(1.0, b.numel() ** 0.5) else max(1.0, b.numel() ** 0.5)))
+
+
+def check(tag, err, tol):
+    if not (err <= tol):
+        FAILS.append((tag, err, tol))
+        print(f'FAIL {tag}: {err:.3e} > {tol:.1e}', flush=True)
+
+
+def fuzz_gemm(rng, n):
+    for it in range(n):
+        M = rng.choice([1, 3, 17, 64, 100, 128, 129, 255, 300, 777, 1024, 2049, rng.randint(1, 3000)])
+        N = 8 * rng.choice([1, 2, 3, 8, 9, 16, 24, 33, 64, 96, rng.randint(1, 200)])
+        K = 8 * rng.choice([1, 2, 8, 9, 16, 24, 64, 96, rng.randint(1, 160)])
+        kn = rng.random() < 0.3 and K % 64 == 0
+        A = torch.randn(M, K, device=dev).to(BF16)
+        W = (torch.randn(N, K, device=dev) * 0.1).to(BF16)
+        Bm = W.t().contiguous() if kn else W
+        ref = A.float() @ W.float().t()
+        bias = torch.randn(N, device=dev) if rng.random() < 0.5 else None
+        alpha = rng.choice([1.0, 0.5])
+        act = rng.choice([0, 0, 1])
+        res = torch.randn(M, N, device=dev) if rng.random() < 0.5 else None
+        beta = 1 if (rng.random() < 0.3) else 0
+        c_bf16 = (rng.random() < 0.5) and not beta
+        c2_mode = rng.choice([0, 0, 1, 2, 3, 4])
+        if c2_mode == 4 and act != 1:
+            c2_mode = 0
+        v = ref * alpha + (bias if bias is not None else 0)
+        pre = v.clone()
+        dgelu = None
+        if act == 1:
+            x = v.clone().requires_grad_(True)
+            y = torch.nn.functional.gelu(x)
+            y.sum().backward()
+            v, dgelu = y.detach(), x.grad
+        post = v.clone()
+        if res is not None:
+            v = v + res
+        C0 = torch.randn(M, N, device=dev)
+        if beta:
+            v = v + C0
+        C = C0.clone().to(BF16) if c_bf16 else C0.clone()
+        C2 = torch.empty(M, N, device=dev, dtype=BF16) if c2_mode else None
+        ops.gemm_nt(A, Bm, M, N, K, ldb=N if kn else K, bias=bias, act=act, res=res, ldres=N, C_out=C, c_bf16=c_bf16, beta=beta,
+                    alpha=alpha, C2=C2, ldc2=N, c2_mode=c2_mode, variant=(1 << 12) if kn else 0)
+        tag = f'gemm M{M} N{N} K{K} kn{int(kn)} act{act} res{int(res is not None)} beta{beta} bf{int(c_bf16)} c2{c2_mode} bias{int(bias is not None)}'
+        check(tag, rel(C.float(), v), 8e-3 if c_bf16 else 2e-4)
+        if c2_mode:
+            want = {1: pre, 2: post, 3: v, 4: dgelu}[c2_mode]
+            check(tag + ' C2', rel(C2.float(), want), 8e-3)
+        # weight gradient of the same problem
+        if N % 8 == 0 and K % 8 == 0:
+            dY = torch.randn(M, N, device=dev).to(BF16)
+            G0 = torch.randn(N, K, device=dev)
+            G = G0.clone()
+            bg0 = torch.randn(N, device=dev)
+            bg = bg0.clone()
+            ops.gemm_tn(dY, A, M, N, K, G, beta=1, bias_grad=bg)
+            check(tag + ' wgrad', rel(G, G0 + dY.float().t() @ A.float()), 3e-4)
+            check(tag + ' bgrad', rel(bg, bg0 + dY.float().sum(0)), 3e-4)
+
+
+def fuzz_attn(rng, n):
+    for it in range(n):
+        dqk, dv = rng.choice([(64, 64), (32, 32), (16, 64), (16, 16)])
+        B, H = rng.randint(1, 3), rng.randint(1, 4)
+        Nk = rng.choice([1, 2, 15, 16, 17, 31, 32, 33, 64, 100, 255, 256, 257, 320, 511, 513, 700, rng.randint(1, 1200)])
+        Nq = rng.choice([1, 5, 16, 17, 33, 64, 129, rng.randint(1, 600)])
+        q = torch.randn(B, Nq, H, dqk, device=dev).to(BF16)
+        k = torch.randn(B, Nk, H, dqk, device=dev).to(BF16)
+        v = torch.randn(B, Nk, H, dv, device=dev).to(BF16)
+        scale = rng.choice([dqk ** -0.5, 0.125])
+        qf, kf, vf = (t.float().permute(0, 2, 1, 3).requires_grad_(True) for t in (q, k, v))
+        s = (qf @ kf.transpose(-2, -1)) * scale
+        ref = s.softmax(-1) @ vf
+        O = torch.empty(B * Nq, H * dv, device=dev, dtype=BF16)
+        LSE = torch.empty(B, H, Nq, device=dev)
+        st = (Nq * H * dqk, H * dqk, Nk * H * dqk, H * dqk, Nk * H * dv, H * dv)
+        ops.attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), O, LSE, B, H, Nq, Nk, dqk, dv, *st, Nq * H * dv, H * dv, scale)
+        tag = f'attn B{B} H{H} {Nq}x{Nk} d{dqk}/{dv}'
+        check(tag + ' fwd', rel(O.view(B, Nq, H, dv).permute(0, 2, 1, 3).float(), ref), 1.2e-2)
+        check(tag + ' lse', rel(LSE, torch.logsumexp(s, -1)), 2e-4)
+        dO = torch.randn(B * Nq, H * dv, device=dev).to(BF16)
+        ref.backward(dO.view(B, Nq, H, dv).permute(0, 2, 1, 3).float())
+        dq, dk, dvv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+        Delta = torch.empty_like(LSE)
+        ops.attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), O, dO, LSE, Delta, dq.data_ptr(), dk.data_ptr(), dvv.data_ptr(), B, H, Nq, Nk,
+                     dqk, dv, *st, Nq * H * dv, H * dv, Nq * H * dv, H * dv, *st, scale)
+        check(tag + ' dq', rel(dq.permute(0, 2, 1, 3).float(), qf.grad), 2.5e-2)
+        check(tag + ' dk', rel(dk.permute(0, 2, 1, 3).float(), kf.grad), 2.5e-2)
+        check(tag + ' dv', rel(dvv.permute(0, 2, 1, 3).float(), vf.grad), 2.5e-2)
+
+
+def fuzz_ln(rng, n):
+    for it in range(n):
+        B = rng.randint(1, 5)
+        r0, r1 = rng.choice([0, 1, 3, 32]), rng.choice([1, 2, 7, 49, 196, rng.randint(1, 400)])
+        D = 4 * rng.choice([1, 8, 32, 48, 96, 128, 192, 256, 320])
+        x0 = torch.randn(B, r0, D, device=dev) if r0 else None
+        x1 = torch.randn(B, r1, D, device=dev)
+        g, bt = torch.randn(D, device=dev) * 0.2 + 1, torch.randn(D, device=dev) * 0.2
+        xc = torch.cat([t for t in (x0, x1) if t is not None], 1).clone().requires_grad_(True)
+        gp, bp = g.clone().requires_grad_(True), bt.clone().requires_grad_(True)
+        eps = rng.choice([1e-5, 1e-6])
+        ref = torch.nn.functional.layer_norm(xc, (D,), gp, bp, eps)
+        R = r0 + r1
+        y, y32 = torch.empty(B * R, D, device=dev, dtype=BF16), torch.empty(B * R, D, device=dev)
+        mean, rstd = torch.empty(B * R, device=dev), torch.empty(B * R, device=dev)
+        a0, a1, n0, n1 = (x0, x1, r0, r1) if x0 is not None else (x1, None, r1, 0)
+        ops.layernorm_fwd(a0, n0 * D, n0, a1, n1 * D, n1, B, D, g, bt, eps, y, y32, mean, rstd)
+        tag = f'ln B{B} {r0}+{r1} D{D}'
+        check(tag + ' fwd', rel(y32, ref.view(-1, D)), 2e-5)
+        dy = torch.randn(B * R, D, device=dev).to(BF16)
+        ref.backward(dy.view(B, R, D).float())
+        dx0 = torch.zeros(B, n0, D, device=dev)
+        dx1 = torch.zeros(B, max(n1, 1), D, device=dev) if n1 else None
+        dg, db = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+        ops.layernorm_bwd(a0, n0 * D, n0, a1, n1 * D, n1, B, D, dy, None, g, mean, rstd, dx0=dx0, dx0_bs=n0 * D, dx1=dx1,
+                          dx1_bs=n1 * D, dgamma=dg, dbeta=db)
+        dxc = torch.cat([t for t in (dx0, dx1) if t is not None], 1)
+        check(tag + ' dx', rel(dxc, xc.grad), 3e-5)
+        check(tag + ' dgamma', rel(dg, gp.grad), 3e-4)
+        check(tag + ' dbeta', rel(db, bp.grad), 3e-4)
+
+
+if __name__ == '__main__':
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    ng, na, nl = (int(sys.argv[i]) if len(sys.argv) > i else d for i, d in ((2, 150), (3, 60), (4, 60)))
+    rng = random.Random(seed)
+    torch.manual_seed(seed)
+    fuzz_gemm(rng, ng)
+    fuzz_attn(rng, na)
+    fuzz_ln(rng, nl)
+    print(f'fuzz seed {seed}: {len(FAILS)} failures')
+    for f in FAILS[:20]:
+        print('  ', f)
+    sys.exit(1 if FAILS else 0)
