@@ -557,3 +557,21 @@ def test_graphed_steps_without_host_sync_use_their_own_hyperparameters():
         logs.append(trace.cpu())
     assert float(logs[0][0]) > float(logs[0][-1])             # it trains
     assert torch.allclose(logs[0], logs[1], rtol=2e-4), (logs[0], logs[1])
+
+
+def test_random_path_configurations_vs_oracle():
+    """A fixed-seed slice of tests/gpu_model_fuzz.py: random input sizes, fusion token counts, mask ratios, fusion widths /
+    architectures, loss modes and batch sizes (incl. 1) on the micro towers, losses + every gradient against the oracle."""
+    import random
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import gpu_model_fuzz as mf
+    rng = random.Random(11)
+    ran, bad = 0, []
+    for i in range(14):
+        r = mf.one_case(rng, 11000 + i)
+        if r is not None:
+            ran += 1
+            bad += r
+    assert ran >= 6 and not bad, bad[:8]
