@@ -65,7 +65,7 @@ def drop_path_scales(owner, blk, B, dev, tag):
 def _vis(enc):
     """The visual tower: ``.image`` of DeepAVFusion (models/deepavfusion.py:20) or ``.video`` of VideoEarlyFusion
     (models/video_earlyfusion.py:32) — the layer loop is the same."""
-    return enc.video if hasattr(enc, 'video') else enc.image
+    return enc.visual if hasattr(enc, 'visual') else (enc.video if hasattr(enc, 'video') else enc.image)
 
 
 # ------------------------------------------------------------------------------------------------

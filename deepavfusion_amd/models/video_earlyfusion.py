@@ -4,75 +4,42 @@ BASELINE.json configs[4]: ``video_efav_base`` on an 8-frame 224x224 clip + a (12
 video rows per sample, which is where the attention kernels stream keys through LDS in chunks.
 """
 import torch
-from torch import nn
 
 from . import video_vits, vits
-from .fusion_blocks import FusionBlock_FactorizedAVInteractions
-from .vits import init_linear_and_norm
+from ._early_fusion import EarlyFusionBase
 
 
-class VideoEarlyFusion(nn.Module):
-    """Same ctor signature / attributes / state-dict keys as models/video_earlyfusion.py:9-57."""
+class VideoEarlyFusion(EarlyFusionBase):
+    """Drop-in for models/video_earlyfusion.py:9-131: ``.video`` (clip tower) + ``.audio`` + the factorised fusion blocks."""
+
+    visual_name = 'video'
+
     def __init__(self, video_arch='video_vit_base', video_pretrained='', video_size=(24, 224, 224),
                  audio_arch='audio_vit_base', audio_pretrained='', audio_size=(128, 298),
                  fusion_layers='all', num_fusion_tkns=(8, 16, 16), fusion_mlp_ratio=1., fusion_attn_ratio=.25,
                  fusion_num_heads=12, drop_path=0., attn_drop=0., drop=0.):
         super().__init__()
-        self.video = video_vits.__dict__[video_arch](pretrained=video_pretrained, input_size=video_size, in_chans=3,
-                                                     use_cls_token=False, drop_path=drop_path, attn_drop=attn_drop, drop=drop)
-        self.audio = vits.__dict__[audio_arch](pretrained=audio_pretrained, input_size=audio_size, in_chans=1,
-                                               use_cls_token=False, drop_path=drop_path, attn_drop=attn_drop, drop=drop)
-        self.embed_dim = self.video.embed_dim
-        self.num_fusion = tuple(num_fusion_tkns)
-        self.fusion_num_heads = fusion_num_heads
-        self.fusion_tokens = nn.Parameter(torch.zeros(1, sum(num_fusion_tkns), self.embed_dim))
-        depth = max(len(self.video.blocks), len(self.audio.blocks))
-        if fusion_layers == 'all':                       # models/video_earlyfusion.py:41-48
-            layers = set(range(depth))
-        elif fusion_layers == 'none':
-            layers = set()
-        elif isinstance(fusion_layers, int):
-            layers = {fusion_layers}
-        else:
-            layers = {int(l) for l in str(fusion_layers).split('-')}
-        self.fusion_blocks = nn.ModuleList([
-            FusionBlock_FactorizedAVInteractions(dim=self.embed_dim, fusion_tkns=num_fusion_tkns, num_heads=fusion_num_heads,
-                                                 attn_ratio=fusion_attn_ratio, mlp_ratio=fusion_mlp_ratio, qkv_bias=True,
-                                                 drop=drop, attn_drop=attn_drop, drop_path=drop_path) if i in layers else None
-            for i in range(depth)])
-        self.fusion_norm = nn.LayerNorm(self.embed_dim)
-        self.initialize_weights()
-
-    def initialize_weights(self):
-        nn.init.normal_(self.fusion_tokens, std=.02)
-        self.fusion_blocks.apply(init_linear_and_norm)
-
-    def params_layer_ids(self):
-        ids = list(self.video.params_layer_ids()) + list(self.audio.params_layer_ids())
-        ids.append((self.fusion_tokens, 0))
-        for i, blk in enumerate(self.fusion_blocks):
-            if blk is not None:
-                ids.extend((p, i + 1) for p in blk.parameters())
-        ids.extend((p, len(self.fusion_blocks) + 1) for p in self.fusion_norm.parameters())
-        return ids
+        tower = dict(use_cls_token=False, drop_path=drop_path, attn_drop=attn_drop, drop=drop)
+        self.video = getattr(video_vits, video_arch)(pretrained=video_pretrained, input_size=video_size, in_chans=3, **tower)
+        self.audio = getattr(vits, audio_arch)(pretrained=audio_pretrained, input_size=audio_size, in_chans=1, **tower)
+        self._build_fusion('factorized_mmi', fusion_layers, num_fusion_tkns, fusion_mlp_ratio, fusion_attn_ratio,
+                           fusion_num_heads, drop_path=drop_path, attn_drop=attn_drop, drop=drop)
 
     def load_checkpoint(self, ckpt_fn, prefix):
-        """models/video_earlyfusion.py:83-93: an image DeepAVFusion checkpoint adapted to the clip tower."""
-        ckpt = torch.load(ckpt_fn, map_location='cpu')['state_dict']
-        ckpt = {k[len(prefix):]: v for k, v in ckpt.items() if k.startswith(prefix)}
-        ckpt = {k.replace('image.', 'video.'): v for k, v in ckpt.items()}
-        ckpt['video.pos_embed'] = self.video.state_dict()['pos_embed']
-        w = ckpt['video.patch_embed.proj.weight']
+        """models/video_earlyfusion.py:83-93: an image DeepAVFusion checkpoint adapted to the clip tower (image.* -> video.*,
+        own 3-D pos table, 2-D patch kernels repeated over the tubelet depth)."""
+        state = torch.load(ckpt_fn, map_location='cpu')['state_dict']
+        state = {k[len(prefix):].replace('image.', 'video.'): v for k, v in state.items() if k.startswith(prefix)}
+        state['video.pos_embed'] = self.video.state_dict()['pos_embed']
+        w = state['video.patch_embed.proj.weight']
         if self.video.patch_embed.proj.weight.ndim > w.ndim:
-            ckpt['video.patch_embed.proj.weight'] = w.unsqueeze(2).repeat(1, 1, self.video.patch_size[0], 1, 1)
-        self.load_state_dict(ckpt, strict=True)
+            state['video.patch_embed.proj.weight'] = w.unsqueeze(2).repeat(1, 1, self.video.patch_size[0], 1, 1)
+        self.load_state_dict(state, strict=True)
         print(f"Loaded pre-trained checkpoint: {ckpt_fn}")
 
     def forward(self, video, audio, video_ids_keep=None, audio_ids_keep=None, return_embs=False):
-        """models/video_earlyfusion.py:95-131: video (b c t h w), audio (b c n t) ->
-        (x_video, x_audio, x_fusion[, embs]) in fp32."""
-        from ..autograd_bridge import encoder_apply
-        return encoder_apply(self, video, audio, video_ids_keep, audio_ids_keep, return_embs)
+        """models/video_earlyfusion.py:95-131: video (b c t h w), audio (b c n t) -> (x_video, x_audio, x_fusion[, embs])."""
+        return self._encode(video, audio, video_ids_keep, audio_ids_keep, return_embs)
 
 
 def _efav(video_arch, audio_arch, tkns, heads):
