@@ -380,7 +380,9 @@ def block_bwd(blk, t, g2, g2b, *, dx_fus=None, dx_fus_acc=0, dx_mod=None, dx_mod
     if dp is not None:
         ops.rows_scale_cast(g1, dp[0], B, n, D, g1b)
     do = lin_bwd(blk.attn.proj, g1b, t['o'], Mq)
-    dqkv = torch.zeros((M, 3 * D), dtype=BF16, device=dev) if nF > 0 else _e((M, 3 * D), BF16, dev)
+    dqkv = _e((M, 3 * D), BF16, dev)
+    if nF > 0:      # attention writes dq for the modality rows and dk / dv for all rows: only the (dropped) queries of the
+        dqkv.view(B, R, 3 * D)[:, :nF, :D].zero_()      # fusion context rows are never written and must read as zero
     qkv = t['qkv']
     attention_bwd((qkv, nF * 3 * D), (qkv, D), (qkv, 2 * D), t['o'], do, t['lse'],
                   (dqkv, nF * 3 * D), (dqkv, D), (dqkv, 2 * D), B, heads, n, R, hd, hd, hd ** -0.5,
