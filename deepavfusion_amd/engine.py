@@ -792,8 +792,10 @@ def decoder_bwd(dec, t, dpred_b, ids_keep32, B):
     Dd = dec.embed.weight.shape[0]
     dev = dpred_b.device
     dhN = lin_bwd(dec.pred, dpred_b, t['hN'], B * L)
-    g = torch.zeros((B, nF + L, Dd), dtype=F32, device=dev)
-    gb = torch.zeros((B * (nF + L), Dd), dtype=BF16, device=dev)
+    g = _e((B, nF + L, Dd), F32, dev)                  # the LayerNorm backward writes the L patch rows; the fusion rows carry no
+    gb = _e((B * (nF + L), Dd), BF16, dev)             # gradient from the head (models/avmae.py:173 drops them)
+    g[:, :nF].zero_()
+    gb.view(B, nF + L, Dd)[:, :nF].zero_()
     xs = t['x_last'].view(-1)[nF * Dd:]
     ops.layernorm_bwd(xs, (nF + L) * Dd, L, None, 0, 0, B, Dd, dhN, None, dec.norm.weight, t['stN'][0], t['stN'][1],
                       g.view(-1)[nF * Dd:], (nF + L) * Dd, 0, None, 0, gb.view(-1)[nF * Dd:], (nF + L) * Dd,
