@@ -130,7 +130,7 @@ if __name__ == '__main__':
             run('base', 2, 23)
         elif w == 'base_b64':          # the bench workload at full size (the oracle needs a few minutes of host time)
             run('base', 64, 26)
-        elif w in ('base_token', 'base_dense'):
+        elif w in ('base_token', 'base_dense', 'base_as', 'base_m75', 'large'):      # BASELINE configs[2] / [3] shapes
             run(w, 2, 25)
         elif w == 'video_micro':
             run_video('video_micro', 2, 31)

@@ -575,3 +575,30 @@ def test_random_path_configurations_vs_oracle():
             ran += 1
             bad += r
     assert ran >= 6 and not bad, bad[:8]
+
+
+@pytest.mark.parametrize('name', ['base_as', 'large'])
+def test_baseline_config_shapes_vs_oracle(name):
+    """BASELINE.json configs[2] (ViT-B, AudioSet-style fusion widths: attn_ratio 1.0, mlp_ratio 4.0) and configs[3] (ViT-L)
+    at their real widths and depths, B = 2 (the oracle needs a few seconds of host time): losses and every gradient."""
+    model, sd, cfg, O = _build(name)
+    image, audio, ni, na = O.synthetic_batch(cfg, 2, seed=25)
+    out = model(image.cuda(), audio.cuda(), torch.from_numpy(ni).cuda(), torch.from_numpy(na).cuda())
+    (out[0] + out[1]).backward()
+    sdo = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in sd.items()}
+    li, la, pi, pa, aux = O.avmae_forward(sdo, cfg, image, audio, ni, na)
+    (li + la).backward()
+    for k in ('image_ids_keep', 'audio_ids_keep', 'image_ids_restore', 'audio_ids_restore'):
+        assert np.array_equal(model._last_masks[k].cpu().numpy(), aux[k]), k
+    assert abs(float(out[0]) - float(li)) <= LOSS_RTOL * float(li) and abs(float(out[1]) - float(la)) <= LOSS_RTOL * float(la)
+    assert rel(out[2], pi) < ACT_TOL and rel(out[3], pa) < ACT_TOL
+    g_all = sum(float(v.grad.double().norm()) ** 2 for v in sdo.values() if v.grad is not None) ** 0.5
+    rels = []
+    for n, p in model.named_parameters():
+        if not p.requires_grad or n.endswith(ZERO_GRADS):
+            continue
+        ref = sdo[n].grad.double()
+        d = float((p.grad.detach().double().cpu() - ref).norm())
+        rels.append(d / max(float(ref.norm()), 1e-30))
+        assert d <= GRAD_TOL * float(ref.norm()) + 1e-4 * g_all, (n, d, float(ref.norm()))
+    assert np.median(rels) < ACT_TOL
