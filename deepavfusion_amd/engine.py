@@ -66,6 +66,10 @@ def wcache(p: torch.nn.Parameter, force: bool = False) -> torch.Tensor:
     if c is None:
         c = p.__dict__['_dav_cache'] = _WCache()
     if c.managed and not force:
+        if c.ver != p._version:        # written from the torch side (load_state_dict, p.copy_()) since the mirror was made:
+            ops.cast_bf16(p.detach().reshape(p.shape[0], -1), c.wb)      # the optimizer kernel's own updates keep it in sync
+            c.ver = p._version
+            p.__dict__['_dav_epoch'] = p.__dict__.get('_dav_epoch', 0) + 1     # transposed copies follow
         return c.wb
     ver, ptr = p._version, p.data_ptr()
     if force or c.wb is None or c.ver != ver or c.ptr != ptr:
@@ -92,11 +96,13 @@ def wcache_t(p: torch.nn.Parameter) -> torch.Tensor:
 
 
 def invalidate_weight_cache(params):
-    """Mark un-managed bf16 copies stale (fp32 masters changed behind torch's version counters)."""
+    """The fp32 masters changed behind torch's version counters (optimizer kernel, flat-buffer cast): un-managed bf16 copies
+    become stale; optimizer-managed mirrors were rewritten by the same kernel and are stamped in sync; transposed copies of
+    either kind are re-derived on next use."""
     for p in params:
         c = p.__dict__.get('_dav_cache')
         if c is not None:
-            c.ver = None
+            c.ver = p._version if c.managed else None
             p.__dict__['_dav_epoch'] = p.__dict__.get('_dav_epoch', 0) + 1
 
 
@@ -106,6 +112,7 @@ def adopt_weight_mirror(p: torch.nn.Parameter, view_bf16: torch.Tensor):
     if c is None:
         c = p.__dict__['_dav_cache'] = _WCache()
     c.wb, c.managed = view_bf16.view(p.shape[0], -1), True
+    c.ver = None                        # first use casts the current fp32 value into the mirror
 
 
 def refresh_weight_cache(module: torch.nn.Module):

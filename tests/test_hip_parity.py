@@ -602,3 +602,36 @@ def test_baseline_config_shapes_vs_oracle(name):
         rels.append(d / max(float(ref.norm()), 1e-30))
         assert d <= GRAD_TOL * float(ref.norm()) + 1e-4 * g_all, (n, d, float(ref.norm()))
     assert np.median(rels) < ACT_TOL
+
+
+def test_load_state_dict_after_optimizer_refreshes_the_bf16_mirror():
+    """With FlatAdamW the GEMMs read a bf16 mirror of the weights that the optimizer kernel maintains; weights written from
+    the torch side afterwards (load_state_dict without any explicit sync) must still be the ones the next forward uses."""
+    from deepavfusion_amd.util.flat import FlatAdamW
+    from oracle import avmae_oracle as O
+    from oracle.configs import CONFIGS as OC
+    model, sd, cfg, _ = _build('micro')
+    opt = FlatAdamW([{'params': [p for p in model.parameters() if p.requires_grad]}], lr=1e-3, model=model)
+    image, audio, ni, na = O.synthetic_batch(cfg, 2, seed=9)
+    args = (image.cuda(), audio.cuda(), torch.from_numpy(ni).cuda(), torch.from_numpy(na).cuda())
+    with torch.no_grad():
+        l0 = float(model(*args)[0])
+    sd2 = O.closed_form_state(OC['micro'], 5)                     # different weights, loaded the plain torch way
+    model.load_state_dict(sd2, strict=True)
+    with torch.no_grad():
+        l1 = float(model(*args)[0])
+    fresh, *_ = _build('micro')
+    fresh.load_state_dict(sd2, strict=True)
+    with torch.no_grad():
+        l2 = float(fresh(*args)[0])
+    assert abs(l1 - l2) <= 1e-6 * abs(l2) and abs(l1 - l0) > 1e-4
+    # and a step of the optimizer keeps mirror and masters together without extra casts
+    out = model(*args)
+    (out[0] + out[1]).backward()
+    opt.step()
+    with torch.no_grad():
+        l3 = float(model(*args)[0])
+    opt.sync_bf16()
+    with torch.no_grad():
+        l4 = float(model(*args)[0])
+    assert l3 == l4 and l3 != l1
