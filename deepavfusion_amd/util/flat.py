@@ -80,6 +80,8 @@ class FlatAdamW(torch.optim.Optimizer):
             if p.ndim >= 2 and p.shape[0] > 1:
                 engine.adopt_weight_mirror(p, self.flat_bf16[o:o + p.numel()])
         self.sync_bf16()
+        if model is not None:      # weights loaded later (also after a step was captured in a hipGraph) reach the mirror at once
+            model.register_load_state_dict_post_hook(lambda module, incompatible_keys: self.sync_bf16())
         self._group_of = {}
         for gi, g in enumerate(self.param_groups):
             for p in g['params']:
