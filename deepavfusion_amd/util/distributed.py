@@ -63,19 +63,46 @@ def setup_for_distributed(is_master, log_fn=None):
     builtins.print = print
 
 
+def _cfg_get(node, key, default=None):
+    try:
+        return getattr(node, key)
+    except (AttributeError, KeyError):
+        return default
+
+
+def _seed_everything(seed):
+    random.seed(seed)
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+
+
 def init_distributed_mode(local_rank, args, log_fn=None):
-    """util/distributed.py:66-100 with env:// support (torchrun) next to the reference's explicit dist_url."""
+    """util/distributed.py:66-100 with env:// support (torchrun) next to the reference's explicit dist_url.
+
+    A process group is created only when there really are peer processes: under ``torch.distributed.run``
+    (WORLD_SIZE > 1 in the environment) or when the launcher spawned one worker per GPU and says so through
+    ``env.spawned`` (train.py does that for ``env.ngpu > 1``, as the reference's launcher.py does).  A plain
+    ``python train.py`` on a multi-GPU host stays single-process on ``cuda:local_rank`` instead of waiting for
+    ranks nobody started.  The RNG streams are seeded on every path (the reference's ``distributed`` is true for any
+    GPU run, so its single-GPU runs are seeded too)."""
     ngpus = torch.cuda.device_count()
     env = args.env
-    env.distributed = ngpus > 0 and (env.world_size * max(ngpus, 1) > 1 or int(os.environ.get('WORLD_SIZE', '1')) > 1)
+    env_world = int(os.environ.get('WORLD_SIZE', '1'))
+    try:
+        spawned = bool(env.spawned)
+    except (AttributeError, KeyError):
+        spawned = False
+    env.distributed = ngpus > 0 and (env_world > 1 or (spawned and env.world_size * max(ngpus, 1) > 1))
     if not env.distributed:
         setup_for_distributed(is_master=True, log_fn=log_fn)
         env.world_size, env.rank = 1, 0
         if ngpus > 0:
             torch.cuda.set_device(local_rank)
+        if _cfg_get(env, 'seed') is not None:
+            _seed_everything(env.seed)
         return
-    if 'RANK' in os.environ and 'WORLD_SIZE' in os.environ:      # launched by torch.distributed.run
-        env.rank, env.world_size = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    if 'RANK' in os.environ and env_world > 1:                   # launched by torch.distributed.run
+        env.rank, env.world_size = int(os.environ['RANK']), env_world
         local_rank = int(os.environ.get('LOCAL_RANK', local_rank))
         url = 'env://'
     else:
@@ -83,14 +110,12 @@ def init_distributed_mode(local_rank, args, log_fn=None):
         env.rank = env.rank * ngpus + local_rank
         url = env.dist_url
     torch.cuda.set_device(local_rank)
-    dist.init_process_group(backend='nccl', init_method=url, world_size=env.world_size, rank=env.rank)
+    dist.init_process_group(backend='nccl', init_method=url, world_size=env.world_size, rank=env.rank,
+                            timeout=datetime.timedelta(seconds=int(os.environ.get('DAV_DIST_TIMEOUT_S', '1800'))))
     dist.barrier()
     setup_for_distributed(env.rank == 0, log_fn=log_fn)
-    if getattr(env, 'seed', None) is not None:
-        seed = env.seed + get_rank()          # per-rank stream -> different masks per rank (util/distributed.py:90-94)
-        random.seed(seed)
-        torch.manual_seed(seed)
-        np.random.seed(seed)
+    if _cfg_get(env, 'seed') is not None:
+        _seed_everything(env.seed + get_rank())   # per-rank stream -> different masks per rank (util/distributed.py:90-94)
 
 
 @torch.no_grad()
@@ -120,6 +145,9 @@ class GradReducer:
         self._launched = [False] * len(self.buckets)
         self._streams = [set() for _ in self.buckets]      # streams on which a bucket's gradients were finished
         self.enabled = True
+        # DDP semantics: whether a backward reduces its gradients is decided when its FORWARD runs (train.py wraps only the
+        # forward in no_sync(); the backward happens later in Trainer.step, outside the context manager)
+        self.sync_this_backward = True
         self.comm_stream = torch.cuda.Stream() if flat.flat_g.is_cuda else None
         self.launch_order: List[int] = []
         # ReduceOp.AVG is native in RCCL; probe it once and fall back to SUM + scale if this build rejects it
@@ -147,6 +175,7 @@ class GradReducer:
         return buckets
 
     def begin_backward(self):
+        self.sync_this_backward = self.enabled
         self._pending = [len(b[2]) for b in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._streams = [set() for _ in self.buckets]
@@ -155,7 +184,7 @@ class GradReducer:
     def grad_ready(self, p):
         """Engine hook: the last gradient kernel of ``p`` has been enqueued on the compute stream."""
         bi = self._bucket_of.get(id(p))
-        if bi is None or not self.enabled:
+        if bi is None or not self.sync_this_backward:
             return
         if self.comm_stream is not None:
             # the engine finishes gradients on several streams (towers / decoders run on their own): the reduction has
@@ -198,7 +227,7 @@ class GradReducer:
 
     def finish(self):
         """Launch whatever is still pending (in bucket order) and make the compute stream wait for the reductions."""
-        if not self.enabled:
+        if not self.sync_this_backward:
             return
         for bi in range(len(self.buckets)):
             if not self._launched[bi]:

@@ -83,8 +83,8 @@ class Trainer:
     def backward(self, loss, create_graph=False):
         loss.backward(create_graph=create_graph)
         self.accums += 1
-        if self.distributed and self.model.reducer.enabled:
-            self.model.reducer.finish()
+        if self.distributed:
+            self.model.reducer.finish()          # no-op when this backward's forward ran under no_sync()
         return self.grad_norm_tensor().item(), self.get_scale()
 
     def step(self, loss, create_graph=False, clip_grad=None, skip_grad=None):

@@ -167,3 +167,44 @@ def test_bucket_layout_follows_backward_order():
     red = GradReducer(flat, bucket_mb=1.0, first_bucket_mb=0.25)
     assert sum(len(b[2]) for b in red.buckets) == len(flat.params) and red.buckets[-1][1] == flat.total
     assert all(b[0] % 64 == 0 for b in red.buckets)
+
+
+def test_init_distributed_mode_single_process_on_multi_gpu_host(monkeypatch):
+    """``python train.py`` without a launcher on an 8-GPU host must NOT open a process group nobody else joins
+    (reference launcher.py spawns the ranks first; util/distributed.py:66-100 only then rendezvous) — and must still seed."""
+    import random
+    import torch
+    import torch.distributed as dist
+    from deepavfusion_amd.util import distributed as du
+
+    class NS(dict):
+        __getattr__ = dict.__getitem__
+        __setattr__ = dict.__setitem__
+    called = []
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 8)
+    monkeypatch.setattr(torch.cuda, 'set_device', lambda d: called.append(('set_device', d)))
+    monkeypatch.setattr(dist, 'init_process_group', lambda *a, **k: called.append(('init', k)))
+    monkeypatch.setattr(dist, 'barrier', lambda *a, **k: called.append(('barrier',)))
+    monkeypatch.setattr(du, 'setup_for_distributed', lambda *a, **k: None)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        monkeypatch.delenv(k, raising=False)
+    args = NS(env=NS(world_size=1, rank=0, dist_url='tcp://127.0.0.1:50000', seed=3, ngpu=1))
+    du.init_distributed_mode(0, args)
+    assert args.env.distributed is False and args.env.world_size == 1 and ('set_device', 0) in called
+    assert not any(c[0] == 'init' for c in called)
+    a = (random.random(), float(torch.rand(())))
+    du.init_distributed_mode(0, args)
+    assert a == (random.random(), float(torch.rand(())))                     # seeded on the single-process path too
+    # spawned by train.py (env.ngpu = 8): ranks exist -> rendezvous over dist_url with world 8, per-rank seed
+    called.clear()
+    args = NS(env=NS(world_size=1, rank=0, dist_url='tcp://127.0.0.1:50000', seed=3, ngpu=8, spawned=True))
+    du.init_distributed_mode(5, args)
+    init = [c for c in called if c[0] == 'init'][0][1]
+    assert args.env.distributed and init['world_size'] == 8 and init['rank'] == 5 and init['backend'] == 'nccl'
+    # torch.distributed.run: env:// with the launcher's ranks
+    called.clear()
+    monkeypatch.setenv('WORLD_SIZE', '4'); monkeypatch.setenv('RANK', '2'); monkeypatch.setenv('LOCAL_RANK', '2')
+    args = NS(env=NS(world_size=1, rank=0, dist_url='tcp://127.0.0.1:50000', seed=None, ngpu=4))
+    du.init_distributed_mode(0, args)
+    init = [c for c in called if c[0] == 'init'][0][1]
+    assert init['init_method'] == 'env://' and init['world_size'] == 4 and init['rank'] == 2 and ('set_device', 2) in called

@@ -1,5 +1,6 @@
 """CPU, world_size 2 over gloo: the bucketed gradient reducer (the DDP replacement of util/misc.py:32-34)
 averages the flat gradient buffer, launches buckets in the same order on every rank, honours no_sync()."""
+import datetime
 import os
 import socket
 
@@ -18,7 +19,7 @@ def _free_port():
 
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     from deepavfusion_amd.util.distributed import DataParallel, get_rank, get_world_size
     from deepavfusion_amd.util.flat import FlatParams
     torch.manual_seed(100 + rank)                     # different init per rank: the wrapper must broadcast rank 0's
@@ -54,6 +55,25 @@ def _worker(rank, world, port, q):
     fake_backward(2.0)
     for i, p in enumerate(flat.params):
         assert torch.allclose(p.grad, torch.full_like(p, 3.0 * mean_rank * (i + 1)))
+    # the train.py pattern (train.py:166-170 of the reference): only the FORWARD sits inside no_sync(), the backward runs
+    # later in Trainer.step — the sync decision must have been latched at forward time, as DistributedDataParallel does
+    flat.zero_grad()
+    with dp.no_sync():
+        dp.reducer.begin_backward()                   # = DataParallel.forward
+    for i, p in enumerate(flat.params):
+        p.grad.add_(torch.full_like(p, float((rank + 1) * (i + 1))))
+        dp.reducer.grad_ready(p)
+    dp.reducer.finish()
+    assert dp.reducer.launch_order == []              # nothing was reduced
+    for i, p in enumerate(flat.params):
+        assert torch.allclose(p.grad, torch.full_like(p, float((rank + 1) * (i + 1))))
+    dp.reducer.begin_backward()                       # next micro-step, forward outside no_sync(): reduces the sum
+    for i, p in enumerate(flat.params):
+        p.grad.add_(torch.full_like(p, 2.0 * (rank + 1) * (i + 1)))
+        dp.reducer.grad_ready(p)
+    dp.reducer.finish()
+    for i, p in enumerate(flat.params):
+        assert torch.allclose(p.grad, torch.full_like(p, 3.0 * mean_rank * (i + 1)))
     # N-rank averaged gradients == single-process gradient of the concatenated batch (mean loss)
     flat.zero_grad()
     torch.manual_seed(7)
@@ -78,9 +98,18 @@ def test_grad_reducer_world2_gloo():
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
+        p.daemon = True
         p.start()
-    for p in procs:
-        p.join(timeout=180)
-        assert p.exitcode == 0
+    try:
+        for p in procs:
+            p.join(timeout=180)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:                               # never leave a worker behind: pytest must always be able to exit
+            if p.is_alive():
+                p.terminate()
+                p.join(5)
+                if p.is_alive():
+                    p.kill()
     res = dict(q.get(timeout=5) for _ in range(world))
     assert res[0] == res[1]          # identical collective order on every rank

@@ -195,6 +195,24 @@ def test_video_long_sequences_vs_oracle():
     _check_video_grads(model, sdo)
 
 
+def test_baseline_config_video_base_vs_oracle():
+    """BASELINE.json configs[4] at its REAL widths: ``video_efav_base`` (ViT-B, depth 12, 12 heads; reference
+    models/video_earlyfusion.py:134-171) on the 8-frame 224x224 clip + 3 s of audio, 784 + 32 rows per clip, B = 1."""
+    model, sd, cfg, O = _build_video('video_base')
+    video, audio = O.synthetic_video_batch(cfg, 1, seed=44)
+    outs = model(video.cuda(), audio.cuda())
+    w, loss = _probe(outs, 45)
+    loss.backward()
+    sdo = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in sd.items()}
+    ov = O.video_earlyfusion_forward(sdo, cfg, video, audio)
+    ref = sum((t * wi).sum() for t, wi in zip(ov, w))
+    ref.backward()
+    for got, r in zip(outs, ov):
+        assert rel(got, r) < ACT_TOL
+    assert abs(float(loss) - float(ref)) <= 1e-2 * abs(float(ref)) + 1e-2 * float(sum(float((t * t).sum()) for t in ov) ** 0.5)
+    _check_video_grads(model, sdo)
+
+
 def test_drop_path_training_mode_vs_oracle_and_golden(golden):
     """drop_path > 0 in training mode (fine-tuning constructor surface): per-sample scaled residual
     branches forward, scaled branch gradients backward, masks injected through the sampler hook."""
@@ -577,12 +595,13 @@ def test_random_path_configurations_vs_oracle():
     assert ran >= 6 and not bad, bad[:8]
 
 
-@pytest.mark.parametrize('name', ['base_as', 'large'])
-def test_baseline_config_shapes_vs_oracle(name):
-    """BASELINE.json configs[2] (ViT-B, AudioSet-style fusion widths: attn_ratio 1.0, mlp_ratio 4.0) and configs[3] (ViT-L)
-    at their real widths and depths, B = 2 (the oracle needs a few seconds of host time): losses and every gradient."""
+@pytest.mark.parametrize('name,batch', [('base', 4), ('base_as', 2), ('large', 2)])
+def test_baseline_config_shapes_vs_oracle(name, batch):
+    """BASELINE.json configs[1] (ViT-B, attn_ratio 0.25 / mlp_ratio 1.0: the bench workload's model), configs[2] (ViT-B,
+    AudioSet-style fusion widths: attn_ratio 1.0, mlp_ratio 4.0) and configs[3] (ViT-L) at their real widths and depths, at
+    small batches (the oracle needs seconds of host time): masking indices, losses and every gradient."""
     model, sd, cfg, O = _build(name)
-    image, audio, ni, na = O.synthetic_batch(cfg, 2, seed=25)
+    image, audio, ni, na = O.synthetic_batch(cfg, batch, seed=25)
     out = model(image.cuda(), audio.cuda(), torch.from_numpy(ni).cuda(), torch.from_numpy(na).cuda())
     (out[0] + out[1]).backward()
     sdo = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in sd.items()}

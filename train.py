@@ -136,7 +136,9 @@ def main_worker(local_rank, args):
                                         save_freq=args.log.save_freq)
     start_epoch = ckpt.resume()[0] if args.opt.resume else 0
     graphed = None
-    if args.opt.get('graph', False) and args.opt.accum_iter == 1:
+    if args.opt.get('graph', False) and args.opt.clip_grad is not None:
+        print('opt.clip_grad is set: the captured step does not clip, running eager launches instead (opt.graph ignored)')
+    elif args.opt.get('graph', False) and args.opt.accum_iter == 1:
         B = args.opt.batch_size
         graphed = misc_utils.GraphedStep(trainer, (B, 3, *image_size), (B, 1, *audio_size))
 
@@ -181,6 +183,26 @@ def train_one_epoch(loader, trainer, epoch, device, args, graphed=None):
     trainer.zero_grad()
 
 
+def _spawned_worker(local_rank, cfg_dict):
+    main_worker(local_rank, _wrap(cfg_dict))
+
+
+def main(argv):
+    """launcher.py:63-72 of the reference: one worker per GPU.  Under torch.distributed.run the ranks already exist;
+    a plain ``python train.py env.ngpu=N`` (N > 1) spawns them itself; N == 1 runs in this process, no process group."""
+    cfg = load_config('deepavfusion', [a for a in argv if '=' in a])
+    under_torchrun = int(os.environ.get('WORLD_SIZE', '1')) > 1
+    ngpu = int(cfg.env.ngpu or 1)
+    if under_torchrun or ngpu <= 1:
+        return main_worker(int(os.environ.get('LOCAL_RANK', '0')), cfg)
+    cfg.env.spawned = True
+    import torch.multiprocessing as mp
+    mp.spawn(_spawned_worker, args=(_to_plain(cfg),), nprocs=ngpu)       # children start before anything touches the GPU here
+
+
+def _to_plain(x):
+    return {k: _to_plain(v) for k, v in x.items()} if isinstance(x, dict) else x
+
+
 if __name__ == '__main__':
-    cfg = load_config('deepavfusion', [a for a in sys.argv[1:] if '=' in a])
-    main_worker(int(os.environ.get('LOCAL_RANK', '0')), cfg)
+    main(sys.argv[1:])
