@@ -50,6 +50,11 @@ SIGNATURES = {
     'dav_cast_transpose_bf16': [_p, _p, _i, _i, _p],
     'dav_l2norm_workspace_bytes': [_l],
     'dav_l2norm': [_p, _l, _f, _p, _p, _sz, _p],
+    'dav_batch_begin': [_i],
+    'dav_batch_lane': [],
+    'dav_batch_end': [],
+    'dav_batch_abort': [],
+    'dav_batch_stats': [_p, _p],
     'dav_adamw_flat': [_p, _p, _p, _p, _p, _l, _p, _p, _i, _f, _f, _f, _p, _f, _p, _i, _p],
 }
 

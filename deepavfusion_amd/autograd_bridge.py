@@ -34,6 +34,12 @@ def _streams(dev):
     return main, sa, sf
 
 
+def _batched():
+    """Launch batching (engine.batch, csrc/batch.h) for the paired tower blocks / decoders; DAV_BATCH=0 restores one HIP
+    stream per tower instead."""
+    return os.environ.get('DAV_BATCH', '1') != '0'
+
+
 def _f32c(x):
     return x.detach().to(dtype=F32).contiguous()
 
@@ -80,27 +86,43 @@ def encoder_fwd(enc, image, audio, ik32, ak32, want_f32=False, collect_embs=Fals
     Hi, Ha, Hf = vis.num_heads, enc.audio.num_heads, enc.fusion_num_heads
     layers, embs = [], []
     main, sa, sf = _streams(image.device)
+    batched = _batched()
     for l, (bi, ba, fb) in enumerate(zip(vis.blocks, enc.audio.blocks, enc.fusion_blocks)):
-        sa.wait_stream(main)
-        sf.wait_stream(main)
-        if fb is None:
-            dpi, dpa = drop_path_scales(enc, bi, B, image.device, f'visual.{l}'), drop_path_scales(enc, ba, B, image.device, f'audio.{l}')
-            with torch.cuda.stream(sa):
-                x_a, ta = E.block_fwd(ba, x_a, None, Ha, ba.norm1.eps, dpa)
-            x_i, ti = E.block_fwd(bi, x_i, None, Hi, bi.norm1.eps, dpi)
-            tf = None
+        # the reference draws in call order: visual block (attn, mlp), audio block, fusion block (:104-106)
+        dpi, dpa = drop_path_scales(enc, bi, B, image.device, f'visual.{l}'), drop_path_scales(enc, ba, B, image.device, f'audio.{l}')
+        dpf = drop_path_scales(enc, fb, B, image.device, f'fusion.{l}') if fb is not None else None
+        xf_ctx = x_f if fb is not None else None
+        tf = None
+        if batched:
+            # fusion block beside the towers (side stream); the two tower blocks as two lanes of ONE launch batch: their
+            # LayerNorms / GEMMs / attentions of equal rank go out as grouped grids on the main stream
+            if fb is not None:
+                sf.wait_stream(main)
+                with torch.cuda.stream(sf):
+                    n_f, tf = E.fusion_block_fwd(fb, x_f, x_i, x_a, Hf, enc.num_fusion, dpf)  # reads the layer INPUT x_i / x_a (:106-107)
+            with E.batch() as bt:
+                bt.lane()
+                n_i, ti = E.block_fwd(bi, x_i, xf_ctx, Hi, bi.norm1.eps, dpi)
+                bt.lane()
+                n_a, ta = E.block_fwd(ba, x_a, xf_ctx, Ha, ba.norm1.eps, dpa)
+            if fb is not None:
+                main.wait_stream(sf)
+                x_f = n_f
+            x_i, x_a = n_i, n_a
         else:
-            # the reference draws in call order: visual block (attn, mlp), audio block, fusion block (:104-106)
-            dpi, dpa = drop_path_scales(enc, bi, B, image.device, f'visual.{l}'), drop_path_scales(enc, ba, B, image.device, f'audio.{l}')
-            dpf = drop_path_scales(enc, fb, B, image.device, f'fusion.{l}')
+            sa.wait_stream(main)
+            sf.wait_stream(main)
             with torch.cuda.stream(sa):
-                n_a, ta = E.block_fwd(ba, x_a, x_f, Ha, ba.norm1.eps, dpa)
-            with torch.cuda.stream(sf):
-                n_f, tf = E.fusion_block_fwd(fb, x_f, x_i, x_a, Hf, enc.num_fusion, dpf)  # reads the layer INPUT x_i / x_a (:106-107)
-            n_i, ti = E.block_fwd(bi, x_i, x_f, Hi, bi.norm1.eps, dpi)
-            x_i, x_a, x_f = n_i, n_a, n_f
-        main.wait_stream(sa)
-        main.wait_stream(sf)
+                n_a, ta = E.block_fwd(ba, x_a, xf_ctx, Ha, ba.norm1.eps, dpa)
+            if fb is not None:
+                with torch.cuda.stream(sf):
+                    n_f, tf = E.fusion_block_fwd(fb, x_f, x_i, x_a, Hf, enc.num_fusion, dpf)
+            n_i, ti = E.block_fwd(bi, x_i, xf_ctx, Hi, bi.norm1.eps, dpi)
+            x_i, x_a = n_i, n_a
+            if fb is not None:
+                x_f = n_f
+            main.wait_stream(sa)
+            main.wait_stream(sf)
         layers.append((ti, ta, tf))
         if collect_embs:
             embs.append((x_i, x_a, x_f))
@@ -135,21 +157,48 @@ def _encoder_bwd(enc, t, dxi_b, dxa_b, dxf_b, dxi32, dxa32, dxf32, layer_cb=None
     g_f, g_fb = final_norm(enc.fusion_norm, t['x_f'], t['st_f'], dxf_b, dxf32)
     blocks = list(zip(vis.blocks, enc.audio.blocks, enc.fusion_blocks))
     main, sa, sf = _streams(dev)
+    batched = _batched()
     for l, ((bi, ba, fb), (ti, ta, tf)) in reversed(list(enumerate(zip(blocks, t['layers'])))):
-        sa.wait_stream(main)
-        sf.wait_stream(main)
         # Memory lifetime across streams: the gradients entering this layer were allocated on one stream (main for the
         # final norms, the fusion / audio stream further down) and are READ by kernels of another.  Dropping the last
         # reference hands the block back to the allocating stream's pool at once, and a later allocation on THAT stream
         # could overwrite it while the reader (concurrent in the captured graph) has not run yet.  So everything consumed
-        # here stays referenced until all three streams have re-joined.
+        # here stays referenced until all streams have re-joined.
         hold = (g_i, g_ib, g_a, g_ab, g_f, g_fb)
-        if fb is None:
+        if batched:
+            # the fusion block's backward (many small kernels) on the side stream; the two tower blocks as two lanes of a
+            # launch batch on the main stream.  Their last kernel — the norm1 backward — accumulates into the buffers the
+            # fusion block's backward produces, so the batch is cut in front of it and the main stream waits there.
+            dx_f = dx_i = dx_a = None
+            if fb is not None:
+                sf.wait_stream(main)
+                with torch.cuda.stream(sf):
+                    dx_f, dx_i, dx_a = E.fusion_block_bwd(fb, tf, g_f, g_fb)
+            with E.batch() as bt:
+                bt.lane()
+                st_i = E.block_bwd_head(bi, ti, g_i, g_ib)
+                bt.lane()
+                st_a = E.block_bwd_head(ba, ta, g_a, g_ab)
+            if fb is not None:
+                main.wait_stream(sf)
+            acc = 1 if fb is not None else 0
+            with E.batch() as bt:
+                bt.lane()
+                g_i, g_ib, dxf_i = E.block_bwd_tail(bi, ti, st_i, dx_fus=dx_f, dx_fus_acc=acc, dx_mod=dx_i, dx_mod_acc=acc)
+                bt.lane()
+                g_a, g_ab, dxf_a = E.block_bwd_tail(ba, ta, st_a, dx_mod=dx_a, dx_mod_acc=acc)
+            if fb is not None:
+                g_f, g_fb = dxf_i.add_(dxf_a), None
+            del st_i, st_a
+        elif fb is None:
+            sa.wait_stream(main)
             with torch.cuda.stream(sa):
                 g_a, g_ab, _ = E.block_bwd(ba, ta, g_a, g_ab)
             g_i, g_ib, _ = E.block_bwd(bi, ti, g_i, g_ib)
             main.wait_stream(sa)
         else:
+            sa.wait_stream(main)
+            sf.wait_stream(main)
             # the fusion block's backward (many tiny kernels) runs beside the two tower blocks; their last
             # LayerNorm backward accumulates into the buffers it produces, so that kernel waits for it
             with torch.cuda.stream(sf):
@@ -263,13 +312,22 @@ def avmae_fwd(model, image, audio, noise_i, noise_a):
     nF = enc.fusion_tokens.shape[1]
     dec_i, dec_a = model.decoder('image'), model.decoder('audio')
     main, sa, _ = _streams(image.device)
-    sa.wait_stream(main)
-    with torch.cuda.stream(sa):
-        pred_a, t_da = E.decoder_fwd(dec_a, xa_b, xf_b, ar32, B, nka, nF)
-        loss_a, t_la = E.loss_fwd(audio, pred_a, am, model.audio_norm_loss)
-    pred_i, t_di = E.decoder_fwd(dec_i, xi_b, xf_b, ir32, B, nki, nF)
-    loss_i, t_li = E.loss_fwd(image, pred_i, im, model.image_norm_loss)
-    main.wait_stream(sa)
+    if _batched():
+        with E.batch() as bt:                 # the two MAE decoders (models/avmae.py:147-180) in lockstep
+            bt.lane()
+            pred_i, t_di = E.decoder_fwd(dec_i, xi_b, xf_b, ir32, B, nki, nF)
+            loss_i, t_li = E.loss_fwd(image, pred_i, im, model.image_norm_loss)
+            bt.lane()
+            pred_a, t_da = E.decoder_fwd(dec_a, xa_b, xf_b, ar32, B, nka, nF)
+            loss_a, t_la = E.loss_fwd(audio, pred_a, am, model.audio_norm_loss)
+    else:
+        sa.wait_stream(main)
+        with torch.cuda.stream(sa):
+            pred_a, t_da = E.decoder_fwd(dec_a, xa_b, xf_b, ar32, B, nka, nF)
+            loss_a, t_la = E.loss_fwd(audio, pred_a, am, model.audio_norm_loss)
+        pred_i, t_di = E.decoder_fwd(dec_i, xi_b, xf_b, ir32, B, nki, nF)
+        loss_i, t_li = E.loss_fwd(image, pred_i, im, model.image_norm_loss)
+        main.wait_stream(sa)
     tape = dict(image=image, audio=audio, im=im, am=am, ik32=ik32, ak32=ak32, t_enc=t_enc, t_di=t_di, t_da=t_da, t_li=t_li,
                 t_la=t_la, pred_i=pred_i, pred_a=pred_a, B=B)
     aux = dict(image_ids_keep=ik, image_mask=im, image_ids_restore=ir, audio_ids_keep=ak, audio_mask=am, audio_ids_restore=ar)
@@ -280,19 +338,33 @@ def avmae_bwd(model, t, g_li, g_la, g_pi=None, g_pa=None, layer_cb=None):
     B = t['B']
     dec_i, dec_a = model.decoder('image'), model.decoder('audio')
     main, sa, _ = _streams(t['image'].device)
-    sa.wait_stream(main)
-    # each decoder's weight gradients are queued and launched as ONE grouped GEMM on that decoder's stream
-    with torch.cuda.stream(sa), E.deferred_wgrads():
-        dpa = E.loss_bwd(t['audio'], t['pred_a'], t['am'], t['t_la'], g_la)
-        if g_pa is not None:
-            dpa = (dpa.float() + g_pa.reshape(dpa.shape)).to(BF16)
-        dxa_b, dxf_a = E.decoder_bwd(dec_a, t['t_da'], dpa, t['ak32'], B)
-    with E.deferred_wgrads():
+    if _batched():
         dpi = E.loss_bwd(t['image'], t['pred_i'], t['im'], t['t_li'], g_li)
+        dpa = E.loss_bwd(t['audio'], t['pred_a'], t['am'], t['t_la'], g_la)
         if g_pi is not None:
             dpi = (dpi.float() + g_pi.reshape(dpi.shape)).to(BF16)
-        dxi_b, dxf_i = E.decoder_bwd(dec_i, t['t_di'], dpi, t['ik32'], B)
-    main.wait_stream(sa)
+        if g_pa is not None:
+            dpa = (dpa.float() + g_pa.reshape(dpa.shape)).to(BF16)
+        with E.deferred_wgrads():             # both decoders' weight gradients: ONE grouped GEMM after the batch
+            with E.batch() as bt:
+                bt.lane()
+                dxi_b, dxf_i = E.decoder_bwd(dec_i, t['t_di'], dpi, t['ik32'], B)
+                bt.lane()
+                dxa_b, dxf_a = E.decoder_bwd(dec_a, t['t_da'], dpa, t['ak32'], B)
+    else:
+        sa.wait_stream(main)
+        # each decoder's weight gradients are queued and launched as ONE grouped GEMM on that decoder's stream
+        with torch.cuda.stream(sa), E.deferred_wgrads():
+            dpa = E.loss_bwd(t['audio'], t['pred_a'], t['am'], t['t_la'], g_la)
+            if g_pa is not None:
+                dpa = (dpa.float() + g_pa.reshape(dpa.shape)).to(BF16)
+            dxa_b, dxf_a = E.decoder_bwd(dec_a, t['t_da'], dpa, t['ak32'], B)
+        with E.deferred_wgrads():
+            dpi = E.loss_bwd(t['image'], t['pred_i'], t['im'], t['t_li'], g_li)
+            if g_pi is not None:
+                dpi = (dpi.float() + g_pi.reshape(dpi.shape)).to(BF16)
+            dxi_b, dxf_i = E.decoder_bwd(dec_i, t['t_di'], dpi, t['ik32'], B)
+        main.wait_stream(sa)
     dxf32 = dxf_i.float() + dxf_a.float()            # both decoders read the same normed fusion tokens
     if layer_cb is not None:
         layer_cb(len(model.encoder.fusion_blocks))    # both decoders' backward done (streams joined): a legal graph cut

@@ -121,7 +121,7 @@ __device__ __forceinline__ float rows_max(float x) {
 }
 
 template <int DQK, int DV, bool CHUNKED, int QT>
-__global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
+__device__ __forceinline__ void attn_fwd_body(const AttnParams& p, const int bh, const int ychunk) {
   constexpr int DQKP = DQK < 32 ? 32 : DQK, KRB = DQKP * 2, KS = DQKP / 32, VC = DV / 16, DVP = DV < 32 ? 32 : DV;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int Nkp = (p.Nk + 31) & ~31;
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
   char* Ks = smem;                 // [CH][DQKP]
   char* Vs = smem + CH * KRB;      // [CH][DV]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  const int b = bh / p.H, h = bh % p.H;
   const int fr = lane & 15, g = lane >> 4;
   const bf16_t* Kg = p.K + b * p.k_bs + h * DQK;
   const bf16_t* Vg = p.V + b * p.v_bs + h * DV;
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
   // A wave works on QT query tiles at once (independent softmax chains for the scheduler to interleave; every K / V
   // fragment read from LDS feeds QT MFMAs).  Chunked: exactly one (possibly out-of-range, then fully masked-off)
   // group per wave so that every wave reaches the chunk barriers.
-  for (int qt = (CHUNKED ? blockIdx.y * nw + wave : wave) * QT; CHUNKED ? qt >= 0 : qt < nqt; qt = CHUNKED ? -1 : qt + nw * QT) {
+  for (int qt = (CHUNKED ? ychunk * nw + wave : wave) * QT; CHUNKED ? qt >= 0 : qt < nqt; qt = CHUNKED ? -1 : qt + nw * QT) {
     bool qok[QT];
     bf16x8 qf[QT][KS];
     float m[QT], lsum[QT];             // m: reference max in the log2 domain
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
 // backward, part 1: dQ (waves own query tiles) + delta
 // ------------------------------------------------------------------------------------------------
 template <int DQK, int DV, bool CHUNKED>
-__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
+__device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int bh, const int ychunk) {
   constexpr int DQKP = DQK < 32 ? 32 : DQK, KRB = DQKP * 2, KS = DQKP / 32, DVP = DV < 32 ? 32 : DV, VRB = DVP * 2, VS = DVP / 32, QC = DQK / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int Nkp = (p.Nk + 31) & ~31;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
   char* Ks = smem;                   // [CH][DQKP]
   char* Vs = Ks + CH * KRB;          // [CH][DV]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  const int b = bh / p.H, h = bh % p.H;
   const int fr = lane & 15, g = lane >> 4;
   const bf16_t* Kg = p.K + b * p.k_bs + h * DQK;
   const bf16_t* Vg = p.V + b * p.v_bs + h * DV;
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
   }
 
   const int nqt = (p.Nq + 15) >> 4;
-  for (int qt = CHUNKED ? blockIdx.y * nw + wave : wave; CHUNKED ? qt >= 0 : qt < nqt; qt = CHUNKED ? -1 : qt + nw) {
+  for (int qt = CHUNKED ? ychunk * nw + wave : wave; CHUNKED ? qt >= 0 : qt < nqt; qt = CHUNKED ? -1 : qt + nw) {
     const int q = qt * 16 + fr;
     const bool qok = q < p.Nq;
     const int qc = qok ? q : p.Nq - 1;
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
 // backward, part 2: dK, dV (waves own key tiles)
 // ------------------------------------------------------------------------------------------------
 template <int DQK, int DV, bool CHUNKED>
-__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
+__device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int bh, const int ychunk) {
   constexpr int DQKP = DQK < 32 ? 32 : DQK, QRB = DQKP * 2, KS = DQKP / 32, DVP = DV < 32 ? 32 : DV, ORB = DVP * 2, VS = DVP / 32, QC = DQK / 16, VC = DV / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int Nqp = (p.Nq + 31) & ~31;
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
   float* lse_s = reinterpret_cast<float*>(dOs + CH * ORB);        // [CH]
   float* del_s = lse_s + CH;                                      // [CH]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  const int b = bh / p.H, h = bh % p.H;
   const int fr = lane & 15, g = lane >> 4;
   const bf16_t* Qg = p.Q + b * p.q_bs + h * DQK;
   const bf16_t* dOg = p.dO + b * p.do_bs + h * DV;
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
 
   const float sl2 = p.scale * 1.44269504088896341f;
   const int nkt = (p.Nk + 15) >> 4;
-  for (int kt = CHUNKED ? blockIdx.y * nw + wave : wave; CHUNKED ? kt >= 0 : kt < nkt; kt = CHUNKED ? -1 : kt + nw) {
+  for (int kt = CHUNKED ? ychunk * nw + wave : wave; CHUNKED ? kt >= 0 : kt < nkt; kt = CHUNKED ? -1 : kt + nw) {
     const int key = kt * 16 + fr;
     const bool kok = key < p.Nk;
     const int kc = kok ? key : p.Nk - 1;
@@ -477,6 +477,38 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
   }
 }
 
+// ---- kernels: one grid per problem, or (resident variants) several problems in one grid (batch.h) ------------------
+template <int DQK, int DV, bool CHUNKED, int QT>
+__global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
+  attn_fwd_body<DQK, DV, CHUNKED, QT>(p, blockIdx.x, blockIdx.y);
+}
+template <int DQK, int DV, bool CHUNKED>
+__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
+  attn_bwd_dq_body<DQK, DV, CHUNKED>(p, blockIdx.x, blockIdx.y);
+}
+template <int DQK, int DV, bool CHUNKED>
+__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
+  attn_bwd_dkv_body<DQK, DV, CHUNKED>(p, blockIdx.x, blockIdx.y);
+}
+
+constexpr int ATTN_GROUP_MAX = 8;
+struct AttnGroup {
+  AttnParams prob[ATTN_GROUP_MAX];
+  int first_block[ATTN_GROUP_MAX + 1];
+  int count;
+};
+// WHICH: 0 forward, 1 dQ, 2 dK/dV.  The workgroup size is the largest any problem of the group asks for: the
+// surplus waves of a smaller problem stage tiles and then find no tile of their own.
+template <int DQK, int DV, int WHICH>
+__global__ __launch_bounds__(512) void attn_grouped_kernel(const AttnGroup g) {
+  int pi = 0;
+  while (pi + 1 < g.count && (int)blockIdx.x >= g.first_block[pi + 1]) ++pi;
+  const int bh = (int)blockIdx.x - g.first_block[pi];
+  if (WHICH == 0) attn_fwd_body<DQK, DV, false, 1>(g.prob[pi], bh, 0);
+  else if (WHICH == 1) attn_bwd_dq_body<DQK, DV, false>(g.prob[pi], bh, 0);
+  else attn_bwd_dkv_body<DQK, DV, false>(g.prob[pi], bh, 0);
+}
+
 template <int DQK> constexpr int padqk() { return DQK < 32 ? 32 : DQK; }      // LDS columns of a q/k (or v/dO) row
 
 // resident-in-LDS variant up to this many bytes (2 workgroups per CU), chunked beyond
@@ -494,18 +526,77 @@ int raise_lds_cap(size_t lds) {
 
 inline int waves_for(int rows) { int nw = (rows + 15) / 16; return nw > 8 ? 8 : (nw < 1 ? 1 : nw); }
 
+// geometry of the resident (all keys / all queries of a head in LDS) variants
+template <int DQK, int DV> constexpr size_t attn_row_bytes() { return (size_t)padqk<DQK>() * 2 + (size_t)padqk<DV>() * 2; }
+template <int DQK, int DV, int WHICH> size_t attn_lds(const AttnParams& p) {
+  const int Nkp = (p.Nk + 31) & ~31, Nqp = (p.Nq + 31) & ~31;
+  return WHICH == 2 ? Nqp * (attn_row_bytes<DQK, DV>() + 8) : Nkp * attn_row_bytes<DQK, DV>();
+}
+template <int WHICH> int attn_waves(const AttnParams& p) { return waves_for(WHICH == 2 ? p.Nk : p.Nq); }
+
+// issues n >= 1 recorded resident-variant problems of one (head widths, pass) family: davb::GroupFn
+template <int DQK, int DV, int WHICH>
+void attn_issue(const void* const* params, int n, hipStream_t stream) {
+  auto single = [&](const AttnParams& p) {
+    const size_t lds = attn_lds<DQK, DV, WHICH>(p);
+    const int nw = attn_waves<WHICH>(p);
+    if (WHICH == 0) {
+      (void)raise_lds_cap<attn_fwd_kernel<DQK, DV, false, 1>>(lds);
+      DAV_LAUNCH_NOW((attn_fwd_kernel<DQK, DV, false, 1>), dim3(p.B * p.H), dim3(nw * 64), lds, stream, p);
+    } else if (WHICH == 1) {
+      (void)raise_lds_cap<attn_bwd_dq_kernel<DQK, DV, false>>(lds);
+      DAV_LAUNCH_NOW((attn_bwd_dq_kernel<DQK, DV, false>), dim3(p.B * p.H), dim3(nw * 64), lds, stream, p);
+    } else {
+      (void)raise_lds_cap<attn_bwd_dkv_kernel<DQK, DV, false>>(lds);
+      DAV_LAUNCH_NOW((attn_bwd_dkv_kernel<DQK, DV, false>), dim3(p.B * p.H), dim3(nw * 64), lds, stream, p);
+    }
+  };
+  for (int base = 0; base < n; base += ATTN_GROUP_MAX) {
+    const int cnt = n - base < ATTN_GROUP_MAX ? n - base : ATTN_GROUP_MAX;
+    if (cnt == 1) {
+      single(*(const AttnParams*)params[base]);
+      continue;
+    }
+    AttnGroup g;
+    int first = 0, nw = 1;
+    size_t lds = 0;
+    for (int i = 0; i < cnt; ++i) {
+      g.prob[i] = *(const AttnParams*)params[base + i];
+      const size_t l = attn_lds<DQK, DV, WHICH>(g.prob[i]);
+      lds = l > lds ? l : lds;
+      const int w = attn_waves<WHICH>(g.prob[i]);
+      nw = w > nw ? w : nw;
+      g.first_block[i] = first;
+      first += g.prob[i].B * g.prob[i].H;
+    }
+    g.first_block[cnt] = first;
+    g.count = cnt;
+    (void)raise_lds_cap<attn_grouped_kernel<DQK, DV, WHICH>>(lds);
+    DAV_LAUNCH_NOW((attn_grouped_kernel<DQK, DV, WHICH>), dim3(first), dim3(nw * 64), lds, stream, g);
+  }
+}
+
+template <int DQK, int DV, int WHICH>
+void attn_resident(const AttnParams& p, hipStream_t stream) {
+  if (davb::recording()) {
+    davb::push_typed(attn_issue<DQK, DV, WHICH>, &p, sizeof(p), stream);
+    return;
+  }
+  const void* one = &p;
+  attn_issue<DQK, DV, WHICH>(&one, 1, stream);
+}
+
 template <int DQK, int DV>
 int launch_fwd(const AttnParams& p, hipStream_t stream) {
-  const int Nkp = (p.Nk + 31) & ~31;
-  const size_t row = (size_t)padqk<DQK>() * 2 + (size_t)padqk<DV>() * 2;
-  const size_t lds = Nkp * row;
+  const size_t row = attn_row_bytes<DQK, DV>();
+  const size_t lds = attn_lds<DQK, DV, 0>(p);
   const bool two = dav_attn_qt == 2 || (dav_attn_qt == 0 && p.Nq >= 1024);      // two query tiles per wave
   const int nw = waves_for(two ? (p.Nq + 1) / 2 : p.Nq);
-  if (lds <= ATTN_RESIDENT_MAX) {
-    auto kern = two ? attn_fwd_kernel<DQK, DV, false, 2> : attn_fwd_kernel<DQK, DV, false, 1>;
-    if (int rc = raise_lds_cap<attn_fwd_kernel<DQK, DV, false, 1>>(lds)) return rc;
+  if (lds <= ATTN_RESIDENT_MAX && !two) {
+    attn_resident<DQK, DV, 0>(p, stream);
+  } else if (lds <= ATTN_RESIDENT_MAX) {
     if (int rc = raise_lds_cap<attn_fwd_kernel<DQK, DV, false, 2>>(lds)) return rc;
-    DAV_LAUNCH(kern, dim3(p.B * p.H), dim3(nw * 64), lds, stream, p);
+    DAV_LAUNCH((attn_fwd_kernel<DQK, DV, false, 2>), dim3(p.B * p.H), dim3(nw * 64), lds, stream, p);
   } else {
     auto kern = two ? attn_fwd_kernel<DQK, DV, true, 2> : attn_fwd_kernel<DQK, DV, true, 1>;
     const size_t ldc = ATTN_CHUNK * row;
@@ -519,15 +610,12 @@ int launch_fwd(const AttnParams& p, hipStream_t stream) {
 
 template <int DQK, int DV>
 int launch_bwd(const AttnParams& p, hipStream_t stream) {
-  const int Nkp = (p.Nk + 31) & ~31, Nqp = (p.Nq + 31) & ~31;
-  const size_t row = (size_t)padqk<DQK>() * 2 + (size_t)padqk<DV>() * 2;
-  const size_t lds1 = Nkp * row, lds2 = Nqp * (row + 8);
+  const size_t row = attn_row_bytes<DQK, DV>();
+  const size_t lds1 = attn_lds<DQK, DV, 1>(p), lds2 = attn_lds<DQK, DV, 2>(p);
   const int nw1 = waves_for(p.Nq), nw2 = waves_for(p.Nk);
   // dQ first: it also writes Delta, which the dK/dV kernel reads
   if (lds1 <= ATTN_RESIDENT_MAX) {
-    auto k1 = attn_bwd_dq_kernel<DQK, DV, false>;
-    if (int rc = raise_lds_cap<attn_bwd_dq_kernel<DQK, DV, false>>(lds1)) return rc;
-    DAV_LAUNCH(k1, dim3(p.B * p.H), dim3(nw1 * 64), lds1, stream, p);
+    attn_resident<DQK, DV, 1>(p, stream);
   } else {
     auto k1 = attn_bwd_dq_kernel<DQK, DV, true>;
     const size_t ldc = ATTN_CHUNK * row;
@@ -535,9 +623,7 @@ int launch_bwd(const AttnParams& p, hipStream_t stream) {
     DAV_LAUNCH(k1, dim3(p.B * p.H, (p.Nq + nw1 * 16 - 1) / (nw1 * 16)), dim3(nw1 * 64), ldc, stream, p);
   }
   if (lds2 <= ATTN_RESIDENT_MAX) {
-    auto k2 = attn_bwd_dkv_kernel<DQK, DV, false>;
-    if (int rc = raise_lds_cap<attn_bwd_dkv_kernel<DQK, DV, false>>(lds2)) return rc;
-    DAV_LAUNCH(k2, dim3(p.B * p.H), dim3(nw2 * 64), lds2, stream, p);
+    attn_resident<DQK, DV, 2>(p, stream);
   } else {
     auto k2 = attn_bwd_dkv_kernel<DQK, DV, true>;
     const size_t ldc = ATTN_CHUNK * (row + 8);

@@ -1,0 +1,119 @@
+// Launch batcher: see batch.h.  Host code only.
+#include "batch.h"
+
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+#include "dav_kernels.h"
+
+namespace davb {
+namespace {
+
+struct Op {
+  GroupFn fn = nullptr;                 // typed (groupable) launch ...
+  std::vector<unsigned char> blob;      // ... and its parameter block
+  hipStream_t stream = nullptr;
+  std::function<void()> opaque;         // or: anything else, replayed as recorded
+};
+
+struct State {
+  bool on = false;
+  bool auto_lanes = false;              // every recorded launch is its own lane (a "parallel region")
+  std::vector<std::vector<Op>> lanes;
+  int last_ops = 0, last_launches = 0;
+};
+thread_local State S;
+
+std::vector<Op>& cur_lane() {
+  if (S.lanes.empty() || S.auto_lanes) S.lanes.emplace_back();
+  return S.lanes.back();
+}
+
+}  // namespace
+
+bool recording() { return S.on; }
+
+void push_opaque(std::function<void()> fn) {
+  Op op;
+  op.opaque = std::move(fn);
+  cur_lane().push_back(std::move(op));
+}
+
+void push_typed(GroupFn fn, const void* params, size_t bytes, hipStream_t stream) {
+  Op op;
+  op.fn = fn;
+  op.blob.assign((const unsigned char*)params, (const unsigned char*)params + bytes);
+  op.stream = stream;
+  cur_lane().push_back(std::move(op));
+}
+
+}  // namespace davb
+
+using namespace davb;
+
+extern "C" int dav_batch_begin(int auto_lanes) {
+  if (S.on) return DAV_ERR_SHAPE;       // no nesting
+  S.on = true;
+  S.auto_lanes = auto_lanes != 0;
+  S.lanes.clear();
+  return DAV_OK;
+}
+
+extern "C" int dav_batch_lane(void) {
+  if (!S.on) return DAV_ERR_SHAPE;
+  if (!S.auto_lanes && (S.lanes.empty() || !S.lanes.back().empty())) S.lanes.emplace_back();
+  return DAV_OK;
+}
+
+extern "C" int dav_batch_end(void) {
+  if (!S.on) return DAV_ERR_SHAPE;
+  S.on = false;                          // from here on launches are real
+  size_t steps = 0;
+  int ops = 0, launches = 0;
+  for (auto& l : S.lanes) { steps = l.size() > steps ? l.size() : steps; ops += (int)l.size(); }
+  std::vector<const void*> params;
+  std::vector<char> done;
+  for (size_t k = 0; k < steps; ++k) {
+    // the k-th launches of all lanes are mutually independent: bucket the typed ones by (family+configuration, stream)
+    std::vector<Op*> row;
+    for (auto& l : S.lanes)
+      if (k < l.size()) row.push_back(&l[k]);
+    done.assign(row.size(), 0);
+    for (size_t i = 0; i < row.size(); ++i) {
+      if (done[i]) continue;
+      Op* a = row[i];
+      if (!a->fn) {
+        a->opaque();
+        ++launches;
+        continue;
+      }
+      params.clear();
+      for (size_t j = i; j < row.size(); ++j) {
+        Op* b = row[j];
+        if (!done[j] && b->fn == a->fn && b->stream == a->stream) {
+          params.push_back(b->blob.data());
+          done[j] = 1;
+        }
+      }
+      a->fn(params.data(), (int)params.size(), a->stream);
+      ++launches;
+    }
+  }
+  S.lanes.clear();
+  S.last_ops = ops;
+  S.last_launches = launches;
+  return dav_launch_status();
+}
+
+extern "C" int dav_batch_abort(void) {
+  S.on = false;
+  S.lanes.clear();
+  return DAV_OK;
+}
+
+extern "C" int dav_batch_stats(int* recorded_ops, int* issued_launches) {
+  if (recorded_ops) *recorded_ops = S.last_ops;
+  if (issued_launches) *issued_launches = S.last_launches;
+  return DAV_OK;
+}

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "batch.h"
+
 #define DAV_OK 0
 #define DAV_ERR_SHAPE (-1)
 #define DAV_ERR_DTYPE (-2)
@@ -74,12 +76,20 @@ __device__ __forceinline__ float gelu_grad_f(float x) { float u, d; gelu_pair_f(
 // latch only errors produced by OUR launches.
 inline thread_local int dav_launch_failed = 0;
 inline thread_local int dav_last_hip_error = 0;
-#define DAV_LAUNCH(...)                                        \
+#define DAV_LAUNCH_NOW(...)                                    \
   do {                                                         \
     (void)hipGetLastError();                                   \
     hipLaunchKernelGGL(__VA_ARGS__);                           \
     const hipError_t _le = hipGetLastError();                  \
     if (_le != hipSuccess) { dav_launch_failed = 1; dav_last_hip_error = (int)_le; } \
+  } while (0)
+// Inside dav_batch_begin() .. dav_batch_end() (batch.h) a launch is recorded — kernel, geometry and arguments captured by
+// value — and replayed by dav_batch_end() in lockstep with the other lanes; families with a grouped kernel record a
+// typed parameter block instead (davb::push_typed) before they get here.
+#define DAV_LAUNCH(...)                                                          \
+  do {                                                                           \
+    if (davb::recording()) davb::push_opaque([=]() { DAV_LAUNCH_NOW(__VA_ARGS__); }); \
+    else DAV_LAUNCH_NOW(__VA_ARGS__);                                            \
   } while (0)
 static inline int dav_launch_status() {
   const int f = dav_launch_failed;

@@ -320,8 +320,8 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4 (&acc)[FM][
   }
 }
 
-template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK = 64>
-__global__ __launch_bounds__(WM_* WN_ * 64) void gemm_nt2_kernel(NTParams p) {
+template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK>
+__device__ __forceinline__ void nt2_body(const NTParams& p, int bid) {
   constexpr int NT = WM_ * WN_ * 64;
   constexpr int WTM = BM / WM_, WTN = BN / WN_, FM = WTM / 16, FN = WTN / 16;
   constexpr int ARB = BK * 2, ACPR = BK / 8;               // LDS row bytes / 16-byte chunks per row of A (and NT-mode B) tiles
@@ -335,9 +335,9 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void gemm_nt2_kernel(NTParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN_, wn = wave % WN_;
   const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-  int bid = blockIdx.x;
   {
     const int nwg = tiles_m * tiles_n;
+    if (bid >= nwg) return;                 // grouped launches pad every problem's block range to a multiple of 8
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
@@ -446,20 +446,97 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void gemm_nt2_kernel(NTParams p) {
   nt_epilogue<FM, FN, WTM, WTN>(p, acc, smem, m0, n0, wave, wm, wn, lane);
 }
 
-template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT = false, int BK = 64>
-void launch_nt2(const NTParams& p, hipStream_t stream) {
-  constexpr int NT = WM_ * WN_ * 64;
+template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK = 64>
+__global__ __launch_bounds__(WM_* WN_ * 64) void gemm_nt2_kernel(NTParams p) {
+  nt2_body<BM, BN, WM_, WN_, STAGES, BT, BK>(p, blockIdx.x);
+}
+
+// Grouped launch: up to NT_GROUP_MAX independent problems (any M / N / K / epilogue, one tile configuration) in ONE grid —
+// e.g. the qkv GEMMs of the image and the audio tower of a layer (738 + 864 tiles = 3.1 rounds of 512 workgroup slots
+// instead of 1.44 -> 2 and 1.69 -> 2).  Each problem's block range starts at a multiple of 8 so that blockIdx & 7 (the XCD
+// a workgroup lands on) is the same in the local numbering the panel order is built on.
+constexpr int NT_GROUP_MAX = 8;
+struct NTGroup {
+  NTParams prob[NT_GROUP_MAX];
+  int first_block[NT_GROUP_MAX + 1];
+  int count;
+};
+
+template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK = 64>
+__global__ __launch_bounds__(WM_* WN_ * 64) void gemm_nt2_grouped_kernel(const NTGroup g) {
+  int pi = 0;
+  while (pi + 1 < g.count && (int)blockIdx.x >= g.first_block[pi + 1]) ++pi;
+  nt2_body<BM, BN, WM_, WN_, STAGES, BT, BK>(g.prob[pi], (int)blockIdx.x - g.first_block[pi]);
+}
+
+template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK>
+constexpr size_t nt2_lds_bytes() {
   constexpr size_t ring = (size_t)STAGES * (BM + BN) * BK * 2;
   constexpr size_t epi = (size_t)WM_ * WN_ * 16 * (BN / WN_ + 4) * 4;
-  constexpr size_t lds = ring > epi ? ring : epi;
+  return ring > epi ? ring : epi;
+}
+
+// launches n >= 1 recorded problems of this tile configuration (davb::GroupFn)
+template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK>
+void nt2_issue(const void* const* params, int n, hipStream_t stream) {
+  constexpr int NT = WM_ * WN_ * 64;
+  constexpr size_t lds = nt2_lds_bytes<BM, BN, WM_, WN_, STAGES, BT, BK>();
   auto kern = gemm_nt2_kernel<BM, BN, WM_, WN_, STAGES, BT, BK>;
+  auto gkern = gemm_nt2_grouped_kernel<BM, BN, WM_, WN_, STAGES, BT, BK>;
   static bool big = false;
   if (lds > 64 * 1024 && !big) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gkern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     big = true;
   }
-  const int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  DAV_LAUNCH(kern, dim3(grid), dim3(NT), lds, stream, p);
+  for (int base = 0; base < n; base += NT_GROUP_MAX) {
+    const int cnt = n - base < NT_GROUP_MAX ? n - base : NT_GROUP_MAX;
+    if (cnt == 1) {
+      const NTParams& p = *(const NTParams*)params[base];
+      const int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+      DAV_LAUNCH_NOW(kern, dim3(grid), dim3(NT), lds, stream, p);
+      continue;
+    }
+    NTGroup g;
+    int first = 0;
+    for (int i = 0; i < cnt; ++i) {
+      g.prob[i] = *(const NTParams*)params[base + i];
+      g.first_block[i] = first;
+      first += (((g.prob[i].M + BM - 1) / BM) * ((g.prob[i].N + BN - 1) / BN) + 7) & ~7;
+    }
+    g.first_block[cnt] = first;
+    g.count = cnt;
+    DAV_LAUNCH_NOW(gkern, dim3(first), dim3(NT), lds, stream, g);
+  }
+}
+
+template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT = false, int BK = 64>
+void launch_nt2(const NTParams& p, hipStream_t stream) {
+  if (davb::recording()) {
+    davb::push_typed(nt2_issue<BM, BN, WM_, WN_, STAGES, BT, BK>, &p, sizeof(p), stream);
+    return;
+  }
+  const void* one = &p;
+  nt2_issue<BM, BN, WM_, WN_, STAGES, BT, BK>(&one, 1, stream);
+}
+
+int nt_auto_config_tiles(long t128, bool narrow);
+
+// Recorded with the tile configuration left open: chosen at issue time from the tile count of the WHOLE group.
+template <bool BT>
+void nt2_issue_auto(const void* const* params, int n, hipStream_t stream) {
+  long t128 = 0;
+  bool narrow = true;
+  for (int i = 0; i < n; ++i) {
+    const NTParams& p = *(const NTParams*)params[i];
+    t128 += (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    narrow = narrow && p.N <= 64;
+  }
+  switch (nt_auto_config_tiles(t128, narrow)) {
+    case 3: nt2_issue<128, 128, 2, 4, 2, BT, 64>(params, n, stream); break;
+    case 8: nt2_issue<128, 64, 2, 2, 2, BT, 64>(params, n, stream); break;
+    default: nt2_issue<64, 64, 2, 2, 2, BT, 64>(params, n, stream); break;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -759,14 +836,16 @@ void launch_tn2(const TNParams& p, int tiles, hipStream_t stream) {
 RowMap mk(const int* m) { return m ? RowMap{m[0], m[1], m[2]} : RowMap{0, 0, 0}; }
 
 // tile configuration heuristic for the second-generation NT kernel (see launch_nt2 cases)
-int nt_auto_config(int M, int N, int K) {
+int nt_auto_config_tiles(long t128, bool narrow) {
   // measured on MI355X over the ViT-B step's shapes (tools/gemm_bench.py): occupancy beats pipeline depth,
   // so 2-stage rings everywhere; 8 waves on 128x128 when there are enough tiles to fill 2 blocks per CU.
-  (void)K;
-  const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-  if (N <= 64 || t128 < 200) return 5;        // 64x64, 4 waves
+  if (narrow || t128 < 200) return 5;         // 64x64, 4 waves
   if (t128 < 400) return 8;                   // 128x64, 4 waves
   return 3;                                   // 128x128, 8 waves (2 x 4)
+}
+int nt_auto_config(int M, int N, int K) {
+  (void)K;
+  return nt_auto_config_tiles((long)((M + 127) / 128) * ((N + 127) / 128), N <= 64);
 }
 
 }  // namespace
@@ -796,6 +875,11 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
   const bool vec_ok = glds_ok && (N & 3) == 0 && (ldc & 3) == 0 && (!res || (ldres & 3) == 0) && (!C2 || (ldc2 & 3) == 0) &&
                       (!aux || (ldaux & 3) == 0) && !(((uintptr_t)C | (uintptr_t)C2 | (uintptr_t)res) & 15) && !((uintptr_t)aux & 7);
   int cfg = variant >> 4;
+  if (vec_ok && cfg == 0 && !(variant & 15) && davb::recording()) {
+    // batched: the tile configuration is chosen when the group is issued, from the tile count of the whole group
+    davb::push_typed(b_kn ? nt2_issue_auto<true> : nt2_issue_auto<false>, &p, sizeof(p), stream);
+    return DAV_OK;
+  }
   if (b_kn) {
     if (!vec_ok) return DAV_ERR_SHAPE;
     if (cfg == 0) cfg = nt_auto_config(M, N, K);

@@ -50,9 +50,9 @@ struct LNBwd {
 };
 
 template <int MAXC>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(LNFwd p) {
+__device__ __forceinline__ void ln_fwd_body(const LNFwd& p, const int vbid, const int vgrid) {
   const int lane = threadIdx.x & 63;
-  const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int gw = (vbid * blockDim.x + threadIdx.x) >> 6, nwaves = (vgrid * blockDim.x) >> 6;
   const int R = p.s0.rows + p.s1.rows, rows = p.B * R, nch = p.D >> 2;
   for (int row = gw; row < rows; row += nwaves) {
     const int b = row / R, j = row % R;
@@ -100,14 +100,34 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LNFwd p) {
   }
 }
 
+template <int MAXC>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LNFwd p) {
+  ln_fwd_body<MAXC>(p, blockIdx.x, gridDim.x);
+}
+
+// grouped launches (batch.h): several independent LayerNorms (same float4-chunk count) in one grid — norm1 of the image
+// and the audio block of a layer, the three input norms of a fusion block, ...
+constexpr int LN_BATCH_MAX = 8;
+struct LNFwdGroup {
+  LNFwd prob[LN_BATCH_MAX];
+  int first_block[LN_BATCH_MAX + 1];
+  int count;
+};
+template <int MAXC>
+__global__ __launch_bounds__(256) void ln_fwd_grouped_kernel(const LNFwdGroup g) {
+  int pi = 0;
+  while (pi + 1 < g.count && (int)blockIdx.x >= g.first_block[pi + 1]) ++pi;
+  ln_fwd_body<MAXC>(g.prob[pi], (int)blockIdx.x - g.first_block[pi], g.first_block[pi + 1] - g.first_block[pi]);
+}
+
 // 8 waves per workgroup (512 workgroups -> 16 waves/CU in flight).  dgamma/dbeta: the waves of a workgroup combine their partial sums in LDS and write ONE partial row
 // [2*D] per workgroup to the caller's workspace; ln_bwd_reduce_kernel then sums the rows (no same-address
 // atomics, which serialise in L2 when hundreds of workgroups hit the same 2*D words).
 template <int MAXC>
-__global__ __launch_bounds__(512) void ln_bwd_kernel(LNBwd p) {
+__device__ __forceinline__ void ln_bwd_body(const LNBwd& p, const int vbid, const int vgrid) {
   extern __shared__ __attribute__((aligned(16))) float lds_red[];   // [waves][2][D]
   const int lane = threadIdx.x & 63;
-  const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int gw = (vbid * blockDim.x + threadIdx.x) >> 6, nwaves = (vgrid * blockDim.x) >> 6;
   const int R = p.s0.rows + p.s1.rows, rows = p.B * R, nch = p.D >> 2;
   float4 dg[MAXC], db[MAXC];
 #pragma unroll
@@ -183,12 +203,29 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(LNBwd p) {
     }
   }
   __syncthreads();
-  float* part = p.partial + (size_t)blockIdx.x * 2 * p.D;
+  float* part = p.partial + (size_t)vbid * 2 * p.D;
   for (int c = threadIdx.x; c < 2 * p.D; c += blockDim.x) {
     float s = 0.f;
     for (int w = 0; w < nw; ++w) s += lds_red[(size_t)w * 2 * p.D + c];
     part[c] = s;
   }
+}
+
+template <int MAXC>
+__global__ __launch_bounds__(512) void ln_bwd_kernel(LNBwd p) {
+  ln_bwd_body<MAXC>(p, blockIdx.x, gridDim.x);
+}
+
+struct LNBwdGroup {
+  LNBwd prob[LN_BATCH_MAX];
+  int first_block[LN_BATCH_MAX + 1];
+  int count;
+};
+template <int MAXC>
+__global__ __launch_bounds__(512) void ln_bwd_grouped_kernel(const LNBwdGroup g) {
+  int pi = 0;
+  while (pi + 1 < g.count && (int)blockIdx.x >= g.first_block[pi + 1]) ++pi;
+  ln_bwd_body<MAXC>(g.prob[pi], (int)blockIdx.x - g.first_block[pi], g.first_block[pi + 1] - g.first_block[pi]);
 }
 
 // 64 columns x 16 row-lanes per workgroup: every thread sums its share of the partial rows with 4 independent
@@ -269,6 +306,60 @@ int ln_grid(int rows) {
   return g > 1024 ? 1024 : (g < 1 ? 1 : g);
 }
 
+template <int MAXC>
+void ln_fwd_issue(const void* const* params, int n, hipStream_t stream) {
+  for (int base = 0; base < n; base += LN_BATCH_MAX) {
+    const int cnt = n - base < LN_BATCH_MAX ? n - base : LN_BATCH_MAX;
+    if (cnt == 1) {
+      const LNFwd& p = *(const LNFwd*)params[base];
+      DAV_LAUNCH_NOW(ln_fwd_kernel<MAXC>, dim3(ln_grid(p.B * (p.s0.rows + p.s1.rows))), dim3(256), 0, stream, p);
+      continue;
+    }
+    LNFwdGroup g;
+    int first = 0;
+    for (int i = 0; i < cnt; ++i) {
+      g.prob[i] = *(const LNFwd*)params[base + i];
+      g.first_block[i] = first;
+      first += ln_grid(g.prob[i].B * (g.prob[i].s0.rows + g.prob[i].s1.rows));
+    }
+    g.first_block[cnt] = first;
+    g.count = cnt;
+    DAV_LAUNCH_NOW(ln_fwd_grouped_kernel<MAXC>, dim3(first), dim3(256), 0, stream, g);
+  }
+}
+
+// the per-problem grid (= number of partial rows the dgamma/dbeta reduction reads) is the one the single launch uses
+template <int MAXC>
+void ln_bwd_issue(const void* const* params, int n, hipStream_t stream) {
+  for (int base = 0; base < n; base += LN_BATCH_MAX) {
+    const int cnt = n - base < LN_BATCH_MAX ? n - base : LN_BATCH_MAX;
+    size_t lds = 0;
+    LNBwdGroup g;
+    int first = 0;
+    for (int i = 0; i < cnt; ++i) {
+      g.prob[i] = *(const LNBwd*)params[base + i];
+      const size_t l = (size_t)g_ln_bwd_waves * 2 * g.prob[i].D * sizeof(float);
+      lds = l > lds ? l : lds;
+      g.first_block[i] = first;
+      first += ln_bwd_grid(g.prob[i].B * (g.prob[i].s0.rows + g.prob[i].s1.rows));
+    }
+    g.first_block[cnt] = first;
+    g.count = cnt;
+    if (cnt == 1) DAV_LAUNCH_NOW(ln_bwd_kernel<MAXC>, dim3(first), dim3(64 * g_ln_bwd_waves), lds, stream, g.prob[0]);
+    else DAV_LAUNCH_NOW(ln_bwd_grouped_kernel<MAXC>, dim3(first), dim3(64 * g_ln_bwd_waves), lds, stream, g);
+  }
+}
+
+template <typename P, davb::GroupFn F>
+void ln_dispatch(const P& p, hipStream_t stream) {
+  if (davb::recording()) {
+    davb::push_typed(F, &p, sizeof(p), stream);
+    return;
+  }
+  const void* one = &p;
+  F(&one, 1, stream);
+}
+
 }  // namespace
 
 extern "C" int dav_layernorm_fwd(const float* x0, long x0_bs, int r0, const float* x1, long x1_bs, int r1, int B, int D,
@@ -278,12 +369,12 @@ extern "C" int dav_layernorm_fwd(const float* x0, long x0_bs, int r0, const floa
   LNFwd p;
   p.s0 = LNSeg{x0, x0_bs, r0}; p.s1 = LNSeg{x1, x1_bs, r1}; p.B = B; p.D = D; p.gamma = gamma; p.beta = beta;
   p.eps = eps; p.y = (bf16_t*)y_bf16; p.y32 = y_f32; p.mean = mean; p.rstd = rstd;
-  const int nch = (D / 4 + 63) / 64, g = ln_grid(B * (r0 + r1));
-  if (nch <= 1) DAV_LAUNCH(ln_fwd_kernel<1>, dim3(g), dim3(256), 0, stream, p);
-  else if (nch == 2) DAV_LAUNCH(ln_fwd_kernel<2>, dim3(g), dim3(256), 0, stream, p);
-  else if (nch == 3) DAV_LAUNCH(ln_fwd_kernel<3>, dim3(g), dim3(256), 0, stream, p);
-  else if (nch == 4) DAV_LAUNCH(ln_fwd_kernel<4>, dim3(g), dim3(256), 0, stream, p);
-  else DAV_LAUNCH(ln_fwd_kernel<8>, dim3(g), dim3(256), 0, stream, p);
+  const int nch = (D / 4 + 63) / 64;
+  if (nch <= 1) ln_dispatch<LNFwd, ln_fwd_issue<1>>(p, stream);
+  else if (nch == 2) ln_dispatch<LNFwd, ln_fwd_issue<2>>(p, stream);
+  else if (nch == 3) ln_dispatch<LNFwd, ln_fwd_issue<3>>(p, stream);
+  else if (nch == 4) ln_dispatch<LNFwd, ln_fwd_issue<4>>(p, stream);
+  else ln_dispatch<LNFwd, ln_fwd_issue<8>>(p, stream);
   return dav_launch_status();
 }
 
@@ -336,12 +427,11 @@ extern "C" int dav_layernorm_bwd(const float* x0, long x0_bs, int r0, const floa
   p.partial = (float*)workspace;
   const int grid = ln_bwd_grid(B * (r0 + r1));
   const int nch = (D / 4 + 63) / 64;
-  const size_t lds = (size_t)g_ln_bwd_waves * 2 * D * sizeof(float);
-  if (nch <= 1) DAV_LAUNCH(ln_bwd_kernel<1>, dim3(grid), dim3(64 * g_ln_bwd_waves), lds, stream, p);
-  else if (nch == 2) DAV_LAUNCH(ln_bwd_kernel<2>, dim3(grid), dim3(64 * g_ln_bwd_waves), lds, stream, p);
-  else if (nch == 3) DAV_LAUNCH(ln_bwd_kernel<3>, dim3(grid), dim3(64 * g_ln_bwd_waves), lds, stream, p);
-  else if (nch == 4) DAV_LAUNCH(ln_bwd_kernel<4>, dim3(grid), dim3(64 * g_ln_bwd_waves), lds, stream, p);
-  else DAV_LAUNCH(ln_bwd_kernel<8>, dim3(grid), dim3(64 * g_ln_bwd_waves), lds, stream, p);
+  if (nch <= 1) ln_dispatch<LNBwd, ln_bwd_issue<1>>(p, stream);
+  else if (nch == 2) ln_dispatch<LNBwd, ln_bwd_issue<2>>(p, stream);
+  else if (nch == 3) ln_dispatch<LNBwd, ln_bwd_issue<3>>(p, stream);
+  else if (nch == 4) ln_dispatch<LNBwd, ln_bwd_issue<4>>(p, stream);
+  else ln_dispatch<LNBwd, ln_bwd_issue<8>>(p, stream);
   if (dgamma) DAV_LAUNCH(ln_bwd_reduce_kernel, dim3((2 * D + 63) / 64), dim3(1024), 0, stream, (const float*)workspace, grid, D, dgamma, dbeta);
   return dav_launch_status();
 }

@@ -35,9 +35,55 @@ def set_grad_ready_hook(fn: Optional[Callable[[torch.nn.Parameter], None]]):
 
 def _ready(*params):
     if _GRAD_READY is not None:
+        if _BATCH is not None:          # the kernels that finish these gradients are only recorded so far: report at batch end
+            _BATCH.pending_ready.extend(params)
+            return
         for p in params:
             if p is not None and p.requires_grad:
                 _GRAD_READY(p)
+
+
+# ------------------------------------------------------------------------------------------------
+# launch batching (csrc/batch.h): ``with batch() as bt: bt.lane(); <chain A>; bt.lane(); <chain B>`` records the kernel
+# launches of independent chains and issues them in lockstep, equal kernels of equal rank as ONE grouped grid — the image
+# and the audio tower block of a layer (models/deepavfusion.py:104-105), the two decoders (models/avmae.py:147-180), the
+# two aggregation cross-attentions of a fusion block.  ``batch(auto_lanes=True)``: every launch inside is independent of
+# the others.  Only library launches may touch live buffers inside a batch (torch ops would run BEFORE the recorded
+# kernels).  Nested use joins the outer batch (lane() then has no effect).  DAV_BATCH=0 turns batching off.
+# ------------------------------------------------------------------------------------------------
+_BATCH = None
+BATCH_STATS = [0, 0]          # launches recorded / issued since the last reset (diagnostics, tests)
+
+
+class batch:
+    def __init__(self, auto_lanes: bool = False):
+        self.auto_lanes = auto_lanes
+        self.active = False
+        self.pending_ready = []
+
+    def __enter__(self):
+        global _BATCH
+        if _BATCH is None and os.environ.get('DAV_BATCH', '1') != '0':
+            ops.batch_begin(self.auto_lanes)
+            _BATCH = self
+            self.active = True
+        return self
+
+    def lane(self):
+        if self.active:
+            ops.batch_lane()
+
+    def __exit__(self, et, ev, tb):
+        global _BATCH
+        if not self.active:
+            return False
+        _BATCH = None
+        rec, iss = ops.batch_end(abort=et is not None)
+        BATCH_STATS[0] += rec
+        BATCH_STATS[1] += iss
+        if et is None and self.pending_ready:
+            _ready(*self.pending_ready)
+        return False
 
 
 def gbuf(p: torch.nn.Parameter) -> torch.Tensor:
@@ -310,6 +356,7 @@ def attention_fwd(q, k, v, B, H, Nq, Nk, dqk, dv, scale, q_bs, q_rs, k_bs, k_rs,
     """q/k/v are (tensor, element_offset) pairs into bf16 buffers. Returns O [B*Nq, H*dv] bf16 and LSE."""
     O = _e((B * Nq, H * dv), BF16, dev)
     LSE = _e((B, H, Nq), F32, dev)
+    ops.hold(q[0], k[0], v[0])
     ops.attn_fwd(q[0].data_ptr() + 2 * q[1], k[0].data_ptr() + 2 * k[1], v[0].data_ptr() + 2 * v[1], O, LSE, B, H, Nq, Nk,
                  dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, Nq * H * dv, H * dv, scale)
     return O, LSE
@@ -318,6 +365,7 @@ def attention_fwd(q, k, v, B, H, Nq, Nk, dqk, dv, scale, q_bs, q_rs, k_bs, k_rs,
 def attention_bwd(q, k, v, O, dO, LSE, dq, dk, dvv, B, H, Nq, Nk, dqk, dv, scale, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs,
                   dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs):
     Delta = torch.empty_like(LSE)
+    ops.hold(q[0], k[0], v[0], dq[0], dk[0], dvv[0])
     p = lambda t: t[0].data_ptr() + 2 * t[1]
     ops.attn_bwd(p(q), p(k), p(v), O, dO, LSE, Delta, p(dq), p(dk), p(dvv), B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs,
                  v_bs, v_rs, Nq * H * dv, H * dv, Nq * H * dv, H * dv, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, scale)
@@ -368,7 +416,17 @@ def block_fwd(blk, x_mod, x_fus, heads, eps, dp=None):
 
 def block_bwd(blk, t, g2, g2b, *, dx_fus=None, dx_fus_acc=0, dx_mod=None, dx_mod_acc=0, need_dx=True, before_ln1=None):
     """g2 fp32 [B,n,D] (+ bf16 twin g2b or None).  Writes/accumulates the fusion-row gradient into dx_fus
-    and the modality-row gradient (incl. the residual path) into dx_mod; returns (dx_mod, dx_mod_bf16, dx_fus)."""
+    and the modality-row gradient (incl. the residual path) into dx_mod; returns (dx_mod, dx_mod_bf16, dx_fus).
+    = block_bwd_head (everything down to the qkv input gradient) + block_bwd_tail (the norm1 backward, the only kernel
+    that touches dx_fus / dx_mod): callers that batch two blocks in lockstep wait for the producers of those buffers
+    between the two halves."""
+    st = block_bwd_head(blk, t, g2, g2b)
+    if before_ln1 is not None and need_dx:
+        before_ln1()          # e.g. wait for the stream that produced the buffers this LayerNorm accumulates into
+    return block_bwd_tail(blk, t, st, dx_fus=dx_fus, dx_fus_acc=dx_fus_acc, dx_mod=dx_mod, dx_mod_acc=dx_mod_acc, need_dx=need_dx)
+
+
+def block_bwd_head(blk, t, g2, g2b):
     x_mod, x_fus, heads, nF = t['x_mod'], t['x_fus'], t['heads'], t['nF']
     B, n, D = x_mod.shape
     R, hd, dev = nF + n, D // heads, x_mod.device
@@ -396,18 +454,24 @@ def block_bwd(blk, t, g2, g2b, *, dx_fus=None, dx_fus_acc=0, dx_mod=None, dx_mod
                   R * 3 * D, 3 * D, R * 3 * D, 3 * D, R * 3 * D, 3 * D,
                   R * 3 * D, 3 * D, R * 3 * D, 3 * D, R * 3 * D, 3 * D)
     dh1 = lin_bwd(blk.attn.qkv, dqkv, t['h1'], M)
+    return dict(dh1=dh1, g1=g1)
+
+
+def block_bwd_tail(blk, t, st, *, dx_fus=None, dx_fus_acc=0, dx_mod=None, dx_mod_acc=0, need_dx=True):
+    x_mod, x_fus, nF = t['x_mod'], t['x_fus'], t['nF']
+    B, n, D = x_mod.shape
+    dev = x_mod.device
+    dh1, g1 = st['dh1'], st['g1']
     if not need_dx:
         ln_bwd(blk.norm1, x_fus, x_mod, B, t['st1'], dy_bf16=dh1)
         return None, None, None
     if dx_mod is None:
         dx_mod = _e((B, n, D), F32, dev)
         dx_mod_acc = 0
-    dx_mod_b = _e((Mq, D), BF16, dev)
+    dx_mod_b = _e((B * n, D), BF16, dev)
     if nF > 0 and dx_fus is None:
         dx_fus = _e((B, nF, D), F32, dev)
         dx_fus_acc = 0
-    if before_ln1 is not None:
-        before_ln1()          # e.g. wait for the stream that produced the buffers this LayerNorm accumulates into
     ln_bwd(blk.norm1, x_fus, x_mod, B, t['st1'], dy_bf16=dh1, dx0=dx_fus, acc0=dx_fus_acc,
            dx1=dx_mod, acc1=dx_mod_acc, res1=g1, dx1_bf16=dx_mod_b)
     return dx_mod, dx_mod_b, dx_fus

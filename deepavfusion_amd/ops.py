@@ -22,12 +22,52 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# While a launch batch is being recorded (engine.batch / dav_batch_begin) kernels run LATER than the Python code that
+# "launches" them, so every tensor handed to the library is kept alive until the batch has been issued: torch's caching
+# allocator would otherwise hand a temporary's block to a later allocation of the same recording, and with lanes issued
+# in lockstep that later kernel may run BEFORE the temporary's last reader.
+HOLD = None          # list while recording, else None
+
+
+def hold(*tensors):
+    if HOLD is not None:
+        HOLD.extend(t for t in tensors if t is not None)
+
+
 def _ptr(t: Optional[torch.Tensor]):
     if t is None:
         return None
     if not t.is_cuda:
         raise RuntimeError('deepavfusion_amd kernels need tensors on an MI355X (cuda) device; there is no CPU fallback')
+    if HOLD is not None:
+        HOLD.append(t)
     return t.data_ptr()
+
+
+def batch_begin(auto_lanes=False):
+    global HOLD
+    _lib.check(_lib.load().dav_batch_begin(int(auto_lanes)), 'dav_batch_begin')
+    HOLD = []
+
+
+def batch_lane():
+    _lib.check(_lib.load().dav_batch_lane(), 'dav_batch_lane')
+
+
+def batch_end(abort=False):
+    """Issue (or drop) the recorded launches; returns (recorded, issued) launch counts."""
+    global HOLD
+    lib = _lib.load()
+    try:
+        if abort:
+            lib.dav_batch_abort()
+            return 0, 0
+        _lib.check(lib.dav_batch_end(), 'dav_batch_end')
+        a, b = C.c_int(0), C.c_int(0)
+        lib.dav_batch_stats(C.byref(a), C.byref(b))
+        return a.value, b.value
+    finally:
+        HOLD = None
 
 
 def _rm(m: Optional[Sequence[int]]):

@@ -171,6 +171,24 @@ int dav_adamw_flat(float* p, float* g, float* m, float* v, void* p_bf16, long n,
                    int nseg, float beta1, float beta2, float eps, const float* bias_corr, float grad_scale, float* sumsq_out,
                    int zero_grad, hipStream_t stream);
 
+/* ---- launch batching ---------------------------------------------------------------------- */
+/* The reference runs the image block, the audio block and the fusion block of a layer one after the other although they
+ * only depend on the layer's inputs (models/deepavfusion.py:104-107), and likewise the two MAE decoders
+ * (models/avmae.py:147-180).  Between dav_batch_begin() and dav_batch_end() every entry point of this library RECORDS its
+ * kernel launches (per calling thread) instead of issuing them; dav_batch_lane() starts a new LANE — a sequence of
+ * launches the caller declares independent of the other lanes.  dav_batch_end() issues the lanes in lockstep: the k-th
+ * launches of all lanes go out together, those of one kernel family (NT GEMM, LayerNorm forward / backward, attention
+ * forward / dQ / dK-dV) as ONE grouped grid whose workgroups look their problem up in a table passed by value, the rest
+ * individually; the order inside a lane is kept.  With auto_lanes != 0 every recorded launch is its own lane (a region of
+ * mutually independent launches).  Requirements on the caller: lanes must not depend on each other; every buffer a recorded
+ * launch touches must stay allocated until dav_batch_end() returns; all launches of a batch use the stream they were
+ * recorded with.  No nesting.  dav_batch_stats reports the last batch: launches recorded / launches issued. */
+int dav_batch_begin(int auto_lanes);
+int dav_batch_lane(void);
+int dav_batch_end(void);
+int dav_batch_abort(void);
+int dav_batch_stats(int* recorded_ops, int* issued_launches);
+
 #ifdef __cplusplus
 }
 #endif

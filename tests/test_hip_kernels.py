@@ -35,3 +35,95 @@ def test_kernel_shape_fuzz():
     fz.fuzz_attn(rng, 25)
     fz.fuzz_ln(rng, 25)
     assert not fz.FAILS, fz.FAILS[:10]
+
+
+def test_batched_grouped_launches_equal_individual_launches():
+    """csrc/batch.h: launches recorded in lanes and issued in lockstep — GEMMs / LayerNorms / attentions of equal rank as
+    ONE grouped grid — must give bit-identical results to issuing the same launches one by one, and really group."""
+    import torch
+
+    from deepavfusion_amd import engine as E
+    from deepavfusion_amd import ops
+    torch.manual_seed(3)
+    dev = 'cuda'
+    bf, f32 = torch.bfloat16, torch.float32
+
+    def chain(M, n_keys, B, H, tag):
+        """LN -> qkv GEMM (bias) -> attention -> proj GEMM (+ residual, bf16 twin) -> LN backward -> b_kn dgrad GEMM:
+        one lane.  Shapes differ per lane (M rows, tile counts, workgroup sizes)."""
+        D, hd = 128, 64
+        g = torch.Generator(device=dev).manual_seed(100 + M)
+        R = M // B
+        x = torch.randn(B, R, D, device=dev, generator=g)
+        gamma, beta = torch.randn(D, device=dev, generator=g), torch.randn(D, device=dev, generator=g)
+        Wqkv = (torch.randn(3 * D, D, device=dev, generator=g) * 0.1).to(bf)
+        bqkv = torch.randn(3 * D, device=dev, generator=g)
+        Wp = (torch.randn(D, D, device=dev, generator=g) * 0.1).to(bf)
+        dy = torch.randn(M, D, device=dev, generator=g).to(bf)
+        out = {}
+
+        def run():
+            y = torch.empty(M, D, dtype=bf, device=dev)
+            mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+            ops.layernorm_fwd(x, R * D, R, None, 0, 0, B, D, gamma, beta, 1e-6, y, None, mean, rstd)
+            qkv = torch.empty(M, 3 * D, dtype=bf, device=dev)
+            ops.gemm_nt(y, Wqkv, M, 3 * D, D, bias=bqkv, C_out=qkv, c_bf16=True)
+            O = torch.empty(M, D, dtype=bf, device=dev)
+            LSE = torch.empty(B, H, R, device=dev)
+            ops.hold(qkv)
+            ops.attn_fwd(qkv.data_ptr(), qkv.data_ptr() + 2 * D, qkv.data_ptr() + 4 * D, O, LSE, B, H, R, R, hd, hd,
+                         R * 3 * D, 3 * D, R * 3 * D, 3 * D, R * 3 * D, 3 * D, R * D, D, hd ** -0.5)
+            x1 = torch.empty(M, D, device=dev)
+            x1b = torch.empty(M, D, dtype=bf, device=dev)
+            ops.gemm_nt(O, Wp, M, D, D, res=x.view(M, D), ldres=D, C_out=x1, C2=x1b, ldc2=D, c2_mode=3)
+            dq = torch.zeros(M, 3 * D, dtype=bf, device=dev)
+            Delta = torch.empty_like(LSE)
+            dO = dy
+            ops.hold(dq)
+            ops.attn_bwd(qkv.data_ptr(), qkv.data_ptr() + 2 * D, qkv.data_ptr() + 4 * D, O, dO, LSE, Delta,
+                         dq.data_ptr(), dq.data_ptr() + 2 * D, dq.data_ptr() + 4 * D, B, H, R, R, hd, hd,
+                         R * 3 * D, 3 * D, R * 3 * D, 3 * D, R * 3 * D, 3 * D, R * D, D, R * D, D,
+                         R * 3 * D, 3 * D, R * 3 * D, 3 * D, R * 3 * D, 3 * D, hd ** -0.5)
+            dh = torch.empty(M, D, dtype=bf, device=dev)
+            ops.gemm_nt(dq, Wqkv, M, D, 3 * D, lda=3 * D, ldb=D, C_out=dh, c_bf16=True, variant=1 << 12)     # dgrad reading W itself
+            dx = torch.empty(B, R, D, device=dev)
+            dxb = torch.empty(M, D, dtype=bf, device=dev)
+            dgam, dbet = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+            ops.layernorm_bwd(x, R * D, R, None, 0, 0, B, D, dh, None, gamma, mean, rstd,
+                              dx1=None, dx0=dx, dx0_bs=R * D, dx0_bf16=dxb, dx0_bf_bs=R * D, dgamma=dgam, dbeta=dbet)
+            out.update(y=y, qkv=qkv, O=O, LSE=LSE, x1=x1, x1b=x1b, dq=dq, dh=dh, dx=dx, dxb=dxb, dgam=dgam, dbet=dbet)
+        return run, out
+
+    lanes = [chain(64 * 49, 49, 64, 2, 'a'), chain(32 * 80, 80, 32, 2, 'b'), chain(4 * 16, 16, 4, 2, 'c')]
+    for run, _ in lanes:
+        run()
+    torch.cuda.synchronize()
+    ref = [{k: v.clone() for k, v in out.items()} for _, out in lanes]
+    E.BATCH_STATS[:] = [0, 0]
+    with E.batch() as bt:
+        for run, _ in lanes:
+            bt.lane()
+            run()
+    torch.cuda.synchronize()
+    rec, iss = E.BATCH_STATS
+    assert rec >= 3 * 9 and iss <= rec // 3 + 2, (rec, iss)          # three equal chains -> one grid per rank
+    for (_, out), r in zip(lanes, ref):
+        for k in r:
+            assert torch.equal(out[k], r[k]), k
+    # a region of mutually independent launches (auto lanes): three GEMMs of different shapes -> one grid
+    E.BATCH_STATS[:] = [0, 0]
+    A = [torch.randn(m, 256, device=dev).to(bf) for m in (520, 64, 1000)]
+    W = [(torch.randn(n, 256, device=dev) * 0.1).to(bf) for n in (192, 768, 64)]
+    single = []
+    for a, w in zip(A, W):
+        c = torch.empty(a.shape[0], w.shape[0], device=dev)
+        ops.gemm_nt(a, w, a.shape[0], w.shape[0], 256, C_out=c)
+        single.append(c)
+    grouped = [torch.empty_like(c) for c in single]
+    with E.batch(auto_lanes=True):
+        for a, w, c in zip(A, W, grouped):
+            ops.gemm_nt(a, w, a.shape[0], w.shape[0], 256, C_out=c)
+    torch.cuda.synchronize()
+    assert E.BATCH_STATS == [3, 1], E.BATCH_STATS
+    for c, r in zip(grouped, single):
+        assert torch.equal(c, r)
