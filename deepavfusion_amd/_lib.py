@@ -52,6 +52,8 @@ SIGNATURES = {
     'dav_l2norm': [_p, _l, _f, _p, _p, _sz, _p],
     'dav_batch_begin': [_i],
     'dav_batch_lane': [],
+    'dav_batch_region': [_i],
+    'dav_batch_suspend': [_i],
     'dav_batch_end': [],
     'dav_batch_abort': [],
     'dav_batch_stats': [_p, _p],

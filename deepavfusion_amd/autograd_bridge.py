@@ -94,19 +94,21 @@ def encoder_fwd(enc, image, audio, ik32, ak32, want_f32=False, collect_embs=Fals
         xf_ctx = x_f if fb is not None else None
         tf = None
         if batched:
-            # fusion block beside the towers (side stream); the two tower blocks as two lanes of ONE launch batch: their
-            # LayerNorms / GEMMs / attentions of equal rank go out as grouped grids on the main stream
-            if fb is not None:
-                sf.wait_stream(main)
-                with torch.cuda.stream(sf):
-                    n_f, tf = E.fusion_block_fwd(fb, x_f, x_i, x_a, Hf, enc.num_fusion, dpf)  # reads the layer INPUT x_i / x_a (:106-107)
+            # ONE launch batch per layer, three lanes — image block, audio block, fusion block (all read the layer inputs
+            # only, models/deepavfusion.py:104-107): LayerNorms / GEMMs / attentions of equal rank go out as grouped grids
+            # on one stream.  (hipGraph branches of this weight start ~150 us late on MI355X)
+            lane_f = fb is not None and E.fusion_block_batchable(fb, dpf)
+            if fb is not None and not lane_f:
+                n_f, tf = E.fusion_block_fwd(fb, x_f, x_i, x_a, Hf, enc.num_fusion, dpf)      # reads the layer INPUT x_i / x_a (:106-107)
             with E.batch() as bt:
                 bt.lane()
                 n_i, ti = E.block_fwd(bi, x_i, xf_ctx, Hi, bi.norm1.eps, dpi)
                 bt.lane()
                 n_a, ta = E.block_fwd(ba, x_a, xf_ctx, Ha, ba.norm1.eps, dpa)
+                if lane_f:
+                    bt.lane()
+                    n_f, tf = E.fusion_block_fwd(fb, x_f, x_i, x_a, Hf, enc.num_fusion, dpf)
             if fb is not None:
-                main.wait_stream(sf)
                 x_f = n_f
             x_i, x_a = n_i, n_a
         else:
@@ -166,21 +168,21 @@ def _encoder_bwd(enc, t, dxi_b, dxa_b, dxf_b, dxi32, dxa32, dxf32, layer_cb=None
         # here stays referenced until all streams have re-joined.
         hold = (g_i, g_ib, g_a, g_ab, g_f, g_fb)
         if batched:
-            # the fusion block's backward (many small kernels) on the side stream; the two tower blocks as two lanes of a
-            # launch batch on the main stream.  Their last kernel — the norm1 backward — accumulates into the buffers the
-            # fusion block's backward produces, so the batch is cut in front of it and the main stream waits there.
+            # one launch batch, three lanes: the two tower blocks down to their qkv input gradient, and the fusion block's
+            # whole backward.  The towers' last kernel — the norm1 backward — accumulates into the buffers the fusion
+            # block's backward produces, so it forms a second (two-lane) batch behind the first.
             dx_f = dx_i = dx_a = None
-            if fb is not None:
-                sf.wait_stream(main)
-                with torch.cuda.stream(sf):
-                    dx_f, dx_i, dx_a = E.fusion_block_bwd(fb, tf, g_f, g_fb)
+            lane_f = fb is not None and E.fusion_block_batchable(fb, tf.get('dp'))
+            if fb is not None and not lane_f:
+                dx_f, dx_i, dx_a = E.fusion_block_bwd(fb, tf, g_f, g_fb)
             with E.batch() as bt:
                 bt.lane()
                 st_i = E.block_bwd_head(bi, ti, g_i, g_ib)
                 bt.lane()
                 st_a = E.block_bwd_head(ba, ta, g_a, g_ab)
-            if fb is not None:
-                main.wait_stream(sf)
+                if lane_f:
+                    bt.lane()
+                    dx_f, dx_i, dx_a = E.fusion_block_bwd(fb, tf, g_f, g_fb)
             acc = 1 if fb is not None else 0
             with E.batch() as bt:
                 bt.lane()

@@ -73,6 +73,10 @@ class batch:
         if self.active:
             ops.batch_lane()
 
+    @staticmethod
+    def current():
+        return _BATCH
+
     def __exit__(self, et, ev, tb):
         global _BATCH
         if not self.active:
@@ -113,7 +117,8 @@ def wcache(p: torch.nn.Parameter, force: bool = False) -> torch.Tensor:
         c = p.__dict__['_dav_cache'] = _WCache()
     if c.managed and not force:
         if c.ver != p._version:        # written from the torch side (load_state_dict, p.copy_()) since the mirror was made:
-            ops.cast_bf16(p.detach().reshape(p.shape[0], -1), c.wb)      # the optimizer kernel's own updates keep it in sync
+            with ops.unbatched():
+                ops.cast_bf16(p.detach().reshape(p.shape[0], -1), c.wb)  # the optimizer kernel's own updates keep it in sync
             c.ver = p._version
             p.__dict__['_dav_epoch'] = p.__dict__.get('_dav_epoch', 0) + 1     # transposed copies follow
         return c.wb
@@ -122,7 +127,8 @@ def wcache(p: torch.nn.Parameter, force: bool = False) -> torch.Tensor:
         w2 = p.detach().reshape(p.shape[0], -1)
         if c.wb is None or c.wb.shape != w2.shape or c.wb.device != w2.device:
             c.wb = torch.empty(w2.shape, dtype=BF16, device=p.device)
-        ops.cast_bf16(w2, c.wb)
+        with ops.unbatched():
+            ops.cast_bf16(w2, c.wb)
         c.ver, c.ptr = ver, ptr
     return c.wb
 
@@ -136,7 +142,8 @@ def wcache_t(p: torch.nn.Parameter) -> torch.Tensor:
         w2 = p.detach().reshape(p.shape[0], -1)
         if c.wtb is None:
             c.wtb = torch.empty((w2.shape[1], w2.shape[0]), dtype=BF16, device=p.device)
-        ops.cast_transpose_bf16(w2, c.wtb)
+        with ops.unbatched():
+            ops.cast_transpose_bf16(w2, c.wtb)
         c.wt_ver = stamp
     return c.wtb
 
@@ -171,6 +178,28 @@ def refresh_weight_cache(module: torch.nn.Module):
 
 def _e(shape, dtype, dev):
     return torch.empty(shape, dtype=dtype, device=dev)
+
+
+class region:
+    """``with region(): <independent launches>``: inside a batch the launches form ONE step of the current lane (so they
+    are grouped with each other and with the other lanes' launches of that step); outside a batch the region is a batch of
+    its own.  Every call inside must be a single-kernel library launch (or calls of identical kernel sequence)."""
+
+    def __enter__(self):
+        self.own = None
+        if _BATCH is not None:
+            ops.batch_region(True)
+        elif os.environ.get('DAV_BATCH', '1') != '0':
+            self.own = batch(auto_lanes=True)
+            self.own.__enter__()
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if self.own is not None:
+            return self.own.__exit__(et, ev, tb)
+        if _BATCH is not None and et is None:
+            ops.batch_region(False)
+        return False
 
 
 # ------------------------------------------------------------------------------------------------
@@ -307,7 +336,8 @@ def lin_fwd(lin, a, M, *, a_rowmap=None, lda=None, act=0, res=None, res_rowmap=N
 
 
 def lin_bwd(lin, dy, a, M, *, dy_rowmap=None, a_rowmap=None, lda=None, need_dx=True, gelu_aux=None, dx=None, dx_bf16=True,
-            dx_rowmap=None, dx_beta=0, dx_C2=None, dx_c2_mode=0, w_col_off=0, k=None, use_bias=True, final=True):
+            dx_rowmap=None, dx_beta=0, dx_C2=None, dx_c2_mode=0, w_col_off=0, k=None, use_bias=True, final=True,
+            dx_res=None, dx_res_rowmap=None):
     """Backward of lin_fwd: dx = dy @ W (optionally * GELU'(aux)), dW += dy^T a, db += colsum(dy).
 
     dy: bf16 [*, N]; a: bf16 [*, K] (the forward input).  Returns dx (bf16 [M, K] unless given)."""
@@ -324,7 +354,8 @@ def lin_bwd(lin, dy, a, M, *, dy_rowmap=None, a_rowmap=None, lda=None, need_dx=T
             WT = wcache_t(lin.weight)
             Bt, ldb, variant = (WT if w_col_off == 0 else WT[w_col_off:]), N, 0
         ops.gemm_nt(dy, Bt, M, K, N, lda=N, ldb=ldb, a_rowmap=dy_rowmap, act=3 if gelu_aux is not None else 0,
-                    aux=gelu_aux, ldaux=K, C_out=dx, ldc=K, c_bf16=dx.dtype == BF16, c_rowmap=dx_rowmap, beta=dx_beta,
+                    aux=gelu_aux, ldaux=K, res=dx_res, ldres=K, res_rowmap=dx_res_rowmap,
+                    C_out=dx, ldc=K, c_bf16=dx.dtype == BF16, c_rowmap=dx_rowmap, beta=dx_beta,
                     C2=dx_C2, ldc2=K, c2_mode=dx_c2_mode, variant=variant)
     gw = gbuf(lin.weight)
     gwv = gw.view(N, -1)
@@ -480,7 +511,150 @@ def block_bwd_tail(blk, t, st, *, dx_fus=None, dx_fus_acc=0, dx_mod=None, dx_mod
 # ------------------------------------------------------------------------------------------------
 # FusionBlock_FactorizedAVInteractions (models/fusion_blocks.py:216-289)
 # ------------------------------------------------------------------------------------------------
-def _cross_fwd(ca, xq_b, q_rowmap, nq, xkv_b, nk, B, D, heads, dev):
+def _factorized_fwd(fb, x_f, x_i, x_a, heads, tkns, dp=None):
+    """FusionBlock_FactorizedAVInteractions forward (models/fusion_blocks.py:266-289) as 11 dependent steps; the
+    independent launches of a step sit in a ``region()`` so that they go out as one grouped grid (and, when the block is a
+    lane of the layer's launch batch, together with the tower blocks' launches of that step).  With DropPath scales the
+    sequential form below is used (it needs torch ops between kernels)."""
+    if dp is not None:
+        return _factorized_fwd_seq(fb, x_f, x_i, x_a, heads, tkns, dp)
+    B, nF, D = x_f.shape
+    nI, nA = x_i.shape[1], x_a.shape[1]
+    nmm, nv, na = tkns
+    dev, at = x_f.device, fb.attn
+    Da, hd = at.q.weight.shape[0], D // heads
+    rm2, rmv, rma = (nmm, nF, 0), (nv, nF, nmm), (na, nF, nmm + nv)
+    # norm-then-residual: the residual base is the NORMED xmm (models/fusion_blocks.py:281-283)
+    with region():
+        xmm_b, xmm32, st_mm = ln_fwd(fb.norm1_mm, None, x_f, B, want_f32=True)
+        xv_b, _, st_v = ln_fwd(fb.norm1_img, None, x_i, B)
+        xa_b, _, st_a = ln_fwd(fb.norm1_aud, None, x_a, B)
+    with region():      # CrossAttention q / kv (models/fusion_blocks.py:46-59) of both aggregations + the pair query
+        q_v = lin_fwd(at.attn_v.q, xmm_b, B * nv, a_rowmap=rmv, out_bf16=True)               # [B*nv, D]
+        kv_v = lin_fwd(at.attn_v.kv, xv_b, B * nI, out_bf16=True)                            # [B*nI, 2D]
+        q_a = lin_fwd(at.attn_a.q, xmm_b, B * na, a_rowmap=rma, out_bf16=True)
+        kv_a = lin_fwd(at.attn_a.kv, xa_b, B * nA, out_bf16=True)
+        q2 = lin_fwd(at.q, xmm_b, B * nmm, a_rowmap=rm2, out_bf16=True)                      # [B*nmm, Da]
+    with region():
+        o_v, lse_v = attention_fwd((q_v, 0), (kv_v, 0), (kv_v, D), B, heads, nv, nI, hd, hd, hd ** -0.5,
+                                   nv * D, D, nI * 2 * D, 2 * D, nI * 2 * D, 2 * D, dev)
+        o_a, lse_a = attention_fwd((q_a, 0), (kv_a, 0), (kv_a, D), B, heads, na, nA, hd, hd, hd ** -0.5,
+                                   na * D, D, nA * 2 * D, 2 * D, nA * 2 * D, 2 * D, dev)
+    cv, ca = dict(q=q_v, kv=kv_v, o=o_v, lse=lse_v), dict(q=q_a, kv=kv_a, o=o_a, lse=lse_a)
+    xmm1 = _e((B, nF, D), F32, dev)
+    # proj of the two aggregations: fp32 result lands in its rows of xmm1 (+ normed-xmm residual),
+    # bf16 twin of the pre-residual value feeds the pair projections
+    xvo_b, xao_b = _e((B * nv, D), BF16, dev), _e((B * na, D), BF16, dev)
+    with region():
+        lin_fwd(at.attn_v.proj, o_v, B * nv, res=xmm32, res_rowmap=rmv, out=xmm1, c_rowmap=rmv, C2=xvo_b, c2_mode=2)
+        lin_fwd(at.attn_a.proj, o_a, B * na, res=xmm32, res_rowmap=rma, out=xmm1, c_rowmap=rma, C2=xao_b, c2_mode=2)
+    # all (v, a) pairs: Linear(cat(xv_i, xa_j)) = W[:, :D] xv_i + W[:, D:] xa_j + b  (never materialised)
+    with region():
+        kv_p = lin_fwd(at.k, xvo_b, B * nv, k=D)
+        ka_p = lin_fwd(at.k, xao_b, B * na, k=D, w_col_off=D, use_bias=False)
+        vv_p = lin_fwd(at.v, xvo_b, B * nv, k=D)
+        va_p = lin_fwd(at.v, xao_b, B * na, k=D, w_col_off=D, use_bias=False)
+    P = nv * na
+    Kp, Vp = _e((B * P, Da), BF16, dev), _e((B * P, D), BF16, dev)
+    with region():
+        ops.pair_expand(kv_p, ka_p, B, nv, na, Da, Kp)
+        ops.pair_expand(vv_p, va_p, B, nv, na, D, Vp)
+    scale = hd ** -0.5                                                                       # NOT (Da/heads)^-0.5 (:220-222)
+    o2, lse2 = attention_fwd((q2, 0), (Kp, 0), (Vp, 0), B, heads, nmm, P, Da // heads, hd, scale,
+                             nmm * Da, Da, P * Da, Da, P * D, D, dev)
+    lin_fwd(at.proj, o2, B * nmm, res=xmm32, res_rowmap=rm2, out=xmm1, c_rowmap=rm2)
+    h2, _, st2 = ln_fwd(fb.norm2, None, xmm1, B)
+    Hd = fb.mlp.fc1.weight.shape[0]
+    z = _e((B * nF, Hd), BF16, dev)
+    u = lin_fwd(fb.mlp.fc1, h2, B * nF, act=1, out_bf16=True, C2=z, c2_mode=4)
+    out = lin_fwd(fb.mlp.fc2, u, B * nF, res=xmm1).view(B, nF, D)
+    tape = dict(dp=None, x_f=x_f, x_i=x_i, x_a=x_a, xmm_b=xmm_b, st_mm=st_mm, xv_b=xv_b, st_v=st_v, xa_b=xa_b, st_a=st_a, cv=cv, ca=ca,
+                xvo_b=xvo_b, xao_b=xao_b, Kp=Kp, Vp=Vp, q2=q2, o2=o2, lse2=lse2, xmm1=xmm1, h2=h2, st2=st2, z=z, u=u,
+                heads=heads, tkns=tkns)
+    return out, tape
+
+
+def _factorized_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
+    """g fp32 [B,nF,D] grad of the block output.  Returns (dx_f fp32, dx_i, dx_a);
+    dx_i / dx_a are freshly STORED (fp32 [B,n,D]) unless buffers are passed.  Same step / region structure as the forward;
+    library launches only (no torch op touches a buffer a recorded kernel produces)."""
+    if t.get('dp') is not None:
+        return _factorized_bwd_seq(fb, t, g, gb, dx_i=dx_i, dx_a=dx_a)
+    x_f, x_i, x_a, heads = t['x_f'], t['x_i'], t['x_a'], t['heads']
+    B, nF, D = x_f.shape
+    nI, nA = x_i.shape[1], x_a.shape[1]
+    nmm, nv, na = t['tkns']
+    dev, at = x_f.device, fb.attn
+    Da, hd = at.q.weight.shape[0], D // heads
+    P = nv * na
+    rm2, rmv, rma = (nmm, nF, 0), (nv, nF, nmm), (na, nF, nmm + nv)
+    cv, ca = t['cv'], t['ca']
+    if gb is None:
+        gb = to_bf16(g)
+    dz = lin_bwd(fb.mlp.fc2, gb, t['u'], B * nF, gelu_aux=t['z'])
+    dh2 = lin_bwd(fb.mlp.fc1, dz, t['h2'], B * nF)
+    g1 = _e((B, nF, D), F32, dev)                 # gradient at xmm1 = residual-path gradient of the normed xmm
+    g1b = _e((B * nF, D), BF16, dev)
+    ln_bwd(fb.norm2, None, t['xmm1'], B, t['st2'], dy_bf16=dh2, dx1=g1, res1=g, dx1_bf16=g1b)
+    # d(normed xmm) from the three projections of its row groups lands in one bf16 buffer
+    dxmm_b = _e((B * nF, D), BF16, dev)
+    # --- pair attention branch (rows [0, nmm)) ---
+    do2 = lin_bwd(at.proj, g1b, t['o2'], B * nmm, dy_rowmap=rm2)                              # [B*nmm, D]
+    dq2, dKp, dVp = _e((B * nmm, Da), BF16, dev), _e((B * P, Da), BF16, dev), _e((B * P, D), BF16, dev)
+    attention_bwd((t['q2'], 0), (t['Kp'], 0), (t['Vp'], 0), t['o2'], do2, t['lse2'], (dq2, 0), (dKp, 0), (dVp, 0),
+                  B, heads, nmm, P, Da // heads, hd, hd ** -0.5, nmm * Da, Da, P * Da, Da, P * D, D,
+                  nmm * Da, Da, P * Da, Da, P * D, D)
+    dkv_p, dka_p = _e((B * nv, Da), BF16, dev), _e((B * na, Da), BF16, dev)
+    dvv_p, dva_p = _e((B * nv, D), BF16, dev), _e((B * na, D), BF16, dev)
+    with region():
+        lin_bwd(at.q, dq2, t['xmm_b'], B * nmm, a_rowmap=rm2, dx=dxmm_b, dx_rowmap=rm2)
+        ops.pair_reduce(dKp, B, nv, na, Da, dkv_p, dka_p)
+        ops.pair_reduce(dVp, B, nv, na, D, dvv_p, dva_p)
+    # d(xv_out) = g1[rows v] + dkv_p Wk[:, :D] + dvv_p Wv[:, :D]   (fp32 accumulate, bf16 twin on the last GEMM):
+    # the first GEMM of each pair brings g1's rows in as its fp32 residual, the second accumulates
+    dxvo, dxao = _e((B * nv, D), F32, dev), _e((B * na, D), F32, dev)
+    dxvo_b, dxao_b = _e((B * nv, D), BF16, dev), _e((B * na, D), BF16, dev)
+    g1r = g1.view(B * nF, D)
+    with region():
+        lin_bwd(at.k, dkv_p, t['xvo_b'], B * nv, k=D, dx=dxvo, dx_res=g1r, dx_res_rowmap=rmv, final=False)
+        lin_bwd(at.k, dka_p, t['xao_b'], B * na, k=D, w_col_off=D, use_bias=False, dx=dxao, dx_res=g1r, dx_res_rowmap=rma)
+    with region():
+        lin_bwd(at.v, dvv_p, t['xvo_b'], B * nv, k=D, dx=dxvo, dx_beta=1, dx_C2=dxvo_b, dx_c2_mode=3, final=False)
+        lin_bwd(at.v, dva_p, t['xao_b'], B * na, k=D, w_col_off=D, use_bias=False, dx=dxao, dx_beta=1, dx_C2=dxao_b, dx_c2_mode=3)
+    # --- the two aggregation cross-attentions ---
+    with region():
+        dov = lin_bwd(at.attn_v.proj, dxvo_b, cv['o'], B * nv)
+        doa = lin_bwd(at.attn_a.proj, dxao_b, ca['o'], B * na)
+    dq_v, dkv_v = _e((B * nv, D), BF16, dev), _e((B * nI, 2 * D), BF16, dev)
+    dq_a, dkv_a = _e((B * na, D), BF16, dev), _e((B * nA, 2 * D), BF16, dev)
+    with region():      # two launches each (dQ, then dK/dV): the region keeps their order and pairs them up
+        attention_bwd((cv['q'], 0), (cv['kv'], 0), (cv['kv'], D), cv['o'], dov, cv['lse'], (dq_v, 0), (dkv_v, 0), (dkv_v, D),
+                      B, heads, nv, nI, hd, hd, hd ** -0.5, nv * D, D, nI * 2 * D, 2 * D, nI * 2 * D, 2 * D,
+                      nv * D, D, nI * 2 * D, 2 * D, nI * 2 * D, 2 * D)
+        attention_bwd((ca['q'], 0), (ca['kv'], 0), (ca['kv'], D), ca['o'], doa, ca['lse'], (dq_a, 0), (dkv_a, 0), (dkv_a, D),
+                      B, heads, na, nA, hd, hd, hd ** -0.5, na * D, D, nA * 2 * D, 2 * D, nA * 2 * D, 2 * D,
+                      na * D, D, nA * 2 * D, 2 * D, nA * 2 * D, 2 * D)
+    with region():
+        lin_bwd(at.attn_v.q, dq_v, t['xmm_b'], B * nv, a_rowmap=rmv, dx=dxmm_b, dx_rowmap=rmv)
+        lin_bwd(at.attn_a.q, dq_a, t['xmm_b'], B * na, a_rowmap=rma, dx=dxmm_b, dx_rowmap=rma)
+        dxv_b = lin_bwd(at.attn_v.kv, dkv_v, t['xv_b'], B * nI)
+        dxa_b = lin_bwd(at.attn_a.kv, dkv_a, t['xa_b'], B * nA)
+    # --- the three input LayerNorms ---
+    acc_i, acc_a = (1 if dx_i is not None else 0), (1 if dx_a is not None else 0)
+    if dx_i is None:
+        dx_i = _e((B, nI, D), F32, dev)
+    if dx_a is None:
+        dx_a = _e((B, nA, D), F32, dev)
+    dx_f = _e((B, nF, D), F32, dev)
+    with region():
+        ln_bwd(fb.norm1_img, None, x_i, B, t['st_v'], dy_bf16=dxv_b, dx1=dx_i, acc1=acc_i)
+        ln_bwd(fb.norm1_aud, None, x_a, B, t['st_a'], dy_bf16=dxa_b, dx1=dx_a, acc1=acc_a)
+        ln_bwd(fb.norm1_mm, None, x_f, B, t['st_mm'], dy_bf16=dxmm_b, dy_f32=g1, dx1=dx_f)
+    return dx_f, dx_i, dx_a
+
+
+# ---- sequential form (DropPath active: per-sample scaled branches need torch ops between the kernels) --------------------
+def _cross_fwd_seq(ca, xq_b, q_rowmap, nq, xkv_b, nk, B, D, heads, dev):
     """CrossAttention (models/fusion_blocks.py:46-59) up to (not incl.) proj. xq_b rows come from the
     normed fusion tokens through q_rowmap; xkv_b is the normed modality [B*nk, D]."""
     hd = D // heads
@@ -491,7 +665,7 @@ def _cross_fwd(ca, xq_b, q_rowmap, nq, xkv_b, nk, B, D, heads, dev):
     return dict(q=q, kv=kv, o=o, lse=lse)
 
 
-def _cross_bwd(ca, c, do, xq_b, q_rowmap, nq, xkv_b, nk, B, D, heads, dxq_out, dxq_rowmap):
+def _cross_bwd_seq(ca, c, do, xq_b, q_rowmap, nq, xkv_b, nk, B, D, heads, dxq_out, dxq_rowmap):
     """do: bf16 [B*nq, D] grad wrt the attention output (pre-proj). Returns d(xkv normed) bf16 [B*nk, D];
     writes d(xq normed) into rows of dxq_out through dxq_rowmap."""
     hd, dev = D // heads, do.device
@@ -504,7 +678,7 @@ def _cross_bwd(ca, c, do, xq_b, q_rowmap, nq, xkv_b, nk, B, D, heads, dxq_out, d
     return lin_bwd(ca.kv, dkv, xkv_b, B * nk)
 
 
-def _factorized_fwd(fb, x_f, x_i, x_a, heads, tkns, dp=None):
+def _factorized_fwd_seq(fb, x_f, x_i, x_a, heads, tkns, dp=None):
     B, nF, D = x_f.shape
     nI, nA = x_i.shape[1], x_a.shape[1]
     nmm, nv, na = tkns
@@ -515,8 +689,8 @@ def _factorized_fwd(fb, x_f, x_i, x_a, heads, tkns, dp=None):
     xv_b, _, st_v = ln_fwd(fb.norm1_img, None, x_i, B)
     xa_b, _, st_a = ln_fwd(fb.norm1_aud, None, x_a, B)
     rm2, rmv, rma = (nmm, nF, 0), (nv, nF, nmm), (na, nF, nmm + nv)
-    cv = _cross_fwd(at.attn_v, xmm_b, rmv, nv, xv_b, nI, B, D, heads, dev)
-    ca = _cross_fwd(at.attn_a, xmm_b, rma, na, xa_b, nA, B, D, heads, dev)
+    cv = _cross_fwd_seq(at.attn_v, xmm_b, rmv, nv, xv_b, nI, B, D, heads, dev)
+    ca = _cross_fwd_seq(at.attn_a, xmm_b, rma, na, xa_b, nA, B, D, heads, dev)
     xmm1 = _e((B, nF, D), F32, dev)
     # proj of the two aggregations: fp32 result lands in its rows of xmm1 (+ normed-xmm residual),
     # bf16 twin of the pre-residual value feeds the pair projections
@@ -552,7 +726,7 @@ def _factorized_fwd(fb, x_f, x_i, x_a, heads, tkns, dp=None):
     return out, tape
 
 
-def _factorized_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
+def _factorized_bwd_seq(fb, t, g, gb, *, dx_i=None, dx_a=None):
     """g fp32 [B,nF,D] grad of the block output.  Returns (dx_f fp32 + bf16 twin, dx_i, dx_a);
     dx_i / dx_a are freshly STORED (fp32 [B,n,D]) unless buffers are passed."""
     x_f, x_i, x_a, heads = t['x_f'], t['x_i'], t['x_a'], t['heads']
@@ -608,8 +782,8 @@ def _factorized_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
     # --- the two aggregation cross-attentions ---
     dov = lin_bwd(at.attn_v.proj, dxvo_b, t['cv']['o'], B * nv)
     doa = lin_bwd(at.attn_a.proj, dxao_b, t['ca']['o'], B * na)
-    dxv_b = _cross_bwd(at.attn_v, t['cv'], dov, t['xmm_b'], rmv, nv, t['xv_b'], nI, B, D, heads, dxmm_b, rmv)
-    dxa_b = _cross_bwd(at.attn_a, t['ca'], doa, t['xmm_b'], rma, na, t['xa_b'], nA, B, D, heads, dxmm_b, rma)
+    dxv_b = _cross_bwd_seq(at.attn_v, t['cv'], dov, t['xmm_b'], rmv, nv, t['xv_b'], nI, B, D, heads, dxmm_b, rmv)
+    dxa_b = _cross_bwd_seq(at.attn_a, t['ca'], doa, t['xmm_b'], rma, na, t['xa_b'], nA, B, D, heads, dxmm_b, rma)
     # --- the three input LayerNorms ---
     acc_i, acc_a = (1 if dx_i is not None else 0), (1 if dx_a is not None else 0)
     if dx_i is None:
@@ -768,6 +942,12 @@ def _dense_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
     dx_f = _e((B, nF, D), F32, dev)
     ln_bwd(fb.norm1_mm, None, x_f, B, t['st_mm'], dy_bf16=dxmm_b, dy_f32=g1, dx1=dx_f)
     return dx_f, dx_i, dx_a
+
+
+def fusion_block_batchable(fb, dp=None):
+    """True when the block's forward / backward consist of library launches only, i.e. may run as a lane of a launch batch
+    (the factorised block without DropPath; the token / dense blocks and DropPath use torch ops between kernels)."""
+    return dp is None and getattr(fb, 'arch', 'factorized_mmi') == 'factorized_mmi'
 
 
 def fusion_block_fwd(fb, x_f, x_i, x_a, heads, tkns, dp=None):

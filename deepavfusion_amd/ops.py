@@ -54,6 +54,25 @@ def batch_lane():
     _lib.check(_lib.load().dav_batch_lane(), 'dav_batch_lane')
 
 
+def batch_region(begin):
+    _lib.check(_lib.load().dav_batch_region(int(begin)), 'dav_batch_region')
+
+
+class unbatched:
+    """Launches inside go out at once even while a batch is being recorded (weight-cache refreshes: nothing recorded
+    so far depends on them, the launches recorded next read their result)."""
+
+    def __enter__(self):
+        self.on = HOLD is not None
+        if self.on:
+            _lib.load().dav_batch_suspend(1)
+
+    def __exit__(self, *exc):
+        if self.on:
+            _lib.load().dav_batch_suspend(0)
+        return False
+
+
 def batch_end(abort=False):
     """Issue (or drop) the recorded launches; returns (recorded, issued) launch counts."""
     global HOLD

@@ -182,9 +182,15 @@ int dav_adamw_flat(float* p, float* g, float* m, float* v, void* p_bf16, long n,
  * individually; the order inside a lane is kept.  With auto_lanes != 0 every recorded launch is its own lane (a region of
  * mutually independent launches).  Requirements on the caller: lanes must not depend on each other; every buffer a recorded
  * launch touches must stay allocated until dav_batch_end() returns; all launches of a batch use the stream they were
- * recorded with.  No nesting.  dav_batch_stats reports the last batch: launches recorded / launches issued. */
+ * recorded with.  No nesting.  dav_batch_stats reports the last batch: launches recorded / launches issued.
+ * dav_batch_region(1) .. dav_batch_region(0): the launches recorded in between are independent of each other and form ONE
+ * step of the current lane (e.g. the q / kv projections of both aggregation cross-attentions of a fusion block). */
 int dav_batch_begin(int auto_lanes);
 int dav_batch_lane(void);
+int dav_batch_region(int begin);
+/* on != 0: launches are issued at once although a batch is open (for work that nothing recorded so far depends on and
+ * that later recorded launches need, e.g. refreshing a bf16 weight copy); on == 0: recording resumes. */
+int dav_batch_suspend(int on);
 int dav_batch_end(void);
 int dav_batch_abort(void);
 int dav_batch_stats(int* recorded_ops, int* issued_launches);

@@ -127,3 +127,20 @@ def test_batched_grouped_launches_equal_individual_launches():
     assert E.BATCH_STATS == [3, 1], E.BATCH_STATS
     for c, r in zip(grouped, single):
         assert torch.equal(c, r)
+    # a region inside a lane: its launches form ONE step and merge with the other lane's launch of that step
+    E.BATCH_STATS[:] = [0, 0]
+    again = [torch.empty_like(c) for c in single]
+    tail = torch.empty_like(single[0])
+    with E.batch() as bt:
+        bt.lane()
+        with E.region():
+            ops.gemm_nt(A[0], W[0], A[0].shape[0], W[0].shape[0], 256, C_out=again[0])
+            ops.gemm_nt(A[1], W[1], A[1].shape[0], W[1].shape[0], 256, C_out=again[1])
+        ops.gemm_nt(A[0], W[0], A[0].shape[0], W[0].shape[0], 256, C_out=tail, res=again[0], ldres=W[0].shape[0])   # depends on step 1
+        bt.lane()
+        ops.gemm_nt(A[2], W[2], A[2].shape[0], W[2].shape[0], 256, C_out=again[2])
+    torch.cuda.synchronize()
+    assert E.BATCH_STATS == [4, 2], E.BATCH_STATS
+    for c, r in zip(again, single):
+        assert torch.equal(c, r)
+    assert torch.equal(tail, single[0] + single[0])
