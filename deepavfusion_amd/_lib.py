@@ -27,6 +27,7 @@ SIGNATURES = {
     'dav_gemm_tn_grouped_bf16': [_p, _i, _p],
     'dav_attn_fwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _i, _l, _i, _l, _i, _l, _i, _f, _p],
     'dav_attn_bwd': [_p] * 10 + [_i] * 6 + [_l, _i] * 8 + [_f, _p],
+    'dav_attn_bwd_part': [_p] * 10 + [_i] * 6 + [_l, _i] * 8 + [_f, _i, _p],
     'dav_layernorm_fwd': [_p, _l, _i, _p, _l, _i, _i, _i, _p, _p, _f, _p, _p, _p, _p, _p],
     'dav_layernorm_bwd': [_p, _l, _i, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p,
                           _p, _l, _i, _p, _l, _p, _l,
@@ -53,6 +54,7 @@ SIGNATURES = {
     'dav_batch_begin': [_i],
     'dav_batch_lane': [],
     'dav_batch_region': [_i],
+    'dav_batch_skip': [_i],
     'dav_batch_suspend': [_i],
     'dav_batch_end': [],
     'dav_batch_abort': [],

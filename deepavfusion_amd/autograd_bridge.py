@@ -100,11 +100,12 @@ def encoder_fwd(enc, image, audio, ik32, ak32, want_f32=False, collect_embs=Fals
             lane_f = fb is not None and E.fusion_block_batchable(fb, dpf)
             if fb is not None and not lane_f:
                 n_f, tf = E.fusion_block_fwd(fb, x_f, x_i, x_a, Hf, enc.num_fusion, dpf)      # reads the layer INPUT x_i / x_a (:106-107)
+            idle = E.FUSION_IDLE_FWD if lane_f else 0
             with E.batch() as bt:
                 bt.lane()
-                n_i, ti = E.block_fwd(bi, x_i, xf_ctx, Hi, bi.norm1.eps, dpi)
+                n_i, ti = E.block_fwd(bi, x_i, xf_ctx, Hi, bi.norm1.eps, dpi, idle_before_mlp=idle)
                 bt.lane()
-                n_a, ta = E.block_fwd(ba, x_a, xf_ctx, Ha, ba.norm1.eps, dpa)
+                n_a, ta = E.block_fwd(ba, x_a, xf_ctx, Ha, ba.norm1.eps, dpa, idle_before_mlp=idle)
                 if lane_f:
                     bt.lane()
                     n_f, tf = E.fusion_block_fwd(fb, x_f, x_i, x_a, Hf, enc.num_fusion, dpf)
@@ -175,11 +176,12 @@ def _encoder_bwd(enc, t, dxi_b, dxa_b, dxf_b, dxi32, dxa32, dxf32, layer_cb=None
             lane_f = fb is not None and E.fusion_block_batchable(fb, tf.get('dp'))
             if fb is not None and not lane_f:
                 dx_f, dx_i, dx_a = E.fusion_block_bwd(fb, tf, g_f, g_fb)
+            idle = E.FUSION_IDLE_BWD if lane_f else 0
             with E.batch() as bt:
                 bt.lane()
-                st_i = E.block_bwd_head(bi, ti, g_i, g_ib)
+                st_i = E.block_bwd_head(bi, ti, g_i, g_ib, idle_before_attn=idle)
                 bt.lane()
-                st_a = E.block_bwd_head(ba, ta, g_a, g_ab)
+                st_a = E.block_bwd_head(ba, ta, g_a, g_ab, idle_before_attn=idle)
                 if lane_f:
                     bt.lane()
                     dx_f, dx_i, dx_a = E.fusion_block_bwd(fb, tf, g_f, g_fb)
@@ -190,7 +192,8 @@ def _encoder_bwd(enc, t, dxi_b, dxa_b, dxf_b, dxi32, dxa32, dxf32, layer_cb=None
                 bt.lane()
                 g_a, g_ab, dxf_a = E.block_bwd_tail(ba, ta, st_a, dx_mod=dx_a, dx_mod_acc=acc)
             if fb is not None:
-                g_f, g_fb = dxf_i.add_(dxf_a), None
+                g_f = dxf_i.add_(dxf_a)
+                g_fb = E.to_bf16(g_f)          # outside the next layer's batch: its fusion lane starts with the fc2 dgrad, like the towers'
             del st_i, st_a
         elif fb is None:
             sa.wait_stream(main)

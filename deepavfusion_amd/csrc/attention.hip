@@ -609,12 +609,13 @@ int launch_fwd(const AttnParams& p, hipStream_t stream) {
 }
 
 template <int DQK, int DV>
-int launch_bwd(const AttnParams& p, hipStream_t stream) {
+int launch_bwd(const AttnParams& p, hipStream_t stream, int part = 3) {
   const size_t row = attn_row_bytes<DQK, DV>();
   const size_t lds1 = attn_lds<DQK, DV, 1>(p), lds2 = attn_lds<DQK, DV, 2>(p);
   const int nw1 = waves_for(p.Nq), nw2 = waves_for(p.Nk);
   // dQ first: it also writes Delta, which the dK/dV kernel reads
-  if (lds1 <= ATTN_RESIDENT_MAX) {
+  if (!(part & 1)) {
+  } else if (lds1 <= ATTN_RESIDENT_MAX) {
     attn_resident<DQK, DV, 1>(p, stream);
   } else {
     auto k1 = attn_bwd_dq_kernel<DQK, DV, true>;
@@ -622,7 +623,8 @@ int launch_bwd(const AttnParams& p, hipStream_t stream) {
     if (int rc = raise_lds_cap<attn_bwd_dq_kernel<DQK, DV, true>>(ldc)) return rc;
     DAV_LAUNCH(k1, dim3(p.B * p.H, (p.Nq + nw1 * 16 - 1) / (nw1 * 16)), dim3(nw1 * 64), ldc, stream, p);
   }
-  if (lds2 <= ATTN_RESIDENT_MAX) {
+  if (!(part & 2)) {
+  } else if (lds2 <= ATTN_RESIDENT_MAX) {
     attn_resident<DQK, DV, 2>(p, stream);
   } else {
     auto k2 = attn_bwd_dkv_kernel<DQK, DV, true>;
@@ -667,7 +669,16 @@ extern "C" int dav_attn_bwd(const void* Q, const void* K, const void* V, const v
                             long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs,
                             long do_bs, int do_rs, long dq_bs, int dq_rs, long dk_bs, int dk_rs, long dv_bs, int dv_rs,
                             float scale, hipStream_t stream) {
-  if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return DAV_ERR_SHAPE;
+  return dav_attn_bwd_part(Q, K, V, O, dO, LSE, Delta, dQ, dK, dV, B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs,
+                           o_bs, o_rs, do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, scale, 3, stream);
+}
+
+extern "C" int dav_attn_bwd_part(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
+                                 float* Delta, void* dQ, void* dK, void* dV, int B, int H, int Nq, int Nk, int dqk, int dv,
+                                 long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs,
+                                 long do_bs, int do_rs, long dq_bs, int dq_rs, long dk_bs, int dk_rs, long dv_bs, int dv_rs,
+                                 float scale, int part, hipStream_t stream) {
+  if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0 || part < 1 || part > 3) return DAV_ERR_SHAPE;
   AttnParams p = {};
   p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.Of = (const bf16_t*)O; p.O = nullptr;
   p.dO = (const bf16_t*)dO; p.LSE = const_cast<float*>(LSE); p.Delta = Delta;
@@ -677,9 +688,9 @@ extern "C" int dav_attn_bwd(const void* Q, const void* K, const void* V, const v
   p.dq_bs = dq_bs; p.dk_bs = dk_bs; p.dv_bs = dv_bs; p.dq_rs = dq_rs; p.dk_rs = dk_rs; p.dv_rs = dv_rs; p.scale = scale;
   p.O = (bf16_t*)O;   // only for the alignment check
   if (!strides_ok(p, true)) return DAV_ERR_ALIGN;
-  if (dqk == 64 && dv == 64) return launch_bwd<64, 64>(p, stream);
-  if (dqk == 32 && dv == 32) return launch_bwd<32, 32>(p, stream);
-  if (dqk == 16 && dv == 64) return launch_bwd<16, 64>(p, stream);
-  if (dqk == 16 && dv == 16) return launch_bwd<16, 16>(p, stream);
+  if (dqk == 64 && dv == 64) return launch_bwd<64, 64>(p, stream, part);
+  if (dqk == 32 && dv == 32) return launch_bwd<32, 32>(p, stream, part);
+  if (dqk == 16 && dv == 64) return launch_bwd<16, 64>(p, stream, part);
+  if (dqk == 16 && dv == 16) return launch_bwd<16, 16>(p, stream, part);
   return DAV_ERR_SHAPE;
 }

@@ -79,6 +79,13 @@ extern "C" int dav_batch_region(int begin) {
   return DAV_OK;
 }
 
+extern "C" int dav_batch_skip(int steps) {
+  if (!S.on || S.auto_lanes || S.in_region || steps < 0) return DAV_ERR_SHAPE;
+  if (S.lanes.empty()) S.lanes.emplace_back();
+  for (int i = 0; i < steps; ++i) S.lanes.back().emplace_back();      // empty steps: this lane idles while the others advance
+  return DAV_OK;
+}
+
 extern "C" int dav_batch_suspend(int on) {
   S.suspended = on != 0;
   return DAV_OK;

@@ -320,8 +320,14 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4 (&acc)[FM][
   }
 }
 
-template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK>
+template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK, bool PROF = false, int PIPE = 0>
 __device__ __forceinline__ void nt2_body(const NTParams& p, int bid) {
+  // PROF (tile configuration 30, tools/gemm_phase_prof.py only): per-wave shader-cycle sums of the k-loop phases —
+  // [wait for the DMA, barrier, DMA issue, fragment reads + MFMAs, prologue, epilogue] — written to the int64 buffer
+  // passed in place of res_rows (s_memtime; the instrumentation itself costs ~10 %).
+  long long pt[6] = {0, 0, 0, 0, 0, 0};
+  long long tk0 = 0, tstart = 0;
+  if (PROF) tstart = tk0 = __builtin_readcyclecounter();
   constexpr int NT = WM_ * WN_ * 64;
   constexpr int WTM = BM / WM_, WTN = BN / WN_, FM = WTM / 16, FN = WTN / 16;
   constexpr int ARB = BK * 2, ACPR = BK / 8;               // LDS row bytes / 16-byte chunks per row of A (and NT-mode B) tiles
@@ -407,14 +413,113 @@ __device__ __forceinline__ void nt2_body(const NTParams& p, int bid) {
     if (s < nk) dma_tile(s);
 
   const int fr = lane & 15, fg = lane >> 4;
+  if (PROF) { const long long t = __builtin_readcyclecounter(); pt[4] = t - tk0; tk0 = t; }
+  if constexpr (PIPE == 1) {
+    // Software-pipelined k-loop (2-stage ring, BK = 64).  Measured on the plain loop below (tools/gemm_phase_prof.py): per
+    // k-step a wave spends 28 % of its time issuing its 4 DMA pieces (all 16 waves of the CU hit the one 64 B/clk
+    // address path at once, right after the barrier) and 43 % in "read fragments -> wait -> 4 MFMAs" rounds.  Here the two
+    // 32-deep halves of a k-step are double-buffered in registers: the fragment reads of the next half are in flight
+    // under the 8 MFMAs of the current one, the DMA pieces of the tile after next are issued one per two MFMAs, and
+    // the one barrier per k-step sits between the halves, where 8 MFMAs are already queued.
+    static_assert(STAGES == 2 && BK == 64, "pipelined loop: 2 stages, BK 64");
+    auto load_frags = [&](const char* Ab, int kk, bf16x8 (&af)[FM], bf16x8 (&bfr)[FN]) {
+      const char* Bb = Ab + A_BYTES;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int row = wm * WTM + i * 16 + fr;
+        af[i] = *reinterpret_cast<const bf16x8*>(Ab + row * ARB + (((kk * 4 + fg) ^ rswz(row)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        if (!BT) {
+          const int row = wn * WTN + j * 16 + fr;
+          bfr[j] = *reinterpret_cast<const bf16x8*>(Bb + row * ARB + (((kk * 4 + fg) ^ rswz(row)) << 4));
+        } else {
+          bfr[j] = tn2_frag<BRB>(Bb, kk * 32, wn * WTN + j * 16, lane);
+        }
+      }
+    };
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // wave-uniform in an SGPR: the DMA's LDS base goes through M0
+    auto dma_piece = [&](int kt, int piece) {
+      const int k0 = kt * BK;
+      char* st = smem + (kt & 1) * STAGE_BYTES;
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i)
+        if (piece == i)
+          __builtin_amdgcn_global_load_lds(GLB_PTR(void, a_src[i] + k0), LDS_PTR(void, st + (wave_u * 64 + NT * i) * 16), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < B_CH; ++i)
+        if (piece == A_CH + i)
+          __builtin_amdgcn_global_load_lds(GLB_PTR(void, BT ? b_src[i] + (long)k0 * p.ldb : b_src[i] + k0),
+                                           LDS_PTR(void, st + A_BYTES + (wave_u * 64 + NT * i) * 16), 16, 0, 0);
+    };
+    constexpr int NMFMA = FM * FN;
+    constexpr int EVERY = NMFMA / LPT > 0 ? NMFMA / LPT : 1;      // one DMA piece per EVERY MFMAs
+    bf16x8 a0[FM], b0[FN], a1[FM], b1[FN];
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                                 // tile 0 is in LDS
+    if (1 < nk) dma_tile(1);
+    load_frags(smem, 0, a0, b0);
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* Ab = smem + (kt & 1) * STAGE_BYTES;
+      // first-half MFMAs; the second half's fragment reads go out behind the first row of them (issued in front, the
+      // compiler's in-order lgkmcnt wait for the first half's fragments would also wait for these)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[0], b0[j], acc[0][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_frags(Ab, 1, a1, b1);                                  // second half of tile kt: in flight under the MFMAs below
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 1; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < nk) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my pieces of tile kt+1 landed; my reads of tile kt are done
+        __builtin_amdgcn_s_barrier();                             // tile kt+1 visible to all, stage kt & 1 free for tile kt+2
+        const bool more = kt + 2 < nk;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+            const int idx = i * FN + j;
+            if (idx == FN - 1) {                                    // behind the first row of MFMAs (see above)
+              __builtin_amdgcn_sched_barrier(0);
+              load_frags(smem + ((kt + 1) & 1) * STAGE_BYTES, 0, a0, b0);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            if (idx % EVERY == EVERY - 1 && idx / EVERY < LPT) {
+              if (more) dma_piece(kt + 2, idx / EVERY);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        if (LPT > NMFMA / EVERY) {                                // more pieces than slots (does not happen for the shipped tiles)
+#pragma unroll
+          for (int q = NMFMA / EVERY; q < LPT; ++q)
+            if (more) dma_piece(kt + 2, q);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  } else
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt must have landed; up to STAGES-2 younger tiles may stay in flight
     const int younger = nk - 1 - kt;
     if (STAGES >= 3 && younger >= STAGES - 2) wait_vmcnt<(STAGES - 2) * LPT>();
     else if (STAGES >= 4 && younger == 1) wait_vmcnt<LPT>();
     else wait_vmcnt<0>();
+    if (PROF) { const long long t = __builtin_readcyclecounter(); pt[0] += t - tk0; tk0 = t; }
     __builtin_amdgcn_s_barrier();          // everyone's pieces of tile kt are in LDS; stage (kt-1)%STAGES is free
+    if (PROF) { const long long t = __builtin_readcyclecounter(); pt[1] += t - tk0; tk0 = t; }
     if (kt + STAGES - 1 < nk) dma_tile(kt + STAGES - 1);
+    if (PROF) { const long long t = __builtin_readcyclecounter(); pt[2] += t - tk0; tk0 = t; }
     const char* Ab = smem + (kt % STAGES) * STAGE_BYTES;
     const char* Bb = Ab + A_BYTES;
 #pragma unroll
@@ -440,15 +545,41 @@ __device__ __forceinline__ void nt2_body(const NTParams& p, int bid) {
         for (int j = 0; j < FN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
+    if (PROF) {
+      asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[FM - 1][FN - 1]));      // the MFMAs have been issued before the stamp
+      const long long t = __builtin_readcyclecounter(); pt[3] += t - tk0; tk0 = t;
+    }
   }
 
   __syncthreads();                          // all waves finished reading the last stage
+  if (PROF) {
+    NTParams q = p;
+    q.res_rows = nullptr;
+    nt_epilogue<FM, FN, WTM, WTN>(q, acc, smem, m0, n0, wave, wm, wn, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long t = __builtin_readcyclecounter(); pt[5] = t - tk0;
+    if (lane == 0) {
+      long long* out = reinterpret_cast<long long*>(const_cast<int*>(p.res_rows)) + ((long)blockIdx.x * (WM_ * WN_) + wave) * 10;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) out[i] = pt[i];
+      out[6] = tstart;
+      out[7] = t;
+      out[8] = __builtin_amdgcn_s_getreg(6164);     // HW_REG_XCC_ID (id 20), offset 0, size 4: ((4-1) << 11) | 20
+      out[9] = __builtin_amdgcn_s_getreg(63492);    // HW_REG_HW_ID (id 4), all 32 bits: ((32-1) << 11) | 4
+    }
+    return;
+  }
   nt_epilogue<FM, FN, WTM, WTN>(p, acc, smem, m0, n0, wave, wm, wn, lane);
 }
 
-template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK = 64>
-__global__ __launch_bounds__(WM_* WN_ * 64) void gemm_nt2_kernel(NTParams p) {
-  nt2_body<BM, BN, WM_, WN_, STAGES, BT, BK>(p, blockIdx.x);
+__global__ __launch_bounds__(512) void gemm_nt2_prof_kernel(NTParams p) {
+  nt2_body<128, 128, 2, 4, 2, false, 64, true>(p, blockIdx.x);
+}
+
+// PIPE: two 512-thread workgroups per CU = 4 waves per SIMD -> at most 128 VGPRs (2nd launch-bounds argument = waves per SIMD)
+template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK = 64, int PIPE = 0>
+__global__ __launch_bounds__(WM_* WN_ * 64, PIPE ? 4 : 1) void gemm_nt2_kernel(NTParams p) {
+  nt2_body<BM, BN, WM_, WN_, STAGES, BT, BK, false, PIPE>(p, blockIdx.x);
 }
 
 // Grouped launch: up to NT_GROUP_MAX independent problems (any M / N / K / epilogue, one tile configuration) in ONE grid —
@@ -462,11 +593,11 @@ struct NTGroup {
   int count;
 };
 
-template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK = 64>
-__global__ __launch_bounds__(WM_* WN_ * 64) void gemm_nt2_grouped_kernel(const NTGroup g) {
+template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK = 64, int PIPE = 0>
+__global__ __launch_bounds__(WM_* WN_ * 64, PIPE ? 4 : 1) void gemm_nt2_grouped_kernel(const NTGroup g) {
   int pi = 0;
   while (pi + 1 < g.count && (int)blockIdx.x >= g.first_block[pi + 1]) ++pi;
-  nt2_body<BM, BN, WM_, WN_, STAGES, BT, BK>(g.prob[pi], (int)blockIdx.x - g.first_block[pi]);
+  nt2_body<BM, BN, WM_, WN_, STAGES, BT, BK, false, PIPE>(g.prob[pi], (int)blockIdx.x - g.first_block[pi]);
 }
 
 template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK>
@@ -477,12 +608,12 @@ constexpr size_t nt2_lds_bytes() {
 }
 
 // launches n >= 1 recorded problems of this tile configuration (davb::GroupFn)
-template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK>
+template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK, int PIPE = 0>
 void nt2_issue(const void* const* params, int n, hipStream_t stream) {
   constexpr int NT = WM_ * WN_ * 64;
   constexpr size_t lds = nt2_lds_bytes<BM, BN, WM_, WN_, STAGES, BT, BK>();
-  auto kern = gemm_nt2_kernel<BM, BN, WM_, WN_, STAGES, BT, BK>;
-  auto gkern = gemm_nt2_grouped_kernel<BM, BN, WM_, WN_, STAGES, BT, BK>;
+  auto kern = gemm_nt2_kernel<BM, BN, WM_, WN_, STAGES, BT, BK, PIPE>;
+  auto gkern = gemm_nt2_grouped_kernel<BM, BN, WM_, WN_, STAGES, BT, BK, PIPE>;
   static bool big = false;
   if (lds > 64 * 1024 && !big) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -510,14 +641,14 @@ void nt2_issue(const void* const* params, int n, hipStream_t stream) {
   }
 }
 
-template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT = false, int BK = 64>
+template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT = false, int BK = 64, int PIPE = 0>
 void launch_nt2(const NTParams& p, hipStream_t stream) {
   if (davb::recording()) {
-    davb::push_typed(nt2_issue<BM, BN, WM_, WN_, STAGES, BT, BK>, &p, sizeof(p), stream);
+    davb::push_typed(nt2_issue<BM, BN, WM_, WN_, STAGES, BT, BK, PIPE>, &p, sizeof(p), stream);
     return;
   }
   const void* one = &p;
-  nt2_issue<BM, BN, WM_, WN_, STAGES, BT, BK>(&one, 1, stream);
+  nt2_issue<BM, BN, WM_, WN_, STAGES, BT, BK, PIPE>(&one, 1, stream);
 }
 
 int nt_auto_config_tiles(long t128, bool narrow);
@@ -885,6 +1016,7 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
     if (cfg == 0) cfg = nt_auto_config(M, N, K);
     switch (cfg) {
       case 3: launch_nt2<128, 128, 2, 4, 2, true>(p, stream); break;
+      case 31: launch_nt2<128, 128, 2, 4, 2, true, 64, 1>(p, stream); break;
       case 8: launch_nt2<128, 64, 2, 2, 2, true>(p, stream); break;
       default: launch_nt2<64, 64, 2, 2, 2, true>(p, stream); break;
     }
@@ -893,6 +1025,13 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
   if (vec_ok && !(variant & 15)) {
     if (cfg == 0) cfg = nt_auto_config(M, N, K);
     switch (cfg) {
+      case 30: {      // phase profile of the dominant configuration (see nt2_body); res_rows carries the int64 output buffer
+        if (res) return DAV_ERR_SHAPE;
+        const int grid = ((M + 127) / 128) * ((N + 127) / 128);
+        DAV_LAUNCH_NOW(gemm_nt2_prof_kernel, dim3(grid), dim3(512), (size_t)65536, stream, p);
+        return dav_launch_status();
+      }
+      case 31: launch_nt2<128, 128, 2, 4, 2, false, 64, 1>(p, stream); return dav_launch_status();
       case 1: launch_nt2<128, 128, 2, 2, 2>(p, stream); return dav_launch_status();
       case 2: launch_nt2<128, 128, 2, 2, 3>(p, stream); return dav_launch_status();
       case 3: launch_nt2<128, 128, 2, 4, 2>(p, stream); return dav_launch_status();

@@ -90,6 +90,13 @@ class batch:
         return False
 
 
+def lane_skip(steps: int):
+    """Inside a batch lane: idle for ``steps`` steps, so that this lane's next launches line up with (and are grouped
+    with) equal launches of a longer lane.  No effect outside a batch."""
+    if _BATCH is not None and steps > 0:
+        ops.batch_skip(steps)
+
+
 def gbuf(p: torch.nn.Parameter) -> torch.Tensor:
     if p.grad is None:
         p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
@@ -394,12 +401,15 @@ def attention_fwd(q, k, v, B, H, Nq, Nk, dqk, dv, scale, q_bs, q_rs, k_bs, k_rs,
 
 
 def attention_bwd(q, k, v, O, dO, LSE, dq, dk, dvv, B, H, Nq, Nk, dqk, dv, scale, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs,
-                  dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs):
-    Delta = torch.empty_like(LSE)
+                  dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, part=3, Delta=None):
+    """``part`` 1 / 2: only the dQ (+ Delta) / only the dK-dV kernel, with the same ``Delta`` buffer passed to both calls
+    (lets a caller put the two kernels of several attentions into two regions of a launch batch)."""
+    if Delta is None:
+        Delta = torch.empty_like(LSE)
     ops.hold(q[0], k[0], v[0], dq[0], dk[0], dvv[0])
     p = lambda t: t[0].data_ptr() + 2 * t[1]
     ops.attn_bwd(p(q), p(k), p(v), O, dO, LSE, Delta, p(dq), p(dk), p(dvv), B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs,
-                 v_bs, v_rs, Nq * H * dv, H * dv, Nq * H * dv, H * dv, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, scale)
+                 v_bs, v_rs, Nq * H * dv, H * dv, Nq * H * dv, H * dv, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, scale, part=part)
 
 
 def to_bf16(x):
@@ -422,7 +432,7 @@ def _res_add(lin, a, M, res, B, rows, D, scale, **kw):
     return out
 
 
-def block_fwd(blk, x_mod, x_fus, heads, eps, dp=None):
+def block_fwd(blk, x_mod, x_fus, heads, eps, dp=None, idle_before_mlp=0):
     """x_mod fp32 [B,n,D]; x_fus fp32 [B,nF,D] or None (context rows: keys/values only —
     models/deepavfusion.py:104-105).  ``dp`` = (s_attn, s_mlp): per-sample DropPath scales (fp32 [B], 0 or 1/keep) of the
     two residual branches, None when inactive.  Returns (x_out fp32 [B,n,D], tape)."""
@@ -435,6 +445,7 @@ def block_fwd(blk, x_mod, x_fus, heads, eps, dp=None):
     o, lse = attention_fwd((qkv, nF * 3 * D), (qkv, D), (qkv, 2 * D), B, heads, n, R, hd, hd, hd ** -0.5,
                            R * 3 * D, 3 * D, R * 3 * D, 3 * D, R * 3 * D, 3 * D, dev)
     x1 = _res_add(blk.attn.proj, o, Mq, x_mod, B, n, D, None if dp is None else dp[0]).view(B, n, D)
+    lane_skip(idle_before_mlp)          # batched beside a fusion block: line norm2 / fc1 / fc2 up with its norm2 / fc1 / fc2
     h2, _, st2 = ln_fwd(blk.norm2, None, x1, B, eps)
     Hd = blk.mlp.fc1.weight.shape[0]
     z = _e((Mq, Hd), BF16, dev)
@@ -457,7 +468,7 @@ def block_bwd(blk, t, g2, g2b, *, dx_fus=None, dx_fus_acc=0, dx_mod=None, dx_mod
     return block_bwd_tail(blk, t, st, dx_fus=dx_fus, dx_fus_acc=dx_fus_acc, dx_mod=dx_mod, dx_mod_acc=dx_mod_acc, need_dx=need_dx)
 
 
-def block_bwd_head(blk, t, g2, g2b):
+def block_bwd_head(blk, t, g2, g2b, idle_before_attn=0):
     x_mod, x_fus, heads, nF = t['x_mod'], t['x_fus'], t['heads'], t['nF']
     B, n, D = x_mod.shape
     R, hd, dev = nF + n, D // heads, x_mod.device
@@ -476,6 +487,7 @@ def block_bwd_head(blk, t, g2, g2b):
     if dp is not None:
         ops.rows_scale_cast(g1, dp[0], B, n, D, g1b)
     do = lin_bwd(blk.attn.proj, g1b, t['o'], Mq)
+    lane_skip(idle_before_attn)         # batched beside a fusion block: line the attention backward up with its cross-attentions
     dqkv = _e((M, 3 * D), BF16, dev)
     if nF > 0:      # attention writes dq for the modality rows and dk / dv for all rows: only the (dropped) queries of the
         dqkv.view(B, R, 3 * D)[:, :nF, :D].zero_()      # fusion context rows are never written and must read as zero
@@ -627,13 +639,15 @@ def _factorized_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
         doa = lin_bwd(at.attn_a.proj, dxao_b, ca['o'], B * na)
     dq_v, dkv_v = _e((B * nv, D), BF16, dev), _e((B * nI, 2 * D), BF16, dev)
     dq_a, dkv_a = _e((B * na, D), BF16, dev), _e((B * nA, 2 * D), BF16, dev)
-    with region():      # two launches each (dQ, then dK/dV): the region keeps their order and pairs them up
-        attention_bwd((cv['q'], 0), (cv['kv'], 0), (cv['kv'], D), cv['o'], dov, cv['lse'], (dq_v, 0), (dkv_v, 0), (dkv_v, D),
-                      B, heads, nv, nI, hd, hd, hd ** -0.5, nv * D, D, nI * 2 * D, 2 * D, nI * 2 * D, 2 * D,
-                      nv * D, D, nI * 2 * D, 2 * D, nI * 2 * D, 2 * D)
-        attention_bwd((ca['q'], 0), (ca['kv'], 0), (ca['kv'], D), ca['o'], doa, ca['lse'], (dq_a, 0), (dkv_a, 0), (dkv_a, D),
-                      B, heads, na, nA, hd, hd, hd ** -0.5, na * D, D, nA * 2 * D, 2 * D, nA * 2 * D, 2 * D,
-                      na * D, D, nA * 2 * D, 2 * D, nA * 2 * D, 2 * D)
+    del_v, del_a = torch.empty_like(cv['lse']), torch.empty_like(ca['lse'])
+    for part in (1, 2):      # dQ kernels of both aggregations, then their dK/dV kernels: two steps, like a tower block's attention
+        with region():
+            attention_bwd((cv['q'], 0), (cv['kv'], 0), (cv['kv'], D), cv['o'], dov, cv['lse'], (dq_v, 0), (dkv_v, 0), (dkv_v, D),
+                          B, heads, nv, nI, hd, hd, hd ** -0.5, nv * D, D, nI * 2 * D, 2 * D, nI * 2 * D, 2 * D,
+                          nv * D, D, nI * 2 * D, 2 * D, nI * 2 * D, 2 * D, part=part, Delta=del_v)
+            attention_bwd((ca['q'], 0), (ca['kv'], 0), (ca['kv'], D), ca['o'], doa, ca['lse'], (dq_a, 0), (dkv_a, 0), (dkv_a, D),
+                          B, heads, na, nA, hd, hd, hd ** -0.5, na * D, D, nA * 2 * D, 2 * D, nA * 2 * D, 2 * D,
+                          na * D, D, nA * 2 * D, 2 * D, nA * 2 * D, 2 * D, part=part, Delta=del_a)
     with region():
         lin_bwd(at.attn_v.q, dq_v, t['xmm_b'], B * nv, a_rowmap=rmv, dx=dxmm_b, dx_rowmap=rmv)
         lin_bwd(at.attn_a.q, dq_a, t['xmm_b'], B * na, a_rowmap=rma, dx=dxmm_b, dx_rowmap=rma)
@@ -944,10 +958,16 @@ def _dense_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
     return dx_f, dx_i, dx_a
 
 
+# steps a tower block idles when it runs as a lane beside the factorised fusion block (see _factorized_fwd / _bwd):
+# forward: k/v pair projections, pair_expand, pair attention, its proj (steps 5-8) sit between the towers' proj and norm2;
+# backward: pair attention dQ, dK/dV, [q2 dgrad + pair_reduce], k dgrads, v dgrads, aggregation-proj dgrads (steps 5-10)
+FUSION_IDLE_FWD, FUSION_IDLE_BWD = 4, 6
+
+
 def fusion_block_batchable(fb, dp=None):
     """True when the block's forward / backward consist of library launches only, i.e. may run as a lane of a launch batch
     (the factorised block without DropPath; the token / dense blocks and DropPath use torch ops between kernels)."""
-    return dp is None and getattr(fb, 'arch', 'factorized_mmi') == 'factorized_mmi'
+    return dp is None and getattr(fb, 'arch', 'factorized_mmi') == 'factorized_mmi' and os.environ.get('DAV_BATCH_FUSION_LANE', '1') != '0'
 
 
 def fusion_block_fwd(fb, x_f, x_i, x_a, heads, tkns, dp=None):

@@ -54,6 +54,10 @@ def batch_lane():
     _lib.check(_lib.load().dav_batch_lane(), 'dav_batch_lane')
 
 
+def batch_skip(steps):
+    _lib.check(_lib.load().dav_batch_skip(int(steps)), 'dav_batch_skip')
+
+
 def batch_region(begin):
     _lib.check(_lib.load().dav_batch_region(int(begin)), 'dav_batch_region')
 
@@ -134,11 +138,12 @@ def attn_fwd(q_ptr, k_ptr, v_ptr, O, LSE, B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_b
 
 
 def attn_bwd(q_ptr, k_ptr, v_ptr, O, dO, LSE, Delta, dq_ptr, dk_ptr, dv_ptr, B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs,
-             v_bs, v_rs, o_bs, o_rs, do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, scale):
+             v_bs, v_rs, o_bs, o_rs, do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, scale, part=3):
+    """part 1: dQ (+ Delta) kernel only, 2: dK/dV kernel only (after part 1), 3: both."""
     lib = _lib.load()
-    _lib.check(lib.dav_attn_bwd(q_ptr, k_ptr, v_ptr, _ptr(O), _ptr(dO), _ptr(LSE), _ptr(Delta), dq_ptr, dk_ptr, dv_ptr,
-                                B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, do_bs, do_rs,
-                                dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, float(scale), _stream()), 'dav_attn_bwd')
+    _lib.check(lib.dav_attn_bwd_part(q_ptr, k_ptr, v_ptr, _ptr(O), _ptr(dO), _ptr(LSE), _ptr(Delta), dq_ptr, dk_ptr, dv_ptr,
+                                     B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, do_bs, do_rs,
+                                     dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, float(scale), part, _stream()), 'dav_attn_bwd')
 
 
 def layernorm_fwd(x0, x0_bs, r0, x1, x1_bs, r1, B, D, gamma, beta, eps, y_bf16, y_f32, mean, rstd):

@@ -93,6 +93,11 @@ int dav_attn_bwd(const void* Q, const void* K, const void* V, const void* O, con
                  void* dQ, void* dK, void* dV, int B, int H, int Nq, int Nk, int dqk, int dv, long q_bs, int q_rs, long k_bs,
                  int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, long do_bs, int do_rs, long dq_bs, int dq_rs, long dk_bs,
                  int dk_rs, long dv_bs, int dv_rs, float scale, hipStream_t stream);
+/* the same in two calls: part 1 = the dQ (+ Delta) kernel, part 2 = the dK/dV kernel (reads Delta), part 3 = both */
+int dav_attn_bwd_part(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, float* Delta,
+                 void* dQ, void* dK, void* dV, int B, int H, int Nq, int Nk, int dqk, int dv, long q_bs, int q_rs, long k_bs,
+                 int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, long do_bs, int do_rs, long dq_bs, int dq_rs, long dk_bs,
+                 int dk_rs, long dv_bs, int dv_rs, float scale, int part, hipStream_t stream);
 
 /* ---- LayerNorm ---------------------------------------------------------------------------- */
 /* nn.LayerNorm over D on rows taken from two fp32 sources per batch element (r0 rows of x0, then r1
@@ -188,6 +193,8 @@ int dav_adamw_flat(float* p, float* g, float* m, float* v, void* p_bf16, long n,
 int dav_batch_begin(int auto_lanes);
 int dav_batch_lane(void);
 int dav_batch_region(int begin);
+/* the current lane idles for `steps` steps (aligns its later launches with equal launches of a longer lane) */
+int dav_batch_skip(int steps);
 /* on != 0: launches are issued at once although a batch is open (for work that nothing recorded so far depends on and
  * that later recorded launches need, e.g. refreshing a bf16 weight copy); on == 0: recording resumes. */
 int dav_batch_suspend(int on);
