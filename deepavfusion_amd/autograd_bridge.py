@@ -282,6 +282,44 @@ def patch_tokens(vit, x, ids_keep):
     return _PatchTokensFn.apply(vit, _f32c(x), _ids32(ids_keep), vit.patch_embed.proj.weight, vit.patch_embed.proj.bias)
 
 
+class _CrossAttentionFn(torch.autograd.Function):
+    """Standalone ``CrossAttention.forward(x1, x2)`` (models/fusion_blocks.py:46-59): q / kv projections, softmax attention,
+    proj — on the HIP kernels, with the hand-written backward."""
+
+    @staticmethod
+    def forward(ctx, ca, x1, x2, *params):
+        ctx.set_materialize_grads(False)
+        B, N1, D = x1.shape
+        N2 = x2.shape[1]
+        x1b, x2b = E.to_bf16(x1.reshape(B * N1, D)), E.to_bf16(x2.reshape(B * N2, D))
+        c = E._cross_fwd_seq(ca, x1b, None, N1, x2b, N2, B, D, ca.num_heads, x1.device)
+        out = E.lin_fwd(ca.proj, c['o'], B * N1)
+        ctx.ca, ctx.c, ctx.x1b, ctx.x2b, ctx.dims, ctx.np = ca, c, x1b, x2b, (B, N1, N2, D), len(params)
+        # the attention matrix the reference also returns: softmax rebuilt from the kernels' own q / k and log-sum-exp
+        H, hd = ca.num_heads, D // ca.num_heads
+        q = c['q'].view(B, N1, H, hd).permute(0, 2, 1, 3).float()
+        k = c['kv'].view(B, N2, 2, H, hd)[:, :, 0].permute(0, 2, 1, 3).float()
+        attn = torch.exp((q @ k.transpose(-2, -1)) * ca.scale - c['lse'].unsqueeze(-1))
+        ctx.mark_non_differentiable(attn)
+        return out.view(B, N1, D), attn
+
+    @staticmethod
+    def backward(ctx, g, _g_attn):
+        B, N1, N2, D = ctx.dims
+        ca = ctx.ca
+        with E.deferred_wgrads():
+            do = E.lin_bwd(ca.proj, E.to_bf16(g.contiguous().view(B * N1, D)), ctx.c['o'], B * N1)
+            dx1 = torch.empty(B * N1, D, dtype=BF16, device=g.device)
+            dx2 = E._cross_bwd_seq(ca, ctx.c, do, ctx.x1b, None, N1, ctx.x2b, N2, B, D, ca.num_heads, dx1, None)
+        E.join_wgrad_stream(g.device)
+        return (None, dx1.float().view(B, N1, D), dx2.float().view(B, N2, D)) + (None,) * ctx.np
+
+
+def cross_attention(ca, x1, x2):
+    params = [p for p in ca.parameters()]
+    return _CrossAttentionFn.apply(ca, _f32c(x1), _f32c(x2), *params)
+
+
 class _FusionBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, fb, xmm, xv, xa, *params):

@@ -16,6 +16,11 @@ class CrossAttention(nn.Module):
         self.kv = nn.Linear(dim, dim * 2, bias=qkv_bias)
         self.proj = nn.Linear(dim, dim)
 
+    def forward(self, x1, x2):
+        """-> (x1', attn) as models/fusion_blocks.py:46-59; attn [B, heads, N1, N2] is returned detached."""
+        from ..autograd_bridge import cross_attention
+        return cross_attention(self, x1, x2)
+
 
 class CrossAttention_FactorizedAVInteractions(nn.Module):
     """models/fusion_blocks.py:216-263.  q/k are dim*dim_ratio wide, v and proj stay full width, and the

@@ -315,6 +315,27 @@ def test_fusion_block_module(golden):
             assert rel(p.grad, g[k]) < GRAD_TOL, k
 
 
+def test_cross_attention_module_forward_backward(golden):
+    """``CrossAttention.forward(x1, x2)`` called standalone (models/fusion_blocks.py:46-59) against the reference's own
+    outputs and gradients (fixture cross_attention.* of tests/golden/gen_golden.py); the attention matrix is a softmax."""
+    g = golden('ops_micro')
+    model, sd, cfg, O = _build('micro')
+    ca = model.encoder.fusion_blocks[0].attn.attn_v
+    ins = [torch.from_numpy(g[f'cross_attention.in{i}']).cuda().requires_grad_(True) for i in range(2)]
+    model.zero_grad()
+    y, attn = ca(*ins)
+    assert rel(y, g['cross_attention.out']) < ACT_TOL
+    assert attn.shape == (ins[0].shape[0], ca.num_heads, ins[0].shape[1], ins[1].shape[1])
+    assert float((attn.sum(-1) - 1).abs().max()) < 2e-2 and float(attn.min()) >= 0
+    y.backward(torch.from_numpy(g['cross_attention.gout']).cuda())
+    for i, x in enumerate(ins):
+        assert rel(x.grad, g[f'cross_attention.gin{i}']) < ACT_TOL, i
+    for k in g.files:
+        if k.startswith('cross_attention.gw.') and not k.endswith(('kv.bias',)):
+            p = dict(ca.named_parameters())[k[len('cross_attention.gw.'):]]
+            assert rel(p.grad, g[k]) < GRAD_TOL, k
+
+
 def test_trainer_step_semantics(golden):
     """util/misc.py Trainer.step: accumulation, grad-norm scaling, AdamW update (fixture from the reference)."""
     from deepavfusion_amd.util import lr_sched
