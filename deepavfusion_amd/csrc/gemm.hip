@@ -10,6 +10,8 @@
 //
 // Replaces the cuBLAS/rocBLAS calls behind F.linear in timm Block / Mlp / Attention and
 // models/fusion_blocks.py:41-44,227-232; models/avmae.py:31,59-60,88.
+#include <cstdlib>
+
 #include "common.h"
 #include "dav_kernels.h"
 
@@ -35,6 +37,7 @@ struct NTParams {
   bf16_t* C2; int ldc2; int c2_mode;   // second bf16 output [M, ldc2]: 1 pre-activation, 2 post-activation/pre-residual, 3 final value
   int beta;                      // C (fp32) += result
   float alpha;
+  int debug;                     // timing experiments only (DAV_NT_DEBUG): 1 = epilogue without global stores, 2 = no epilogue
 };
 
 struct TNParams {
@@ -248,6 +251,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 template <int FM, int FN, int WTM, int WTN>
 __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4 (&acc)[FM][FN], char* patch_base, int m0, int n0, int wave,
                                             int wm, int wn, int lane) {
+  if (p.debug & 2) return;
   const int fr = lane & 15, fg = lane >> 4;
   constexpr int LDW = WTN + 4;              // floats per patch row (+4: at most 2-way ds_write conflicts)
   float* patch = reinterpret_cast<float*>(patch_base) + wave * (16 * LDW);
@@ -271,6 +275,7 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4 (&acc)[FM][
         const int m = m0 + wm * WTM + i * 16 + lr;
         if (lr >= 16 || m >= p.M) continue;
         float4 v = *reinterpret_cast<const float4*>(patch + lr * LDW + cc * 4);
+        if (p.debug & 1) { if (v.x == 123.456f) reinterpret_cast<float*>(p.C)[0] = v.y; continue; }
         if (p.c2_mode == 1) {
           uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
           *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
@@ -315,6 +320,158 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4 (&acc)[FM][
           uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
           *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
         }
+      }
+    }
+  }
+}
+
+// Epilogue for TRANSPOSED accumulators.  The k-loops of the second / third generation kernels issue their MFMAs with the
+// operands swapped (B fragment first): the 16 x 16 result block then comes out transposed, i.e. lane (fr = lane & 15,
+// fg = lane >> 4) holds C[m = fr][n = 4 fg .. 4 fg + 3] — FOUR CONSECUTIVE COLUMNS OF ONE ROW — instead of four rows of one
+// column.  Every epilogue access (bias, residual, aux, C, C2) is then a 16-byte (fp32) / 8-byte (bf16) per-lane piece of a
+// row straight from registers: no LDS round trip, no waits.  Measured on the LDS-staged epilogue above (DAV_NT_DEBUG):
+// 31 % of the 11264 x 2304 x 768 GEMM and 45 % of the K = 512 decoder GEMMs were epilogue, more than half of it the
+// registers -> LDS -> registers transposition.
+template <int FM, int FN, int WTM, int WTN>
+__device__ __forceinline__ void nt_epilogue_t(const NTParams& p, f32x4 (&acc)[FM][FN], int m0, int n0, int wm, int wn, int lane) {
+  if (p.debug & 2) return;
+  const int fr = lane & 15, fg = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int m = m0 + wm * WTM + i * 16 + fr;
+    if (m >= p.M) continue;
+    const long crow = p.C ? map_row(m, p.cmap) : 0;
+    long rrow = 0;
+    if (p.res) rrow = p.res_rows ? (long)p.res_rows[m] : map_row(m, p.rmap);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int n = n0 + wn * WTN + j * 16 + fg * 4;
+      if (n >= p.N) continue;
+      float4 v;
+      v.x = acc[i][j][0] * p.alpha; v.y = acc[i][j][1] * p.alpha; v.z = acc[i][j][2] * p.alpha; v.w = acc[i][j][3] * p.alpha;
+      if (p.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+      }
+      if (p.debug & 1) { if (v.x == 123.456f) reinterpret_cast<float*>(p.C)[0] = v.y; continue; }
+      if (p.c2_mode == 1) {
+        uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
+        *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
+      }
+      if (p.act == 1) {
+        float4 d;
+        gelu_pair_f(v.x, v.x, d.x); gelu_pair_f(v.y, v.y, d.y); gelu_pair_f(v.z, v.z, d.z); gelu_pair_f(v.w, v.w, d.w);
+        if (p.c2_mode == 4) {          // bf16 twin = GELU'(pre-activation): the fc2 input gradient only multiplies by it
+          uint2 w; w.x = pack2bf(d.x, d.y); w.y = pack2bf(d.z, d.w);
+          *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
+        }
+      } else if (p.act == 2) {
+        const uint2 a = *reinterpret_cast<const uint2*>(p.aux + (long)m * p.ldaux + n);
+        v.x *= gelu_grad_f(__uint_as_float(a.x << 16)); v.y *= gelu_grad_f(__uint_as_float(a.x & 0xffff0000u));
+        v.z *= gelu_grad_f(__uint_as_float(a.y << 16)); v.w *= gelu_grad_f(__uint_as_float(a.y & 0xffff0000u));
+      } else if (p.act == 3) {
+        const uint2 a = *reinterpret_cast<const uint2*>(p.aux + (long)m * p.ldaux + n);
+        v.x *= __uint_as_float(a.x << 16); v.y *= __uint_as_float(a.x & 0xffff0000u);
+        v.z *= __uint_as_float(a.y << 16); v.w *= __uint_as_float(a.y & 0xffff0000u);
+      }
+      if (p.c2_mode == 2) {
+        uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
+        *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
+      }
+      if (p.res) {
+        const float4 t = *reinterpret_cast<const float4*>(p.res + rrow * p.ldres + n);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+      if (p.C) {
+        if (p.c_bf16) {
+          uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
+          *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + crow * p.ldc + n) = w;
+        } else {
+          float4* c = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + crow * p.ldc + n);
+          if (p.beta) { const float4 o = *c; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+          *c = v;
+        }
+      }
+      if (p.c2_mode == 3) {
+        uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
+        *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
+      }
+    }
+  }
+}
+
+// Staged epilogue for the bf16-output GEMMs (qkv / fc1 forward, every input-gradient GEMM): the whole workgroup tile goes
+// through LDS ONCE as bf16 so that the global stores are full rows — 16 lanes x 16 bytes = the tile row's whole
+// BN * 2 bytes (two 128-byte lines for BN = 128) per instruction — instead of the 32-byte pieces the transposed accumulators
+// give directly (measured slower than even the old LDS-staged 64-byte pieces: partial-line writes).  Elementwise work
+// (alpha, bias, GELU / GELU' twin, multiply by aux) happens on the registers, four consecutive columns at a time; the tile
+// image has 16 bytes of padding per row (the 16 rows of a ds_write_b64 lane group land on distinct banks).  One or two outputs (C and
+// the bf16 twin C2) are staged side by side.  Eligible: bf16 C, no residual, N % 8 == 0, ldc % 8 == 0 (nt_staged_ok).
+template <int BM, int BN>
+constexpr int nt_stage_bytes() { return BM * (BN * 2 + 16); }
+
+__device__ __forceinline__ bool nt_staged_ok(const NTParams& p) {
+  return p.C && p.c_bf16 && !p.res && !p.beta && !(p.N & 7) && !(p.ldc & 7) && (p.c2_mode == 0 || (p.c2_mode != 3 && !(p.ldc2 & 7))) &&
+         !(p.debug & 3);
+}
+
+template <int BM, int BN, int NTHREADS, int FM, int FN, int WTM, int WTN>
+__device__ __forceinline__ void nt_epilogue_s(const NTParams& p, f32x4 (&acc)[FM][FN], char* lds, int m0, int n0, int wm, int wn,
+                                              int lane, int tid) {
+  constexpr int RB = BN * 2 + 16;                         // padded tile row (16: keeps the b128 row reads aligned)
+  const int fr = lane & 15, fg = lane >> 4;
+  char* img2 = lds + BM * RB;
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int ml = wm * WTM + i * 16 + fr;
+    const int m = m0 + ml;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int nl = wn * WTN + j * 16 + fg * 4;
+      const int n = n0 + nl;
+      float4 v;
+      v.x = acc[i][j][0] * p.alpha; v.y = acc[i][j][1] * p.alpha; v.z = acc[i][j][2] * p.alpha; v.w = acc[i][j][3] * p.alpha;
+      const bool ok = m < p.M && n < p.N;
+      if (p.bias && ok) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+      }
+      uint2 w2 = uint2{0, 0};
+      if (p.c2_mode == 1) { w2.x = pack2bf(v.x, v.y); w2.y = pack2bf(v.z, v.w); }
+      if (p.act == 1) {
+        float4 d;
+        gelu_pair_f(v.x, v.x, d.x); gelu_pair_f(v.y, v.y, d.y); gelu_pair_f(v.z, v.z, d.z); gelu_pair_f(v.w, v.w, d.w);
+        if (p.c2_mode == 4) { w2.x = pack2bf(d.x, d.y); w2.y = pack2bf(d.z, d.w); }
+      } else if ((p.act == 2 || p.act == 3) && ok) {
+        const uint2 a = *reinterpret_cast<const uint2*>(p.aux + (long)m * p.ldaux + n);
+        float4 g;
+        g.x = __uint_as_float(a.x << 16); g.y = __uint_as_float(a.x & 0xffff0000u);
+        g.z = __uint_as_float(a.y << 16); g.w = __uint_as_float(a.y & 0xffff0000u);
+        if (p.act == 2) { g.x = gelu_grad_f(g.x); g.y = gelu_grad_f(g.y); g.z = gelu_grad_f(g.z); g.w = gelu_grad_f(g.w); }
+        v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w;
+      }
+      if (p.c2_mode == 2) { w2.x = pack2bf(v.x, v.y); w2.y = pack2bf(v.z, v.w); }
+      uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
+      *reinterpret_cast<uint2*>(lds + ml * RB + nl * 2) = w;
+      if (p.c2_mode) *reinterpret_cast<uint2*>(img2 + ml * RB + nl * 2) = w2;
+    }
+  }
+  __syncthreads();
+  constexpr int CPR = BN / 8;                             // 16-byte chunks per tile row
+  constexpr int RPI = NTHREADS / CPR;                     // rows per pass
+  const int ch = tid % CPR, r0 = tid / CPR;
+  const int n = n0 + ch * 8;
+  if (n < p.N) {
+#pragma unroll
+    for (int it = 0; it < BM / RPI; ++it) {
+      const int ml = it * RPI + r0;
+      const int m = m0 + ml;
+      if (m >= p.M) continue;
+      const uint4 w = *reinterpret_cast<const uint4*>(lds + ml * RB + ch * 16);
+      *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + map_row(m, p.cmap) * p.ldc + n) = w;
+      if (p.c2_mode) {
+        const uint4 w2 = *reinterpret_cast<const uint4*>(img2 + ml * RB + ch * 16);
+        *reinterpret_cast<uint4*>(p.C2 + (long)m * p.ldc2 + n) = w2;
       }
     }
   }
@@ -465,7 +622,7 @@ __device__ __forceinline__ void nt2_body(const NTParams& p, int bid) {
       // first-half MFMAs; the second half's fragment reads go out behind the first row of them (issued in front, the
       // compiler's in-order lgkmcnt wait for the first half's fragments would also wait for these)
 #pragma unroll
-      for (int j = 0; j < FN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[0], b0[j], acc[0][j], 0, 0, 0);
+      for (int j = 0; j < FN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j], a0[0], acc[0][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       load_frags(Ab, 1, a1, b1);                                  // second half of tile kt: in flight under the MFMAs below
       __builtin_amdgcn_sched_barrier(0);
@@ -473,7 +630,7 @@ __device__ __forceinline__ void nt2_body(const NTParams& p, int bid) {
       for (int i = 1; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j], a0[i], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       if (kt + 1 < nk) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my pieces of tile kt+1 landed; my reads of tile kt are done
@@ -483,7 +640,7 @@ __device__ __forceinline__ void nt2_body(const NTParams& p, int bid) {
         for (int i = 0; i < FM; ++i)
 #pragma unroll
           for (int j = 0; j < FN; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a1[i], acc[i][j], 0, 0, 0);
             const int idx = i * FN + j;
             if (idx == FN - 1) {                                    // behind the first row of MFMAs (see above)
               __builtin_amdgcn_sched_barrier(0);
@@ -505,7 +662,7 @@ __device__ __forceinline__ void nt2_body(const NTParams& p, int bid) {
         for (int i = 0; i < FM; ++i)
 #pragma unroll
           for (int j = 0; j < FN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a1[i], acc[i][j], 0, 0, 0);
       }
     }
   } else
@@ -543,7 +700,7 @@ __device__ __forceinline__ void nt2_body(const NTParams& p, int bid) {
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
     if (PROF) {
       asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[FM - 1][FN - 1]));      // the MFMAs have been issued before the stamp
@@ -555,7 +712,7 @@ __device__ __forceinline__ void nt2_body(const NTParams& p, int bid) {
   if (PROF) {
     NTParams q = p;
     q.res_rows = nullptr;
-    nt_epilogue<FM, FN, WTM, WTN>(q, acc, smem, m0, n0, wave, wm, wn, lane);
+    nt_epilogue_t<FM, FN, WTM, WTN>(q, acc, m0, n0, wm, wn, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const long long t = __builtin_readcyclecounter(); pt[5] = t - tk0;
     if (lane == 0) {
@@ -569,13 +726,216 @@ __device__ __forceinline__ void nt2_body(const NTParams& p, int bid) {
     }
     return;
   }
-  nt_epilogue<FM, FN, WTM, WTN>(p, acc, smem, m0, n0, wave, wm, wn, lane);
+  if (nt_staged_ok(p)) nt_epilogue_s<BM, BN, NT, FM, FN, WTM, WTN>(p, acc, smem, m0, n0, wm, wn, lane, tid);
+  else nt_epilogue_t<FM, FN, WTM, WTN>(p, acc, m0, n0, wm, wn, lane);
 }
 
 __global__ __launch_bounds__(512) void gemm_nt2_prof_kernel(NTParams p) {
   nt2_body<128, 128, 2, 4, 2, false, 64, true>(p, blockIdx.x);
 }
 
+// ------------------------------------------------------------------------------------------------
+// NT kernel, third generation ("staggered halves"): 256 x 128 tile, 8 waves of 64 x 64, six 24 KB ring stages of
+// 32 contraction rows each (144 KB, one workgroup per CU).
+//
+// Why: the 128 x 128 kernel above needs 32 KB of operands per 2.1 MFLOP k-step — at the CU's ~64 B/clk operand path
+// that is as long as the k-step's MFMAs, and its LDS traffic is as long again, so three equally loaded units would have
+// to overlap perfectly; measured (tools/gemm_phase_prof.py) its waves spend 28 % of a k-step queueing DMA pieces, 43 % in
+// read -> wait -> MFMA rounds, 24 % of a tile in the epilogue.  A 256 x 128 tile halves the operand and LDS bytes per
+// flop, and the overlap is built in rather than hoped for: the workgroup's two halves (waves 0-3 / 4-7: one wave of each
+// on every SIMD) run the same phase sequence ONE BARRIER APART, so that whenever one half issues the 16 MFMAs of a stage
+// the other half reads the fragments of its next stage and issues its DMA pieces.  Per stage and half:
+// L (4 A + 4 B fragment reads, 3 DMA pieces, counted vmcnt) | M (16 MFMAs) |, '|' = s_barrier.
+//
+// Ring protocol (t = stage index along K, ring slot t % 6; H0's L(t) / M(t) run in barrier intervals 2t+1 / 2t+2, H1's one
+// later):
+//  * stage u's three DMA pieces per wave are issued in L(u-4): the slot held stage u-6, whose last reads (H1's, retired by
+//    the lgkmcnt(0) of its M(u-6)) finished several barriers earlier; a DMA is in flight for three stages (~6 phases)
+//    before anyone waits for it;
+//  * the counted wait at the end of L(t) — vmcnt(9): everything but the pieces of stages t+2 .. t+4 — retires this wave's
+//    pieces of stage t+1; the barriers behind it (H1 runs it one interval before H0 first reads stage t+1) publish them.
+// ------------------------------------------------------------------------------------------------
+// ABL (profiling builds only): 1 = no DMA inside the loop, 2 = no fragment reads inside the loop, 3 = no s_setprio,
+// 4 = no MFMAs
+template <bool BT, bool PROF = false, int ABL = 0>
+__device__ __forceinline__ void nt3_body(const NTParams& p, int bid) {
+  constexpr int BM = 256, BN = 128, BK = 32, NT = 512, NS = 6, D = 4;   // D = stages a DMA runs ahead
+  long long pt[6] = {0, 0, 0, 0, 0, 0};      // PROF (configuration 33): cycles in L / barrier / M / barrier, prologue, epilogue
+  long long tk0 = 0, tstart = 0;
+  if (PROF) tstart = tk0 = __builtin_readcyclecounter();
+#define NT3_STAMP(i) if (PROF) { const long long t_ = __builtin_readcyclecounter(); pt[i] += t_ - tk0; tk0 = t_; }
+  constexpr int WTM = 64, WTN = 64, FM = 4, FN = 4;
+  constexpr int ARB = BK * 2, ACPR = BK / 8;
+  constexpr int A_CH = BM * ACPR / NT, B_CH = BN * ACPR / NT, LPT = A_CH + B_CH;   // 2 + 1 DMA pieces per wave and stage
+  constexpr int A_BYTES = BM * ARB, STAGE_BYTES = (BM + BN) * ARB;      // 24 KB
+  constexpr int BRB = BN * 2, BCPR = BN / 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = wave >> 2, wr = wave & 3;
+  const int wm = (wr >> 1) + 2 * half, wn = wr & 1;                     // 4 x 2 waves
+  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+  {
+    const int nwg = tiles_m * tiles_n;
+    if (bid >= nwg) return;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int bm, bn;
+  {
+    const int npan = (tiles_n + 7) >> 3;
+    const int wn_ = (tiles_n + npan - 1) / npan;
+    const int per = tiles_m * wn_;
+    const int pnl = bid / per, rem = bid - pnl * per;
+    const int wp = (tiles_n - pnl * wn_) < wn_ ? (tiles_n - pnl * wn_) : wn_;
+    bm = rem / wp;
+    bn = pnl * wn_ + rem % wp;
+  }
+  const int m0 = bm * BM, n0 = bn * BN;
+  auto rswz = [](int row) { return (0 - (row >> 2)) & 3; };           // 64-byte rows: 4 slots, 4 rows per bank row
+
+  const bf16_t* a_src[A_CH];
+  const bf16_t* b_src[B_CH];
+#pragma unroll
+  for (int i = 0; i < A_CH; ++i) {
+    const int c = tid + NT * i, row = c / ACPR, ls = (c % ACPR) ^ rswz(row);
+    int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;
+    a_src[i] = p.A + map_row(gm, p.amap) * p.lda + ls * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < B_CH; ++i) {
+    const int c = tid + NT * i;
+    if (!BT) {
+      const int row = c / ACPR, ls = (c % ACPR) ^ rswz(row);
+      int gn = n0 + row; gn = gn < p.N ? gn : p.N - 1;
+      b_src[i] = p.B + (long)gn * p.ldb + ls * 8;
+    } else {
+      const int row = c / BCPR, pc = c % BCPR;
+      const int lc = (((pc >> 1) ^ tn2_swz<BRB>(row)) << 1) | (pc & 1);
+      int gc = n0 + lc * 8; gc = gc < p.N ? gc : p.N - 8;
+      b_src[i] = p.B + (long)row * p.ldb + gc;
+    }
+  }
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto dma_stage = [&](int t) {
+    const int k0 = t * BK;
+    char* st = smem + (t % NS) * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(void, a_src[i] + k0), LDS_PTR(void, st + (wave_u * 64 + NT * i) * 16), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(void, BT ? b_src[i] + (long)k0 * p.ldb : b_src[i] + k0),
+                                       LDS_PTR(void, st + A_BYTES + (wave_u * 64 + NT * i) * 16), 16, 0, 0);
+  };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;
+  const int fr = lane & 15, fg = lane >> 4;
+  // prologue: stages 0 .. D-1
+#pragma unroll
+  for (int t = 0; t < D; ++t)
+    if (t < nk) dma_stage(t);
+  // stage 0 landed: everything but the (up to) D-1 younger stages
+  if (nk >= D) wait_vmcnt<(D - 1) * LPT>();
+  else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();                       // stage 0 published
+  if (half == 1) __builtin_amdgcn_s_barrier();        // the second half runs one barrier behind the first
+  __builtin_amdgcn_sched_barrier(0);
+
+  bf16x8 af[FM], bfr[FN];
+  NT3_STAMP(4)
+  for (int t = 0; t < nk; ++t) {
+    const char* Ab = smem + (t % NS) * STAGE_BYTES;
+    const char* Bb = Ab + A_BYTES;
+    // ---- L(t): fragments of stage t; DMA of stage t+D; retire this wave's pieces of stage t+1
+    if (ABL != 2 || t == 0) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int row = wm * WTM + i * 16 + fr;
+      af[i] = *reinterpret_cast<const bf16x8*>(Ab + row * ARB + ((fg ^ rswz(row)) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      if (!BT) {
+        const int row = wn * WTN + j * 16 + fr;
+        bfr[j] = *reinterpret_cast<const bf16x8*>(Bb + row * ARB + ((fg ^ rswz(row)) << 4));
+      } else {
+        bfr[j] = tn2_frag<BRB>(Bb, 0, wn * WTN + j * 16, lane);
+      }
+    }
+    }
+    if (t + D < nk) {
+      if (ABL != 1) dma_stage(t + D);
+      wait_vmcnt<(D - 1) * LPT>();                   // younger: stages t+2 .. t+D
+    } else {
+      // tail: fewer younger stages are in flight; the exact count is (nk-1) - (t+1) stages
+      const int younger = nk - 2 - t;
+      if (younger >= 2) wait_vmcnt<2 * LPT>();
+      else if (younger == 1) wait_vmcnt<LPT>();
+      else wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    NT3_STAMP(0)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    NT3_STAMP(1)
+    // ---- M(t)
+    if (ABL != 3) __builtin_amdgcn_s_setprio(1);
+    if (ABL != 4) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(af[0]), "v"(bfr[0]), "v"(af[FM - 1]), "v"(bfr[FN - 1]));
+    }
+    if (ABL != 3) __builtin_amdgcn_s_setprio(0);
+    if (PROF) asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[FM - 1][FN - 1]));
+    __builtin_amdgcn_sched_barrier(0);
+    NT3_STAMP(2)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    NT3_STAMP(3)
+  }
+  if (half == 0) __builtin_amdgcn_s_barrier();        // match the second half's extra barrier
+  __syncthreads();                                    // every wave is done with the ring: the epilogue reuses it
+  if (PROF) {
+    NTParams q = p;
+    q.res_rows = nullptr;
+    nt_epilogue_t<FM, FN, WTM, WTN>(q, acc, m0, n0, wm, wn, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long t = __builtin_readcyclecounter();
+    pt[5] = t - tk0;
+    if (lane == 0) {
+      long long* out = reinterpret_cast<long long*>(const_cast<int*>(p.res_rows)) + ((long)blockIdx.x * 8 + wave) * 10;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) out[i] = pt[i];
+      out[6] = tstart; out[7] = t;
+      out[8] = __builtin_amdgcn_s_getreg(6164);
+      out[9] = __builtin_amdgcn_s_getreg(63492);
+    }
+    return;
+  }
+  if (nt_staged_ok(p)) nt_epilogue_s<BM, BN, NT, FM, FN, WTM, WTN>(p, acc, smem, m0, n0, wm, wn, lane, tid);
+  else nt_epilogue_t<FM, FN, WTM, WTN>(p, acc, m0, n0, wm, wn, lane);
+#undef NT3_STAMP
+}
+
+template <int ABL>
+__global__ __launch_bounds__(512) void gemm_nt3_prof_kernel(NTParams p) {
+  nt3_body<false, true, ABL>(p, blockIdx.x);
+}
+
+template <bool BT>
+__global__ __launch_bounds__(512) void gemm_nt3_kernel(NTParams p) {
+  nt3_body<BT>(p, blockIdx.x);
+}
 // PIPE: two 512-thread workgroups per CU = 4 waves per SIMD -> at most 128 VGPRs (2nd launch-bounds argument = waves per SIMD)
 template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK = 64, int PIPE = 0>
 __global__ __launch_bounds__(WM_* WN_ * 64, PIPE ? 4 : 1) void gemm_nt2_kernel(NTParams p) {
@@ -603,8 +963,56 @@ __global__ __launch_bounds__(WM_* WN_ * 64, PIPE ? 4 : 1) void gemm_nt2_grouped_
 template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK>
 constexpr size_t nt2_lds_bytes() {
   constexpr size_t ring = (size_t)STAGES * (BM + BN) * BK * 2;
-  constexpr size_t epi = (size_t)WM_ * WN_ * 16 * (BN / WN_ + 4) * 4;
+  constexpr size_t epi = (size_t)2 * nt_stage_bytes<BM, BN>();      // staged epilogue: C and its bf16 twin
   return ring > epi ? ring : epi;
+}
+
+template <bool BT>
+__global__ __launch_bounds__(512) void gemm_nt3_grouped_kernel(const NTGroup g) {
+  int pi = 0;
+  while (pi + 1 < g.count && (int)blockIdx.x >= g.first_block[pi + 1]) ++pi;
+  nt3_body<BT>(g.prob[pi], (int)blockIdx.x - g.first_block[pi]);
+}
+
+// staggered-halves kernel: n >= 1 recorded problems (davb::GroupFn)
+template <bool BT>
+void nt3_issue(const void* const* params, int n, hipStream_t stream) {
+  constexpr int BM = 256, BN = 128;
+  constexpr size_t lds = 6 * (BM + BN) * 64;
+  static bool big = false;
+  if (!big) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt3_kernel<BT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemm_nt3_grouped_kernel<BT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    big = true;
+  }
+  for (int base = 0; base < n; base += NT_GROUP_MAX) {
+    const int cnt = n - base < NT_GROUP_MAX ? n - base : NT_GROUP_MAX;
+    if (cnt == 1) {
+      const NTParams& p = *(const NTParams*)params[base];
+      const int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+      DAV_LAUNCH_NOW(gemm_nt3_kernel<BT>, dim3(grid), dim3(512), lds, stream, p);
+      continue;
+    }
+    NTGroup g;
+    int first = 0;
+    for (int i = 0; i < cnt; ++i) {
+      g.prob[i] = *(const NTParams*)params[base + i];
+      g.first_block[i] = first;
+      first += (((g.prob[i].M + BM - 1) / BM) * ((g.prob[i].N + BN - 1) / BN) + 7) & ~7;
+    }
+    g.first_block[cnt] = first;
+    g.count = cnt;
+    DAV_LAUNCH_NOW(gemm_nt3_grouped_kernel<BT>, dim3(first), dim3(512), lds, stream, g);
+  }
+}
+template <bool BT>
+void launch_nt3(const NTParams& p, hipStream_t stream) {
+  if (davb::recording()) {
+    davb::push_typed(nt3_issue<BT>, &p, sizeof(p), stream);
+    return;
+  }
+  const void* one = &p;
+  nt3_issue<BT>(&one, 1, stream);
 }
 
 // launches n >= 1 recorded problems of this tile configuration (davb::GroupFn)
@@ -1002,6 +1410,8 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
   p.res = res; p.ldres = ldres; p.rmap = mk(res_rowmap); p.res_rows = res_rows;
   p.C = C; p.ldc = ldc; p.c_bf16 = c_is_bf16; p.cmap = mk(c_rowmap); p.C2 = (bf16_t*)C2; p.ldc2 = ldc2; p.c2_mode = C2 ? c2_mode : 0;
   p.beta = beta; p.alpha = alpha; p.b_kn = b_kn;
+  static const int nt_debug = getenv("DAV_NT_DEBUG") ? atoi(getenv("DAV_NT_DEBUG")) : 0;
+  p.debug = nt_debug;
   const bool glds_ok = (K & 63) == 0;
   const bool vec_ok = glds_ok && (N & 3) == 0 && (ldc & 3) == 0 && (!res || (ldres & 3) == 0) && (!C2 || (ldc2 & 3) == 0) &&
                       (!aux || (ldaux & 3) == 0) && !(((uintptr_t)C | (uintptr_t)C2 | (uintptr_t)res) & 15) && !((uintptr_t)aux & 7);
@@ -1017,6 +1427,7 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
     switch (cfg) {
       case 3: launch_nt2<128, 128, 2, 4, 2, true>(p, stream); break;
       case 31: launch_nt2<128, 128, 2, 4, 2, true, 64, 1>(p, stream); break;
+      case 32: launch_nt3<true>(p, stream); break;
       case 8: launch_nt2<128, 64, 2, 2, 2, true>(p, stream); break;
       default: launch_nt2<64, 64, 2, 2, 2, true>(p, stream); break;
     }
@@ -1032,6 +1443,17 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
         return dav_launch_status();
       }
       case 31: launch_nt2<128, 128, 2, 4, 2, false, 64, 1>(p, stream); return dav_launch_status();
+      case 32: launch_nt3<false>(p, stream); return dav_launch_status();
+      case 33: case 34: case 35: case 36: case 37: {      // phase profile of the staggered-halves kernel (+ ablations 1..4); res_rows = int64 output
+        if (res) return DAV_ERR_SHAPE;
+        const int grid = ((M + 255) / 256) * ((N + 127) / 128);
+        const size_t lds = (size_t)6 * 384 * 64;
+#define NT3_PROF(A) { (void)hipFuncSetAttribute((const void*)gemm_nt3_prof_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                      DAV_LAUNCH_NOW(gemm_nt3_prof_kernel<A>, dim3(grid), dim3(512), lds, stream, p); }
+        if (cfg == 33) NT3_PROF(0) else if (cfg == 34) NT3_PROF(1) else if (cfg == 35) NT3_PROF(2) else if (cfg == 36) NT3_PROF(3) else NT3_PROF(4)
+#undef NT3_PROF
+        return dav_launch_status();
+      }
       case 1: launch_nt2<128, 128, 2, 2, 2>(p, stream); return dav_launch_status();
       case 2: launch_nt2<128, 128, 2, 2, 3>(p, stream); return dav_launch_status();
       case 3: launch_nt2<128, 128, 2, 4, 2>(p, stream); return dav_launch_status();

@@ -15,29 +15,31 @@ dev = 'cuda'
 bf = torch.bfloat16
 args = [int(a) for a in sys.argv[1:]]
 shapes = [tuple(args[i:i + 3]) for i in range(0, len(args), 3)] or [(5184, 2304, 768), (11264, 2304, 768), (7168, 3072, 768), (7168, 768, 3072), (22528, 2048, 512)]
+NT3 = os.environ.get('PROF_NT3', '0') != '0'
+NT3_CFG = 32 + int(os.environ.get('PROF_NT3', '0'))      # 1: full, 2..5: ablations (no DMA / no reads / no setprio / no MFMA)      # profile the staggered-halves kernel (configuration 33 / 32) instead
 for M, N, K in shapes:
     A = torch.randn(M, K, device=dev).to(bf)
     W = (torch.randn(N, K, device=dev) * 0.05).to(bf)
     C = torch.empty(M, N, device=dev, dtype=bf)
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    tiles = ((M + 255) // 256) * ((N + 127) // 128) if NT3 else ((M + 127) // 128) * ((N + 127) // 128)
     buf = torch.zeros(tiles * 8 * 10, dtype=torch.int64, device=dev)
     for _ in range(3):
-        ops.gemm_nt(A, W, M, N, K, C_out=C, c_bf16=True, res_rows=buf.view(torch.int32), variant=30 << 4)
+        ops.gemm_nt(A, W, M, N, K, C_out=C, c_bf16=True, res_rows=buf.view(torch.int32), variant=(NT3_CFG if NT3 else 30) << 4)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    ops.gemm_nt(A, W, M, N, K, C_out=C, c_bf16=True, res_rows=buf.view(torch.int32), variant=30 << 4)
+    ops.gemm_nt(A, W, M, N, K, C_out=C, c_bf16=True, res_rows=buf.view(torch.int32), variant=(NT3_CFG if NT3 else 30) << 4)
     e1.record()
     torch.cuda.synchronize()
     us_prof = e0.elapsed_time(e1) * 1e3
     e0.record()
-    ops.gemm_nt(A, W, M, N, K, C_out=C, c_bf16=True, variant=3 << 4)
+    ops.gemm_nt(A, W, M, N, K, C_out=C, c_bf16=True, variant=(32 if NT3 else 3) << 4)
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3
     raw = buf.view(tiles, 8, 10).cpu()
     r = raw.double()
-    nk = K // 64
+    nk = K // (32 if NT3 else 64)
     ph = r[:, :, :6].mean(dim=(0, 1))
     tot = float(ph.sum())
     print(f'{M}x{N}x{K}: {tiles} tiles, {nk} k-steps, plain {us:.1f} us ({2.0 * M * N * K / us / 1e6:.0f} TF), instrumented {us_prof:.1f} us')
