@@ -317,7 +317,8 @@ class _CrossAttentionFn(torch.autograd.Function):
 
 def cross_attention(ca, x1, x2):
     params = [p for p in ca.parameters()]
-    return _CrossAttentionFn.apply(ca, _f32c(x1), _f32c(x2), *params)
+    c = lambda x: x.to(dtype=F32).contiguous()          # no detach: the inputs receive gradients
+    return _CrossAttentionFn.apply(ca, c(x1), c(x2), *params)
 
 
 class _FusionBlockFn(torch.autograd.Function):
