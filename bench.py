@@ -115,29 +115,42 @@ def main():
     audio = (torch.randn(B, 1, *cfg.audio_size, device=dev, generator=g) * 2.0 - 3.0).clamp(-7, 4)
     torch.manual_seed(0 + rank)                            # masking noise stream, per rank (util/distributed.py:90-94)
 
-    gemm_log = []
+    # ---- record the launch mix of ONE step (rank 0): NT launches as the library really issues them (grouped or single,
+    # from the library's own issue log), the grouped weight-gradient launches and the attention calls ------------------
+    tn_log, attn_log = [], []
     if rank == 0:
-        orig = ops.gemm_nt
+        orig_tn, orig_af, orig_ab = ops.gemm_tn_grouped, ops.attn_fwd, ops.attn_bwd
 
-        def logged(A, Bm, M, N, K, **kw):
-            gemm_log.append((M, N, K, (kw.get('variant', 0) >> 12) & 1))
-            return orig(A, Bm, M, N, K, **kw)
-        ops.gemm_nt = logged
+        def log_tn(problems):
+            tn_log.append([(d['Mc'], d['N'], d['K']) for d in problems])
+            return orig_tn(problems)
 
+        def log_af(q, k, v, O, LSE, B_, H, Nq, Nk, dqk, dv, *rest):
+            attn_log.append(('fwd', B_, H, Nq, Nk, dqk, dv))
+            return orig_af(q, k, v, O, LSE, B_, H, Nq, Nk, dqk, dv, *rest)
+
+        def log_ab(q, k, v, O, dO, LSE, Delta, dq, dk, dv_, B_, H, Nq, Nk, dqk, dv, *rest, **kw):
+            if kw.get('part', 3) & 1:
+                attn_log.append(('bwd', B_, H, Nq, Nk, dqk, dv))
+            return orig_ab(q, k, v, O, dO, LSE, Delta, dq, dk, dv_, B_, H, Nq, Nk, dqk, dv, *rest, **kw)
+        ops.gemm_tn_grouped, ops.attn_fwd, ops.attn_bwd = log_tn, log_af, log_ab
+        ops.nt_issue_log(True)
+
+    def eager_step():
+        li, la = trainer.model(image, audio)[:2]
+        trainer.step(li + la)
+        return li, la
+    eager_step()                          # every rank (collectives inside); also the first warm-up pass
+    nt_log = []
+    if rank == 0:
+        nt_log = ops.nt_issue_log()
+        ops.nt_issue_log(False)
+        ops.gemm_tn_grouped, ops.attn_fwd, ops.attn_bwd = orig_tn, orig_af, orig_ab
     if a.no_graph or a.roofline_only:
-        def step():
-            li, la = trainer.model(image, audio)[:2]
-            trainer.step(li + la)
-            return li, la
-        step()
+        step = eager_step
     else:
         gs = GraphedStep(trainer, image.shape, audio.shape)
         step = lambda: gs(image, audio)
-    if rank == 0:
-        from deepavfusion_amd import ops as _o
-        _o.gemm_nt = orig
-        n_per_pass = len(gemm_log) // (1 if (a.no_graph or a.roofline_only) else 3)     # GraphedStep: 2 warm-up passes + 1 capture pass
-        gemm_log = gemm_log[-n_per_pass:]
 
     if a.roofline_only:
         a.warmup, a.steps, a.no_cpu_baseline = 0, 1, True
@@ -150,11 +163,16 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize()
     sync()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    ev[0].record()
+    for i in range(a.steps):
         out = step()
+        ev[i + 1].record()
     sync()
     dt = time.perf_counter() - t0
+    step_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(a.steps))       # device-event time per step
+    median_ms = step_ms[len(step_ms) // 2]
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -175,6 +193,7 @@ def main():
                                f'masks {cfg.image_mask_ratio}/{cfg.audio_mask_ratio}, fusion attn_ratio {cfg.fusion_attn_ratio} mlp_ratio {cfg.fusion_mlp_ratio}',
                    'global_batch': B * world, 'parallelism': f'dp{world}', 'graph': not (a.no_graph or a.roofline_only)},
         'pairs_per_s_per_gpu': round(pairs_per_s / world, 2),
+        'median_ms_per_step_device_events': round(median_ms, 3),
         'loss': round(loss, 5),
         'step_necessary_gflop_per_pair': round(flops_pair / 1e9, 1),
         'step_mfma_frac': round(flops_pair * pairs_per_s / world / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
@@ -183,41 +202,135 @@ def main():
     if a.roofline_only:
         result['note'] = 'roofline-only run: value/ms_per_step are ONE eager step, not the metric; see roofline'
 
-    # ---- roofline of the dominant kernel (gemm_nt_kernel<128,128>): replay this step's launch mix --------------
-    # the launches the library's dispatch (gemm.hip: nt_auto_config) sends to the 128x128 / 8-wave kernel
-    big = [(M, N, K, kn) for (M, N, K, kn) in gemm_log if N > 64 and N % 4 == 0 and K % 64 == 0 and ((M + 127) // 128) * ((N + 127) // 128) >= 400]
-    if big and not a.no_roofline:
-        bufs = {}
-        for (M, N, K, kn) in set(big):
-            Bm = (torch.randn(K, N, device=dev) * 0.05).bfloat16() if kn else (torch.randn(N, K, device=dev) * 0.05).bfloat16()
-            bufs[(M, N, K, kn)] = (torch.randn(M, K, device=dev).bfloat16(), Bm, torch.empty(M, N, device=dev, dtype=torch.bfloat16))
+    # ---- BASELINE.md section 4 asks for the audio-mask-0.75 variant beside the default 0.8 (80 instead of 63 kept audio
+    # tokens): same model and optimizer, a second captured step, a short timed run; labelled secondary -----------------
+    if world == 1 and not (a.no_graph or a.roofline_only) and abs(cfg.audio_mask_ratio - 0.8) < 1e-9:
+        model.audio_mask_ratio = 0.75
+        gs75 = GraphedStep(trainer, image.shape, audio.shape)
+        for _ in range(3):
+            gs75(image, audio)
+        torch.cuda.synchronize()
+        n75 = 10
+        t75 = time.perf_counter()
+        for _ in range(n75):
+            gs75(image, audio)
+        torch.cuda.synchronize()
+        t75 = time.perf_counter() - t75
+        result['secondary'] = {'what': 'same workload with audio mask ratio 0.75 (BASELINE.md section 4)', 'value': round(B * n75 / t75, 2),
+                               'unit': 'AV-pairs/s', 'ms_per_step': round(t75 / n75 * 1e3, 3), 'steps': n75}
+        model.audio_mask_ratio = cfg.audio_mask_ratio
+        del gs75
 
-        def replay():
-            for key in big:
-                M, N, K, kn = key
-                A, Bm, C = bufs[key]
-                ops.gemm_nt(A, Bm, M, N, K, ldb=N if kn else K, C_out=C, c_bf16=True, variant=kn << 12)
-        replay()
+    from deepavfusion_amd import engine as E
+
+    def time_replay(fn, reps):
+        fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
-        reps = 20 if a.roofline_only else 5
         e0.record()                     # torch's current stream == the stream ops.* launch on
         for _ in range(reps):
-            replay()
+            fn()
         e1.record()
         torch.cuda.synchronize()
-        total_ms = e0.elapsed_time(e1) / reps
-        fl = sum(2.0 * M * N * K for (M, N, K, _) in big)
+        return e0.elapsed_time(e1) / reps
+
+    reps = 20 if a.roofline_only else 5
+    # ---- roofline of the dominant kernel: gemm_nt2_grouped_kernel<128,128,2,4,2,*> — the grouped launches (image tower +
+    # audio tower + fusion block problems of one step of a layer, the two decoders) exactly as the library issued them
+    # in the recorded step (tile configuration 3, forward NT and b_kn input-gradient forms) -------------------------------
+    big = [(bt, probs) for (cfg_id, bt, probs) in nt_log if cfg_id == 3]
+    if big and not a.no_roofline:
+        bufs = {}
+        for bt, probs in big:
+            for (M, N, K) in probs:
+                if (M, N, K, bt) not in bufs:
+                    Bm = (torch.randn(K, N, device=dev) * 0.05).bfloat16() if bt else (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+                    bufs[(M, N, K, bt)] = (torch.randn(M, K, device=dev).bfloat16(), Bm, torch.empty(M, N, device=dev, dtype=torch.bfloat16))
+
+        def replay_nt():
+            for bt, probs in big:
+                with E.batch(auto_lanes=True):           # ONE grouped launch, as in the step
+                    for (M, N, K) in probs:
+                        A, Bm, C = bufs[(M, N, K, bt)]
+                        ops.gemm_nt(A, Bm, M, N, K, ldb=N if bt else K, C_out=C, c_bf16=True, variant=(3 << 4) | (bt << 12))
+        total_ms = time_replay(replay_nt, reps)
+        fl = sum(2.0 * M * N * K for _, probs in big for (M, N, K) in probs)
         ach = fl / (total_ms * 1e-3) / 1e12
-        traffic = None          # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KiB), see profiles/
+        traffic = None          # HBM bytes per launch: offline rocprofv3 PMC passes over THIS replay (profiles/), only for the profiled workload
         tf = os.path.join(ROOT, 'profiles', 'dominant_kernel_traffic.json')
         if os.path.exists(tf):
-            traffic = json.load(open(tf)).get(a.config, {}).get('hbm_bytes_per_launch')
-        result['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_nt2_kernel<128,128,2,4,2> (fwd + b_kn dgrad)', 'achieved': round(ach, 1),
-                              'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-                              'traffic': traffic, 'launches_per_step': len(big),
+            rec = json.load(open(tf)).get(f'{a.config}_b{B}', {})
+            traffic = rec.get('hbm_bytes_per_launch')
+        result['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_nt2_grouped_kernel<128,128,2,4,2> (forward + b_kn dgrad, grouped launches)',
+                              'achieved': round(ach, 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                              'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': traffic,
+                              'traffic_note': 'offline rocprofv3 --pmc FETCH_SIZE (x2, gfx950 note) + WRITE_SIZE over this replay; null unless profiled for this workload',
+                              'launches_per_step': len(big), 'problems_per_step': sum(len(pr) for _, pr in big),
                               'avg_launch_us': round(total_ms * 1e3 / len(big), 2),
                               'avg_gflop_per_launch': round(fl / len(big) / 1e9, 3)}
+        del bufs
+    # ---- weight-gradient kernel (gemm_tn_grouped_kernel<128,2,4>): the step's grouped launches, one per layer / decoder pair
+    if tn_log and not a.no_roofline:
+        tbufs = {}
+        for probs in tn_log:
+            for (Mc, N, K) in probs:
+                if (Mc, N, K) not in tbufs:
+                    tbufs[(Mc, N, K)] = (torch.randn(Mc, N, device=dev).bfloat16(), torch.randn(Mc, K, device=dev).bfloat16(),
+                                         torch.zeros(N, K, device=dev), torch.zeros(N, device=dev))
+
+        def replay_tn():
+            for probs in tn_log:
+                ops.gemm_tn_grouped([dict(A=tbufs[q][0], B=tbufs[q][1], Mc=q[0], N=q[1], K=q[2], C=tbufs[q][2], lda=q[1], ldb=q[2], ldc=q[2],
+                                          bias_grad=tbufs[q][3]) for q in dict.fromkeys(probs)])
+        uniq = [list(dict.fromkeys(probs)) for probs in tn_log]      # one buffer set per shape: equal shapes of a launch would race on C
+        ms_tn = time_replay(replay_tn, reps)
+        fl_tn = sum(2.0 * Mc * N * K for probs in uniq for (Mc, N, K) in probs)
+        result['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'gemm_tn_grouped_kernel<128,2,4> (all weight gradients of a layer / of both decoders per launch)',
+                                    'achieved': round(fl_tn / (ms_tn * 1e-3) / 1e12, 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                    'frac': round(fl_tn / (ms_tn * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
+                                    'launches_per_step': len(tn_log), 'avg_launch_us': round(ms_tn * 1e3 / len(tn_log), 1),
+                                    'note': 'replay holds one problem per distinct shape of each launch (equal shapes would share the output buffer)'}
+        del tbufs
+    # ---- attention family (isolated replays of the step's shapes; in the step equal-rank calls of both towers are one grid)
+    if attn_log and not a.no_roofline:
+        classes = {}
+        for (kind, B_, H, Nq, Nk, dqk, dv) in attn_log:
+            classes.setdefault((B_, H, Nq, Nk, dqk, dv), {'fwd': 0, 'bwd': 0})[kind] += 1
+        names = {}
+        nI, nA = int(cfg.image_grid[0] * cfg.image_grid[1] * (1 - cfg.image_mask_ratio)), int(cfg.audio_grid[0] * cfg.audio_grid[1] * (1 - cfg.audio_mask_ratio))
+        nF = sum(cfg.fusion_tkns)
+        for key in classes:
+            B_, H, Nq, Nk, dqk, dv = key
+            if dqk == 16: names[key] = 'K6 factorised pair attention'
+            elif dqk == 32: names[key] = f'K4 decoder self-attention ({Nq} rows, d 32)'
+            elif Nq in (nI, nA) and Nk in (nI + nF, nA + nF): names[key] = f'K4 tower self-attention ({Nq} x {Nk}, fusion rows as context)'
+            else: names[key] = f'K5 aggregation cross-attention ({Nq} x {Nk})'
+        entries = []
+        for key, cnt in classes.items():
+            B_, H, Nq, Nk, dqk, dv = key
+            q = torch.randn(B_, Nq, H, dqk, device=dev).bfloat16()
+            k = torch.randn(B_, Nk, H, dqk, device=dev).bfloat16()
+            v = torch.randn(B_, Nk, H, dv, device=dev).bfloat16()
+            O = torch.empty(B_, Nq, H, dv, device=dev, dtype=torch.bfloat16)
+            dO = torch.randn(B_, Nq, H, dv, device=dev).bfloat16()
+            LSE, Dl = torch.empty(B_, H, Nq, device=dev), torch.empty(B_, H, Nq, device=dev)
+            dq, dk, dvv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            sc = float(dqk) ** -0.5
+            fwd = lambda: ops.attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), O, LSE, B_, H, Nq, Nk, dqk, dv, Nq * H * dqk, H * dqk,
+                                       Nk * H * dqk, H * dqk, Nk * H * dv, H * dv, Nq * H * dv, H * dv, sc)
+            bwd = lambda: ops.attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), O, dO, LSE, Dl, dq.data_ptr(), dk.data_ptr(), dvv.data_ptr(),
+                                       B_, H, Nq, Nk, dqk, dv, Nq * H * dqk, H * dqk, Nk * H * dqk, H * dqk, Nk * H * dv, H * dv,
+                                       Nq * H * dv, H * dv, Nq * H * dv, H * dv, Nq * H * dqk, H * dqk, Nk * H * dqk, H * dqk, Nk * H * dv, H * dv, sc)
+            ms_f, ms_b = time_replay(fwd, 20), time_replay(bwd, 20)
+            ff = attn(Nq, Nk, dqk, dv) * B_ * H
+            entries.append({'what': names[key], 'B': B_, 'heads': H, 'Nq': Nq, 'Nk': Nk, 'dqk': dqk, 'dv': dv,
+                            'calls_per_step': cnt, 'fwd_us': round(ms_f * 1e3, 1), 'bwd_us': round(ms_b * 1e3, 1),
+                            'fwd_tflops': round(ff / (ms_f * 1e-3) / 1e12, 1), 'bwd_tflops': round(2.5 * ff / (ms_b * 1e-3) / 1e12, 1),
+                            'fwd_frac': round(ff / (ms_f * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)})
+        entries.sort(key=lambda e: -(e['fwd_us'] + e['bwd_us']) * e['calls_per_step']['fwd'])
+        result['roofline_attention'] = {'bound': 'mfma (nominal; softmax VALU work dominates at head widths 16-64, see DESIGN.md section 3)',
+                                        'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'kernels': 'attn_fwd / attn_bwd_dq / attn_bwd_dkv (isolated replays)',
+                                        'shapes': entries}
 
     # ---- CPU baseline: the fp32 oracle (a port of the reference's path) on this box's host cores ---------------
     if world == 1 and not a.no_cpu_baseline:

@@ -23,6 +23,7 @@ SIGNATURES = {
     'dav_last_error_string': [],
     'dav_tune': [_i, _i],
     'dav_gemm_nt_bf16': [_p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _f, _i, _p],
+    'dav_nt_issue_log': [_i, _p, _i],
     'dav_gemm_tn_bf16': [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _i, _p],
     'dav_gemm_tn_grouped_bf16': [_p, _i, _p],
     'dav_attn_fwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _i, _l, _i, _l, _i, _l, _i, _f, _p],

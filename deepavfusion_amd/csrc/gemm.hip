@@ -11,6 +11,7 @@
 // Replaces the cuBLAS/rocBLAS calls behind F.linear in timm Block / Mlp / Attention and
 // models/fusion_blocks.py:41-44,227-232; models/avmae.py:31,59-60,88.
 #include <cstdlib>
+#include <vector>
 
 #include "common.h"
 #include "dav_kernels.h"
@@ -1061,6 +1062,19 @@ void launch_nt2(const NTParams& p, hipStream_t stream) {
 
 int nt_auto_config_tiles(long t128, bool narrow);
 
+// Issue log (bench.py's roofline leg): which grouped / single launches the NT family really issued, so that the launch mix
+// of a step can be replayed kernel for kernel.  Entry: cfg, b_kn, n, then n x (M, N, K).
+thread_local bool nt_log_on = false;
+thread_local std::vector<int> nt_log;
+void nt_log_issue(int cfg, bool bt, const void* const* params, int n) {
+  if (!nt_log_on) return;
+  nt_log.push_back(cfg); nt_log.push_back(bt ? 1 : 0); nt_log.push_back(n);
+  for (int i = 0; i < n; ++i) {
+    const NTParams& p = *(const NTParams*)params[i];
+    nt_log.push_back(p.M); nt_log.push_back(p.N); nt_log.push_back(p.K);
+  }
+}
+
 // Recorded with the tile configuration left open: chosen at issue time from the tile count of the WHOLE group.
 template <bool BT>
 void nt2_issue_auto(const void* const* params, int n, hipStream_t stream) {
@@ -1071,7 +1085,9 @@ void nt2_issue_auto(const void* const* params, int n, hipStream_t stream) {
     t128 += (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     narrow = narrow && p.N <= 64;
   }
-  switch (nt_auto_config_tiles(t128, narrow)) {
+  const int cfg = nt_auto_config_tiles(t128, narrow);
+  nt_log_issue(cfg, BT, params, n);
+  switch (cfg) {
     case 3: nt2_issue<128, 128, 2, 4, 2, BT, 64>(params, n, stream); break;
     case 8: nt2_issue<128, 64, 2, 2, 2, BT, 64>(params, n, stream); break;
     default: nt2_issue<64, 64, 2, 2, 2, BT, 64>(params, n, stream); break;
@@ -1421,6 +1437,10 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
     davb::push_typed(b_kn ? nt2_issue_auto<true> : nt2_issue_auto<false>, &p, sizeof(p), stream);
     return DAV_OK;
   }
+  if (vec_ok && cfg == 0 && !(variant & 15)) {
+    const void* one = &p;
+    nt_log_issue(nt_auto_config(M, N, K), b_kn != 0, &one, 1);
+  }
   if (b_kn) {
     if (!vec_ok) return DAV_ERR_SHAPE;
     if (cfg == 0) cfg = nt_auto_config(M, N, K);
@@ -1495,6 +1515,19 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
     else DAV_LAUNCH((gemm_nt_kernel<128, 128, false>), dim3(grid), dim3(256), lds, stream, p);
   }
   return dav_launch_status();
+}
+
+extern "C" int dav_nt_issue_log(int enable, int* out, int capacity) {
+  // enable: 1 start (clears), 0 stop; out != NULL: copy the log (returns its length in ints, or -needed if capacity is short)
+  if (out) {
+    const int n = (int)nt_log.size();
+    if (n > capacity) return -n;
+    for (int i = 0; i < n; ++i) out[i] = nt_log[i];
+    return n;
+  }
+  nt_log_on = enable != 0;
+  if (enable) nt_log.clear();
+  return 0;
 }
 
 extern "C" int dav_gemm_tn_grouped_bf16(const DavTnProblem* probs, int count, hipStream_t stream) {

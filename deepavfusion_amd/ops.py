@@ -108,6 +108,26 @@ def gemm_nt(A, B, M, N, K, *, lda=None, ldb=None, a_rowmap=None, bias=None, act=
                                     _ptr(C2), ldc2, c2_mode, beta, float(alpha), variant, _stream()), 'dav_gemm_nt_bf16')
 
 
+def nt_issue_log(enable=None):
+    """enable True / False: start (clearing) / stop logging the NT launches the library issues; None: fetch the log as a
+    list of (cfg, b_kn, [(M, N, K), ...]) — one entry per launch (grouped launches have several problems)."""
+    lib = _lib.load()
+    if enable is not None:
+        lib.dav_nt_issue_log(int(enable), None, 0)
+        return None
+    n = -lib.dav_nt_issue_log(0, (C.c_int * 1)(), 0)
+    if n <= 0:
+        return []
+    buf = (C.c_int * n)()
+    lib.dav_nt_issue_log(0, buf, n)
+    out, i = [], 0
+    while i < n:
+        cfg, bt, cnt = buf[i], buf[i + 1], buf[i + 2]
+        out.append((cfg, bt, [(buf[i + 3 + 3 * j], buf[i + 4 + 3 * j], buf[i + 5 + 3 * j]) for j in range(cnt)]))
+        i += 3 + 3 * cnt
+    return out
+
+
 def gemm_tn(A, B, Mc, N, K, C_out, *, lda=None, ldb=None, ldc=None, a_rowmap=None, b_rowmap=None, beta=1, bias_grad=None,
             variant=0):
     """C[N,K] (+)= A[Mc,N]^T . B[Mc,K]; see dav_gemm_tn_bf16."""

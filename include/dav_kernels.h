@@ -60,6 +60,11 @@ int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int K, int lda,
                      const int* res_rowmap, const int* res_rows, void* C, int ldc, int c_is_bf16, const int* c_rowmap,
                      void* C2, int ldc2, int c2_mode, int beta, float alpha, int variant, hipStream_t stream);
 
+/* Diagnostics for benchmarks: log which launches the NT family issues (grouped or single).  enable 1 / 0 with out == NULL
+ * starts (and clears) / stops logging on the calling thread; with out != NULL the log is copied: entries of
+ * {tile configuration, b_kn, n, n x (M, N, K)}; returns the number of ints, or -needed when capacity is too small. */
+int dav_nt_issue_log(int enable, int* out, int capacity);
+
 /* C[N,K] (+)= A[Mc,N]^T . B[Mc,K] in fp32: the weight gradient of every nn.Linear above (autograd of
  * F.linear).  beta != 0 accumulates into the live gradient (split over the contraction with fp32
  * atomics); bias_grad (optional) receives the column sums of A (atomic accumulate).
