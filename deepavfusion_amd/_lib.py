@@ -52,6 +52,16 @@ SIGNATURES = {
     'dav_cast_transpose_bf16': [_p, _p, _i, _i, _p],
     'dav_l2norm_workspace_bytes': [_l],
     'dav_l2norm': [_p, _l, _f, _p, _p, _sz, _p],
+    'dav_gemm_nt_f32': [_p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _p, _p, _i, _i, _i, _f, _i, _p],
+    'dav_gemm_tn_f32': [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _p],
+    'dav_attn_fwd_f32': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _i, _l, _i, _l, _i, _l, _i, _f, _p],
+    'dav_attn_bwd_f32': [_p] * 10 + [_i] * 6 + [_l, _i] * 8 + [_f, _i, _p],
+    'dav_patch_gather_f32': [_p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p],
+    'dav_rows_gather_f32': [_p, _l, _i, _p, _i, _i, _i, _p, _l, _p],
+    'dav_pair_expand_f32': [_p, _p, _i, _i, _i, _i, _p, _p],
+    'dav_pair_reduce_f32': [_p, _i, _i, _i, _i, _p, _p, _p],
+    'dav_patch_mse_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p],
+    'dav_add_f32': [_p, _p, _p, _l, _p],
     'dav_batch_begin': [_i],
     'dav_batch_lane': [],
     'dav_batch_region': [_i],

@@ -14,7 +14,7 @@ import torch
 
 from . import engine as E
 from . import ops
-from .ops import BF16, F32
+from .ops import F32
 
 
 _SIDE_STREAMS = {}
@@ -37,7 +37,7 @@ def _streams(dev):
 def _batched():
     """Launch batching (engine.batch, csrc/batch.h) for the paired tower blocks / decoders; DAV_BATCH=0 restores one HIP
     stream per tower instead."""
-    return os.environ.get('DAV_BATCH', '1') != '0'
+    return os.environ.get('DAV_BATCH', '1') != '0' and E.PRECISION == 'bf16'
 
 
 def _f32c(x):
@@ -150,7 +150,7 @@ def _encoder_bwd(enc, t, dxi_b, dxa_b, dxf_b, dxi32, dxa32, dxf32, layer_cb=None
 
     def final_norm(norm, x, st, dy_b, dy32):
         g = torch.empty_like(x)
-        gb = torch.empty(x.shape, dtype=BF16, device=dev)
+        gb = torch.empty(x.shape, dtype=E.BF16, device=dev)
         if dy_b is None and dy32 is None:
             return g.zero_(), gb.zero_()
         E.ln_bwd(norm, None, x, B, st, dy_bf16=dy_b, dy_f32=dy32, dx1=g, dx1_bf16=gb)
@@ -309,7 +309,7 @@ class _CrossAttentionFn(torch.autograd.Function):
         ca = ctx.ca
         with E.deferred_wgrads():
             do = E.lin_bwd(ca.proj, E.to_bf16(g.contiguous().view(B * N1, D)), ctx.c['o'], B * N1)
-            dx1 = torch.empty(B * N1, D, dtype=BF16, device=g.device)
+            dx1 = torch.empty(B * N1, D, dtype=E.BF16, device=g.device)
             dx2 = E._cross_bwd_seq(ca, ctx.c, do, ctx.x1b, None, N1, ctx.x2b, N2, B, D, ca.num_heads, dx1, None)
         E.join_wgrad_stream(g.device)
         return (None, dx1.float().view(B, N1, D), dx2.float().view(B, N2, D)) + (None,) * ctx.np
@@ -386,9 +386,9 @@ def avmae_bwd(model, t, g_li, g_la, g_pi=None, g_pa=None, layer_cb=None):
         dpi = E.loss_bwd(t['image'], t['pred_i'], t['im'], t['t_li'], g_li)
         dpa = E.loss_bwd(t['audio'], t['pred_a'], t['am'], t['t_la'], g_la)
         if g_pi is not None:
-            dpi = (dpi.float() + g_pi.reshape(dpi.shape)).to(BF16)
+            dpi = (dpi.float() + g_pi.reshape(dpi.shape)).to(E.BF16)
         if g_pa is not None:
-            dpa = (dpa.float() + g_pa.reshape(dpa.shape)).to(BF16)
+            dpa = (dpa.float() + g_pa.reshape(dpa.shape)).to(E.BF16)
         with E.deferred_wgrads():             # both decoders' weight gradients: ONE grouped GEMM after the batch
             with E.batch() as bt:
                 bt.lane()
@@ -401,12 +401,12 @@ def avmae_bwd(model, t, g_li, g_la, g_pi=None, g_pa=None, layer_cb=None):
         with torch.cuda.stream(sa), E.deferred_wgrads():
             dpa = E.loss_bwd(t['audio'], t['pred_a'], t['am'], t['t_la'], g_la)
             if g_pa is not None:
-                dpa = (dpa.float() + g_pa.reshape(dpa.shape)).to(BF16)
+                dpa = (dpa.float() + g_pa.reshape(dpa.shape)).to(E.BF16)
             dxa_b, dxf_a = E.decoder_bwd(dec_a, t['t_da'], dpa, t['ak32'], B)
         with E.deferred_wgrads():
             dpi = E.loss_bwd(t['image'], t['pred_i'], t['im'], t['t_li'], g_li)
             if g_pi is not None:
-                dpi = (dpi.float() + g_pi.reshape(dpi.shape)).to(BF16)
+                dpi = (dpi.float() + g_pi.reshape(dpi.shape)).to(E.BF16)
             dxi_b, dxf_i = E.decoder_bwd(dec_i, t['t_di'], dpi, t['ik32'], B)
         main.wait_stream(sa)
     dxf32 = dxf_i.float() + dxf_a.float()            # both decoders read the same normed fusion tokens

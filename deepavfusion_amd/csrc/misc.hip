@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void patch_mse_fwd_kernel(const float* img, co
 template <int C>
 __global__ __launch_bounds__(256) void patch_mse_bwd_kernel(const float* img, const float* pred, const float* mask,
                                                             const float* tmean, const float* trstd, const float* mask_sum,
-                                                            const float* gout, int B, int H, int W, bf16_t* dpred) {
+                                                            const float* gout, int B, int H, int W, bf16_t* dpred, float* dpred32) {
   constexpr int P = 256 * C, PER = P / 64;
   const int lane = threadIdx.x & 63;
   const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -231,7 +231,8 @@ __global__ __launch_bounds__(256) void patch_mse_bwd_kernel(const float* img, co
         const float t = img[(((long)b * C + c) * H + gy * 16 + (pix >> 4)) * W + gx * 16 + (pix & 15)];
         g = m * (pred[(long)row * P + e] - (t - mean) * rstd);
       }
-      dpred[(long)row * P + e] = f2bf(g);
+      if (dpred32) dpred32[(long)row * P + e] = g;      // fp32 path (f32_path.hip)
+      else dpred[(long)row * P + e] = f2bf(g);
     }
   }
 }
@@ -498,8 +499,17 @@ extern "C" int dav_patch_mse_bwd(const float* img, const float* pred, const floa
                                  hipStream_t stream) {
   if (B <= 0 || (H & 15) || (W & 15) || (C != 1 && C != 3)) return DAV_ERR_SHAPE;
   const long rows = (long)B * (H >> 4) * (W >> 4);
-  if (C == 3) DAV_LAUNCH(patch_mse_bwd_kernel<3>, dim3(wave_grid(rows)), dim3(256), 0, stream, img, pred, mask, tmean, trstd, mask_sum, gout, B, H, W, (bf16_t*)dpred_bf16);
-  else DAV_LAUNCH(patch_mse_bwd_kernel<1>, dim3(wave_grid(rows)), dim3(256), 0, stream, img, pred, mask, tmean, trstd, mask_sum, gout, B, H, W, (bf16_t*)dpred_bf16);
+  if (C == 3) DAV_LAUNCH(patch_mse_bwd_kernel<3>, dim3(wave_grid(rows)), dim3(256), 0, stream, img, pred, mask, tmean, trstd, mask_sum, gout, B, H, W, (bf16_t*)dpred_bf16, (float*)nullptr);
+  else DAV_LAUNCH(patch_mse_bwd_kernel<1>, dim3(wave_grid(rows)), dim3(256), 0, stream, img, pred, mask, tmean, trstd, mask_sum, gout, B, H, W, (bf16_t*)dpred_bf16, (float*)nullptr);
+  return dav_launch_status();
+}
+
+extern "C" int dav_patch_mse_bwd_f32(const float* img, const float* pred, const float* mask, const float* tmean, const float* trstd,
+                                     const float* mask_sum, const float* gout, int B, int C, int H, int W, float* dpred, hipStream_t stream) {
+  if ((C != 1 && C != 3) || (H & 15) || (W & 15)) return DAV_ERR_SHAPE;
+  const long rows = (long)B * (H >> 4) * (W >> 4);
+  if (C == 3) DAV_LAUNCH(patch_mse_bwd_kernel<3>, dim3(wave_grid(rows)), dim3(256), 0, stream, img, pred, mask, tmean, trstd, mask_sum, gout, B, H, W, (bf16_t*)nullptr, dpred);
+  else DAV_LAUNCH(patch_mse_bwd_kernel<1>, dim3(wave_grid(rows)), dim3(256), 0, stream, img, pred, mask, tmean, trstd, mask_sum, gout, B, H, W, (bf16_t*)nullptr, dpred);
   return dav_launch_status();
 }
 

@@ -22,7 +22,21 @@ from typing import Callable, Dict, List, Optional
 import torch
 
 from . import ops
-from .ops import BF16, F32
+from .ops import F32
+
+BF16 = torch.bfloat16        # dtype of GEMM / attention OPERAND buffers (set_precision('fp32') rebinds it to torch.float32)
+PRECISION = 'bf16'
+
+
+def set_precision(p: str):
+    """'bf16' (product path: bf16 operands, fp32 accumulate, MFMA kernels) or 'fp32' (every operand and intermediate fp32 on
+    the kernels of csrc/f32_path.hip: the parity cross-check of the engine itself, see include/dav_kernels.h).  The fp32
+    path issues its launches one by one (no launch batching)."""
+    global BF16, PRECISION
+    if p not in ('bf16', 'fp32'):
+        raise ValueError(p)
+    PRECISION = p
+    BF16 = torch.float32 if p == 'fp32' else torch.bfloat16
 
 _GRAD_READY: Optional[Callable[[torch.nn.Parameter], None]] = None
 
@@ -63,7 +77,7 @@ class batch:
 
     def __enter__(self):
         global _BATCH
-        if _BATCH is None and os.environ.get('DAV_BATCH', '1') != '0':
+        if _BATCH is None and os.environ.get('DAV_BATCH', '1') != '0' and PRECISION == 'bf16':
             ops.batch_begin(self.auto_lanes)
             _BATCH = self
             self.active = True
@@ -118,7 +132,9 @@ class _WCache:
 
 
 def wcache(p: torch.nn.Parameter, force: bool = False) -> torch.Tensor:
-    """bf16 [out, in] copy of ``p`` (re-cast when the fp32 master changed)."""
+    """bf16 [out, in] copy of ``p`` (re-cast when the fp32 master changed); the fp32 master itself on the fp32 path."""
+    if PRECISION == 'fp32':
+        return p.detach().reshape(p.shape[0], -1)
     c = p.__dict__.get('_dav_cache')
     if c is None:
         c = p.__dict__['_dav_cache'] = _WCache()
@@ -196,7 +212,7 @@ class region:
         self.own = None
         if _BATCH is not None:
             ops.batch_region(True)
-        elif os.environ.get('DAV_BATCH', '1') != '0':
+        elif os.environ.get('DAV_BATCH', '1') != '0' and PRECISION == 'bf16':
             self.own = batch(auto_lanes=True)
             self.own.__enter__()
         return self
@@ -301,6 +317,8 @@ def ln_fwd(norm, x0, x1, B, eps=None, want_f32=False, want_bf16=True):
     M = B * (r0 + r1)
     y = _e((M, D), BF16, dev) if want_bf16 else None
     y32 = _e((M, D), F32, dev) if want_f32 else None
+    if PRECISION == 'fp32' and y is not None and y32 is not None:
+        y32 = y                           # one fp32 output serves as operand copy and as fp32 result
     mean, rstd = _e((M,), F32, dev), _e((M,), F32, dev)
     ops.layernorm_fwd(x0, r0 * D, r0, x1, r1 * D, r1, B, D, norm.weight, norm.bias, norm.eps if eps is None else eps,
                       y, y32, mean, rstd)
@@ -355,7 +373,7 @@ def lin_bwd(lin, dy, a, M, *, dy_rowmap=None, a_rowmap=None, lda=None, need_dx=T
     if need_dx:
         if dx is None:
             dx = _e((M, K), BF16 if dx_bf16 else F32, dev)
-        if N % 64 == 0:      # read W [N, K] itself as the [contraction, out] operand (transposing LDS reads)
+        if N % 64 == 0 or PRECISION == 'fp32':      # read W [N, K] itself as the [contraction, out] operand (transposing LDS reads)
             Bt, ldb, variant = (W if w_col_off == 0 else W.view(-1)[w_col_off:]), Kfull, 1 << 12
         else:
             WT = wcache_t(lin.weight)
@@ -395,7 +413,8 @@ def attention_fwd(q, k, v, B, H, Nq, Nk, dqk, dv, scale, q_bs, q_rs, k_bs, k_rs,
     O = _e((B * Nq, H * dv), BF16, dev)
     LSE = _e((B, H, Nq), F32, dev)
     ops.hold(q[0], k[0], v[0])
-    ops.attn_fwd(q[0].data_ptr() + 2 * q[1], k[0].data_ptr() + 2 * k[1], v[0].data_ptr() + 2 * v[1], O, LSE, B, H, Nq, Nk,
+    es = q[0].element_size()
+    ops.attn_fwd(q[0].data_ptr() + es * q[1], k[0].data_ptr() + es * k[1], v[0].data_ptr() + es * v[1], O, LSE, B, H, Nq, Nk,
                  dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, Nq * H * dv, H * dv, scale)
     return O, LSE
 
@@ -407,12 +426,14 @@ def attention_bwd(q, k, v, O, dO, LSE, dq, dk, dvv, B, H, Nq, Nk, dqk, dv, scale
     if Delta is None:
         Delta = torch.empty_like(LSE)
     ops.hold(q[0], k[0], v[0], dq[0], dk[0], dvv[0])
-    p = lambda t: t[0].data_ptr() + 2 * t[1]
+    p = lambda t: t[0].data_ptr() + t[0].element_size() * t[1]
     ops.attn_bwd(p(q), p(k), p(v), O, dO, LSE, Delta, p(dq), p(dk), p(dvv), B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs,
                  v_bs, v_rs, Nq * H * dv, H * dv, Nq * H * dv, H * dv, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, scale, part=part)
 
 
 def to_bf16(x):
+    if PRECISION == 'fp32':
+        return x.contiguous()
     y = torch.empty(x.shape, dtype=BF16, device=x.device)
     ops.cast_bf16(x.contiguous(), y)
     return y

@@ -100,8 +100,14 @@ def _rm(m: Optional[Sequence[int]]):
 def gemm_nt(A, B, M, N, K, *, lda=None, ldb=None, a_rowmap=None, bias=None, act=0, aux=None, ldaux=0, res=None, ldres=0,
             res_rowmap=None, res_rows=None, C_out=None, ldc=None, c_bf16=False, c_rowmap=None, C2=None, ldc2=0, c2_mode=0,
             beta=0, alpha=1.0, variant=0):
-    """C[M,N] = epi(A[M,K] . B[N,K]^T); see dav_gemm_nt_bf16."""
+    """C[M,N] = epi(A[M,K] . B[N,K]^T); see dav_gemm_nt_bf16 (fp32 operands: dav_gemm_nt_f32, csrc/f32_path.hip)."""
     lib = _lib.load()
+    if A.dtype == F32:                  # (c_bf16 is meaningless here: every output of the fp32 path is fp32)
+        _lib.check(lib.dav_gemm_nt_f32(_ptr(A), _ptr(B), M, N, K, lda if lda is not None else K, ldb if ldb is not None else K,
+                                       _rm(a_rowmap), _ptr(bias), act, _ptr(aux), ldaux, _ptr(res), ldres, _rm(res_rowmap),
+                                       _ptr(res_rows), _ptr(C_out), ldc if ldc is not None else N, _rm(c_rowmap), _ptr(C2), ldc2,
+                                       c2_mode, beta, float(alpha), (variant >> 12) & 1, _stream()), 'dav_gemm_nt_f32')
+        return
     _lib.check(lib.dav_gemm_nt_bf16(_ptr(A), _ptr(B), M, N, K, lda if lda is not None else K, ldb if ldb is not None else K,
                                     _rm(a_rowmap), _ptr(bias), act, _ptr(aux), ldaux, _ptr(res), ldres, _rm(res_rowmap),
                                     _ptr(res_rows), _ptr(C_out), ldc if ldc is not None else N, int(c_bf16), _rm(c_rowmap),
@@ -130,8 +136,13 @@ def nt_issue_log(enable=None):
 
 def gemm_tn(A, B, Mc, N, K, C_out, *, lda=None, ldb=None, ldc=None, a_rowmap=None, b_rowmap=None, beta=1, bias_grad=None,
             variant=0):
-    """C[N,K] (+)= A[Mc,N]^T . B[Mc,K]; see dav_gemm_tn_bf16."""
+    """C[N,K] (+)= A[Mc,N]^T . B[Mc,K]; see dav_gemm_tn_bf16 (fp32 operands: dav_gemm_tn_f32)."""
     lib = _lib.load()
+    if A.dtype == F32:
+        _lib.check(lib.dav_gemm_tn_f32(_ptr(A), _ptr(B), Mc, N, K, lda if lda is not None else N, ldb if ldb is not None else K,
+                                       _rm(a_rowmap), _rm(b_rowmap), _ptr(C_out), ldc if ldc is not None else K, beta,
+                                       _ptr(bias_grad), _stream()), 'dav_gemm_tn_f32')
+        return
     _lib.check(lib.dav_gemm_tn_bf16(_ptr(A), _ptr(B), Mc, N, K, lda if lda is not None else N, ldb if ldb is not None else K,
                                     _rm(a_rowmap), _rm(b_rowmap), _ptr(C_out), ldc if ldc is not None else K, beta,
                                     _ptr(bias_grad), variant, _stream()), 'dav_gemm_tn_bf16')
@@ -140,6 +151,11 @@ def gemm_tn(A, B, Mc, N, K, C_out, *, lda=None, ldb=None, ldc=None, a_rowmap=Non
 def gemm_tn_grouped(problems):
     """problems: list of dicts(A, B, Mc, N, K, C, lda, ldb, ldc, a_rowmap, b_rowmap, bias_grad); see dav_gemm_tn_grouped_bf16."""
     lib = _lib.load()
+    if problems and problems[0]['A'].dtype == F32:      # fp32 path: one launch per problem
+        for d in problems:
+            gemm_tn(d['A'], d['B'], d['Mc'], d['N'], d['K'], d['C'], lda=d['lda'], ldb=d['ldb'], ldc=d['ldc'],
+                    a_rowmap=d.get('a_rowmap'), b_rowmap=d.get('b_rowmap'), beta=1, bias_grad=d.get('bias_grad'))
+        return
     for i in range(0, len(problems), 32):
         chunk = problems[i:i + 32]
         arr = (_lib.DavTnProblem * len(chunk))()
@@ -152,7 +168,12 @@ def gemm_tn_grouped(problems):
 
 
 def attn_fwd(q_ptr, k_ptr, v_ptr, O, LSE, B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, scale):
+    """q / k / v are raw addresses (views into fused projection buffers) of the dtype of ``O``."""
     lib = _lib.load()
+    if O.dtype == F32:
+        _lib.check(lib.dav_attn_fwd_f32(q_ptr, k_ptr, v_ptr, _ptr(O), _ptr(LSE), B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs,
+                                        v_bs, v_rs, o_bs, o_rs, float(scale), _stream()), 'dav_attn_fwd_f32')
+        return
     _lib.check(lib.dav_attn_fwd(q_ptr, k_ptr, v_ptr, _ptr(O), _ptr(LSE), B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs,
                                 v_bs, v_rs, o_bs, o_rs, float(scale), _stream()), 'dav_attn_fwd')
 
@@ -161,6 +182,11 @@ def attn_bwd(q_ptr, k_ptr, v_ptr, O, dO, LSE, Delta, dq_ptr, dk_ptr, dv_ptr, B, 
              v_bs, v_rs, o_bs, o_rs, do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, scale, part=3):
     """part 1: dQ (+ Delta) kernel only, 2: dK/dV kernel only (after part 1), 3: both."""
     lib = _lib.load()
+    if O.dtype == F32:
+        _lib.check(lib.dav_attn_bwd_f32(q_ptr, k_ptr, v_ptr, _ptr(O), _ptr(dO), _ptr(LSE), _ptr(Delta), dq_ptr, dk_ptr, dv_ptr,
+                                        B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, do_bs, do_rs,
+                                        dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, float(scale), part, _stream()), 'dav_attn_bwd_f32')
+        return
     _lib.check(lib.dav_attn_bwd_part(q_ptr, k_ptr, v_ptr, _ptr(O), _ptr(dO), _ptr(LSE), _ptr(Delta), dq_ptr, dk_ptr, dv_ptr,
                                      B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, do_bs, do_rs,
                                      dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, float(scale), part, _stream()), 'dav_attn_bwd')
@@ -168,6 +194,10 @@ def attn_bwd(q_ptr, k_ptr, v_ptr, O, dO, LSE, Delta, dq_ptr, dk_ptr, dv_ptr, B, 
 
 def layernorm_fwd(x0, x0_bs, r0, x1, x1_bs, r1, B, D, gamma, beta, eps, y_bf16, y_f32, mean, rstd):
     lib = _lib.load()
+    if y_bf16 is not None and y_bf16.dtype == F32:      # fp32 path: the "operand copy" of the output is fp32 too
+        if y_f32 is not None and y_f32.data_ptr() != y_bf16.data_ptr():
+            raise RuntimeError('fp32 LayerNorm: pass one output buffer')
+        y_bf16, y_f32 = None, y_bf16
     _lib.check(lib.dav_layernorm_fwd(_ptr(x0), x0_bs, r0, _ptr(x1), x1_bs, r1, B, D, _ptr(gamma), _ptr(beta), float(eps),
                                      _ptr(y_bf16), _ptr(y_f32), _ptr(mean), _ptr(rstd), _stream()), 'dav_layernorm_fwd')
 
@@ -179,6 +209,21 @@ def layernorm_bwd(x0, x0_bs, r0, x1, x1_bs, r1, B, D, dy_bf16, dy_f32, gamma, me
     """``defer``: a list; when given, only the partial dgamma/dbeta rows are produced and
     (workspace, dgamma, dbeta, rows, D) is appended for a later ``layernorm_bwd_reduce_grouped``."""
     lib = _lib.load()
+    twins = []
+    if dy_bf16 is not None and dy_bf16.dtype == F32:    # fp32 path: both gradient inputs are fp32 -> one (summed) fp32 input
+        if dy_f32 is not None:
+            tmp = torch.empty_like(dy_bf16)
+            _lib.check(lib.dav_add_f32(_ptr(dy_bf16), _ptr(dy_f32), _ptr(tmp), tmp.numel(), _stream()), 'dav_add_f32')
+            dy_f32 = tmp
+        else:
+            dy_f32 = dy_bf16
+        dy_bf16 = None
+    if dx0_bf16 is not None and dx0_bf16.dtype == F32:  # ... and the "bf16 twins" of the outputs are fp32 row copies
+        twins.append((dx0, dx0_bs, r0, dx0_bf16, dx0_bf_bs))
+        dx0_bf16 = None
+    if dx1_bf16 is not None and dx1_bf16.dtype == F32:
+        twins.append((dx1, dx1_bs, r1, dx1_bf16, dx1_bf_bs))
+        dx1_bf16 = None
     ws = None
     if dgamma is not None:
         ws = torch.empty(lib.dav_layernorm_bwd_workspace_bytes(B * (r0 + r1), D) // 4, dtype=F32, device=dgamma.device)
@@ -191,6 +236,8 @@ def layernorm_bwd(x0, x0_bs, r0, x1, x1_bs, r1, B, D, dy_bf16, dy_f32, gamma, me
                                      _ptr(dx1), dx1_bs, acc1, _ptr(res1), res1_bs, _ptr(dx1_bf16), dx1_bf_bs,
                                      _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel() * 4 if ws is not None else 0, _stream()),
                'dav_layernorm_bwd')
+    for (dx, bs, rows, twin, twin_bs) in twins:
+        _lib.check(lib.dav_rows_gather_f32(_ptr(dx), bs, 0, None, B, rows, D, _ptr(twin), twin_bs, _stream()), 'dav_rows_gather_f32')
 
 
 def layernorm_bwd_reduce_grouped(items):
@@ -221,6 +268,13 @@ def mask_build(noise: torch.Tensor, len_keep: int):
 def patch_gather(img, ids_keep32, nk, out, pt=1):
     """img [B,C,H,W] with 16x16 patches, or a clip [B,C,T,H,W] with (pt,16,16) tubelets."""
     lib = _lib.load()
+    if out.dtype == F32:
+        if img.dim() == 5:
+            B, Cc, T, H, W = img.shape
+        else:
+            (B, Cc, H, W), T = img.shape, 1
+        _lib.check(lib.dav_patch_gather_f32(_ptr(img), B, Cc, T, H, W, pt, _ptr(ids_keep32), nk, _ptr(out), _stream()), 'dav_patch_gather_f32')
+        return
     if img.dim() == 5:
         B, Cc, T, H, W = img.shape
         _lib.check(lib.dav_patch_gather3d(_ptr(img), B, Cc, T, H, W, pt, _ptr(ids_keep32), nk, _ptr(out), _stream()),
@@ -238,6 +292,9 @@ def unshuffle_fwd(emb, mask_token, pos, ids_restore32, B, L, nk, D, out, out_bs,
 
 def rows_gather_cast(x, x_bs, row_off, ids32, B, n, D, out):
     lib = _lib.load()
+    if out.dtype == F32:
+        _lib.check(lib.dav_rows_gather_f32(_ptr(x), x_bs, row_off, _ptr(ids32), B, n, D, _ptr(out), 0, _stream()), 'dav_rows_gather_f32')
+        return
     _lib.check(lib.dav_rows_gather_cast(_ptr(x), x_bs, row_off, _ptr(ids32), B, n, D, _ptr(out), _stream()), 'dav_rows_gather_cast')
 
 
@@ -257,17 +314,27 @@ def patch_mse_fwd(img, pred, mask, norm_pix, loss_patch, tmean, trstd, loss, mas
 def patch_mse_bwd(img, pred, mask, tmean, trstd, mask_sum, gout, dpred_bf16):
     lib = _lib.load()
     B, Cc, H, W = img.shape
+    if dpred_bf16.dtype == F32:
+        _lib.check(lib.dav_patch_mse_bwd_f32(_ptr(img), _ptr(pred), _ptr(mask), _ptr(tmean), _ptr(trstd), _ptr(mask_sum), _ptr(gout),
+                                             B, Cc, H, W, _ptr(dpred_bf16), _stream()), 'dav_patch_mse_bwd_f32')
+        return
     _lib.check(lib.dav_patch_mse_bwd(_ptr(img), _ptr(pred), _ptr(mask), _ptr(tmean), _ptr(trstd), _ptr(mask_sum), _ptr(gout),
                                      B, Cc, H, W, _ptr(dpred_bf16), _stream()), 'dav_patch_mse_bwd')
 
 
 def pair_expand(Pv, Pa, B, nv, na, Wd, out):
     lib = _lib.load()
+    if out.dtype == F32:
+        _lib.check(lib.dav_pair_expand_f32(_ptr(Pv), _ptr(Pa), B, nv, na, Wd, _ptr(out), _stream()), 'dav_pair_expand_f32')
+        return
     _lib.check(lib.dav_pair_expand(_ptr(Pv), _ptr(Pa), B, nv, na, Wd, _ptr(out), _stream()), 'dav_pair_expand')
 
 
 def pair_reduce(d, B, nv, na, Wd, dPv, dPa):
     lib = _lib.load()
+    if d.dtype == F32:
+        _lib.check(lib.dav_pair_reduce_f32(_ptr(d), B, nv, na, Wd, _ptr(dPv), _ptr(dPa), _stream()), 'dav_pair_reduce_f32')
+        return
     _lib.check(lib.dav_pair_reduce(_ptr(d), B, nv, na, Wd, _ptr(dPv), _ptr(dPa), _stream()), 'dav_pair_reduce')
 
 

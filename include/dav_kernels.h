@@ -181,6 +181,35 @@ int dav_adamw_flat(float* p, float* g, float* m, float* v, void* p_bf16, long n,
                    int nseg, float beta1, float beta2, float eps, const float* bias_corr, float grad_scale, float* sumsq_out,
                    int zero_grad, hipStream_t stream);
 
+/* ---- fp32-operand twins (csrc/f32_path.hip) ------------------------------------------------ */
+/* The same contracts as the bf16 entry points above with every operand, second output and intermediate in fp32 (plain
+ * one-thread-per-output kernels, untuned).  They exist so that the whole hand-written forward / backward can run in fp32
+ * (engine.set_precision('fp32')) and be compared with the oracle and the reference's fixtures at 1e-4 instead of bf16's
+ * 2e-2 — SURVEY.md section 8(b) "fp32-everything variants for tight parity tests".  b_kn as variant bit 12 above; part as
+ * dav_attn_bwd_part.  LayerNorm, the loss forward, unshuffle and the optimizer are fp32 already. */
+int dav_gemm_nt_f32(const float* A, const float* B, int M, int N, int K, int lda, int ldb, const int* a_rowmap,
+                    const float* bias, int act, const float* aux, int ldaux, const float* res, int ldres,
+                    const int* res_rowmap, const int* res_rows, float* C, int ldc, const int* c_rowmap, float* C2, int ldc2,
+                    int c2_mode, int beta, float alpha, int b_kn, hipStream_t stream);
+int dav_gemm_tn_f32(const float* A, const float* B, int Mc, int N, int K, int lda, int ldb, const int* a_rowmap,
+                    const int* b_rowmap, float* C, int ldc, int beta, float* bias_grad, hipStream_t stream);
+int dav_attn_fwd_f32(const float* Q, const float* K, const float* V, float* O, float* LSE, int B, int H, int Nq, int Nk, int dqk,
+                     int dv, long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, float scale,
+                     hipStream_t stream);
+int dav_attn_bwd_f32(const float* Q, const float* K, const float* V, const float* O, const float* dO, const float* LSE,
+                     float* Delta, float* dQ, float* dK, float* dV, int B, int H, int Nq, int Nk, int dqk, int dv, long q_bs,
+                     int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, long do_bs, int do_rs, long dq_bs,
+                     int dq_rs, long dk_bs, int dk_rs, long dv_bs, int dv_rs, float scale, int part, hipStream_t stream);
+int dav_patch_gather_f32(const float* img, int B, int C, int T, int H, int W, int pt, const int* ids_keep32, int nk, float* A,
+                         hipStream_t stream);
+int dav_rows_gather_f32(const float* x, long x_bs, int row_off, const int* ids32, int B, int n, int D, float* out, long out_bs,
+                        hipStream_t stream);      /* out_bs: batch stride of out in elements (0 = dense) */
+int dav_pair_expand_f32(const float* Pv, const float* Pa, int B, int nv, int na, int Wd, float* out, hipStream_t stream);
+int dav_pair_reduce_f32(const float* d, int B, int nv, int na, int Wd, float* dPv, float* dPa, hipStream_t stream);
+int dav_patch_mse_bwd_f32(const float* img, const float* pred, const float* mask, const float* tmean, const float* trstd,
+                          const float* mask_sum, const float* gout, int B, int C, int H, int W, float* dpred, hipStream_t stream);
+int dav_add_f32(const float* a, const float* b, float* out, long n, hipStream_t stream);   /* out = a + b */
+
 /* ---- launch batching ---------------------------------------------------------------------- */
 /* The reference runs the image block, the audio block and the fusion block of a layer one after the other although they
  * only depend on the layer's inputs (models/deepavfusion.py:104-107), and likewise the two MAE decoders

@@ -70,6 +70,52 @@ def test_end_to_end_vs_oracle_and_golden(golden, name):
     assert abs(tot - float(g['grad_norm_total'])) < 5e-3 * float(g['grad_norm_total'])
 
 
+@pytest.mark.parametrize('name,batch', [('micro', 2), ('micro', 64), ('tiny', 2), ('micro_token', 2), ('micro_dense', 2)])
+def test_end_to_end_fp32(golden, name, batch):
+    """The WHOLE hand-written forward + backward in fp32 (engine.set_precision('fp32'): the fp32-operand twins of every
+    kernel, csrc/f32_path.hip) against the fp32 oracle and the reference's own fixture numbers at 1e-4 — what bf16's 2e-2
+    tolerance cannot show: every row map, stride, epilogue order, tape and gradient formula of the engine is exact."""
+    from deepavfusion_amd import engine as E
+    E.set_precision('fp32')
+    try:
+        model, sd, cfg, O = _build(name)
+        g = golden(f'e2e_{name}')
+        same_as_fixture = batch == int(g['B'])
+        image, audio, ni, na = O.synthetic_batch(cfg, batch, seed=int(g['seed']) if same_as_fixture else 91)
+        out = model(image.cuda(), audio.cuda(), torch.from_numpy(ni).cuda(), torch.from_numpy(na).cuda())
+        (out[0] + out[1]).backward()
+        sdo = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in sd.items()}
+        li, la, pi, pa, aux = O.avmae_forward(sdo, cfg, image, audio, ni, na)
+        (li + la).backward()
+        TOL = 1e-4
+        for got, ref in ((out[0], li), (out[1], la)):
+            assert abs(float(got) - float(ref)) <= 1e-5 * abs(float(ref)), (float(got), float(ref))
+        assert rel(out[2], pi) < TOL and rel(out[3], pa) < TOL
+        if same_as_fixture:                                   # the reference's own numbers
+            assert abs(float(out[0]) - float(g['loss_image'])) <= 1e-5 * abs(float(g['loss_image']))
+            assert abs(float(out[1]) - float(g['loss_audio'])) <= 1e-5 * abs(float(g['loss_audio']))
+            if 'pred_image' in g.files:
+                assert rel(out[2], g['pred_image']) < TOL and rel(out[3], g['pred_audio']) < TOL
+        g_all = sum(float(v.grad.double().norm()) ** 2 for v in sdo.values() if v.grad is not None) ** 0.5
+        worst = []
+        for n, p in model.named_parameters():
+            if not p.requires_grad:
+                continue
+            assert p.grad is not None, n
+            ref = sdo[n].grad.double()
+            d = float((p.grad.detach().double().cpu() - ref).norm())
+            # exact-zero gradients (key biases) included: in fp32 they are ~1e-7 on both sides
+            if d > TOL * float(ref.norm()) + 1e-6 * g_all:
+                worst.append((n, d, float(ref.norm())))
+        assert not worst, worst[:6]
+        tot = sum(float(p.grad.double().norm()) ** 2 for p in model.parameters() if p.grad is not None) ** 0.5
+        assert abs(tot - g_all) < 1e-5 * g_all
+        if same_as_fixture:
+            assert abs(tot - float(g['grad_norm_total'])) < 1e-4 * float(g['grad_norm_total'])
+    finally:
+        E.set_precision('bf16')
+
+
 def test_batch64_grouped_wgrad_path_vs_oracle():
     """B = 64 makes every token count a multiple of 64: the deferred, grouped weight-gradient GEMMs
     (dav_gemm_tn_grouped_bf16), the LDS-DMA kernels and the grouped LayerNorm reductions are all on the path."""
@@ -175,6 +221,36 @@ def test_video_earlyfusion_vs_oracle_and_golden(golden):
     # kept-token subsets do not broadcast against the full pos_embed in the reference (models/video_vits.py:229-232)
     with pytest.raises(RuntimeError):
         model(video.cuda(), audio.cuda(), video_ids_keep=torch.zeros(int(g['B']), 3, dtype=torch.int64, device='cuda'))
+
+
+def test_video_earlyfusion_fp32(golden):
+    """configs[4] family on the fp32 kernels (tubelet gather, joint space-time blocks, fusion blocks): outputs and every
+    gradient against the oracle AND the reference's own fixture at 1e-4."""
+    from deepavfusion_amd import engine as E
+    E.set_precision('fp32')
+    try:
+        g = golden('e2e_video_micro')
+        model, sd, cfg, O = _build_video('video_micro')
+        video, audio = O.synthetic_video_batch(cfg, int(g['B']), seed=int(g['seed']))
+        outs = model(video.cuda(), audio.cuda())
+        for got, key in zip(outs, ('x_video', 'x_audio', 'x_fusion')):
+            assert rel(got, g[key]) < 1e-4, key
+        w, loss = _probe(outs, int(g['seed']) + 1)
+        loss.backward()
+        sdo = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in sd.items()}
+        ov = O.video_earlyfusion_forward(sdo, cfg, video, audio)
+        sum((t * wi).sum() for t, wi in zip(ov, w)).backward()
+        g_all = sum(float(v.grad.double().norm()) ** 2 for v in sdo.values() if v.grad is not None) ** 0.5
+        for n, p in model.named_parameters():
+            if p.requires_grad and sdo[n].grad is not None:
+                d = float((p.grad.detach().double().cpu() - sdo[n].grad.double()).norm())
+                assert d <= 1e-4 * float(sdo[n].grad.double().norm()) + 1e-6 * g_all, (n, d)
+        for k in g.files:
+            if k.startswith('grad.'):
+                got = dict(model.named_parameters())[k[5:]].grad.detach().double().cpu().numpy()
+                assert float(np.linalg.norm(got - g[k])) <= 1e-4 * float(np.linalg.norm(g[k])) + 1e-6 * g_all, k
+    finally:
+        E.set_precision('bf16')
 
 
 def test_video_long_sequences_vs_oracle():
