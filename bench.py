@@ -265,6 +265,7 @@ def main():
                               'achieved': round(ach, 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                               'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': traffic,
                               'traffic_note': 'offline rocprofv3 --pmc FETCH_SIZE (x2, gfx950 note) + WRITE_SIZE over this replay; null unless profiled for this workload',
+                              'algorithmic_bytes_per_launch': int(sum(2.0 * (M * K + N * K + M * N) for _, probs in big for (M, N, K) in probs) / len(big)),
                               'launches_per_step': len(big), 'problems_per_step': sum(len(pr) for _, pr in big),
                               'avg_launch_us': round(total_ms * 1e3 / len(big), 2),
                               'avg_gflop_per_launch': round(fl / len(big) / 1e9, 3)}

@@ -10,7 +10,9 @@
 //
 // Replaces the cuBLAS/rocBLAS calls behind F.linear in timm Block / Mlp / Attention and
 // models/fusion_blocks.py:41-44,227-232; models/avmae.py:31,59-60,88.
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -1064,10 +1066,13 @@ int nt_auto_config_tiles(long t128, bool narrow);
 
 // Issue log (bench.py's roofline leg): which grouped / single launches the NT family really issued, so that the launch mix
 // of a step can be replayed kernel for kernel.  Entry: cfg, b_kn, n, then n x (M, N, K).
-thread_local bool nt_log_on = false;
-thread_local std::vector<int> nt_log;
+// process-wide (autograd runs the backward on its own thread), guarded by a mutex
+std::atomic<bool> nt_log_on{false};
+std::vector<int> nt_log;
+std::mutex nt_log_mu;
 void nt_log_issue(int cfg, bool bt, const void* const* params, int n) {
-  if (!nt_log_on) return;
+  if (!nt_log_on.load(std::memory_order_relaxed)) return;
+  std::lock_guard<std::mutex> lk(nt_log_mu);
   nt_log.push_back(cfg); nt_log.push_back(bt ? 1 : 0); nt_log.push_back(n);
   for (int i = 0; i < n; ++i) {
     const NTParams& p = *(const NTParams*)params[i];
@@ -1448,6 +1453,8 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
       case 3: launch_nt2<128, 128, 2, 4, 2, true>(p, stream); break;
       case 31: launch_nt2<128, 128, 2, 4, 2, true, 64, 1>(p, stream); break;
       case 32: launch_nt3<true>(p, stream); break;
+      case 40: launch_nt2<256, 128, 4, 4, 3, true>(p, stream); break;      // 16 waves, one workgroup per CU, 3 x 48 KB ring
+      case 41: launch_nt2<128, 256, 4, 4, 3, true>(p, stream); break;
       case 8: launch_nt2<128, 64, 2, 2, 2, true>(p, stream); break;
       default: launch_nt2<64, 64, 2, 2, 2, true>(p, stream); break;
     }
@@ -1464,6 +1471,9 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
       }
       case 31: launch_nt2<128, 128, 2, 4, 2, false, 64, 1>(p, stream); return dav_launch_status();
       case 32: launch_nt3<false>(p, stream); return dav_launch_status();
+      case 40: launch_nt2<256, 128, 4, 4, 3>(p, stream); return dav_launch_status();   // 16 waves, one workgroup per CU, 3 x 48 KB ring
+      case 41: launch_nt2<128, 256, 4, 4, 3>(p, stream); return dav_launch_status();
+      case 42: launch_nt2<256, 128, 4, 4, 2>(p, stream); return dav_launch_status();
       case 33: case 34: case 35: case 36: case 37: {      // phase profile of the staggered-halves kernel (+ ablations 1..4); res_rows = int64 output
         if (res) return DAV_ERR_SHAPE;
         const int grid = ((M + 255) / 256) * ((N + 127) / 128);
@@ -1519,6 +1529,7 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
 
 extern "C" int dav_nt_issue_log(int enable, int* out, int capacity) {
   // enable: 1 start (clears), 0 stop; out != NULL: copy the log (returns its length in ints, or -needed if capacity is short)
+  std::lock_guard<std::mutex> lk(nt_log_mu);
   if (out) {
     const int n = (int)nt_log.size();
     if (n > capacity) return -n;

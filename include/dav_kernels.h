@@ -61,7 +61,7 @@ int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int K, int lda,
                      void* C2, int ldc2, int c2_mode, int beta, float alpha, int variant, hipStream_t stream);
 
 /* Diagnostics for benchmarks: log which launches the NT family issues (grouped or single).  enable 1 / 0 with out == NULL
- * starts (and clears) / stops logging on the calling thread; with out != NULL the log is copied: entries of
+ * starts (and clears) / stops logging (process-wide: autograd runs the backward on its own thread); with out != NULL the log is copied: entries of
  * {tile configuration, b_kn, n, n x (M, N, K)}; returns the number of ints, or -needed when capacity is too small. */
 int dav_nt_issue_log(int enable, int* out, int capacity);
 
