@@ -145,7 +145,9 @@ class GraphedStep:
         self.dist_active = self.world > 1 or (self.reducer is not None and self.reducer.force)
         if segments <= 0:
             segments = int(os.environ.get('DAV_SEGMENTS', '0')) or (5 if self.dist_active else 1)
-        depth = len(self.model.encoder.image.blocks)
+        enc = self.model.encoder
+        vis = enc.visual if hasattr(enc, 'visual') else (enc.video if hasattr(enc, 'video') else enc.image)      # image or video tower
+        depth = len(vis.blocks)
         segments = max(1, min(segments, depth + 1))
         # The backward runs: both decoders, then encoder layers depth-1 .. 0.  A segment ends after "layer" l when l is in
         # `cuts`; l == depth stands for "after the decoders".  That is always the first cut: the decoders' gradients

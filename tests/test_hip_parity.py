@@ -449,6 +449,64 @@ def test_trainer_step_semantics(golden):
     assert len(bad) <= 3, bad
 
 
+def test_trainer_and_loss_curve_fp32(golden):
+    """Optimizer-in-the-loop parity on the fp32 kernels: (1) the reference's Trainer.step fixture (gradient accumulation,
+    grad-norm scaling, lr schedule, AdamW with per-group weight decay: util/misc.py:96-136, train.py:89-93) at 1e-5 / 1e-4
+    instead of bf16's 3e-3 / 2e-2; (2) the first 30 steps of the reference's ViT-Tiny loss curve at 2e-4 per step."""
+    from deepavfusion_amd import engine as E
+    from deepavfusion_amd.util import lr_sched
+    from deepavfusion_amd.util.flat import FlatAdamW
+    from deepavfusion_amd.util.misc import Trainer
+
+    class NS(dict):
+        __getattr__ = dict.__getitem__
+    E.set_precision('fp32')
+    try:
+        g = golden('trainer_steps')
+        model, sd, cfg, O = _build('micro')
+        nd = [n for n, p in model.named_parameters() if 'bias' in n or 'norm' in n]
+        groups = lr_sched.param_groups_pretrained(model, 0.05, no_weight_decay_list=nd, image_pt='', audio_pt='')
+        opt = FlatAdamW(groups, lr=1e-3, betas=(0.9, 0.95), model=model)
+        tr = Trainer(model, optimizer=opt, accum_iter=2, use_amp=True, distributed=False)
+        args = NS(opt=NS(lr=1e-3, warmup_epochs=1, epochs=4, pt_warmup_epochs='4/2', pt_lr_mult_start=0, pt_lr_mult_end=1))
+        for step in range(6):
+            if step % 2 == 0:
+                lr_sched.adjust_learning_rate(opt, step / 6 * 4, args)
+            image, audio, ni, na = O.synthetic_batch(cfg, 2, seed=300 + step)
+            with tr.autocast(), tr.autosync():
+                li, la = tr.model(image.cuda(), audio.cuda(), torch.from_numpy(ni).cuda(), torch.from_numpy(na).cuda())[:2]
+            norm, _ = tr.step(li + la)
+            assert abs(float(li + la) - g['loss'][step]) < 2e-5 * g['loss'][step], (step, float(li + la), g['loss'][step])
+            assert abs(norm - g['grad_norm'][step]) < 2e-4 * g['grad_norm'][step], (step, norm, g['grad_norm'][step])
+        sums = dict(zip(g['param_names'].tolist(), g['param_sums'].tolist()))
+        bad = [n for n, p in model.named_parameters()
+               if p.numel() >= 64 and not n.endswith(('qkv.bias', 'kv.bias', '.k.bias'))
+               and abs(float(p.detach().double().sum()) - sums[n]) > 1e-4 * max(abs(sums[n]), 1.0) + 2e-5 * p.numel() ** 0.5]
+        assert not bad, bad[:5]
+        # (2) loss curve
+        try:
+            gc = golden('curve_tiny')
+        except FileNotFoundError:
+            return
+        model, sd, cfg, O = _build('tiny')
+        nd = [n for n, p in model.named_parameters() if 'bias' in n or 'norm' in n]
+        groups = lr_sched.param_groups_pretrained(model, 0.05, no_weight_decay_list=nd, image_pt='', audio_pt='')
+        lr, Bc, spe = float(gc['lr']), int(gc['B']), int(gc['steps_per_epoch'])
+        opt = FlatAdamW(groups, lr=lr, betas=(0.9, 0.95), model=model)
+        tr = Trainer(model, optimizer=opt, accum_iter=1)
+        n_total = len(gc['loss_image'])
+        args = NS(opt=NS(lr=lr, warmup_epochs=1, epochs=n_total // spe, pt_warmup_epochs=f'{n_total // spe}/2', pt_lr_mult_start=0, pt_lr_mult_end=1))
+        for s_ in range(30):
+            lr_sched.adjust_learning_rate(opt, s_ / spe, args)
+            image, audio, ni, na = O.structured_batch(cfg, Bc, seed=10_000 + s_)
+            li, la = tr.model(image.cuda(), audio.cuda(), torch.from_numpy(ni).cuda(), torch.from_numpy(na).cuda())[:2]
+            tr.step(li + la)
+            ref = gc['loss_image'][s_] + gc['loss_audio'][s_]
+            assert abs(float(li + la) - ref) < 2e-4 * ref, (s_, float(li + la), ref)
+    finally:
+        E.set_precision('bf16')
+
+
 def test_graphed_step_equals_eager_step():
     from deepavfusion_amd.util import lr_sched
     from deepavfusion_amd.util.flat import FlatAdamW
