@@ -120,6 +120,20 @@ class Trainer:
         return contextlib.nullcontext()
 
 
+def segment_cuts(depth: int, segments: int):
+    """Where the captured backward is cut into ``segments`` graphs (pure function: tested on CPU).  The backward runs both
+    decoders, then encoder layers depth-1 .. 0; a segment ends after "layer" l for every l in the returned list, l == depth
+    standing for "after the decoders".  That is always the first cut — the decoders' gradients (a sixth of the bytes) start
+    their all-reduce while the whole encoder backward is still ahead — and the remaining cuts leave quadratically fewer
+    layers behind them (depth 12, 5 segments: 11..7 | 6..3 | 2..1 | 0), so the last reduction, the only one nothing is left
+    to overlap with, is one layer's worth of bytes."""
+    segments = max(1, min(segments, depth + 1))
+    if segments < 2:
+        return []
+    enc_parts = segments - 1
+    return sorted({depth} | ({round(depth * ((enc_parts - s) / enc_parts) ** 2) for s in range(1, enc_parts)} - {0, depth}), reverse=True)
+
+
 class GraphedStep:
     """One pre-training step (forward -> backward -> grad norm -> AdamW) captured in hipGraphs and replayed per
     iteration: ~1900 kernel launches become a handful of graph launches.
@@ -154,11 +168,7 @@ class GraphedStep:
         # (a sixth of the bytes) start their all-reduce while the whole encoder backward is still ahead; the remaining cuts
         # leave quadratically fewer layers behind them (depth 12, 5 segments: layers 11..7 | 6..3 | 2..1 | 0), so the last
         # reduction — the only one nothing is left to overlap with — is one layer's worth of bytes.
-        self.cuts = []
-        if segments >= 2:
-            enc_parts = segments - 1
-            self.cuts = sorted({depth} | ({round(depth * ((enc_parts - s) / enc_parts) ** 2) for s in range(1, enc_parts)} - {0, depth}),
-                               reverse=True)
+        self.cuts = segment_cuts(depth, segments)
         self.n_seg = len(self.cuts) + 1
         saved_hook = engine._GRAD_READY
         engine.set_grad_ready_hook(None)

@@ -113,3 +113,93 @@ def test_grad_reducer_world2_gloo():
                     p.kill()
     res = dict(q.get(timeout=5) for _ in range(world))
     assert res[0] == res[1]          # identical collective order on every rank
+
+
+def test_segment_cuts_are_pure_and_decoders_first():
+    from deepavfusion_amd.util.misc import segment_cuts
+    assert segment_cuts(12, 1) == []
+    assert segment_cuts(12, 2) == [12]
+    assert segment_cuts(12, 5) == [12, 7, 3, 1]                 # [decoders] | 11..7 | 6..3 | 2..1 | 0
+    for depth in (2, 12, 24):
+        for seg in range(2, depth + 3):
+            c = segment_cuts(depth, seg)
+            assert c[0] == depth and c == sorted(set(c), reverse=True) and all(0 < x <= depth for x in c) and len(c) <= seg - 1
+    for depth, seg in ((12, 5), (24, 6), (12, 4)):              # ever fewer layers left behind a cut (up to rounding at many cuts)
+        c = segment_cuts(depth, seg)
+        gaps = [a - b for a, b in zip(c, c[1:] + [0])][1:]
+        assert gaps == sorted(gaps, reverse=True), (depth, seg, c)
+
+
+def _sched_worker(rank, world, port, q):
+    """The segmented step's collective schedule without a GPU: each 'graph segment' finishes a contiguous range of
+    parameters (the flat buffer is in backward order), then its completed buckets are all-reduced — exactly what
+    GraphedStep.__call__ does between replayed segments (launch_buckets per segment, finish() before the optimizer)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    from deepavfusion_amd.util.distributed import DataParallel
+    from deepavfusion_amd.util.flat import FlatParams
+    from deepavfusion_amd.util.misc import segment_cuts
+    torch.manual_seed(5)
+    depth = 6
+    layers = [torch.nn.Linear(48, 48) for _ in range(depth)]
+    dec = torch.nn.Linear(48, 200)
+    model = torch.nn.Sequential(*layers, dec)
+    flat = FlatParams(reversed(list(model.parameters())))       # decoder first: the order the backward finishes gradients
+    dp = DataParallel(model, flat, bucket_mb=0.012, first_bucket_mb=0.004)
+    dp.reducer.comm_stream = None
+    red = dp.reducer
+    cuts = segment_cuts(depth, 4)
+    # capture-time bookkeeping: which buckets does each segment complete?
+    pending = [len(b[2]) for b in red.buckets]
+    sched, seg = [[] for _ in range(len(cuts) + 1)], 0
+    order = [(depth, list(dec.parameters()))] + [(l, list(layers[l].parameters())) for l in reversed(range(depth))]
+    for l, params in order:
+        for p in reversed(params):
+            bi = red._bucket_of[id(p)]
+            pending[bi] -= 1
+            if pending[bi] == 0:
+                sched[seg].append(bi)
+        if l in cuts:
+            seg += 1
+    assert sorted(b for s in sched for b in s) == list(range(len(red.buckets))) and sched[0] and 0 in sched[0]
+    # replay: gradients appear segment by segment, buckets are reduced between segments
+    red.begin_backward()
+    seg = 0
+    for l, params in order:
+        for i, p in enumerate(params):
+            p.grad.add_(torch.full_like(p, float((rank + 1) * (l + 1) + i)))
+        if l in cuts:
+            red.launch_buckets(sched[seg])
+            seg += 1
+    red.launch_buckets(sched[seg])
+    red.finish()
+    mean_rank = sum(r + 1 for r in range(world)) / world
+    for l, params in order:
+        for i, p in enumerate(params):
+            assert torch.allclose(p.grad, torch.full_like(p, mean_rank * (l + 1) + i)), (l, i)
+    q.put((rank, list(red.launch_order), sched))
+    dist.destroy_process_group()
+
+
+def test_segment_schedule_world4_gloo():
+    world, port = 4, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sched_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.daemon = True
+        p.start()
+    try:
+        for p in procs:
+            p.join(timeout=180)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+                p.join(5)
+                if p.is_alive():
+                    p.kill()
+    res = [q.get(timeout=5) for _ in range(world)]
+    assert all(r[1] == res[0][1] and r[2] == res[0][2] for r in res)      # same collective order and schedule on every rank
+    assert res[0][1] == [b for s in res[0][2] for b in s]                 # buckets go out segment by segment
