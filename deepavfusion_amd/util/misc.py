@@ -120,6 +120,13 @@ class Trainer:
         return contextlib.nullcontext()
 
 
+# hipStreamCaptureModeThreadLocal: with the default (global) mode ANY thread's event query is an error while a capture is
+# open — and the RCCL process group's watchdog thread polls the events of earlier collectives (the rank-0 broadcast, an eager
+# warm-up step) at its own pace: "operation not permitted when stream is capturing" kills the process (seen with a 1-rank
+# RCCL group under torch.distributed.run).  Only the capturing thread's calls need policing.
+CAPTURE_MODE = 'thread_local'
+
+
 def segment_cuts(depth: int, segments: int):
     """Where the captured backward is cut into ``segments`` graphs (pure function: tested on CPU).  The backward runs both
     decoders, then encoder layers depth-1 .. 0; a segment ends after "layer" l for every l in the returned list, l == depth
@@ -201,12 +208,12 @@ class GraphedStep:
             if l in self.cuts:
                 self.graphs[seg[0]].capture_end()
                 seg[0] += 1
-                self.graphs[seg[0]].capture_begin(pool=self.graphs[0].pool())
+                self.graphs[seg[0]].capture_begin(pool=self.graphs[0].pool(), capture_error_mode=CAPTURE_MODE)
         cap = torch.cuda.Stream()
         cap.wait_stream(torch.cuda.current_stream())
         self.opt.flat.zero_grad()            # the AdamW pass leaves the gradients zeroed for the next replay
         with torch.cuda.stream(cap):
-            self.graphs[0].capture_begin()
+            self.graphs[0].capture_begin(capture_error_mode=CAPTURE_MODE)
             # every derived bf16 copy (casts of un-mirrored weights, TRANSPOSED copies) must be re-derived INSIDE the graph:
             # copies left over from the warm-up passes would otherwise be read, stale, by every replay
             engine.invalidate_weight_cache(self.model.parameters())
@@ -219,7 +226,7 @@ class GraphedStep:
             self.opt_graph = None
             if self.dist_active:
                 self.opt_graph = torch.cuda.CUDAGraph()
-                self.opt_graph.capture_begin(pool=self.graphs[0].pool())
+                self.opt_graph.capture_begin(pool=self.graphs[0].pool(), capture_error_mode=CAPTURE_MODE)
                 self.opt.launch_step(fused_norm_and_zero=True)
                 self.grad_norm = self.opt.sumsq.sqrt()
                 self.opt_graph.capture_end()
