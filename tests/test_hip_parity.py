@@ -2,6 +2,8 @@
 
 Tolerances (bf16 operands, fp32 accumulate): losses 1e-3 relative, activations and
 gradients 2e-2 relative L2 (5e-2 for individual small-norm gradients), masking indices bit-exact."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -809,3 +811,24 @@ def test_load_state_dict_after_optimizer_refreshes_the_bf16_mirror():
     with torch.no_grad():
         l4 = float(model(*args)[0])
     assert l3 == l4 and l3 != l1
+
+
+@pytest.mark.timeout(300)
+def test_train_py_runs_and_resumes(tmp_path):
+    """train.py (drop-in for the reference's pre-training worker, train.py:20-187) end to end as a fresh process: ViT-Tiny,
+    64 px + 2 s audio, 6 captured steps over 2 epochs, checkpoint written; a second invocation resumes from it."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    over = ['model.image.backbone=vit_tiny', 'model.audio.backbone=vit_tiny', 'model.fusion.num_heads=3', 'data.image_size=64',
+            'data.audio_dur=2.', 'opt.batch_size=4', 'opt.epochs=2', 'opt.warmup_epochs=1', 'data.steps_per_epoch=3',
+            'log.print_freq=1', f'output_dir={tmp_path}', 'job_name=t', 'env.workers=0']
+    for run in range(2):
+        r = subprocess.run([sys.executable, os.path.join(root, 'train.py')] + over + (['opt.epochs=3'] if run else []),
+                           cwd=root, capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        assert '[Train]' in r.stdout and 'loss' in r.stdout
+    assert os.path.isfile(os.path.join(str(tmp_path), 't', 'checkpoints', 'checkpoint_latest.pth'))
+    import torch as _t
+    ck = _t.load(os.path.join(str(tmp_path), 't', 'checkpoints', 'checkpoint_latest.pth'), map_location='cpu')
+    assert ck['epoch'] == 3 and int(ck['n_steps']) == 9           # resumed at epoch 2, ran one more epoch
