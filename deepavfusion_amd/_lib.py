@@ -62,6 +62,8 @@ SIGNATURES = {
     'dav_pair_reduce_f32': [_p, _i, _i, _i, _i, _p, _p, _p],
     'dav_patch_mse_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p],
     'dav_add_f32': [_p, _p, _p, _l, _p],
+    'dav_logmel': [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _f, _i, _i, _p, _p],
+    'dav_log10_eps': [_p, _f, _l, _p, _p],
     'dav_batch_begin': [_i],
     'dav_batch_lane': [],
     'dav_batch_region': [_i],

@@ -181,6 +181,19 @@ int dav_adamw_flat(float* p, float* g, float* m, float* v, void* p_bf16, long n,
                    int nseg, float beta1, float beta2, float eps, const float* bias_corr, float grad_scale, float* sumsq_out,
                    int zero_grad, hipStream_t stream);
 
+/* ---- log-mel front-end (csrc/mel.hip) ------------------------------ */
+/* out[b, m, t] = log10(mel_m(|STFT_t(wave[b])|^2) + eps): the reference's audio transform
+ * aT.MelSpectrogram(sample_rate, n_fft, hop_length, n_mels) -> aT.Log() (train.py:50-54, util/audio_transforms.py:29-35) and
+ * the [:, :, :-1] of datasets.py:242, computed on the device from raw waveforms [B, S] instead of in CPU loader workers.
+ * Semantics of torchaudio's Spectrogram + MelScale defaults: centre padding by reflection, the caller's window of n_fft
+ * samples (periodic Hann), one-sided power spectrum, dense filterbank fbank[n_fft/2+1, n_mels] with each filter's non-zero bin
+ * range [band_lo[m], band_hi[m]); cos_tab / sin_tab[n] = cos / sin(2 pi n / n_fft).  frames = S / hop + 1; drop_last removes
+ * the final frame (out is [B, n_mels, frames - drop_last]); apply_log = 0 returns the mel power itself. */
+int dav_logmel(const float* wave, int B, int S, int n_fft, int hop, int n_mels, const float* window, const float* cos_tab,
+               const float* sin_tab, const float* fbank, const int* band_lo, const int* band_hi, float eps, int apply_log,
+               int drop_last, float* out, hipStream_t stream);
+int dav_log10_eps(const float* x, float eps, long n, float* y, hipStream_t stream);      /* aT.Log: y = log10(x + eps) */
+
 /* ---- fp32-operand twins (csrc/f32_path.hip) ------------------------------------------------ */
 /* The same contracts as the bf16 entry points above with every operand, second output and intermediate in fp32 (plain
  * one-thread-per-output kernels, untuned).  They exist so that the whole hand-written forward / backward can run in fp32

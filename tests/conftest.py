@@ -20,6 +20,7 @@ _FILE_RANK = {
     'test_hip_fp32.py': 3,
     'test_hip_parity.py': 4,
     'test_baseline_configs.py': 5,
+    'test_audio_frontend_gpu.py': 7,
     'test_dp_gloo.py': 8,
     'test_dp_rccl_gpu.py': 9,
 }

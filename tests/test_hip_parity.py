@@ -816,7 +816,8 @@ def test_load_state_dict_after_optimizer_refreshes_the_bf16_mirror():
 @pytest.mark.timeout(300)
 def test_train_py_runs_and_resumes(tmp_path):
     """train.py (drop-in for the reference's pre-training worker, train.py:20-187) end to end as a fresh process: ViT-Tiny,
-    64 px + 2 s audio, 6 captured steps over 2 epochs, checkpoint written; a second invocation resumes from it."""
+    64 px + 2 s audio, 6 captured steps over 2 epochs, checkpoint written; a second invocation resumes from it — with
+    the device-side log-mel front-end (waveforms from the loader, data.audio_frontend=gpu)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -824,7 +825,7 @@ def test_train_py_runs_and_resumes(tmp_path):
             'data.audio_dur=2.', 'opt.batch_size=4', 'opt.epochs=2', 'opt.warmup_epochs=1', 'data.steps_per_epoch=3',
             'log.print_freq=1', f'output_dir={tmp_path}', 'job_name=t', 'env.workers=0']
     for run in range(2):
-        r = subprocess.run([sys.executable, os.path.join(root, 'train.py')] + over + (['opt.epochs=3'] if run else []),
+        r = subprocess.run([sys.executable, os.path.join(root, 'train.py')] + over + (['opt.epochs=3', 'data.audio_frontend=gpu'] if run else []),
                            cwd=root, capture_output=True, text=True, timeout=240)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
         assert '[Train]' in r.stdout and 'loss' in r.stdout

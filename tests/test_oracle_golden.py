@@ -287,3 +287,31 @@ def test_trainer_step_semantics(golden):
             continue
         got = float(tr.sd[k].detach().double().sum())
         assert abs(got - ref) < 1e-4 * max(abs(ref), 1.0), k
+
+
+def test_audio_frontend_oracle_stft_pinned_and_filterbank_properties():
+    """oracle/audio_oracle.py: the STFT half equals the defining DFT sum (torch.stft's centre / reflect / periodic-Hann /
+    one-sided conventions), the HTK filterbank is non-negative, triangular, peaks at 1 between mel-equidistant edges, and
+    the output has the reference's shape (128, 64 * dur) after the [:, :, :-1] of datasets.py:242."""
+    import torch
+
+    from oracle import audio_oracle as A
+    torch.manual_seed(0)
+    w = torch.randn(2, 5000, dtype=torch.float64).clamp(-1, 1)
+    n_fft, hop = 800, 250
+    win = torch.hann_window(n_fft, periodic=True, dtype=torch.float64)
+    spec = torch.stft(w, n_fft, hop_length=hop, win_length=n_fft, window=win, center=True, pad_mode='reflect',
+                      return_complex=True).abs() ** 2
+    xp = torch.nn.functional.pad(w[:, None], (n_fft // 2, n_fft // 2), mode='reflect')[:, 0]
+    for (b, t) in ((0, 0), (1, 7), (0, spec.shape[-1] - 1)):
+        d = A.dft_power_direct((xp[b, t * hop:t * hop + n_fft] * win).numpy())
+        assert np.abs(spec[b, :, t].numpy() - d).max() <= 1e-12 * d.max()
+    fb = A.melscale_fbanks(401, 0.0, 8000.0, 128, 16000)
+    assert fb.shape == (401, 128) and fb.min() >= 0 and fb.max() <= 1.0 + 1e-12
+    nz = fb > 0
+    assert all(np.all(np.diff(np.flatnonzero(nz[:, m])) == 1) for m in range(128) if nz[:, m].any())      # one contiguous band each
+    centres = np.array([fb[:, m].argmax() for m in range(128)])
+    assert np.all(np.diff(centres) >= 0) and centres[-1] < 400
+    out = A.log_mel(torch.zeros(1, 160000))
+    assert out.shape == (1, 1, 128, 640) and torch.allclose(out, torch.full_like(out, -7.0))               # log10(0 + 1e-7)
+    assert A.pad(torch.arange(5.)[None], 0.5, 16)[0].tolist() == [0., 1., 2., 3., 4., 4., 3., 2.]            # mirror extension

@@ -69,9 +69,11 @@ def load_config(name='deepavfusion', overrides=()):
 
 
 class SyntheticAV(torch.utils.data.Dataset):
-    """ImageNet-normalised frames ~ N(0,1); log10-mel spectrograms in about [-7, 4] (train.py:50-54, datasets.py:242)."""
-    def __init__(self, n, image_size, audio_size, seed=0):
-        self.n, self.image_size, self.audio_size, self.seed = n, image_size, audio_size, seed
+    """ImageNet-normalised frames ~ N(0,1); log10-mel spectrograms in about [-7, 4] (train.py:50-54, datasets.py:242) — or,
+    with ``wave_samples`` set (data.audio_frontend=gpu), raw waveforms in [-1, 1] that the device-side front-end
+    (deepavfusion_amd.util.audio_transforms.LogMelSpectrogram) turns into the same log-mel tensor."""
+    def __init__(self, n, image_size, audio_size, seed=0, wave_samples=0):
+        self.n, self.image_size, self.audio_size, self.seed, self.wave_samples = n, image_size, audio_size, seed, wave_samples
 
     def __len__(self):
         return self.n
@@ -79,6 +81,9 @@ class SyntheticAV(torch.utils.data.Dataset):
     def __getitem__(self, i):
         g = torch.Generator().manual_seed(self.seed * 1_000_003 + i)
         image = torch.randn(3, *self.image_size, generator=g)
+        if self.wave_samples:
+            audio = (torch.randn(self.wave_samples, generator=g) * 0.1).clamp(-1, 1)
+            return image, audio, i
         audio = (torch.randn(1, *self.audio_size, generator=g) * 2.0 - 3.0).clamp(-7, 4)
         return image, audio, i
 
@@ -107,7 +112,9 @@ def main_worker(local_rank, args):
     audio_size = (args.data.audio_mels, int(args.data.audio_dur * 64))  # train.py:65
     if args.data.dataset != 'synthetic':
         raise NotImplementedError('only data.dataset=synthetic is on the MI355X path (the reference datasets need PyAV/torchaudio)')
-    dataset = SyntheticAV(args.data.steps_per_epoch * eff_batch_size, image_size, audio_size, seed=args.env.seed or 0)
+    gpu_frontend = args.data.get('audio_frontend', 'loader') == 'gpu'     # waveforms in, log-mel computed on the device
+    dataset = SyntheticAV(args.data.steps_per_epoch * eff_batch_size, image_size, audio_size, seed=args.env.seed or 0,
+                          wave_samples=int(args.data.audio_dur * args.data.audio_rate) if gpu_frontend else 0)
     sampler = torch.utils.data.DistributedSampler(dataset, shuffle=True) if num_tasks > 1 else torch.utils.data.RandomSampler(dataset)
     loader = torch.utils.data.DataLoader(dataset, batch_size=args.opt.batch_size, sampler=sampler, num_workers=args.env.workers,
                                          pin_memory=True, drop_last=True)
@@ -142,15 +149,19 @@ def main_worker(local_rank, args):
         B = args.opt.batch_size
         graphed = misc_utils.GraphedStep(trainer, (B, 3, *image_size), (B, 1, *audio_size))
 
+    frontend = None
+    if gpu_frontend:
+        from deepavfusion_amd.util.audio_transforms import LogMelSpectrogram
+        frontend = LogMelSpectrogram(sample_rate=args.data.audio_rate, n_mels=args.data.audio_mels).to(device)
     print(f'Start training for {args.opt.epochs} epochs')
     for epoch in range(start_epoch, args.opt.epochs):
         if num_tasks > 1:
             loader.sampler.set_epoch(epoch)
-        train_one_epoch(loader, trainer, epoch, device, args, graphed)
+        train_one_epoch(loader, trainer, epoch, device, args, graphed, frontend)
         ckpt.checkpoint(epoch + 1, {'epoch': epoch + 1})
 
 
-def train_one_epoch(loader, trainer, epoch, device, args, graphed=None):
+def train_one_epoch(loader, trainer, epoch, device, args, graphed=None, frontend=None):
     from deepavfusion_amd.util import lr_sched
     trainer.model.train(True)
     trainer.zero_grad()
@@ -160,6 +171,8 @@ def train_one_epoch(loader, trainer, epoch, device, args, graphed=None):
             lr = lr_sched.adjust_learning_rate(trainer.optimizer, epoch + step / len(loader), args)
         image = image.to(device, non_blocking=True).float()
         audio = audio.to(device, non_blocking=True).float()
+        if frontend is not None:
+            audio = frontend(audio)                 # [B, samples] -> [B, 1, n_mels, 64 * dur] on the device
         if graphed is not None:
             loss_image, loss_audio, grad_norm = graphed(image, audio)
             loss = loss_image + loss_audio
