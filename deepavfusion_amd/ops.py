@@ -26,12 +26,16 @@ def _stream():
 # "launches" them, so every tensor handed to the library is kept alive until the batch has been issued: torch's caching
 # allocator would otherwise hand a temporary's block to a later allocation of the same recording, and with lanes issued
 # in lockstep that later kernel may run BEFORE the temporary's last reader.
-HOLD = None          # list while recording, else None
+import threading
+
+_TLS = threading.local()          # .hold: list while THIS thread records a batch (the library's batch state is per thread too:
+                                  # autograd runs the backward — and its batches — on its own thread)
 
 
 def hold(*tensors):
-    if HOLD is not None:
-        HOLD.extend(t for t in tensors if t is not None)
+    h = getattr(_TLS, 'hold', None)
+    if h is not None:
+        h.extend(t for t in tensors if t is not None)
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -39,15 +43,15 @@ def _ptr(t: Optional[torch.Tensor]):
         return None
     if not t.is_cuda:
         raise RuntimeError('deepavfusion_amd kernels need tensors on an MI355X (cuda) device; there is no CPU fallback')
-    if HOLD is not None:
-        HOLD.append(t)
+    h = getattr(_TLS, 'hold', None)
+    if h is not None:
+        h.append(t)
     return t.data_ptr()
 
 
 def batch_begin(auto_lanes=False):
-    global HOLD
     _lib.check(_lib.load().dav_batch_begin(int(auto_lanes)), 'dav_batch_begin')
-    HOLD = []
+    _TLS.hold = []
 
 
 def batch_lane():
@@ -67,7 +71,7 @@ class unbatched:
     so far depends on them, the launches recorded next read their result)."""
 
     def __enter__(self):
-        self.on = HOLD is not None
+        self.on = getattr(_TLS, 'hold', None) is not None
         if self.on:
             _lib.load().dav_batch_suspend(1)
 
@@ -79,7 +83,6 @@ class unbatched:
 
 def batch_end(abort=False):
     """Issue (or drop) the recorded launches; returns (recorded, issued) launch counts."""
-    global HOLD
     lib = _lib.load()
     try:
         if abort:
@@ -90,7 +93,7 @@ def batch_end(abort=False):
         lib.dav_batch_stats(C.byref(a), C.byref(b))
         return a.value, b.value
     finally:
-        HOLD = None
+        _TLS.hold = None
 
 
 def _rm(m: Optional[Sequence[int]]):
