@@ -10,6 +10,7 @@
 //
 // Replaces the cuBLAS/rocBLAS calls behind F.linear in timm Block / Mlp / Attention and
 // models/fusion_blocks.py:41-44,227-232; models/avmae.py:31,59-60,88.
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <mutex>
@@ -1082,7 +1083,11 @@ void nt_log_issue(int cfg, bool bt, const void* const* params, int n) {
 
 // Recorded with the tile configuration left open: chosen at issue time from the tile count of the WHOLE group.
 template <bool BT>
-void nt2_issue_auto(const void* const* params, int n, hipStream_t stream) {
+void nt2_issue_auto(const void* const* params_in, int n, hipStream_t stream) {
+  // longest k-loops first: workgroups are dispatched in block order as slots free up, so the short tiles fill the tail
+  std::vector<const void*> sorted(params_in, params_in + n);
+  std::stable_sort(sorted.begin(), sorted.end(), [](const void* a, const void* b) { return ((const NTParams*)a)->K > ((const NTParams*)b)->K; });
+  const void* const* params = sorted.data();
   long t128 = 0;
   bool narrow = true;
   for (int i = 0; i < n; ++i) {

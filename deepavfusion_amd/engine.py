@@ -272,6 +272,9 @@ def flush_wgrads():
             key = pr['C'].data_ptr()
             (later if key in seen else now).append(pr)
             seen.add(key)
+        # longest contractions first: tiles are dispatched in list order as workgroup slots free up, and a tile's run time is
+        # proportional to its contraction length (49 .. 95 k-steps in one launch) — the short ones fill the tail
+        now.sort(key=lambda pr: -pr['Mc'])
         ops.gemm_tn_grouped(now)
         for pr in now:
             _ready(*pr['ready'])
