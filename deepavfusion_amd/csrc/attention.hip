@@ -15,6 +15,9 @@
 //   * CrossAttention                     models/fusion_blocks.py:46-59
 //   * the factorised pair attention      models/fusion_blocks.py:250-258 (q/k width 16, v width 64,
 //     scale (D/heads)^-0.5 passed by the caller)
+#include <algorithm>
+#include <vector>
+
 #include "common.h"
 #include "dav_kernels.h"
 
@@ -536,7 +539,14 @@ template <int WHICH> int attn_waves(const AttnParams& p) { return waves_for(WHIC
 
 // issues n >= 1 recorded resident-variant problems of one (head widths, pass) family: davb::GroupFn
 template <int DQK, int DV, int WHICH>
-void attn_issue(const void* const* params, int n, hipStream_t stream) {
+void attn_issue(const void* const* params_in, int n, hipStream_t stream) {
+  // longest sequences first: a (batch, head) workgroup's run time grows with Nq * Nk and workgroups start in block order
+  std::vector<const void*> sorted(params_in, params_in + n);
+  std::stable_sort(sorted.begin(), sorted.end(), [](const void* a, const void* b) {
+    const AttnParams &x = *(const AttnParams*)a, &y = *(const AttnParams*)b;
+    return (long)x.Nq * x.Nk > (long)y.Nq * y.Nk;
+  });
+  const void* const* params = sorted.data();
   auto single = [&](const AttnParams& p) {
     const size_t lds = attn_lds<DQK, DV, WHICH>(p);
     const int nw = attn_waves<WHICH>(p);
