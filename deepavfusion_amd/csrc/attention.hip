@@ -89,6 +89,27 @@ __device__ __forceinline__ bf16x8 tile_frag_tr(const char* tile, int r0, int col
   return u.v;
 }
 
+// The same two fragment reads through per-lane LDS byte addresses that the kernels compute ONCE per tile walk and advance by
+// a constant per 32-row step (the tile's own rows only move the address by multiples of 32 rows, which neither swizzle sees):
+// the key / query loops then carry one integer add per operand column block instead of re-deriving row * RB + swizzle — and
+// the (link-time) LDS base of the dynamic array — for every fragment.
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)LDS_PTR(const char, p); }
+template <int RB> __device__ __forceinline__ uint32_t frag_off(int fr, int kk, int g) {        // tile_frag(tile, fr, kk, g)
+  return (uint32_t)(fr * RB + ((((kk * 4 + g) ^ row_swz<RB>(fr))) << 4));
+}
+template <int RB> __device__ __forceinline__ uint32_t frag_tr_off(int colbase, int lane) {      // tile_frag_tr(tile, 0, colbase, lane), h = 0
+  const int g = lane >> 4, li = lane & 15, row = 4 * g + (li >> 2), colb = (colbase + 4 * (li & 3)) * 2;
+  return (uint32_t)(row * RB + ((((colb >> 4) ^ row_swz<RB>(row)) << 4) | (colb & 15)));
+}
+__device__ __forceinline__ bf16x8 lds_frag(uint32_t a) { return *LDS_PTR(const bf16x8, (uintptr_t)a); }
+template <int RB> __device__ __forceinline__ bf16x8 lds_frag_tr(uint32_t a) {                   // rows +0..3 and +16..19 of the lane's column
+  union { s16x4 h[2]; bf16x8 v; } u;
+  u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, (uintptr_t)a));
+  u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, (uintptr_t)(a + 16 * RB)));
+  return u.v;
+}
+__device__ __forceinline__ f32x4 lds_f4(uint32_t a) { return *LDS_PTR(const f32x4, (uintptr_t)a); }
+
 __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
   union { uint32_t w[4]; bf16x8 v; } u;
   u.w[0] = pack2bf(a[0], a[1]); u.w[1] = pack2bf(a[2], a[3]);
@@ -146,6 +167,11 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, const int bh,
 
   const int nqt = (p.Nq + 15) >> 4;
   const float sl2 = p.scale * 1.44269504088896341f;
+  uint32_t ka0[KS], va0[VC];           // this lane's fragment addresses at key row 0
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) ka0[kk] = lds_addr(Ks) + frag_off<KRB>(fr, kk, g);
+#pragma unroll
+  for (int c = 0; c < VC; ++c) va0[c] = lds_addr(Vs) + frag_tr_off<VRB>(c * 16, lane);
   // A wave works on QT query tiles at once (independent softmax chains for the scheduler to interleave; every K / V
   // fragment read from LDS feeds QT MFMAs).  Chunked: exactly one (possibly out-of-range, then fully masked-off)
   // group per wave so that every wave reaches the chunk barriers.
@@ -175,14 +201,17 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, const int bh,
         __syncthreads();
       }
       const int cend = c0 + CH < Nkp ? c0 + CH : Nkp;
+      uint32_t ka[KS], va[VC];
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) ka[kk] = ka0[kk];
+#pragma unroll
+      for (int c = 0; c < VC; ++c) va[c] = va0[c];
       for (int k0 = c0; k0 < cend; k0 += 32) {
-        const char* Kst = Ks + (k0 - c0) * KRB;    // this key step's 32 rows inside the resident chunk
-        const char* Vst = Vs + (k0 - c0) * VRB;
         bf16x8 kf[2][KS];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int kk = 0; kk < KS; ++kk) kf[t][kk] = tile_frag<KRB>(Kst, t * 16 + fr, kk, g);
+          for (int kk = 0; kk < KS; ++kk) kf[t][kk] = lds_frag(ka[kk] + t * 16 * KRB);
         f32x4 st[QT][2];
 #pragma unroll
         for (int u = 0; u < QT; ++u)
@@ -193,6 +222,9 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, const int bh,
             for (int kk = 0; kk < KS; ++kk)
               st[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][kk], qf[u][kk], st[u][t], 0, 0, 0);
           }
+        bf16x8 vf[VC];                   // issued here so that the softmax arithmetic covers their LDS latency
+#pragma unroll
+        for (int c = 0; c < VC; ++c) vf[c] = lds_frag_tr<VRB>(va[c]);
         // only the last key tile can hold padded keys
         if (k0 + 32 > p.Nk) {
 #pragma unroll
@@ -221,7 +253,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, const int bh,
 #pragma unroll
               for (int r = 0; r < 4; ++r) oacc[u][c][r] *= alpha;
           }
-          float ps = 0.f;
+          float ps = 0.f;                // fp32 sum of the UNROUNDED probabilities, as torch's softmax has it
 #pragma unroll
           for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -233,12 +265,14 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, const int bh,
           pf[u] = pack8(st[u][0], st[u][1]);
         }
 #pragma unroll
-        for (int c = 0; c < VC; ++c) {
-          const bf16x8 vf = tile_frag_tr<VRB>(Vst, 0, c * 16, lane);
+        for (int c = 0; c < VC; ++c)
 #pragma unroll
           for (int u = 0; u < QT; ++u)
-            oacc[u][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[u], oacc[u][c], 0, 0, 0);
-        }
+            oacc[u][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[c], pf[u], oacc[u][c], 0, 0, 0);
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) ka[kk] += 32 * KRB;
+#pragma unroll
+        for (int c = 0; c < VC; ++c) va[c] += 32 * VRB;
       }
     }
 #pragma unroll
@@ -325,9 +359,15 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
       __syncthreads();
     }
     const int cend = c0 + CH < Nkp ? c0 + CH : Nkp;
+    uint32_t ka[KS], va[VS], kta[QC];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) ka[kk] = lds_addr(Ks) + frag_off<KRB>(fr, kk, g);
+#pragma unroll
+    for (int kk = 0; kk < VS; ++kk) va[kk] = lds_addr(Vs) + frag_off<VRB>(fr, kk, g);
+#pragma unroll
+    for (int c = 0; c < QC; ++c) kta[c] = lds_addr(Ks) + frag_tr_off<KRB>(c * 16, lane);
+    // no key mask: the padded key rows of the K tile are zero, so whatever dS they get multiplies zeros in dQ = dS.K
     for (int k0 = c0; k0 < cend; k0 += 32) {
-      const char* Kst = Ks + (k0 - c0) * KRB;
-      const char* Vst = Vs + (k0 - c0) * VRB;
       f32x4 st[2], dp[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -335,21 +375,26 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
         dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk)
-          st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag<KRB>(Kst, t * 16 + fr, kk, g), qf[kk], st[t], 0, 0, 0);
+          st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(ka[kk] + t * 16 * KRB), qf[kk], st[t], 0, 0, 0);
 #pragma unroll
         for (int kk = 0; kk < VS; ++kk)
-          dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag<VRB>(Vst, t * 16 + fr, kk, g), dof[kk], dp[t], 0, 0, 0);
+          dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(va[kk] + t * 16 * VRB), dof[kk], dp[t], 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int key = k0 + t * 16 + 4 * g + r;
-          const float pr = key < p.Nk ? __builtin_amdgcn_exp2f(st[t][r] * sl2 - lse2) : 0.f;
+          const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(st[t][r], sl2, -lse2));
           st[t][r] = pr * (dp[t][r] - delta);     // dS^T
         }
       }
       const bf16x8 dsf = pack8(st[0], st[1]);
 #pragma unroll
       for (int c = 0; c < QC; ++c)
-        dq[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag_tr<KRB>(Kst, 0, c * 16, lane), dsf, dq[c], 0, 0, 0);
+        dq[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_tr<KRB>(kta[c]), dsf, dq[c], 0, 0, 0);
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) ka[kk] += 32 * KRB;
+#pragma unroll
+      for (int kk = 0; kk < VS; ++kk) va[kk] += 32 * VRB;
+#pragma unroll
+      for (int c = 0; c < QC; ++c) kta[c] += 32 * KRB;
     }
     }
     if (qok) {
@@ -426,10 +471,17 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
       __syncthreads();
     }
     const int cend = c0 + CH < Nqp ? c0 + CH : Nqp;
+    uint32_t qa_[KS], oa[VS], ota[VC], qta[QC];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) qa_[kk] = lds_addr(Qs) + frag_off<QRB>(fr, kk, g);
+#pragma unroll
+    for (int kk = 0; kk < VS; ++kk) oa[kk] = lds_addr(dOs) + frag_off<ORB>(fr, kk, g);
+#pragma unroll
+    for (int c = 0; c < VC; ++c) ota[c] = lds_addr(dOs) + frag_tr_off<ORB>(c * 16, lane);
+#pragma unroll
+    for (int c = 0; c < QC; ++c) qta[c] = lds_addr(Qs) + frag_tr_off<QRB>(c * 16, lane);
+    uint32_t la = lds_addr(lse_s) + 16 * g, da = lds_addr(del_s) + 16 * g;     // this lane's four query rows' statistics
     for (int qa = c0; qa < cend; qa += 32) {
-      const int q0 = qa - c0;            // row inside the resident chunk
-      const char* Qst = Qs + q0 * QRB;
-      const char* dOst = dOs + q0 * ORB;
       f32x4 s[2], dp[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -437,26 +489,35 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
         dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk)
-          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag<QRB>(Qst, t * 16 + fr, kk, g), kf[kk], s[t], 0, 0, 0);
+          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(qa_[kk] + t * 16 * QRB), kf[kk], s[t], 0, 0, 0);
 #pragma unroll
         for (int kk = 0; kk < VS; ++kk)
-          dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag<ORB>(dOst, t * 16 + fr, kk, g), vf[kk], dp[t], 0, 0, 0);
+          dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(oa[kk] + t * 16 * ORB), vf[kk], dp[t], 0, 0, 0);
+        const f32x4 lse4 = lds_f4(la + t * 64), del4 = lds_f4(da + t * 64);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int qi = q0 + t * 16 + 4 * g + r;
-          const float pr = __builtin_amdgcn_exp2f(s[t][r] * sl2 - lse_s[qi]);
+          const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], sl2, -lse4[r]));
           s[t][r] = pr;                              // P[q][key]
-          dp[t][r] = pr * (dp[t][r] - del_s[qi]);    // dS[q][key]
+          dp[t][r] = pr * (dp[t][r] - del4[r]);      // dS[q][key]
         }
       }
       const bf16x8 pf = pack8(s[0], s[1]);
       const bf16x8 dsf = pack8(dp[0], dp[1]);
 #pragma unroll
       for (int c = 0; c < VC; ++c)
-        dv[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag_tr<ORB>(dOst, 0, c * 16, lane), pf, dv[c], 0, 0, 0);
+        dv[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_tr<ORB>(ota[c]), pf, dv[c], 0, 0, 0);
 #pragma unroll
       for (int c = 0; c < QC; ++c)
-        dk[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tile_frag_tr<QRB>(Qst, 0, c * 16, lane), dsf, dk[c], 0, 0, 0);
+        dk[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_tr<QRB>(qta[c]), dsf, dk[c], 0, 0, 0);
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) qa_[kk] += 32 * QRB;
+#pragma unroll
+      for (int kk = 0; kk < VS; ++kk) oa[kk] += 32 * ORB;
+#pragma unroll
+      for (int c = 0; c < VC; ++c) ota[c] += 32 * ORB;
+#pragma unroll
+      for (int c = 0; c < QC; ++c) qta[c] += 32 * QRB;
+      la += 128; da += 128;
     }
     }
     if (kok) {
