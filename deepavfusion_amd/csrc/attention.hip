@@ -21,6 +21,8 @@
 #include "common.h"
 #include "dav_kernels.h"
 
+#include <cstdlib>
+static int attn_debug() { static const int v = [] { const char* e = getenv("DAV_ATTN_DEBUG"); return e ? atoi(e) : 0; }(); return v; }
 int dav_attn_qt = 0;      // dav_tune knob 3: 0 = auto, 1 / 2 = query tiles per wave in the forward kernel
 
 namespace {
@@ -40,6 +42,7 @@ struct AttnParams {
   bf16_t *dQ, *dK, *dV;
   long dq_bs, dk_bs, dv_bs;
   int dq_rs, dk_rs, dv_rs;
+  int debug;          // DAV_ATTN_DEBUG ablations (timing experiments only): 1 = no tile loop, 2 = no staging
 };
 
 // 16-byte-slot XOR swizzle of a row-major LDS tile, chosen so that BOTH access patterns are conflict-free:
@@ -64,6 +67,33 @@ __device__ __forceinline__ void stage_tile(char* dst, const bf16_t* src, int nro
     *reinterpret_cast<uint4*>(dst + row * RB + ((ch ^ row_swz<RB>(row)) << 4)) = v;
   }
 }
+
+// The same tile through the LDS-DMA path (global_load_lds_dwordx4: no register round trip, every 1 KB piece of a wave in
+// flight at once — the register version pays one global-load latency per loop trip, ~10 us per workgroup on the decoder
+// sequences, a quarter of the kernel).  A DMA lane's LDS position is fixed (piece base + 16 * lane), so the swizzle moves to
+// the SOURCE side: the lane at linear slot s' of row r fetches global slot s' ^ swz(r).  Lanes of padded rows are masked off
+// the DMA (it honours EXEC) and store zeros instead.  Only for rows as wide as their LDS tile (head widths 32 / 64).
+// The caller waits (s_waitcnt vmcnt(0)) before its barrier.
+template <int COLS>
+__device__ __forceinline__ void stage_tile_dma(char* dst, const bf16_t* src, int nrows, int nrows_p, int rs, int tid, int nthreads) {
+  constexpr int CPR = COLS / 8, RB = COLS * 2;
+  const int lane = tid & 63, wave = tid >> 6, nw = nthreads >> 6;
+  const int npieces = nrows_p * CPR / 64;          // nrows_p is a multiple of 32, CPR of 4
+  for (int pc = wave; pc < npieces; pc += nw) {
+    const int c = pc * 64 + lane, row = c / CPR, slot = (c % CPR) ^ row_swz<RB>(row);
+    if (row < nrows)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(void, src + (long)row * rs + slot * 8), LDS_PTR(void, dst + pc * 1024), 16, 0, 0);
+    else
+      *reinterpret_cast<uint4*>(dst + c * 16) = uint4{0, 0, 0, 0};
+  }
+}
+// picks the DMA path when the rows are as wide as the tile
+template <int COLS, int COLSP>
+__device__ __forceinline__ void stage_rows(char* dst, const bf16_t* src, int nrows, int nrows_p, int rs, int tid, int nthreads) {
+  if constexpr (COLS == COLSP) stage_tile_dma<COLS>(dst, src, nrows, nrows_p, rs, tid, nthreads);
+  else stage_tile<COLS, COLSP>(dst, src, nrows, nrows_p, rs, tid, nthreads);
+}
+__device__ __forceinline__ void stage_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // 16-byte fragment (8 consecutive columns of one row) out of a swizzled row-major tile
 template <int RB>
@@ -159,13 +189,14 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, const int bh,
   const bf16_t* Kg = p.K + b * p.k_bs + h * DQK;
   const bf16_t* Vg = p.V + b * p.v_bs + h * DV;
 
-  if (!CHUNKED) {
-    stage_tile<DQK, DQKP>(Ks, Kg, p.Nk, Nkp, p.k_rs, tid, blockDim.x);
-    stage_tile<DV, DVP>(Vs, Vg, p.Nk, Nkp, p.v_rs, tid, blockDim.x);
+  if (!CHUNKED && p.debug != 2) {
+    stage_rows<DQK, DQKP>(Ks, Kg, p.Nk, Nkp, p.k_rs, tid, blockDim.x);
+    stage_rows<DV, DVP>(Vs, Vg, p.Nk, Nkp, p.v_rs, tid, blockDim.x);
+    stage_wait();
     __syncthreads();
   }
 
-  const int nqt = (p.Nq + 15) >> 4;
+  const int nqt = p.debug == 1 ? 0 : (p.Nq + 15) >> 4;
   const float sl2 = p.scale * 1.44269504088896341f;
   uint32_t ka0[KS], va0[VC];           // this lane's fragment addresses at key row 0
 #pragma unroll
@@ -196,8 +227,9 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, const int bh,
       if (CHUNKED) {
         const int rows = p.Nk - c0 < CH ? p.Nk - c0 : CH, rows_p = Nkp - c0 < CH ? Nkp - c0 : CH;
         __syncthreads();                 // every wave is done with the previous chunk
-        stage_tile<DQK, DQKP>(Ks, Kg + (long)c0 * p.k_rs, rows, rows_p, p.k_rs, tid, blockDim.x);
-        stage_tile<DV, DVP>(Vs, Vg + (long)c0 * p.v_rs, rows, rows_p, p.v_rs, tid, blockDim.x);
+        stage_rows<DQK, DQKP>(Ks, Kg + (long)c0 * p.k_rs, rows, rows_p, p.k_rs, tid, blockDim.x);
+        stage_rows<DV, DVP>(Vs, Vg + (long)c0 * p.v_rs, rows, rows_p, p.v_rs, tid, blockDim.x);
+        stage_wait();
         __syncthreads();
       }
       const int cend = c0 + CH < Nkp ? c0 + CH : Nkp;
@@ -300,7 +332,8 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, const int bh,
 // ------------------------------------------------------------------------------------------------
 // backward, part 1: dQ (waves own query tiles) + delta
 // ------------------------------------------------------------------------------------------------
-template <int DQK, int DV, bool CHUNKED>
+// QT query tiles per wave: each K / V fragment (and each transposed K fragment for dQ) read from LDS feeds QT MFMAs.
+template <int DQK, int DV, bool CHUNKED, int QT = 1>
 __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int bh, const int ychunk) {
   constexpr int DQKP = DQK < 32 ? 32 : DQK, KRB = DQKP * 2, KS = DQKP / 32, DVP = DV < 32 ? 32 : DV, VRB = DVP * 2, VS = DVP / 32, QC = DQK / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -314,48 +347,55 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
   const bf16_t* Kg = p.K + b * p.k_bs + h * DQK;
   const bf16_t* Vg = p.V + b * p.v_bs + h * DV;
 
-  if (!CHUNKED) {
-    stage_tile<DQK, DQKP>(Ks, Kg, p.Nk, Nkp, p.k_rs, tid, blockDim.x);
-    stage_tile<DV, DVP>(Vs, Vg, p.Nk, Nkp, p.v_rs, tid, blockDim.x);
+  if (!CHUNKED && p.debug != 2) {
+    stage_rows<DQK, DQKP>(Ks, Kg, p.Nk, Nkp, p.k_rs, tid, blockDim.x);
+    stage_rows<DV, DVP>(Vs, Vg, p.Nk, Nkp, p.v_rs, tid, blockDim.x);
+    stage_wait();
     __syncthreads();
   }
 
-  const int nqt = (p.Nq + 15) >> 4;
-  for (int qt = CHUNKED ? ychunk * nw + wave : wave; CHUNKED ? qt >= 0 : qt < nqt; qt = CHUNKED ? -1 : qt + nw) {
-    const int q = qt * 16 + fr;
-    const bool qok = q < p.Nq;
-    const int qc = qok ? q : p.Nq - 1;
-    const bf16_t* qrow = p.Q + b * p.q_bs + (long)qc * p.q_rs + h * DQK;
-    const bf16_t* dorow = p.dO + b * p.do_bs + (long)qc * p.do_rs + h * DV;
-    const bf16_t* orow = p.Of + b * p.o_bs + (long)qc * p.o_rs + h * DV;
-    bf16x8 qf[KS], dof[VS];
+  const int nqt = p.debug == 1 ? 0 : (p.Nq + 15) >> 4;
+  const float sl2 = p.scale * 1.44269504088896341f;
+  for (int qt = (CHUNKED ? ychunk * nw + wave : wave) * QT; CHUNKED ? qt >= 0 : qt < nqt; qt = CHUNKED ? -1 : qt + nw * QT) {
+    bool qok[QT];
+    bf16x8 qf[QT][KS], dof[QT][VS];
+    float delta[QT], lse2[QT];
+    f32x4 dq[QT][QC];
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) qf[kk] = gfrag(qrow, kk * 32 + 8 * g, kk * 32 + 8 * g < DQK);
-    float delta = 0.f;
+    for (int u = 0; u < QT; ++u) {
+      const int q = (qt + u) * 16 + fr;
+      qok[u] = q < p.Nq;
+      const int qc = qok[u] ? q : p.Nq - 1;
+      const bf16_t* qrow = p.Q + b * p.q_bs + (long)qc * p.q_rs + h * DQK;
+      const bf16_t* dorow = p.dO + b * p.do_bs + (long)qc * p.do_rs + h * DV;
+      const bf16_t* orow = p.Of + b * p.o_bs + (long)qc * p.o_rs + h * DV;
 #pragma unroll
-    for (int kk = 0; kk < VS; ++kk) {
-      dof[kk] = gfrag(dorow, kk * 32 + 8 * g, kk * 32 + 8 * g < DV);
-      const bf16x8 of = gfrag(orow, kk * 32 + 8 * g, kk * 32 + 8 * g < DV);
+      for (int kk = 0; kk < KS; ++kk) qf[u][kk] = gfrag(qrow, kk * 32 + 8 * g, kk * 32 + 8 * g < DQK);
+      float d = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) delta += (float)dof[kk][e] * (float)of[e];
+      for (int kk = 0; kk < VS; ++kk) {
+        dof[u][kk] = gfrag(dorow, kk * 32 + 8 * g, kk * 32 + 8 * g < DV);
+        const bf16x8 of = gfrag(orow, kk * 32 + 8 * g, kk * 32 + 8 * g < DV);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d += (float)dof[u][kk][e] * (float)of[e];
+      }
+      d += __shfl_xor(d, 16, 64);
+      d += __shfl_xor(d, 32, 64);
+      delta[u] = d;
+      const long sidx = ((long)b * p.H + h) * p.Nq + qc;
+      lse2[u] = p.LSE[sidx] * 1.44269504088896341f;      // log2 domain
+      if (qok[u] && g == 0) p.Delta[sidx] = d;
+#pragma unroll
+      for (int c = 0; c < QC; ++c) dq[u][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    delta += __shfl_xor(delta, 16, 64);
-    delta += __shfl_xor(delta, 32, 64);
-    const long sidx = ((long)b * p.H + h) * p.Nq + qc;
-    const float lse2 = p.LSE[sidx] * 1.44269504088896341f;      // log2 domain
-    const float sl2 = p.scale * 1.44269504088896341f;
-    if (qok && g == 0) p.Delta[sidx] = delta;
-
-    f32x4 dq[QC];
-#pragma unroll
-    for (int c = 0; c < QC; ++c) dq[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int c0 = 0; c0 < Nkp; c0 += CH) {
     if (CHUNKED) {
       const int rows = p.Nk - c0 < CH ? p.Nk - c0 : CH, rows_p = Nkp - c0 < CH ? Nkp - c0 : CH;
       __syncthreads();
-      stage_tile<DQK, DQKP>(Ks, Kg + (long)c0 * p.k_rs, rows, rows_p, p.k_rs, tid, blockDim.x);
-      stage_tile<DV, DVP>(Vs, Vg + (long)c0 * p.v_rs, rows, rows_p, p.v_rs, tid, blockDim.x);
+      stage_rows<DQK, DQKP>(Ks, Kg + (long)c0 * p.k_rs, rows, rows_p, p.k_rs, tid, blockDim.x);
+      stage_rows<DV, DVP>(Vs, Vg + (long)c0 * p.v_rs, rows, rows_p, p.v_rs, tid, blockDim.x);
+      stage_wait();
       __syncthreads();
     }
     const int cend = c0 + CH < Nkp ? c0 + CH : Nkp;
@@ -368,27 +408,42 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
     for (int c = 0; c < QC; ++c) kta[c] = lds_addr(Ks) + frag_tr_off<KRB>(c * 16, lane);
     // no key mask: the padded key rows of the K tile are zero, so whatever dS they get multiplies zeros in dQ = dS.K
     for (int k0 = c0; k0 < cend; k0 += 32) {
-      f32x4 st[2], dp[2];
+      f32x4 st[QT][2], dp[QT][2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 kf[KS], vf[VS];
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk)
-          st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(ka[kk] + t * 16 * KRB), qf[kk], st[t], 0, 0, 0);
+        for (int kk = 0; kk < KS; ++kk) kf[kk] = lds_frag(ka[kk] + t * 16 * KRB);
 #pragma unroll
-        for (int kk = 0; kk < VS; ++kk)
-          dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(va[kk] + t * 16 * VRB), dof[kk], dp[t], 0, 0, 0);
+        for (int kk = 0; kk < VS; ++kk) vf[kk] = lds_frag(va[kk] + t * 16 * VRB);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(st[t][r], sl2, -lse2));
-          st[t][r] = pr * (dp[t][r] - delta);     // dS^T
+        for (int u = 0; u < QT; ++u) {
+          st[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+          dp[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kk = 0; kk < KS; ++kk)
+            st[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kk], qf[u][kk], st[u][t], 0, 0, 0);
+#pragma unroll
+          for (int kk = 0; kk < VS; ++kk)
+            dp[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kk], dof[u][kk], dp[u][t], 0, 0, 0);
         }
-      }
-      const bf16x8 dsf = pack8(st[0], st[1]);
 #pragma unroll
-      for (int c = 0; c < QC; ++c)
-        dq[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_tr<KRB>(kta[c]), dsf, dq[c], 0, 0, 0);
+        for (int u = 0; u < QT; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(st[u][t][r], sl2, -lse2[u]));
+            st[u][t][r] = pr * (dp[u][t][r] - delta[u]);     // dS^T
+          }
+      }
+      bf16x8 dsf[QT];
+#pragma unroll
+      for (int u = 0; u < QT; ++u) dsf[u] = pack8(st[u][0], st[u][1]);
+#pragma unroll
+      for (int c = 0; c < QC; ++c) {
+        const bf16x8 kt = lds_frag_tr<KRB>(kta[c]);
+#pragma unroll
+        for (int u = 0; u < QT; ++u) dq[u][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsf[u], dq[u][c], 0, 0, 0);
+      }
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) ka[kk] += 32 * KRB;
 #pragma unroll
@@ -397,14 +452,17 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
       for (int c = 0; c < QC; ++c) kta[c] += 32 * KRB;
     }
     }
-    if (qok) {
-      bf16_t* dqrow = p.dQ + b * p.dq_bs + (long)q * p.dq_rs + h * DQK;
 #pragma unroll
-      for (int c = 0; c < QC; ++c) {
-        uint2 w;
-        w.x = pack2bf(dq[c][0] * p.scale, dq[c][1] * p.scale);
-        w.y = pack2bf(dq[c][2] * p.scale, dq[c][3] * p.scale);
-        *reinterpret_cast<uint2*>(dqrow + c * 16 + 4 * g) = w;
+    for (int u = 0; u < QT; ++u) {
+      if (qok[u]) {
+        bf16_t* dqrow = p.dQ + b * p.dq_bs + (long)((qt + u) * 16 + fr) * p.dq_rs + h * DQK;
+#pragma unroll
+        for (int c = 0; c < QC; ++c) {
+          uint2 w;
+          w.x = pack2bf(dq[u][c][0] * p.scale, dq[u][c][1] * p.scale);
+          w.y = pack2bf(dq[u][c][2] * p.scale, dq[u][c][3] * p.scale);
+          *reinterpret_cast<uint2*>(dqrow + c * 16 + 4 * g) = w;
+        }
       }
     }
   }
@@ -413,7 +471,10 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
 // ------------------------------------------------------------------------------------------------
 // backward, part 2: dK, dV (waves own key tiles)
 // ------------------------------------------------------------------------------------------------
-template <int DQK, int DV, bool CHUNKED>
+// KT key tiles per wave: every Q / dO fragment read from LDS (the row-major one for S and dP, the transposed one for dV and
+// dK) then feeds KT MFMAs.  With one tile per wave the kernel is bound by the LDS pipe — 16 fragment reads per 8 MFMAs at
+// d = 32, 128 of the CU's LDS cycles per wave-step against 70 VALU and 32 MFMA cycles per SIMD.
+template <int DQK, int DV, bool CHUNKED, int KT = 1>
 __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int bh, const int ychunk) {
   constexpr int DQKP = DQK < 32 ? 32 : DQK, QRB = DQKP * 2, KS = DQKP / 32, DVP = DV < 32 ? 32 : DV, ORB = DVP * 2, VS = DVP / 32, QC = DQK / 16, VC = DV / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -431,38 +492,42 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
 
   auto stage_q = [&](int c0) {
     const int rows = p.Nq - c0 < CH ? p.Nq - c0 : CH, rows_p = Nqp - c0 < CH ? Nqp - c0 : CH;
-    stage_tile<DQK, DQKP>(Qs, Qg + (long)c0 * p.q_rs, rows, rows_p, p.q_rs, tid, blockDim.x);
-    stage_tile<DV, DVP>(dOs, dOg + (long)c0 * p.do_rs, rows, rows_p, p.do_rs, tid, blockDim.x);
+    stage_rows<DQK, DQKP>(Qs, Qg + (long)c0 * p.q_rs, rows, rows_p, p.q_rs, tid, blockDim.x);
+    stage_rows<DV, DVP>(dOs, dOg + (long)c0 * p.do_rs, rows, rows_p, p.do_rs, tid, blockDim.x);
     for (int i = tid; i < rows_p; i += blockDim.x) {
       const long sidx = ((long)b * p.H + h) * p.Nq + c0 + i;
       lse_s[i] = i < rows ? p.LSE[sidx] * 1.44269504088896341f : 1e30f;      // log2 domain; 2^(s - 1e30) == 0 for padded query rows
       del_s[i] = i < rows ? p.Delta[sidx] : 0.f;
     }
+    stage_wait();
   };
-  if (!CHUNKED) {
+  if (!CHUNKED && p.debug != 2) {
     stage_q(0);
     __syncthreads();
   }
 
   const float sl2 = p.scale * 1.44269504088896341f;
-  const int nkt = (p.Nk + 15) >> 4;
-  for (int kt = CHUNKED ? ychunk * nw + wave : wave; CHUNKED ? kt >= 0 : kt < nkt; kt = CHUNKED ? -1 : kt + nw) {
-    const int key = kt * 16 + fr;
-    const bool kok = key < p.Nk;
-    const int kc = kok ? key : p.Nk - 1;
-    const bf16_t* krow = p.K + b * p.k_bs + (long)kc * p.k_rs + h * DQK;
-    const bf16_t* vrow = p.V + b * p.v_bs + (long)kc * p.v_rs + h * DV;
-    bf16x8 kf[KS], vf[VS];
+  const int nkt = p.debug == 1 ? 0 : (p.Nk + 15) >> 4;
+  for (int kt = (CHUNKED ? ychunk * nw + wave : wave) * KT; CHUNKED ? kt >= 0 : kt < nkt; kt = CHUNKED ? -1 : kt + nw * KT) {
+    bool kok[KT];
+    bf16x8 kf[KT][KS], vf[KT][VS];
+    f32x4 dk[KT][QC], dv[KT][VC];
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) kf[kk] = gfrag(krow, kk * 32 + 8 * g, kk * 32 + 8 * g < DQK);
+    for (int u = 0; u < KT; ++u) {
+      const int key = (kt + u) * 16 + fr;
+      kok[u] = key < p.Nk;
+      const int kc = kok[u] ? key : p.Nk - 1;       // a tile past the end works on a clamped row and stores nothing
+      const bf16_t* krow = p.K + b * p.k_bs + (long)kc * p.k_rs + h * DQK;
+      const bf16_t* vrow = p.V + b * p.v_bs + (long)kc * p.v_rs + h * DV;
 #pragma unroll
-    for (int kk = 0; kk < VS; ++kk) vf[kk] = gfrag(vrow, kk * 32 + 8 * g, kk * 32 + 8 * g < DV);
-
-    f32x4 dk[QC], dv[VC];
+      for (int kk = 0; kk < KS; ++kk) kf[u][kk] = gfrag(krow, kk * 32 + 8 * g, kk * 32 + 8 * g < DQK);
 #pragma unroll
-    for (int c = 0; c < QC; ++c) dk[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int kk = 0; kk < VS; ++kk) vf[u][kk] = gfrag(vrow, kk * 32 + 8 * g, kk * 32 + 8 * g < DV);
 #pragma unroll
-    for (int c = 0; c < VC; ++c) dv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < QC; ++c) dk[u][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < VC; ++c) dv[u][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     for (int c0 = 0; c0 < Nqp; c0 += CH) {
     if (CHUNKED) {
@@ -482,33 +547,53 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
     for (int c = 0; c < QC; ++c) qta[c] = lds_addr(Qs) + frag_tr_off<QRB>(c * 16, lane);
     uint32_t la = lds_addr(lse_s) + 16 * g, da = lds_addr(del_s) + 16 * g;     // this lane's four query rows' statistics
     for (int qa = c0; qa < cend; qa += 32) {
-      f32x4 s[2], dp[2];
+      f32x4 s[KT][2], dp[KT][2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 qf[KS], dof[VS];
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk)
-          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(qa_[kk] + t * 16 * QRB), kf[kk], s[t], 0, 0, 0);
+        for (int kk = 0; kk < KS; ++kk) qf[kk] = lds_frag(qa_[kk] + t * 16 * QRB);
 #pragma unroll
-        for (int kk = 0; kk < VS; ++kk)
-          dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(oa[kk] + t * 16 * ORB), vf[kk], dp[t], 0, 0, 0);
+        for (int kk = 0; kk < VS; ++kk) dof[kk] = lds_frag(oa[kk] + t * 16 * ORB);
         const f32x4 lse4 = lds_f4(la + t * 64), del4 = lds_f4(da + t * 64);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], sl2, -lse4[r]));
-          s[t][r] = pr;                              // P[q][key]
-          dp[t][r] = pr * (dp[t][r] - del4[r]);      // dS[q][key]
+        for (int u = 0; u < KT; ++u) {
+          s[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+          dp[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kk = 0; kk < KS; ++kk)
+            s[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[kk], kf[u][kk], s[u][t], 0, 0, 0);
+#pragma unroll
+          for (int kk = 0; kk < VS; ++kk)
+            dp[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof[kk], vf[u][kk], dp[u][t], 0, 0, 0);
         }
+#pragma unroll
+        for (int u = 0; u < KT; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][t][r], sl2, -lse4[r]));
+            s[u][t][r] = pr;                                 // P[q][key]
+            dp[u][t][r] = pr * (dp[u][t][r] - del4[r]);      // dS[q][key]
+          }
       }
-      const bf16x8 pf = pack8(s[0], s[1]);
-      const bf16x8 dsf = pack8(dp[0], dp[1]);
+      bf16x8 pf[KT], dsf[KT];
 #pragma unroll
-      for (int c = 0; c < VC; ++c)
-        dv[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_tr<ORB>(ota[c]), pf, dv[c], 0, 0, 0);
+      for (int u = 0; u < KT; ++u) {
+        pf[u] = pack8(s[u][0], s[u][1]);
+        dsf[u] = pack8(dp[u][0], dp[u][1]);
+      }
 #pragma unroll
-      for (int c = 0; c < QC; ++c)
-        dk[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag_tr<QRB>(qta[c]), dsf, dk[c], 0, 0, 0);
+      for (int c = 0; c < VC; ++c) {
+        const bf16x8 dot = lds_frag_tr<ORB>(ota[c]);
+#pragma unroll
+        for (int u = 0; u < KT; ++u) dv[u][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pf[u], dv[u][c], 0, 0, 0);
+      }
+#pragma unroll
+      for (int c = 0; c < QC; ++c) {
+        const bf16x8 qt = lds_frag_tr<QRB>(qta[c]);
+#pragma unroll
+        for (int u = 0; u < KT; ++u) dk[u][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsf[u], dk[u][c], 0, 0, 0);
+      }
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) qa_[kk] += 32 * QRB;
 #pragma unroll
@@ -520,22 +605,26 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
       la += 128; da += 128;
     }
     }
-    if (kok) {
-      bf16_t* dkrow = p.dK + b * p.dk_bs + (long)key * p.dk_rs + h * DQK;
-      bf16_t* dvrow = p.dV + b * p.dv_bs + (long)key * p.dv_rs + h * DV;
 #pragma unroll
-      for (int c = 0; c < QC; ++c) {
-        uint2 w;
-        w.x = pack2bf(dk[c][0] * p.scale, dk[c][1] * p.scale);
-        w.y = pack2bf(dk[c][2] * p.scale, dk[c][3] * p.scale);
-        *reinterpret_cast<uint2*>(dkrow + c * 16 + 4 * g) = w;
-      }
+    for (int u = 0; u < KT; ++u) {
+      const int key = (kt + u) * 16 + fr;
+      if (kok[u]) {
+        bf16_t* dkrow = p.dK + b * p.dk_bs + (long)key * p.dk_rs + h * DQK;
+        bf16_t* dvrow = p.dV + b * p.dv_bs + (long)key * p.dv_rs + h * DV;
 #pragma unroll
-      for (int c = 0; c < VC; ++c) {
-        uint2 w;
-        w.x = pack2bf(dv[c][0], dv[c][1]);
-        w.y = pack2bf(dv[c][2], dv[c][3]);
-        *reinterpret_cast<uint2*>(dvrow + c * 16 + 4 * g) = w;
+        for (int c = 0; c < QC; ++c) {
+          uint2 w;
+          w.x = pack2bf(dk[u][c][0] * p.scale, dk[u][c][1] * p.scale);
+          w.y = pack2bf(dk[u][c][2] * p.scale, dk[u][c][3] * p.scale);
+          *reinterpret_cast<uint2*>(dkrow + c * 16 + 4 * g) = w;
+        }
+#pragma unroll
+        for (int c = 0; c < VC; ++c) {
+          uint2 w;
+          w.x = pack2bf(dv[u][c][0], dv[u][c][1]);
+          w.y = pack2bf(dv[u][c][2], dv[u][c][3]);
+          *reinterpret_cast<uint2*>(dvrow + c * 16 + 4 * g) = w;
+        }
       }
     }
   }
@@ -546,13 +635,18 @@ template <int DQK, int DV, bool CHUNKED, int QT>
 __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
   attn_fwd_body<DQK, DV, CHUNKED, QT>(p, blockIdx.x, blockIdx.y);
 }
+// own tiles per wave in the RESIDENT backward kernels.  Two tiles per wave halve the LDS fragment traffic per MFMA; measured
+// on the decoders' d = 32, 228 / 352-row problems it changes nothing (73.5 / 131 us vs 73.3 / 126 us): those kernels are bound
+// by the softmax recomputation on the VALU (8 v_exp_f32 + 30 plain slots per 32 x 16 scores in EACH of the two kernels), not by
+// the LDS pipe, and 11 tile pairs balance worse over the waves than 22 tiles.  Kept at one; the bodies take the tile count.
+template <int DQK, int DV> constexpr int bwd_tiles() { return 1; }
 template <int DQK, int DV, bool CHUNKED>
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
-  attn_bwd_dq_body<DQK, DV, CHUNKED>(p, blockIdx.x, blockIdx.y);
+  attn_bwd_dq_body<DQK, DV, CHUNKED, CHUNKED ? 1 : bwd_tiles<DQK, DV>()>(p, blockIdx.x, blockIdx.y);
 }
 template <int DQK, int DV, bool CHUNKED>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
-  attn_bwd_dkv_body<DQK, DV, CHUNKED>(p, blockIdx.x, blockIdx.y);
+  attn_bwd_dkv_body<DQK, DV, CHUNKED, CHUNKED ? 1 : bwd_tiles<DQK, DV>()>(p, blockIdx.x, blockIdx.y);
 }
 
 constexpr int ATTN_GROUP_MAX = 8;
@@ -569,8 +663,8 @@ __global__ __launch_bounds__(512) void attn_grouped_kernel(const AttnGroup g) {
   while (pi + 1 < g.count && (int)blockIdx.x >= g.first_block[pi + 1]) ++pi;
   const int bh = (int)blockIdx.x - g.first_block[pi];
   if (WHICH == 0) attn_fwd_body<DQK, DV, false, 1>(g.prob[pi], bh, 0);
-  else if (WHICH == 1) attn_bwd_dq_body<DQK, DV, false>(g.prob[pi], bh, 0);
-  else attn_bwd_dkv_body<DQK, DV, false>(g.prob[pi], bh, 0);
+  else if (WHICH == 1) attn_bwd_dq_body<DQK, DV, false, bwd_tiles<DQK, DV>()>(g.prob[pi], bh, 0);
+  else attn_bwd_dkv_body<DQK, DV, false, bwd_tiles<DQK, DV>()>(g.prob[pi], bh, 0);
 }
 
 template <int DQK> constexpr int padqk() { return DQK < 32 ? 32 : DQK; }      // LDS columns of a q/k (or v/dO) row
@@ -589,6 +683,13 @@ int raise_lds_cap(size_t lds) {
 }
 
 inline int waves_for(int rows) { int nw = (rows + 15) / 16; return nw > 8 ? 8 : (nw < 1 ? 1 : nw); }
+// waves of a resident workgroup whose waves own `per` 16-row tiles at a time: the fewest rounds 8 waves allow, then the
+// fewest waves that still finish in that many rounds (11 tile pairs -> 2 rounds -> 6 waves, not 8 of which 5 idle in round 2)
+inline int waves_for_tiles(int rows, int per) {
+  const int units = ((rows + 15) / 16 + per - 1) / per, rounds = (units + 7) / 8;
+  const int nw = (units + rounds - 1) / rounds;
+  return nw < 1 ? 1 : nw;
+}
 
 // geometry of the resident (all keys / all queries of a head in LDS) variants
 template <int DQK, int DV> constexpr size_t attn_row_bytes() { return (size_t)padqk<DQK>() * 2 + (size_t)padqk<DV>() * 2; }
@@ -596,7 +697,9 @@ template <int DQK, int DV, int WHICH> size_t attn_lds(const AttnParams& p) {
   const int Nkp = (p.Nk + 31) & ~31, Nqp = (p.Nq + 31) & ~31;
   return WHICH == 2 ? Nqp * (attn_row_bytes<DQK, DV>() + 8) : Nkp * attn_row_bytes<DQK, DV>();
 }
-template <int WHICH> int attn_waves(const AttnParams& p) { return waves_for(WHICH == 2 ? p.Nk : p.Nq); }
+template <int DQK, int DV, int WHICH> int attn_waves(const AttnParams& p) {
+  return WHICH == 0 ? waves_for(p.Nq) : waves_for_tiles(WHICH == 2 ? p.Nk : p.Nq, bwd_tiles<DQK, DV>());
+}
 
 // issues n >= 1 recorded resident-variant problems of one (head widths, pass) family: davb::GroupFn
 template <int DQK, int DV, int WHICH>
@@ -610,7 +713,7 @@ void attn_issue(const void* const* params_in, int n, hipStream_t stream) {
   const void* const* params = sorted.data();
   auto single = [&](const AttnParams& p) {
     const size_t lds = attn_lds<DQK, DV, WHICH>(p);
-    const int nw = attn_waves<WHICH>(p);
+    const int nw = attn_waves<DQK, DV, WHICH>(p);
     if (WHICH == 0) {
       (void)raise_lds_cap<attn_fwd_kernel<DQK, DV, false, 1>>(lds);
       DAV_LAUNCH_NOW((attn_fwd_kernel<DQK, DV, false, 1>), dim3(p.B * p.H), dim3(nw * 64), lds, stream, p);
@@ -635,7 +738,7 @@ void attn_issue(const void* const* params_in, int n, hipStream_t stream) {
       g.prob[i] = *(const AttnParams*)params[base + i];
       const size_t l = attn_lds<DQK, DV, WHICH>(g.prob[i]);
       lds = l > lds ? l : lds;
-      const int w = attn_waves<WHICH>(g.prob[i]);
+      const int w = attn_waves<DQK, DV, WHICH>(g.prob[i]);
       nw = w > nw ? w : nw;
       g.first_block[i] = first;
       first += g.prob[i].B * g.prob[i].H;
@@ -724,6 +827,7 @@ extern "C" int dav_attn_fwd(const void* Q, const void* K, const void* V, void* O
                             long o_bs, int o_rs, float scale, hipStream_t stream) {
   if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return DAV_ERR_SHAPE;
   AttnParams p = {};
+  p.debug = attn_debug();
   p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (bf16_t*)O; p.LSE = LSE;
   p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.q_bs = q_bs; p.k_bs = k_bs; p.v_bs = v_bs; p.o_bs = o_bs;
   p.q_rs = q_rs; p.k_rs = k_rs; p.v_rs = v_rs; p.o_rs = o_rs; p.scale = scale;
@@ -751,6 +855,7 @@ extern "C" int dav_attn_bwd_part(const void* Q, const void* K, const void* V, co
                                  float scale, int part, hipStream_t stream) {
   if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0 || part < 1 || part > 3) return DAV_ERR_SHAPE;
   AttnParams p = {};
+  p.debug = attn_debug();
   p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.Of = (const bf16_t*)O; p.O = nullptr;
   p.dO = (const bf16_t*)dO; p.LSE = const_cast<float*>(LSE); p.Delta = Delta;
   p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV;
