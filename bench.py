@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+BIG_TILE_CFGS = (3, 44, 45)        # tile configurations of the dominant GEMM kernel (csrc/gemm.hip nt2_issue_auto)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -146,6 +147,9 @@ def main():
         nt_log = ops.nt_issue_log()
         ops.nt_issue_log(False)
         ops.gemm_tn_grouped, ops.attn_fwd, ops.attn_bwd = orig_tn, orig_af, orig_ab
+        if os.environ.get('DAV_DUMP_MIX'):            # the step's NT launches: [tile configuration, b_kn, [(M, N, K) ...]]
+            with open(os.environ['DAV_DUMP_MIX'], 'w') as f:
+                json.dump({'nt': nt_log, 'tn': tn_log, 'attn': attn_log}, f)
     if a.no_graph or a.roofline_only:
         step = eager_step
     else:
@@ -235,38 +239,41 @@ def main():
         return e0.elapsed_time(e1) / reps
 
     reps = 20 if a.roofline_only else 5
-    # ---- roofline of the dominant kernel: gemm_nt2_grouped_kernel<128,128,2,4,2,*> — the grouped launches (image tower +
-    # audio tower + fusion block problems of one step of a layer, the two decoders) exactly as the library issued them
-    # in the recorded step (tile configuration 3, forward NT and b_kn input-gradient forms) -------------------------------
-    big = [(bt, probs) for (cfg_id, bt, probs) in nt_log if cfg_id == 3]
+    # ---- roofline of the dominant kernel: gemm_nt2_grouped_kernel, 8 waves, big tiles — the grouped launches (image tower +
+    # audio tower + fusion block problems of one step of a layer, the two decoders) exactly as the library issued them in the
+    # recorded step, each with the tile configuration it ran with there (3 = 128x128 / 64-deep 2-stage ring, 44 = 128x256 and
+    # 45 = 256x128 on 32-deep rings; forward NT and b_kn input-gradient forms).  ALL of them: leaving the slower K = 512
+    # launches out because they moved to another tile shape would flatter the figure ------------------------------------
+    big = [(cfg_id, bt, probs) for (cfg_id, bt, probs) in nt_log if cfg_id in BIG_TILE_CFGS]
     if big and not a.no_roofline:
         bufs = {}
-        for bt, probs in big:
+        for _c, bt, probs in big:
             for (M, N, K) in probs:
                 if (M, N, K, bt) not in bufs:
                     Bm = (torch.randn(K, N, device=dev) * 0.05).bfloat16() if bt else (torch.randn(N, K, device=dev) * 0.05).bfloat16()
                     bufs[(M, N, K, bt)] = (torch.randn(M, K, device=dev).bfloat16(), Bm, torch.empty(M, N, device=dev, dtype=torch.bfloat16))
 
         def replay_nt():
-            for bt, probs in big:
-                with E.batch(auto_lanes=True):           # ONE grouped launch, as in the step
+            for c, bt, probs in big:
+                with E.batch(auto_lanes=True):           # ONE grouped launch with the step's tile configuration
                     for (M, N, K) in probs:
                         A, Bm, C = bufs[(M, N, K, bt)]
-                        ops.gemm_nt(A, Bm, M, N, K, ldb=N if bt else K, C_out=C, c_bf16=True, variant=(3 << 4) | (bt << 12))
+                        ops.gemm_nt(A, Bm, M, N, K, ldb=N if bt else K, C_out=C, c_bf16=True, variant=(c << 4) | (bt << 12))
         total_ms = time_replay(replay_nt, reps)
-        fl = sum(2.0 * M * N * K for _, probs in big for (M, N, K) in probs)
+        fl = sum(2.0 * M * N * K for _c, _b, probs in big for (M, N, K) in probs)
         ach = fl / (total_ms * 1e-3) / 1e12
         traffic = None          # HBM bytes per launch: offline rocprofv3 PMC passes over THIS replay (profiles/), only for the profiled workload
         tf = os.path.join(ROOT, 'profiles', 'dominant_kernel_traffic.json')
         if os.path.exists(tf):
             rec = json.load(open(tf)).get(f'{a.config}_b{B}', {})
             traffic = rec.get('hbm_bytes_per_launch')
-        result['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_nt2_grouped_kernel<128,128,2,4,2> (forward + b_kn dgrad, grouped launches)',
+        result['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_nt2_grouped_kernel, 8-wave big-tile configurations (128x128 / 128x256 / 256x128) as the step issues them: forward + b_kn dgrad, grouped launches',
+                              'launches_by_config': {str(c): sum(1 for cc, _b, _p in big if cc == c) for c in sorted({cc for cc, _b, _p in big})},
                               'achieved': round(ach, 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                               'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': traffic,
                               'traffic_note': 'offline rocprofv3 --pmc FETCH_SIZE (x2, gfx950 note) + WRITE_SIZE over this replay; null unless profiled for this workload',
-                              'algorithmic_bytes_per_launch': int(sum(2.0 * (M * K + N * K + M * N) for _, probs in big for (M, N, K) in probs) / len(big)),
-                              'launches_per_step': len(big), 'problems_per_step': sum(len(pr) for _, pr in big),
+                              'algorithmic_bytes_per_launch': int(sum(2.0 * (M * K + N * K + M * N) for _c, _b, probs in big for (M, N, K) in probs) / len(big)),
+                              'launches_per_step': len(big), 'problems_per_step': sum(len(pr) for _c, _b, pr in big),
                               'avg_launch_us': round(total_ms * 1e3 / len(big), 2),
                               'avg_gflop_per_launch': round(fl / len(big) / 1e9, 3)}
         del bufs

@@ -42,6 +42,7 @@ struct NTParams {
   int beta;                      // C (fp32) += result
   float alpha;
   int debug;                     // timing experiments only (DAV_NT_DEBUG): 1 = epilogue without global stores, 2 = no epilogue
+  int force_cfg;                 // host side only: tile configuration asked for explicitly (0 = chosen per group at issue time)
 };
 
 struct TNParams {
@@ -413,18 +414,23 @@ __device__ __forceinline__ void nt_epilogue_t(const NTParams& p, f32x4 (&acc)[FM
 // the bf16 twin C2) are staged side by side.  Eligible: bf16 C, no residual, N % 8 == 0, ldc % 8 == 0 (nt_staged_ok).
 template <int BM, int BN>
 constexpr int nt_stage_bytes() { return BM * (BN * 2 + 16); }
+// C and its bf16 twin side by side, or (tiles above 128 x 128) one image at a time inside the ring's footprint
+template <int BM, int BN> constexpr bool nt_epi_split() { return BM * BN > 128 * 128; }
 
 __device__ __forceinline__ bool nt_staged_ok(const NTParams& p) {
   return p.C && p.c_bf16 && !p.res && !p.beta && !(p.N & 7) && !(p.ldc & 7) && (p.c2_mode == 0 || (p.c2_mode != 3 && !(p.ldc2 & 7))) &&
          !(p.debug & 3);
 }
 
-template <int BM, int BN, int NTHREADS, int FM, int FN, int WTM, int WTN>
+// SPLIT: the ring only holds ONE tile image (256-row tiles at two workgroups per CU) -> C and the twin go through it one
+// after the other, the twin's packed values waiting in registers.
+template <int BM, int BN, int NTHREADS, int FM, int FN, int WTM, int WTN, bool SPLIT = false>
 __device__ __forceinline__ void nt_epilogue_s(const NTParams& p, f32x4 (&acc)[FM][FN], char* lds, int m0, int n0, int wm, int wn,
                                               int lane, int tid) {
   constexpr int RB = BN * 2 + 16;                         // padded tile row (16: keeps the b128 row reads aligned)
   const int fr = lane & 15, fg = lane >> 4;
-  char* img2 = lds + BM * RB;
+  char* img2 = SPLIT ? lds : lds + BM * RB;
+  uint2 w2r[SPLIT ? FM : 1][SPLIT ? FN : 1];
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
     const int ml = wm * WTM + i * 16 + fr;
@@ -457,7 +463,8 @@ __device__ __forceinline__ void nt_epilogue_s(const NTParams& p, f32x4 (&acc)[FM
       if (p.c2_mode == 2) { w2.x = pack2bf(v.x, v.y); w2.y = pack2bf(v.z, v.w); }
       uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
       *reinterpret_cast<uint2*>(lds + ml * RB + nl * 2) = w;
-      if (p.c2_mode) *reinterpret_cast<uint2*>(img2 + ml * RB + nl * 2) = w2;
+      if (SPLIT) w2r[SPLIT ? i : 0][SPLIT ? j : 0] = w2;
+      else if (p.c2_mode) *reinterpret_cast<uint2*>(img2 + ml * RB + nl * 2) = w2;
     }
   }
   __syncthreads();
@@ -473,9 +480,27 @@ __device__ __forceinline__ void nt_epilogue_s(const NTParams& p, f32x4 (&acc)[FM
       if (m >= p.M) continue;
       const uint4 w = *reinterpret_cast<const uint4*>(lds + ml * RB + ch * 16);
       *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + map_row(m, p.cmap) * p.ldc + n) = w;
-      if (p.c2_mode) {
+      if (!SPLIT && p.c2_mode) {
         const uint4 w2 = *reinterpret_cast<const uint4*>(img2 + ml * RB + ch * 16);
         *reinterpret_cast<uint4*>(p.C2 + (long)m * p.ldc2 + n) = w2;
+      }
+    }
+  }
+  if (SPLIT && p.c2_mode) {
+    __syncthreads();                                      // the C image has been read
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        *reinterpret_cast<uint2*>(lds + (wm * WTM + i * 16 + fr) * RB + (wn * WTN + j * 16 + fg * 4) * 2) = w2r[SPLIT ? i : 0][SPLIT ? j : 0];
+    __syncthreads();
+    if (n < p.N) {
+#pragma unroll
+      for (int it = 0; it < BM / RPI; ++it) {
+        const int ml = it * RPI + r0;
+        const int m = m0 + ml;
+        if (m >= p.M) continue;
+        *reinterpret_cast<uint4*>(p.C2 + (long)m * p.ldc2 + n) = *reinterpret_cast<const uint4*>(lds + ml * RB + ch * 16);
       }
     }
   }
@@ -496,7 +521,6 @@ __device__ __forceinline__ void nt2_body(const NTParams& p, int bid) {
   constexpr int A_BYTES = BM * ARB, STAGE_BYTES = (BM + BN) * ARB;
   static_assert(BM * ACPR % NT == 0 && BN * ACPR % NT == 0, "tile/threads mismatch");
   static_assert(BK == 64 || BK == 32, "BK");
-  static_assert(!BT || BK == 64, "b_kn mode is built for BK = 64");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -730,7 +754,7 @@ __device__ __forceinline__ void nt2_body(const NTParams& p, int bid) {
     }
     return;
   }
-  if (nt_staged_ok(p)) nt_epilogue_s<BM, BN, NT, FM, FN, WTM, WTN>(p, acc, smem, m0, n0, wm, wn, lane, tid);
+  if (nt_staged_ok(p)) nt_epilogue_s<BM, BN, NT, FM, FN, WTM, WTN, nt_epi_split<BM, BN>()>(p, acc, smem, m0, n0, wm, wn, lane, tid);
   else nt_epilogue_t<FM, FN, WTM, WTN>(p, acc, m0, n0, wm, wn, lane);
 }
 
@@ -967,7 +991,7 @@ __global__ __launch_bounds__(WM_* WN_ * 64, PIPE ? 4 : 1) void gemm_nt2_grouped_
 template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK>
 constexpr size_t nt2_lds_bytes() {
   constexpr size_t ring = (size_t)STAGES * (BM + BN) * BK * 2;
-  constexpr size_t epi = (size_t)2 * nt_stage_bytes<BM, BN>();      // staged epilogue: C and its bf16 twin
+  constexpr size_t epi = (size_t)(nt_epi_split<BM, BN>() ? 1 : 2) * nt_stage_bytes<BM, BN>();
   return ring > epi ? ring : epi;
 }
 
@@ -1081,6 +1105,9 @@ void nt_log_issue(int cfg, bool bt, const void* const* params, int n) {
   }
 }
 
+// DAV_NT_WIDE=0 switches the 128 x 256 configuration off (A/B timing of the same box)
+static bool nt_wide_on() { static const bool on = [] { const char* e = getenv("DAV_NT_WIDE"); return !(e && e[0] == '0'); }(); return on; }
+
 // Recorded with the tile configuration left open: chosen at issue time from the tile count of the WHOLE group.
 template <bool BT>
 void nt2_issue_auto(const void* const* params_in, int n, hipStream_t stream) {
@@ -1088,16 +1115,35 @@ void nt2_issue_auto(const void* const* params_in, int n, hipStream_t stream) {
   std::vector<const void*> sorted(params_in, params_in + n);
   std::stable_sort(sorted.begin(), sorted.end(), [](const void* a, const void* b) { return ((const NTParams*)a)->K > ((const NTParams*)b)->K; });
   const void* const* params = sorted.data();
-  long t128 = 0;
+  long t128 = 0, t256 = 0, t256m = 0, t128_tall = 0;
+  bool wide = true;
   bool narrow = true;
   for (int i = 0; i < n; ++i) {
     const NTParams& p = *(const NTParams*)params[i];
     t128 += (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    t256 += (long)((p.M + 127) / 128) * ((p.N + 255) / 256);
     narrow = narrow && p.N <= 64;
+    wide = wide && p.K <= 512 && !(p.N & 255) && p.N >= 1024;     // (512-wide outputs, the decoder proj: 5 % slower with it)
+    if (!BT && p.K <= 768 && p.act == 0 && p.N >= 1536 && !(p.N & 127)) t128_tall += (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    t256m += (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
   }
-  const int cfg = nt_auto_config_tiles(t128, narrow);
+  int cfg = nt_auto_config_tiles(t128, narrow);
+  // short contractions into wide outputs (the decoders' qkv / fc1, K = 512): a 128 x 256 tile on a 3 x 24 KB ring of 32-deep
+  // stages moves 3/4 of the operand bytes per flop and spends half as many tile prologues / epilogues: +14 % on both
+  // (tools/group_bench.py cfg 44 vs 3); longer contractions and 768-wide outputs measured equal or worse.
+  int forced = ((const NTParams*)params[0])->force_cfg;          // an explicit configuration shared by the whole group wins
+  for (int i = 1; i < n; ++i) if (((const NTParams*)params[i])->force_cfg != forced) forced = 0;
+  if (forced) cfg = forced;
+  else if (cfg == 3 && wide && t256 >= 512 && nt_wide_on()) cfg = 44;
+  // the towers' qkv projection (K = 768, 2304 wide, plain epilogue): 256 x 128 tiles on a 2 x 24 KB ring, +14 % (cfg 45 vs 3);
+  // the GELU (fc1) and every 768-wide GEMM of the same depth measured equal or worse with it
+  // (the fusion block's small problems ride along in the same launch: at least 90 % of the tiles must be of that kind)
+  else if (cfg == 3 && t128_tall * 10 >= t128 * 9 && t256m >= 512 && nt_wide_on()) cfg = 45;
   nt_log_issue(cfg, BT, params, n);
   switch (cfg) {
+    case 44: nt2_issue<128, 256, 2, 4, 3, BT, 32>(params, n, stream); break;
+    case 45:
+      if constexpr (!BT) { nt2_issue<256, 128, 4, 2, 2, false, 32>(params, n, stream); break; }
     case 3: nt2_issue<128, 128, 2, 4, 2, BT, 64>(params, n, stream); break;
     case 8: nt2_issue<128, 64, 2, 2, 2, BT, 64>(params, n, stream); break;
     default: nt2_issue<64, 64, 2, 2, 2, BT, 64>(params, n, stream); break;
@@ -1442,31 +1488,45 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
   const bool vec_ok = glds_ok && (N & 3) == 0 && (ldc & 3) == 0 && (!res || (ldres & 3) == 0) && (!C2 || (ldc2 & 3) == 0) &&
                       (!aux || (ldaux & 3) == 0) && !(((uintptr_t)C | (uintptr_t)C2 | (uintptr_t)res) & 15) && !((uintptr_t)aux & 7);
   int cfg = variant >> 4;
-  if (vec_ok && cfg == 0 && !(variant & 15) && davb::recording()) {
+  const bool groupable_cfg = cfg == 0 || cfg == 3 || cfg == 5 || cfg == 8 || cfg == 44 || (cfg == 45 && !b_kn);
+  p.force_cfg = cfg;
+  if (vec_ok && groupable_cfg && !(variant & 15) && davb::recording()) {
     // batched: the tile configuration is chosen when the group is issued, from the tile count of the whole group
     davb::push_typed(b_kn ? nt2_issue_auto<true> : nt2_issue_auto<false>, &p, sizeof(p), stream);
     return DAV_OK;
   }
   if (vec_ok && cfg == 0 && !(variant & 15)) {
     const void* one = &p;
-    nt_log_issue(nt_auto_config(M, N, K), b_kn != 0, &one, 1);
+    int c = nt_auto_config(M, N, K);
+    if (c == 3 && K <= 512 && !(N & 255) && N >= 1024 && (long)((M + 127) / 128) * (N / 256) >= 512 && nt_wide_on()) c = 44;
+    nt_log_issue(c, b_kn != 0, &one, 1);
   }
   if (b_kn) {
     if (!vec_ok) return DAV_ERR_SHAPE;
-    if (cfg == 0) cfg = nt_auto_config(M, N, K);
+    if (cfg == 0) {
+      cfg = nt_auto_config(M, N, K);
+      if (cfg == 3 && K <= 512 && !(N & 255) && N >= 1024 && (long)((M + 127) / 128) * (N / 256) >= 512 && nt_wide_on()) cfg = 44;     // as nt2_issue_auto
+    }
     switch (cfg) {
       case 3: launch_nt2<128, 128, 2, 4, 2, true>(p, stream); break;
       case 31: launch_nt2<128, 128, 2, 4, 2, true, 64, 1>(p, stream); break;
       case 32: launch_nt3<true>(p, stream); break;
       case 40: launch_nt2<256, 128, 4, 4, 3, true>(p, stream); break;      // 16 waves, one workgroup per CU, 3 x 48 KB ring
       case 41: launch_nt2<128, 256, 4, 4, 3, true>(p, stream); break;
+      case 44: launch_nt2<128, 256, 2, 4, 3, true, 32>(p, stream); break;
+      case 43: launch_nt2<256, 128, 4, 2, 3, true, 32>(p, stream); break;
+      case 45: launch_nt2<256, 128, 4, 2, 2, true, 32>(p, stream); break;
+      case 46: launch_nt2<128, 256, 2, 4, 2, true, 32>(p, stream); break;
       case 8: launch_nt2<128, 64, 2, 2, 2, true>(p, stream); break;
       default: launch_nt2<64, 64, 2, 2, 2, true>(p, stream); break;
     }
     return dav_launch_status();
   }
   if (vec_ok && !(variant & 15)) {
-    if (cfg == 0) cfg = nt_auto_config(M, N, K);
+    if (cfg == 0) {
+      cfg = nt_auto_config(M, N, K);
+      if (cfg == 3 && K <= 512 && !(N & 255) && N >= 1024 && (long)((M + 127) / 128) * (N / 256) >= 512 && nt_wide_on()) cfg = 44;     // as nt2_issue_auto
+    }
     switch (cfg) {
       case 30: {      // phase profile of the dominant configuration (see nt2_body); res_rows carries the int64 output buffer
         if (res) return DAV_ERR_SHAPE;
@@ -1479,6 +1539,10 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
       case 40: launch_nt2<256, 128, 4, 4, 3>(p, stream); return dav_launch_status();   // 16 waves, one workgroup per CU, 3 x 48 KB ring
       case 41: launch_nt2<128, 256, 4, 4, 3>(p, stream); return dav_launch_status();
       case 42: launch_nt2<256, 128, 4, 4, 2>(p, stream); return dav_launch_status();
+      case 43: launch_nt2<256, 128, 4, 2, 3, false, 32>(p, stream); return dav_launch_status();   // 8 waves of 64x64, 3 x 24 KB ring, two workgroups per CU
+      case 44: launch_nt2<128, 256, 2, 4, 3, false, 32>(p, stream); return dav_launch_status();
+      case 45: launch_nt2<256, 128, 4, 2, 2, false, 32>(p, stream); return dav_launch_status();
+      case 46: launch_nt2<128, 256, 2, 4, 2, false, 32>(p, stream); return dav_launch_status();
       case 33: case 34: case 35: case 36: case 37: {      // phase profile of the staggered-halves kernel (+ ablations 1..4); res_rows = int64 output
         if (res) return DAV_ERR_SHAPE;
         const int grid = ((M + 255) / 256) * ((N + 127) / 128);

@@ -79,13 +79,18 @@ def run(p, cfg):
     ops.gemm_nt(A, W, M, N, K, **kw)
 
 
+ONLY = os.environ.get('GB_ONLY', '').split(',') if os.environ.get('GB_ONLY') else None
 SHAPES = [('qkv', 5184, 6080, 2304, 768, 'plain'), ('proj', 3136, 4032, 768, 768, 'res'), ('fc1', 3136, 4032, 3072, 768, 'gelu'),
           ('fc2', 3136, 4032, 768, 3072, 'res'), ('d_fc2', 3136, 4032, 3072, 768, 'dgrad'), ('d_fc1', 3136, 4032, 768, 3072, 'dgrad'),
           ('d_proj', 3136, 4032, 768, 768, 'dgrad'), ('d_qkv', 5184, 6080, 768, 2304, 'dgrad'),
-          ('dec_qkv', 14592, 22528, 1536, 512, 'plain'), ('dec_fc1', 14592, 22528, 2048, 512, 'gelu'), ('dec_fc2', 14592, 22528, 512, 2048, 'res')]
+          ('dec_qkv', 14592, 22528, 1536, 512, 'plain'), ('dec_fc1', 14592, 22528, 2048, 512, 'gelu'), ('dec_fc2', 14592, 22528, 512, 2048, 'res'),
+          ('dec_proj', 14592, 22528, 512, 512, 'res'), ('d_decprj', 14592, 22528, 512, 512, 'dgrad'), ('d_decfc2', 14592, 22528, 2048, 512, 'dgrad'),
+          ('f_kv', 3136, 4032, 1536, 768, 'plain')]
 cfgs = [int(a) for a in sys.argv[1:]] or [0, 3, 8, 5]
 print(f'{"gemm":8s} {"GF":>6s} | ' + ' | '.join(f'cfg{c}: indiv us   TF  group us   TF' for c in cfgs))
 for name, Mi, Ma, N, K, kind in SHAPES:
+    if ONLY and name not in ONLY:
+        continue
     pi, pa = problem(Mi, N, K, kind), problem(Ma, N, K, kind)
     gf = 2.0 * (Mi + Ma) * N * K / 1e9
     cells = []
