@@ -24,6 +24,7 @@ SIGNATURES = {
     'dav_tune': [_i, _i],
     'dav_gemm_nt_bf16': [_p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _f, _i, _p],
     'dav_nt_issue_log': [_i, _p, _i],
+    'dav_nt_tune_set': [_p, _i],
     'dav_gemm_tn_bf16': [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _i, _p],
     'dav_gemm_tn_grouped_bf16': [_p, _i, _p],
     'dav_attn_fwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _i, _l, _i, _l, _i, _l, _i, _f, _p],
@@ -106,7 +107,30 @@ def load():
     if lib.dav_abi_version() != 1:
         raise RuntimeError('libdavfusion_hip.so ABI version mismatch')
     _lib = lib
+    load_nt_tuning(NT_TUNING_PATH)
     return lib
+
+
+NT_TUNING_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuning', 'nt_gfx950.json')
+
+
+def load_nt_tuning(path):
+    """Hands the tuned tile-configuration table (tools/mix_sweep.py --write) to the library; DAV_NT_TUNE=0 or a missing file
+    leave the built-in rules alone.  Returns the number of entries installed."""
+    if os.environ.get('DAV_NT_TUNE', '1') == '0' or not path or not os.path.exists(path):
+        _lib.dav_nt_tune_set(None, 0)
+        return 0
+    import json
+    blob = []
+    for e in json.load(open(path))['entries']:
+        blob += [int(e['cfg']), int(e['b_kn']), len(e['problems'])]
+        for q in e['problems']:
+            blob += [int(x) for x in q]            # M, N, K, epilogue flags
+    arr = (C.c_int * len(blob))(*blob)
+    n = _lib.dav_nt_tune_set(arr, len(blob))
+    if n < 0:
+        raise RuntimeError(f'{path}: malformed tuning table ({ERRORS.get(n, n)})')
+    return n
 
 
 def check(code: int, what: str):

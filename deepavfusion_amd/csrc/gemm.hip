@@ -11,8 +11,10 @@
 // Replaces the cuBLAS/rocBLAS calls behind F.linear in timm Block / Mlp / Attention and
 // models/fusion_blocks.py:41-44,227-232; models/avmae.py:31,59-60,88.
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cstdlib>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -1090,11 +1092,13 @@ void launch_nt2(const NTParams& p, hipStream_t stream) {
 int nt_auto_config_tiles(long t128, bool narrow);
 
 // Issue log (bench.py's roofline leg): which grouped / single launches the NT family really issued, so that the launch mix
-// of a step can be replayed kernel for kernel.  Entry: cfg, b_kn, n, then n x (M, N, K).
+// of a step can be replayed kernel for kernel.  Entry: cfg, b_kn, n, then n x (M, N, K, epilogue flags).
 // process-wide (autograd runs the backward on its own thread), guarded by a mutex
 std::atomic<bool> nt_log_on{false};
 std::vector<int> nt_log;
 std::mutex nt_log_mu;
+// epilogue kind of a problem (issue log, tuned-table signature)
+static int nt_flags(const NTParams& p) { return p.act | (p.c_bf16 ? 4 : 0) | (p.res ? 8 : 0) | (p.c2_mode << 4) | (p.beta ? 256 : 0); }
 void nt_log_issue(int cfg, bool bt, const void* const* params, int n) {
   if (!nt_log_on.load(std::memory_order_relaxed)) return;
   std::lock_guard<std::mutex> lk(nt_log_mu);
@@ -1102,7 +1106,31 @@ void nt_log_issue(int cfg, bool bt, const void* const* params, int n) {
   for (int i = 0; i < n; ++i) {
     const NTParams& p = *(const NTParams*)params[i];
     nt_log.push_back(p.M); nt_log.push_back(p.N); nt_log.push_back(p.K);
+    nt_log.push_back(nt_flags(p));   // epilogue kind
   }
+}
+
+// Tuned table: group signature -> tile configuration, measured offline on the target by tools/mix_sweep.py (every distinct
+// grouped launch of a training step timed under each candidate configuration) and handed over once by the host
+// (dav_nt_tune_set).  Signature = b_kn, then the problems' (M, N, K, epilogue flags) sorted.  The rule-based choice below
+// remains the fallback for every group the table does not hold.
+std::map<std::vector<int>, int> nt_tuned;
+std::mutex nt_tuned_mu;
+static int nt_tuned_lookup(bool bt, const void* const* params, int n) {
+  if (nt_tuned.empty()) return 0;
+  std::vector<std::array<int, 4>> v(n);
+  for (int i = 0; i < n; ++i) {
+    const NTParams& p = *(const NTParams*)params[i];
+    v[i] = {p.M, p.N, p.K, nt_flags(p)};
+  }
+  std::sort(v.begin(), v.end());
+  std::vector<int> key;
+  key.reserve(1 + 4 * n);
+  key.push_back(bt ? 1 : 0);
+  for (auto& q : v) key.insert(key.end(), q.begin(), q.end());
+  std::lock_guard<std::mutex> lk(nt_tuned_mu);
+  auto it = nt_tuned.find(key);
+  return it == nt_tuned.end() ? 0 : it->second;
 }
 
 // DAV_NT_WIDE=0 switches the 128 x 256 configuration off (A/B timing of the same box)
@@ -1115,7 +1143,7 @@ void nt2_issue_auto(const void* const* params_in, int n, hipStream_t stream) {
   std::vector<const void*> sorted(params_in, params_in + n);
   std::stable_sort(sorted.begin(), sorted.end(), [](const void* a, const void* b) { return ((const NTParams*)a)->K > ((const NTParams*)b)->K; });
   const void* const* params = sorted.data();
-  long t128 = 0, t256 = 0, t256m = 0, t128_tall = 0;
+  long t128 = 0, t256 = 0;
   bool wide = true;
   bool narrow = true;
   for (int i = 0; i < n; ++i) {
@@ -1124,8 +1152,6 @@ void nt2_issue_auto(const void* const* params_in, int n, hipStream_t stream) {
     t256 += (long)((p.M + 127) / 128) * ((p.N + 255) / 256);
     narrow = narrow && p.N <= 64;
     wide = wide && p.K <= 512 && !(p.N & 255) && p.N >= 1024;     // (512-wide outputs, the decoder proj: 5 % slower with it)
-    if (!BT && p.K <= 768 && p.act == 0 && p.N >= 1536 && !(p.N & 127)) t128_tall += (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    t256m += (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
   }
   int cfg = nt_auto_config_tiles(t128, narrow);
   // short contractions into wide outputs (the decoders' qkv / fc1, K = 512): a 128 x 256 tile on a 3 x 24 KB ring of 32-deep
@@ -1133,17 +1159,16 @@ void nt2_issue_auto(const void* const* params_in, int n, hipStream_t stream) {
   // (tools/group_bench.py cfg 44 vs 3); longer contractions and 768-wide outputs measured equal or worse.
   int forced = ((const NTParams*)params[0])->force_cfg;          // an explicit configuration shared by the whole group wins
   for (int i = 1; i < n; ++i) if (((const NTParams*)params[i])->force_cfg != forced) forced = 0;
+  const int tuned = forced ? 0 : nt_tuned_lookup(BT, params, n);
   if (forced) cfg = forced;
+  else if (tuned) cfg = tuned;
   else if (cfg == 3 && wide && t256 >= 512 && nt_wide_on()) cfg = 44;
-  // the towers' qkv projection (K = 768, 2304 wide, plain epilogue): 256 x 128 tiles on a 2 x 24 KB ring, +14 % (cfg 45 vs 3);
-  // the GELU (fc1) and every 768-wide GEMM of the same depth measured equal or worse with it
-  // (the fusion block's small problems ride along in the same launch: at least 90 % of the tiles must be of that kind)
-  else if (cfg == 3 && t128_tall * 10 >= t128 * 9 && t256m >= 512 && nt_wide_on()) cfg = 45;
   nt_log_issue(cfg, BT, params, n);
   switch (cfg) {
     case 44: nt2_issue<128, 256, 2, 4, 3, BT, 32>(params, n, stream); break;
-    case 45:
-      if constexpr (!BT) { nt2_issue<256, 128, 4, 2, 2, false, 32>(params, n, stream); break; }
+    case 45: nt2_issue<256, 128, 4, 2, 2, BT, 32>(params, n, stream); break;
+    case 43: nt2_issue<256, 128, 4, 2, 3, BT, 32>(params, n, stream); break;      // (43 / 46: tools/mix_sweep.py candidates)
+    case 46: nt2_issue<128, 256, 2, 4, 2, BT, 32>(params, n, stream); break;
     case 3: nt2_issue<128, 128, 2, 4, 2, BT, 64>(params, n, stream); break;
     case 8: nt2_issue<128, 64, 2, 2, 2, BT, 64>(params, n, stream); break;
     default: nt2_issue<64, 64, 2, 2, 2, BT, 64>(params, n, stream); break;
@@ -1488,7 +1513,7 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
   const bool vec_ok = glds_ok && (N & 3) == 0 && (ldc & 3) == 0 && (!res || (ldres & 3) == 0) && (!C2 || (ldc2 & 3) == 0) &&
                       (!aux || (ldaux & 3) == 0) && !(((uintptr_t)C | (uintptr_t)C2 | (uintptr_t)res) & 15) && !((uintptr_t)aux & 7);
   int cfg = variant >> 4;
-  const bool groupable_cfg = cfg == 0 || cfg == 3 || cfg == 5 || cfg == 8 || cfg == 44 || (cfg == 45 && !b_kn);
+  const bool groupable_cfg = cfg == 0 || cfg == 3 || cfg == 5 || cfg == 8 || cfg == 43 || cfg == 44 || cfg == 45 || cfg == 46;
   p.force_cfg = cfg;
   if (vec_ok && groupable_cfg && !(variant & 15) && davb::recording()) {
     // batched: the tile configuration is chosen when the group is issued, from the tile count of the whole group
@@ -1594,6 +1619,29 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
     else DAV_LAUNCH((gemm_nt_kernel<128, 128, false>), dim3(grid), dim3(256), lds, stream, p);
   }
   return dav_launch_status();
+}
+
+extern "C" int dav_nt_tune_set(const int* blob, int n_ints) {
+  // blob: entries [cfg, b_kn, n, n x (M, N, K, flags)] as dav_nt_issue_log writes them; n_ints == 0 clears the table
+  std::map<std::vector<int>, int> m;
+  int i = 0;
+  while (i < n_ints) {
+    if (i + 3 > n_ints) return DAV_ERR_SHAPE;
+    const int cfg = blob[i], bt = blob[i + 1], n = blob[i + 2];
+    if (n <= 0 || i + 3 + 4 * n > n_ints) return DAV_ERR_SHAPE;
+    if (!(cfg == 3 || cfg == 5 || cfg == 8 || cfg == 43 || cfg == 44 || cfg == 45 || cfg == 46)) return DAV_ERR_SHAPE;
+    std::vector<std::array<int, 4>> v(n);
+    for (int j = 0; j < n; ++j) v[j] = {blob[i + 3 + 4 * j], blob[i + 4 + 4 * j], blob[i + 5 + 4 * j], blob[i + 6 + 4 * j]};
+    std::sort(v.begin(), v.end());
+    std::vector<int> key;
+    key.push_back(bt ? 1 : 0);
+    for (auto& q : v) key.insert(key.end(), q.begin(), q.end());
+    m[key] = cfg;
+    i += 3 + 4 * n;
+  }
+  std::lock_guard<std::mutex> lk(nt_tuned_mu);
+  nt_tuned.swap(m);
+  return (int)nt_tuned.size();
 }
 
 extern "C" int dav_nt_issue_log(int enable, int* out, int capacity) {

@@ -117,9 +117,10 @@ def gemm_nt(A, B, M, N, K, *, lda=None, ldb=None, a_rowmap=None, bias=None, act=
                                     _ptr(C2), ldc2, c2_mode, beta, float(alpha), variant, _stream()), 'dav_gemm_nt_bf16')
 
 
-def nt_issue_log(enable=None):
+def nt_issue_log(enable=None, with_flags=False):
     """enable True / False: start (clearing) / stop logging the NT launches the library issues; None: fetch the log as a
-    list of (cfg, b_kn, [(M, N, K), ...]) — one entry per launch (grouped launches have several problems)."""
+    list of (cfg, b_kn, [(M, N, K), ...]) — one entry per launch (grouped launches have several problems); with_flags adds a
+    fourth element, the problems' epilogue flags (act | c_bf16 << 2 | has_res << 3 | c2_mode << 4 | beta << 8)."""
     lib = _lib.load()
     if enable is not None:
         lib.dav_nt_issue_log(int(enable), None, 0)
@@ -132,8 +133,10 @@ def nt_issue_log(enable=None):
     out, i = [], 0
     while i < n:
         cfg, bt, cnt = buf[i], buf[i + 1], buf[i + 2]
-        out.append((cfg, bt, [(buf[i + 3 + 3 * j], buf[i + 4 + 3 * j], buf[i + 5 + 3 * j]) for j in range(cnt)]))
-        i += 3 + 3 * cnt
+        probs = [(buf[i + 3 + 4 * j], buf[i + 4 + 4 * j], buf[i + 5 + 4 * j]) for j in range(cnt)]
+        flags = [buf[i + 6 + 4 * j] for j in range(cnt)]
+        out.append((cfg, bt, probs, flags) if with_flags else (cfg, bt, probs))
+        i += 3 + 4 * cnt
     return out
 
 

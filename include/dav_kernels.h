@@ -62,8 +62,16 @@ int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int K, int lda,
 
 /* Diagnostics for benchmarks: log which launches the NT family issues (grouped or single).  enable 1 / 0 with out == NULL
  * starts (and clears) / stops logging (process-wide: autograd runs the backward on its own thread); with out != NULL the log is copied: entries of
- * {tile configuration, b_kn, n, n x (M, N, K)}; returns the number of ints, or -needed when capacity is too small. */
+ * {tile configuration, b_kn, n, n x (M, N, K, epilogue flags)}; returns the number of ints, or -needed when capacity is too small.
+ * flags = act | c_is_bf16 << 2 | has_res << 3 | c2_mode << 4 | beta << 8. */
 int dav_nt_issue_log(int enable, int* out, int capacity);
+
+/* Tuned tile-configuration table for grouped NT launches (the role cuBLAS' / hipBLASLt's per-size solution tables play
+ * behind torch's F.linear in the reference, models/vits.py:32-34): `blob` holds entries in dav_nt_issue_log's format; a
+ * group recorded between dav_batch_begin / dav_batch_end whose b_kn + sorted (M, N, K, flags) list matches an entry is issued
+ * with that entry's tile configuration, any other group by the built-in rules.  n_ints == 0 clears.  Returns the number of
+ * entries held, or a negative DAV_ERR_*.  Written by tools/mix_sweep.py, loaded by deepavfusion_amd/_lib.py. */
+int dav_nt_tune_set(const int* blob, int n_ints);
 
 /* C[N,K] (+)= A[Mc,N]^T . B[Mc,K] in fp32: the weight gradient of every nn.Linear above (autograd of
  * F.linear).  beta != 0 accumulates into the live gradient (split over the contraction with fp32

@@ -208,3 +208,25 @@ def test_init_distributed_mode_single_process_on_multi_gpu_host(monkeypatch):
     du.init_distributed_mode(0, args)
     init = [c for c in called if c[0] == 'init'][0][1]
     assert init['init_method'] == 'env://' and init['world_size'] == 4 and init['rank'] == 2 and ('set_device', 2) in called
+
+
+def test_nt_tuning_table_loads_and_rejects_malformed_blobs():
+    """The shipped tile-configuration table installs through dav_nt_tune_set (host-only call), DAV_NT_TUNE=0 leaves the
+    built-in rules alone, and blobs that are cut short or name an unknown configuration are refused."""
+    import ctypes as C
+    from deepavfusion_amd import _lib
+    lib = _lib.load()
+    n = _lib.load_nt_tuning(_lib.NT_TUNING_PATH)
+    assert n >= 1
+    ok = (C.c_int * 7)(3, 0, 1, 256, 256, 64, 4)
+    assert lib.dav_nt_tune_set(ok, 7) == 1
+    assert lib.dav_nt_tune_set(ok, 6) < 0                       # truncated entry
+    bad = (C.c_int * 7)(99, 0, 1, 256, 256, 64, 4)              # unknown tile configuration
+    assert lib.dav_nt_tune_set(bad, 7) < 0
+    assert lib.dav_nt_tune_set(None, 0) == 0                    # cleared
+    os.environ['DAV_NT_TUNE'] = '0'
+    try:
+        assert _lib.load_nt_tuning(_lib.NT_TUNING_PATH) == 0
+    finally:
+        del os.environ['DAV_NT_TUNE']
+    assert _lib.load_nt_tuning(_lib.NT_TUNING_PATH) == n        # back to the shipped table for the rest of the session
