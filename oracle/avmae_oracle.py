@@ -51,6 +51,7 @@ class PathConfig:
     decoder_depth: int = 8
     decoder_heads: int = 16
     decoder_mlp_ratio: float = 4.0
+    decoder_arch: str = 'plain'             # 'plain' | 'swin' for both decoders (models/avmae.py:37-51, 67-81)
     image_mask_ratio: float = 0.75
     audio_mask_ratio: float = 0.8
     image_norm_loss: bool = True
@@ -434,8 +435,106 @@ def forward_loss(target: Tensor, pred: Tensor, mask: Tensor, norm_pix_loss: bool
     return (loss * mask).sum() / mask.sum()
 
 
+# --------------------------------------------------------------------------- #
+# Swin decoder blocks (models/swin.py; decoder_arch == 'swin', models/avmae.py:37-51, 174-176)
+# --------------------------------------------------------------------------- #
+SWIN_WINDOW = 4          # models/avmae.py:42, 72
+
+
+def swin_geometry(res: Tuple[int, int], index: int):
+    """(window, shift) of decoder block ``index`` on a ``res`` token grid: models/avmae.py:42-43 (window 4, shift 2 on odd
+    blocks) after the clamp of models/swin.py:121-124 (a grid no larger than the window is ONE unshifted window)."""
+    window, shift = SWIN_WINDOW, (index % 2) * 2
+    if min(res) <= window:
+        window, shift = min(res), 0
+    return window, shift
+
+
+def relative_position_index(win: int) -> Tensor:
+    """timm 0.9.2 ``get_relative_position_index(win, win)`` (not vendored in the reference; published algorithm: pairwise
+    coordinate differences of the window's tokens, shifted to start at 0, row difference scaled by 2*win - 1)."""
+    coords = torch.stack(torch.meshgrid(torch.arange(win), torch.arange(win), indexing='ij')).flatten(1)      # [2, A]
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0) + (win - 1)
+    return rel[..., 0] * (2 * win - 1) + rel[..., 1]                                                          # [A, A]
+
+
+def window_rows(res: Tuple[int, int], window: int, shift: int) -> Tensor:
+    """Token index (row of the [H*W] sequence) of every window slot after the cyclic shift: ``out[w, i]`` is the token
+    that ``window_partition(torch.roll(x, (-shift, -shift), (1, 2)), window)`` puts at slot i of window w
+    (models/swin.py:172-179; timm window_partition: windows row-major over the grid, slots row-major inside a window)."""
+    H, W = res
+    ids = torch.arange(H * W).view(H, W)
+    if shift > 0:
+        ids = torch.roll(ids, shifts=(-shift, -shift), dims=(0, 1))
+    return ids.view(H // window, window, W // window, window).permute(0, 2, 1, 3).reshape(-1, window * window)
+
+
+def shifted_window_mask(res: Tuple[int, int], window: int, shift: int) -> Optional[Tensor]:
+    """models/swin.py:136-156: region ids of the 3 x 3 slices of the (shifted) grid; pairs of window slots from different
+    regions get -100.  None for unshifted blocks."""
+    if shift == 0:
+        return None
+    H, W = res
+    img = torch.zeros(H, W)
+    cnt = 0
+    for h in (slice(0, -window), slice(-window, -shift), slice(-shift, None)):
+        for w in (slice(0, -window), slice(-window, -shift), slice(-shift, None)):
+            img[h, w] = cnt
+            cnt += 1
+    mw = img.view(H // window, window, W // window, window).permute(0, 2, 1, 3).reshape(-1, window * window)
+    diff = mw[:, None, :] - mw[:, :, None]
+    return torch.where(diff != 0, torch.full_like(diff, -100.0), torch.zeros_like(diff))                    # [nW, A, A]
+
+
+def window_attention(x: Tensor, sd, name: str, heads: int, win: int, mask: Optional[Tensor]) -> Tensor:
+    """models/swin.py:55-87 on [nW*B, N, C] sequences of A = win*win window tokens followed by N - A fusion tokens: the
+    relative-position bias (and the shift mask) cover the A x A corner, zero elsewhere (:69-72, :75-78)."""
+    B_, N, C = x.shape
+    A = win * win
+    qkv = linear(x, sd, name + '.qkv').reshape(B_, N, 3, heads, -1).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv.unbind(0)
+    scale = q.shape[-1] ** -0.5
+    attn = (q * scale) @ k.transpose(-2, -1)
+    idx = sd.get(name + '.relative_position_index')
+    idx = relative_position_index(win) if idx is None else idx.long()
+    bias = sd[name + '.relative_position_bias_table'][idx.reshape(-1)].view(A, A, -1).permute(2, 0, 1)      # [heads, A, A]
+    attn = attn + torch.nn.functional.pad(bias, (0, N - A, 0, N - A))[None]
+    if mask is not None:
+        nW = mask.shape[0]
+        m = torch.nn.functional.pad(mask, (0, N - A, 0, N - A))
+        attn = (attn.view(B_ // nW, nW, heads, N, N) + m[None, :, None]).view(-1, heads, N, N)
+    attn = attn.softmax(dim=-1)
+    x = (attn @ v).transpose(1, 2).reshape(B_, N, -1)
+    return linear(x, sd, name + '.proj')
+
+
+def swin_block(x: Tensor, x_fusion: Tensor, sd, name: str, heads: int, res: Tuple[int, int], index: int, eps: float):
+    """models/swin.py:160-209 with x_fusion given (the decoder always passes it, models/avmae.py:176): every window attends
+    over its 16 tokens + ALL fusion tokens; the fusion tokens' outputs are averaged over the windows (:199)."""
+    B, L, C = x.shape
+    Lf = x_fusion.shape[1]
+    win, shift = swin_geometry(res, index)
+    rows = window_rows(res, win, shift)                            # [nW, A]
+    nW, A = rows.shape
+    xn = layer_norm(x, sd, name + '.norm1', eps)
+    fn = layer_norm(x_fusion, sd, name + '.norm1', eps)
+    xw = xn[:, rows.reshape(-1)].reshape(B * nW, A, C)             # window_partition(roll(.)) as one gather
+    seq = torch.cat([xw, fn[:, None].expand(B, nW, Lf, C).reshape(B * nW, Lf, C)], dim=1)
+    mask = sd.get(name + '.attn_mask')
+    if mask is None:
+        mask = shifted_window_mask(res, win, shift)
+    y = window_attention(seq, sd, name + '.attn', heads, win, mask)
+    yw, yf = y[:, :A], y[:, A:]
+    merged = torch.zeros_like(x)
+    merged[:, rows.reshape(-1)] = yw.reshape(B, nW * A, C)         # window_reverse + roll back = the inverse scatter
+    yf = yf.reshape(B, nW, Lf, C).mean(1)
+    z = torch.cat([x, x_fusion], dim=1) + torch.cat([merged, yf], dim=1)
+    z = z + timm_mlp(layer_norm(z, sd, name + '.norm2', eps), sd, name + '.mlp')
+    return z[:, :L], z[:, L:]
+
+
 def forward_decoder(x: Tensor, x_fusion: Tensor, ids_restore: Tensor, sd, cfg: PathConfig, modality: str) -> Tensor:
-    """models/avmae.py:147-180, decoder_arch='plain'.  ``embed`` is shared by
+    """models/avmae.py:147-180, decoder_arch 'plain' or 'swin'.  ``embed`` is shared by
     modality tokens and fusion tokens (:158)."""
     B, nF = x.shape[0], x_fusion.shape[1]
     L = ids_restore.shape[1]
@@ -446,6 +545,11 @@ def forward_decoder(x: Tensor, x_fusion: Tensor, ids_restore: Tensor, sd, cfg: P
     x = torch.cat([x, sd[p + 'mask_token'].expand(B, n_mask, -1)], dim=1)
     x = x.gather(1, ids_restore.unsqueeze(-1).expand(-1, -1, x.shape[2]))
     x = x + sd[p + 'pos_embed']
+    if cfg.decoder_arch == 'swin':                                 # models/avmae.py:174-176
+        res = cfg.image_grid if modality == 'image' else cfg.audio_grid
+        for l in range(cfg.decoder_depth):
+            x, x_fusion = swin_block(x, x_fusion, sd, f'{p}blocks.{l}', cfg.decoder_heads, res, l, cfg.dec_eps)
+        return linear(layer_norm(x, sd, p + 'norm', cfg.dec_eps), sd, p + 'pred')
     x = torch.cat([x_fusion, x], dim=1)
     for l in range(cfg.decoder_depth):
         x = timm_block(x, sd, f'{p}blocks.{l}', cfg.decoder_heads, cfg.dec_eps)
@@ -559,6 +663,12 @@ def state_shapes(cfg) -> Dict[str, Tuple[int, ...]]:
         s[pre + 'pos_embed'] = (1, grid[0] * grid[1], Dd)
         for l in range(cfg.decoder_depth):
             s.update(_block_shapes(f'{pre}blocks.{l}', Dd, int(Dd * cfg.decoder_mlp_ratio)))
+            if cfg.decoder_arch == 'swin':          # models/swin.py:36-39, 158: bias table + two registered buffers
+                win, shift = swin_geometry(grid, l)
+                s[f'{pre}blocks.{l}.attn.relative_position_bias_table'] = ((2 * win - 1) ** 2, cfg.decoder_heads)
+                s[f'{pre}blocks.{l}.attn.relative_position_index'] = (win * win, win * win)
+                if shift > 0:
+                    s[f'{pre}blocks.{l}.attn_mask'] = ((grid[0] // win) * (grid[1] // win), win * win, win * win)
         s[pre + 'norm.weight'] = (Dd,); s[pre + 'norm.bias'] = (Dd,)
         s[pre + 'pred.weight'] = (p * p * cin, Dd); s[pre + 'pred.bias'] = (p * p * cin,)
     return s
@@ -566,6 +676,11 @@ def state_shapes(cfg) -> Dict[str, Tuple[int, ...]]:
 
 FROZEN = ('encoder.image.pos_embed', 'encoder.audio.pos_embed',   # models/vits.py:29
           'video.pos_embed', 'audio.pos_embed')                    # models/video_vits.py:148 (pos_trainable=False)
+
+
+def is_buffer(name: str) -> bool:
+    """State-dict entries that are registered buffers, not parameters (models/swin.py:39, 158)."""
+    return name.endswith('.relative_position_index') or name.endswith('.attn_mask')
 
 
 def closed_form_state(cfg: PathConfig, seed: int = 0) -> Dict[str, Tensor]:
@@ -576,6 +691,12 @@ def closed_form_state(cfg: PathConfig, seed: int = 0) -> Dict[str, Tensor]:
     sd: Dict[str, Tensor] = {}
     for name, shape in state_shapes(cfg).items():
         rs = np.random.RandomState((zlib.crc32(name.encode()) + 7919 * seed) & 0x7FFFFFFF)
+        if is_buffer(name):
+            mod, l = name.split('_decoder_')[0], int(name.split('blocks.')[1].split('.')[0])
+            grid = cfg.image_grid if mod == 'image' else cfg.audio_grid
+            win, shift = swin_geometry(grid, l)
+            sd[name] = relative_position_index(win) if name.endswith('index') else shifted_window_mask(grid, win, shift)
+            continue
         if name == 'video.pos_embed':
             arr = sincos_3d(shape[-1], cfg.video_grid)[None]
         elif name in FROZEN:
@@ -590,6 +711,8 @@ def closed_form_state(cfg: PathConfig, seed: int = 0) -> Dict[str, Tensor]:
             arr = 0.05 * rs.standard_normal(shape)
         elif name.endswith('tokens') or name.endswith('mask_token'):
             arr = 0.5 * rs.standard_normal(shape)
+        elif name.endswith('relative_position_bias_table'):
+            arr = 0.5 * rs.standard_normal(shape)       # O(1) logits: the bias must matter in the fixtures
         else:
             fan_in = int(np.prod(shape[1:]))
             arr = rs.standard_normal(shape) / math.sqrt(fan_in)

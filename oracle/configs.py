@@ -20,6 +20,11 @@ CONFIGS = {
     'micro_dense': PathConfig(embed_dim=128, depth=2, num_heads=2, image_size=(64, 64), audio_size=(32, 112),
                               fusion_tkns=(4, 3, 2), fusion_layers=(0, 1), fusion_num_heads=2, decoder_dim=64, decoder_depth=2,
                               decoder_heads=2, fusion_arch='dense_mmi'),
+    # Swin decoders: 8 x 8 image grid -> 4 windows, 8 x 12 audio grid -> 6; block 1 is shifted by 2;
+    # 16 window tokens + 9 fusion tokens = 25-row attention sequences at head width 32
+    'micro_swin': PathConfig(embed_dim=128, depth=2, num_heads=2, image_size=(128, 128), audio_size=(128, 192),
+                             fusion_tkns=(4, 3, 2), fusion_layers=(0, 1), fusion_num_heads=2, decoder_dim=64, decoder_depth=2,
+                             decoder_heads=2, decoder_arch='swin'),
     'tiny': PathConfig(embed_dim=192, depth=12, num_heads=3, image_size=(64, 64), audio_size=(128, 128),
                        fusion_tkns=(16, 8, 8), fusion_layers=tuple(range(12)), fusion_mlp_ratio=1.0,
                        fusion_attn_ratio=0.25, fusion_num_heads=3),

@@ -47,7 +47,8 @@ def register_archs():
     vits.vit_tiny = mk(192, 12, 3)
 
 
-ARCH_OF = {'micro': 'vit_micro', 'micro_token': 'vit_micro', 'micro_dense': 'vit_micro', 'tiny': 'vit_tiny', 'base': 'vit_base'}
+ARCH_OF = {'micro': 'vit_micro', 'micro_token': 'vit_micro', 'micro_dense': 'vit_micro', 'micro_swin': 'vit_micro', 'tiny': 'vit_tiny',
+           'base': 'vit_base'}
 
 
 def build_reference(name):
@@ -59,12 +60,15 @@ def build_reference(name):
         fusion_mlp_ratio=cfg.fusion_mlp_ratio, fusion_attn_ratio=cfg.fusion_attn_ratio,
         fusion_num_heads=cfg.fusion_num_heads)
     model = AVMAE(enc, enc.embed_dim,
-                  image_decoder_arch='plain', image_decoder_depth=cfg.decoder_depth,
+                  image_decoder_arch=cfg.decoder_arch, image_decoder_depth=cfg.decoder_depth,
                   image_mask_ratio=cfg.image_mask_ratio, image_norm_loss=cfg.image_norm_loss,
-                  audio_decoder_arch='plain', audio_decoder_depth=cfg.decoder_depth,
+                  audio_decoder_arch=cfg.decoder_arch, audio_decoder_depth=cfg.decoder_depth,
                   audio_mask_ratio=cfg.audio_mask_ratio, audio_norm_loss=cfg.audio_norm_loss,
                   decoder_dim=cfg.decoder_dim, num_heads=cfg.decoder_heads, mlp_ratio=cfg.decoder_mlp_ratio)
     sd = O.closed_form_state(cfg, seed=0)
+    for k, v in model.state_dict().items():         # the reference's own registered buffers (models/swin.py:39, 158) pin the
+        if O.is_buffer(k):                          # oracle's restatement of the window index / shift mask BEFORE they are overwritten
+            assert torch.equal(v.float(), sd[k].float()), k
     model.load_state_dict(sd, strict=True)          # also pins the state-dict contract (names + shapes)
     return cfg, model, sd
 
@@ -242,8 +246,10 @@ def gen_e2e(name, B, seed, keep_preds):
     out['grad_norm_total'] = np.float64(ref_misc.get_grad_norm_(model.parameters()).item())   # util/misc.py:151-163
     # a few full gradients
     fk = 'encoder.fusion_blocks.0.attn.k.weight' if cfg.fusion_arch == 'factorized_mmi' else 'encoder.fusion_blocks.0.attn.kv.weight'
+    extra = (('image_decoder_blocks.1.attn.relative_position_bias_table', 'audio_decoder_blocks.0.attn.relative_position_bias_table',
+              'audio_decoder_blocks.1.attn.qkv.weight') if cfg.decoder_arch == 'swin' else ())
     for n in ('encoder.fusion_tokens', 'image_decoder_mask_token', 'encoder.image.patch_embed.proj.bias',
-              fk, 'encoder.audio.blocks.0.attn.qkv.bias'):
+              fk, 'encoder.audio.blocks.0.attn.qkv.bias') + extra:
         out['grad.' + n] = dict(model.named_parameters())[n].grad.numpy().copy()
     np.savez_compressed(os.path.join(OUT, f'e2e_{name}.npz'), **out)
     print(f'e2e[{name}] loss_image={float(li):.6f} loss_audio={float(la):.6f} gnorm={float(out["grad_norm_total"]):.6f}')
@@ -454,7 +460,8 @@ if __name__ == '__main__':
             'video_micro': lambda: gen_video('video_micro', 2, 31),
             'droppath': gen_droppath,
             'e2e_micro_token': lambda: gen_e2e('micro_token', 3, 23, False),
-            'e2e_micro_dense': lambda: gen_e2e('micro_dense', 3, 24, False)}
+            'e2e_micro_dense': lambda: gen_e2e('micro_dense', 3, 24, False),
+            'e2e_micro_swin': lambda: gen_e2e('micro_swin', 2, 25, True)}
     if a.curve:
         jobs = {'curve': gen_curve}
     for k, f in jobs.items():

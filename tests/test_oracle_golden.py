@@ -147,11 +147,11 @@ def test_patchify_and_loss(golden):
             close(p.grad.numpy(), g[f'loss.{mod}.{norm}.gpred'])
 
 
-@pytest.mark.parametrize('name', ['micro', 'tiny', 'micro_token', 'micro_dense'])
+@pytest.mark.parametrize('name', ['micro', 'tiny', 'micro_token', 'micro_dense', 'micro_swin'])
 def test_end_to_end(golden, name):
     g = golden(f'e2e_{name}')
     cfg = CONFIGS[name]
-    sd = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in O.closed_form_state(cfg, 0).items()}
+    sd = {k: v.clone().requires_grad_(k not in O.FROZEN and not O.is_buffer(k)) for k, v in O.closed_form_state(cfg, 0).items()}
     image, audio, ni, na = O.synthetic_batch(cfg, int(g['B']), seed=int(g['seed']))
     li, la, pi, pa, aux = O.avmae_forward(sd, cfg, image, audio, ni, na)
     close(li.detach().numpy(), g['loss_image'])
