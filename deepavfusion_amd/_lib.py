@@ -30,6 +30,12 @@ SIGNATURES = {
     'dav_attn_fwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _i, _l, _i, _l, _i, _l, _i, _f, _p],
     'dav_attn_bwd': [_p] * 10 + [_i] * 6 + [_l, _i] * 8 + [_f, _p],
     'dav_attn_bwd_part': [_p] * 10 + [_i] * 6 + [_l, _i] * 8 + [_f, _i, _p],
+    'dav_attn_bias_fwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _i, _l, _i, _l, _i, _l, _i, _f, _p, _i, _i, _p],
+    'dav_attn_bias_bwd': [_p] * 10 + [_i] * 6 + [_l, _i] * 8 + [_f, _p, _i, _i, _p, _i, _p],
+    'dav_window_unfold': [_p, _i, _p, _i, _i, _i, _i, _i, _i, _f, _p, _i, _p],
+    'dav_window_fold': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _p],
+    'dav_relpos_bias_build': [_p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p],
+    'dav_relpos_bias_bwd': [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
     'dav_layernorm_fwd': [_p, _l, _i, _p, _l, _i, _i, _i, _p, _p, _f, _p, _p, _p, _p, _p],
     'dav_layernorm_bwd': [_p, _l, _i, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p,
                           _p, _l, _i, _p, _l, _p, _l,
@@ -57,6 +63,8 @@ SIGNATURES = {
     'dav_gemm_tn_f32': [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _p],
     'dav_attn_fwd_f32': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _i, _l, _i, _l, _i, _l, _i, _f, _p],
     'dav_attn_bwd_f32': [_p] * 10 + [_i] * 6 + [_l, _i] * 8 + [_f, _i, _p],
+    'dav_attn_bias_fwd_f32': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _i, _l, _i, _l, _i, _l, _i, _f, _p, _i, _i, _p],
+    'dav_attn_bias_bwd_f32': [_p] * 10 + [_i] * 6 + [_l, _i] * 8 + [_f, _p, _i, _i, _p, _i, _p],
     'dav_patch_gather_f32': [_p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p],
     'dav_rows_gather_f32': [_p, _l, _i, _p, _i, _i, _i, _p, _l, _p],
     'dav_pair_expand_f32': [_p, _p, _i, _i, _i, _i, _p, _p],

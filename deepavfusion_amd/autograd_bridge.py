@@ -321,6 +321,32 @@ def cross_attention(ca, x1, x2):
     return _CrossAttentionFn.apply(ca, c(x1), c(x2), *params)
 
 
+class _SwinBlockFn(torch.autograd.Function):
+    """One SwinTransformerBlock with fusion tokens (models/swin.py:160-209) as a differentiable op: the module-level API
+    of models/swin.py; AVMAE's decoder drives the same engine functions directly."""
+    @staticmethod
+    def forward(ctx, blk, xcat, nF, *params):
+        ctx.set_materialize_grads(False)
+        out, tape = E.swin_block_fwd(blk, xcat, nF)
+        ctx.blk, ctx.tape, ctx.np = blk, tape, len(params)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        with E.deferred_wgrads():
+            dx, _ = E.swin_block_bwd(ctx.blk, ctx.tape, g.contiguous(), None)
+        E.join_wgrad_stream(g.device)
+        return (None, dx, None) + (None,) * ctx.np
+
+
+def swin_block_apply(blk, x, x_fusion):
+    """(x [B, L, C], x_fusion [B, Lf, C]) -> (x, x_fusion) as models/swin.py:160-209 returns them."""
+    nF = x_fusion.shape[1]
+    xcat = torch.cat([x_fusion.to(dtype=F32), x.to(dtype=F32)], dim=1).contiguous()      # the engine's [fusion | tokens] layout
+    out = _SwinBlockFn.apply(blk, xcat, nF, *list(blk.parameters()))
+    return out[:, nF:], out[:, :nF]
+
+
 class _FusionBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, fb, xmm, xv, xa, *params):

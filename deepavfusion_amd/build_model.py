@@ -17,9 +17,9 @@ def build_avmae(cfg):
                        fusion_mlp_ratio=cfg.fusion_mlp_ratio, fusion_attn_ratio=cfg.fusion_attn_ratio,
                        fusion_num_heads=cfg.fusion_num_heads)
     return AVMAE(enc, enc.embed_dim,
-                 image_decoder_arch='plain', image_decoder_depth=cfg.decoder_depth, image_mask_ratio=cfg.image_mask_ratio,
+                 image_decoder_arch=getattr(cfg, 'decoder_arch', 'plain'), image_decoder_depth=cfg.decoder_depth, image_mask_ratio=cfg.image_mask_ratio,
                  image_norm_loss=cfg.image_norm_loss,
-                 audio_decoder_arch='plain', audio_decoder_depth=cfg.decoder_depth, audio_mask_ratio=cfg.audio_mask_ratio,
+                 audio_decoder_arch=getattr(cfg, 'decoder_arch', 'plain'), audio_decoder_depth=cfg.decoder_depth, audio_mask_ratio=cfg.audio_mask_ratio,
                  audio_norm_loss=cfg.audio_norm_loss,
                  decoder_dim=cfg.decoder_dim, num_heads=cfg.decoder_heads, mlp_ratio=cfg.decoder_mlp_ratio)
 

@@ -23,6 +23,7 @@ class PathConfig:
     decoder_depth: int = 8
     decoder_heads: int = 16
     decoder_mlp_ratio: float = 4.0
+    decoder_arch: str = 'plain'                         # 'plain' | 'swin' (models/avmae.py:37, 67; configs/deepavfusion.yaml: plain)
     image_mask_ratio: float = 0.75
     audio_mask_ratio: float = 0.8
     image_norm_loss: bool = True
@@ -72,11 +73,17 @@ CONFIGS = {
                               fusion_layers=(0, 1), fusion_num_heads=2, decoder_dim=64, decoder_depth=2, decoder_heads=2, fusion_arch='token'),
     'micro_dense': PathConfig(embed_dim=128, depth=2, num_heads=2, image_size=(64, 64), audio_size=(32, 112), fusion_tkns=(4, 3, 2),
                               fusion_layers=(0, 1), fusion_num_heads=2, decoder_dim=64, decoder_depth=2, decoder_heads=2, fusion_arch='dense_mmi'),
+    # Swin decoders: 8 x 8 / 8 x 12 token grids -> 4 / 6 windows of 16 tokens + 9 fusion tokens
+    'micro_swin': PathConfig(embed_dim=128, depth=2, num_heads=2, image_size=(128, 128), audio_size=(128, 192), fusion_tkns=(4, 3, 2),
+                             fusion_layers=(0, 1), fusion_num_heads=2, decoder_dim=64, decoder_depth=2, decoder_heads=2, decoder_arch='swin'),
     # BASELINE.json configs[0]: ViT-Tiny, 64x64 image + 2 s audio
     'tiny': PathConfig(embed_dim=192, depth=12, num_heads=3, image_size=(64, 64), audio_size=(128, 128), fusion_num_heads=3),
     # configs[1] (bench workload): ViT-B, README VGGSound recipe (attn_ratio 0.25, mlp_ratio 1.0), 10 s audio
     'base': PathConfig(),
     'base_m75': PathConfig(audio_mask_ratio=0.75),
+    # ViT-B with the Swin decoders: 256 x 256 frames (16 x 16 tokens; 14 x 14 is not a multiple of the window) -> 16 + 20 windows
+    # of 16 tokens + 32 fusion tokens
+    'base_swin': PathConfig(image_size=(256, 256), decoder_arch='swin'),
     'base_token': PathConfig(fusion_arch='token'),
     'base_dense': PathConfig(fusion_arch='dense_mmi'),      # 63 x 49 = 3087 (audio, image) pairs per sample
     # configs[2]: AudioSet-style fusion widths

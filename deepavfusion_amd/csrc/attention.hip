@@ -43,6 +43,11 @@ struct AttnParams {
   long dq_bs, dk_bs, dv_bs;
   int dq_rs, dk_rs, dv_rs;
   int debug;          // DAV_ATTN_DEBUG ablations (timing experiments only): 1 = no tile loop, 2 = no staging
+  // additive score bias (window attention, models/swin.py:66-80): bias[b % bias_nb][h][q][0 .. bias_ld) in LOG2 units (already
+  // multiplied by log2 e), bias_ld = Nk rounded up to 32 with zero padding; dS (backward, optional): gradient of the biased
+  // logits [B][H][Nq][bias_ld] in natural units, what the relative-position table's gradient is reduced from
+  const float* bias; int bias_nb, bias_ld;
+  float* dS;
 };
 
 // 16-byte-slot XOR swizzle of a row-major LDS tile, chosen so that BOTH access patterns are conflict-free:
@@ -198,6 +203,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, const int bh,
 
   const int nqt = p.debug == 1 ? 0 : (p.Nq + 15) >> 4;
   const float sl2 = p.scale * 1.44269504088896341f;
+  const float mul = p.bias ? 1.f : sl2;        // with a bias the scores are scaled when it is added
   uint32_t ka0[KS], va0[VC];           // this lane's fragment addresses at key row 0
 #pragma unroll
   for (int kk = 0; kk < KS; ++kk) ka0[kk] = lds_addr(Ks) + frag_off<KRB>(fr, kk, g);
@@ -254,6 +260,19 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, const int bh,
             for (int kk = 0; kk < KS; ++kk)
               st[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][kk], qf[u][kk], st[u][t], 0, 0, 0);
           }
+        if (p.bias) {                    // logits = scale * q.k + bias, all in log2 units from here on (mul == 1)
+#pragma unroll
+          for (int u = 0; u < QT; ++u) {
+            const int q = (qt + u) * 16 + fr;
+            const float* br = p.bias + (((long)(b % p.bias_nb) * p.H + h) * p.Nq + (q < p.Nq ? q : p.Nq - 1)) * p.bias_ld + k0 + 4 * g;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const float4 bv = *reinterpret_cast<const float4*>(br + t * 16);
+              st[u][t][0] = __builtin_fmaf(st[u][t][0], sl2, bv.x); st[u][t][1] = __builtin_fmaf(st[u][t][1], sl2, bv.y);
+              st[u][t][2] = __builtin_fmaf(st[u][t][2], sl2, bv.z); st[u][t][3] = __builtin_fmaf(st[u][t][3], sl2, bv.w);
+            }
+          }
+        }
         bf16x8 vf[VC];                   // issued here so that the softmax arithmetic covers their LDS latency
 #pragma unroll
         for (int c = 0; c < VC; ++c) vf[c] = lds_frag_tr<VRB>(va[c]);
@@ -272,7 +291,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, const int bh,
         for (int u = 0; u < QT; ++u) {
           float mx = fmaxf(fmaxf(fmaxf(st[u][0][0], st[u][0][1]), fmaxf(st[u][0][2], st[u][0][3])),
                            fmaxf(fmaxf(st[u][1][0], st[u][1][1]), fmaxf(st[u][1][2], st[u][1][3])));
-          mx = rows_max(mx) * sl2;       // log2 domain (scale * log2(e) > 0 commutes with max)
+          mx = rows_max(mx) * mul;       // log2 domain (scale * log2(e) > 0 commutes with max)
           // deferred rescale: keep the reference max while no row's tile max exceeds it by more than 2^8 — the
           // probabilities then stay <= 256 (bf16 keeps its relative precision), O and the row sum need no multiply
           if (!__all(mx - m[u] <= 8.f)) {
@@ -290,7 +309,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, const int bh,
           for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              st[u][t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[u][t][r], sl2, -m[u]));    // v_exp_f32 is 2^x
+              st[u][t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[u][t][r], mul, -m[u]));    // v_exp_f32 is 2^x
               ps += st[u][t][r];
             }
           lsum[u] += ps;
@@ -428,12 +447,19 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
             dp[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[kk], dof[u][kk], dp[u][t], 0, 0, 0);
         }
 #pragma unroll
-        for (int u = 0; u < QT; ++u)
+        for (int u = 0; u < QT; ++u) {
+          float4 bv = float4{0.f, 0.f, 0.f, 0.f};
+          const int q = (qt + u) * 16 + fr;
+          const long srow = (((long)b * p.H + h) * p.Nq + (q < p.Nq ? q : p.Nq - 1)) * p.bias_ld + k0 + t * 16 + 4 * g;
+          if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + srow - ((long)(b - b % p.bias_nb) * p.H * p.Nq) * p.bias_ld);
+          const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(st[u][t][r], sl2, -lse2[u]));
+            const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(st[u][t][r], sl2, bb[r] - lse2[u]));
             st[u][t][r] = pr * (dp[u][t][r] - delta[u]);     // dS^T
           }
+          if (p.dS && qok[u]) *reinterpret_cast<float4*>(p.dS + srow) = float4{st[u][t][0], st[u][t][1], st[u][t][2], st[u][t][3]};
+        }
       }
       bf16x8 dsf[QT];
 #pragma unroll
@@ -568,13 +594,23 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
             dp[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof[kk], vf[u][kk], dp[u][t], 0, 0, 0);
         }
 #pragma unroll
-        for (int u = 0; u < KT; ++u)
+        for (int u = 0; u < KT; ++u) {
+          float bb[4] = {0.f, 0.f, 0.f, 0.f};
+          if (p.bias) {                                      // bias[q][this lane's key]: four query rows, one column
+            const int key = (kt + u) * 16 + fr, kc = key < p.Nk ? key : p.Nk - 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int qg = qa + t * 16 + 4 * g + r;        // row in the head (chunk offset included)
+              bb[r] = qg < p.Nq ? p.bias[(((long)(b % p.bias_nb) * p.H + h) * p.Nq + qg) * p.bias_ld + kc] : 0.f;
+            }
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][t][r], sl2, -lse4[r]));
+            const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][t][r], sl2, bb[r] - lse4[r]));
             s[u][t][r] = pr;                                 // P[q][key]
             dp[u][t][r] = pr * (dp[u][t][r] - del4[r]);      // dS[q][key]
           }
+        }
       }
       bf16x8 pf[KT], dsf[KT];
 #pragma unroll
@@ -822,21 +858,37 @@ bool strides_ok(const AttnParams& p, bool bwd) {
 
 }  // namespace
 
-extern "C" int dav_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int Nq,
-                            int Nk, int dqk, int dv, long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs,
-                            long o_bs, int o_rs, float scale, hipStream_t stream) {
+static bool bias_ok(const float* bias, int bias_nb, int bias_ld, const float* dS, int B, int Nk) {
+  if (!bias) return dS == nullptr;
+  const int Nkp = (Nk + 31) & ~31;
+  return bias_nb > 0 && B % bias_nb == 0 && bias_ld >= Nkp && !(bias_ld & 3) && !(((uintptr_t)bias | (uintptr_t)dS) & 15);
+}
+
+extern "C" int dav_attn_bias_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int Nq,
+                                 int Nk, int dqk, int dv, long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs,
+                                 long o_bs, int o_rs, float scale, const float* bias, int bias_nb, int bias_ld,
+                                 hipStream_t stream) {
   if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return DAV_ERR_SHAPE;
+  if (!bias_ok(bias, bias_nb, bias_ld, nullptr, B, Nk)) return DAV_ERR_SHAPE;
   AttnParams p = {};
   p.debug = attn_debug();
   p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (bf16_t*)O; p.LSE = LSE;
   p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.q_bs = q_bs; p.k_bs = k_bs; p.v_bs = v_bs; p.o_bs = o_bs;
   p.q_rs = q_rs; p.k_rs = k_rs; p.v_rs = v_rs; p.o_rs = o_rs; p.scale = scale;
+  p.bias = bias; p.bias_nb = bias_nb; p.bias_ld = bias_ld;
   if (!strides_ok(p, false)) return DAV_ERR_ALIGN;
   if (dqk == 64 && dv == 64) return launch_fwd<64, 64>(p, stream);
   if (dqk == 32 && dv == 32) return launch_fwd<32, 32>(p, stream);
   if (dqk == 16 && dv == 64) return launch_fwd<16, 64>(p, stream);
   if (dqk == 16 && dv == 16) return launch_fwd<16, 16>(p, stream);
   return DAV_ERR_SHAPE;
+}
+
+extern "C" int dav_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int Nq,
+                            int Nk, int dqk, int dv, long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs,
+                            long o_bs, int o_rs, float scale, hipStream_t stream) {
+  return dav_attn_bias_fwd(Q, K, V, O, LSE, B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, scale,
+                           nullptr, 0, 0, stream);
 }
 
 extern "C" int dav_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
@@ -848,12 +900,14 @@ extern "C" int dav_attn_bwd(const void* Q, const void* K, const void* V, const v
                            o_bs, o_rs, do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, scale, 3, stream);
 }
 
-extern "C" int dav_attn_bwd_part(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
+extern "C" int dav_attn_bias_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
                                  float* Delta, void* dQ, void* dK, void* dV, int B, int H, int Nq, int Nk, int dqk, int dv,
                                  long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs,
                                  long do_bs, int do_rs, long dq_bs, int dq_rs, long dk_bs, int dk_rs, long dv_bs, int dv_rs,
-                                 float scale, int part, hipStream_t stream) {
+                                 float scale, const float* bias, int bias_nb, int bias_ld, float* dS, int part,
+                                 hipStream_t stream) {
   if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0 || part < 1 || part > 3) return DAV_ERR_SHAPE;
+  if (!bias_ok(bias, bias_nb, bias_ld, dS, B, Nk)) return DAV_ERR_SHAPE;
   AttnParams p = {};
   p.debug = attn_debug();
   p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.Of = (const bf16_t*)O; p.O = nullptr;
@@ -862,6 +916,7 @@ extern "C" int dav_attn_bwd_part(const void* Q, const void* K, const void* V, co
   p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.q_bs = q_bs; p.k_bs = k_bs; p.v_bs = v_bs; p.o_bs = o_bs;
   p.q_rs = q_rs; p.k_rs = k_rs; p.v_rs = v_rs; p.o_rs = o_rs; p.do_bs = do_bs; p.do_rs = do_rs;
   p.dq_bs = dq_bs; p.dk_bs = dk_bs; p.dv_bs = dv_bs; p.dq_rs = dq_rs; p.dk_rs = dk_rs; p.dv_rs = dv_rs; p.scale = scale;
+  p.bias = bias; p.bias_nb = bias_nb; p.bias_ld = bias_ld; p.dS = dS;
   p.O = (bf16_t*)O;   // only for the alignment check
   if (!strides_ok(p, true)) return DAV_ERR_ALIGN;
   if (dqk == 64 && dv == 64) return launch_bwd<64, 64>(p, stream, part);
@@ -869,4 +924,14 @@ extern "C" int dav_attn_bwd_part(const void* Q, const void* K, const void* V, co
   if (dqk == 16 && dv == 64) return launch_bwd<16, 64>(p, stream, part);
   if (dqk == 16 && dv == 16) return launch_bwd<16, 16>(p, stream, part);
   return DAV_ERR_SHAPE;
+}
+
+extern "C" int dav_attn_bwd_part(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
+                                 float* Delta, void* dQ, void* dK, void* dV, int B, int H, int Nq, int Nk, int dqk, int dv,
+                                 long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs,
+                                 long do_bs, int do_rs, long dq_bs, int dq_rs, long dk_bs, int dk_rs, long dv_bs, int dv_rs,
+                                 float scale, int part, hipStream_t stream) {
+  return dav_attn_bias_bwd(Q, K, V, O, dO, LSE, Delta, dQ, dK, dV, B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs,
+                           o_bs, o_rs, do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, scale, nullptr, 0, 0, nullptr,
+                           part, stream);
 }

@@ -1067,8 +1067,12 @@ def decoder_fwd(dec, x_b, xf_b, ids_restore32, B, nk, nF):
     lin_fwd(dec.embed, xf_b, B * nF, out=x, c_rowmap=(nF, nF + L, 0))                        # embed is shared (:158)
     ops.unshuffle_fwd(emb, dec.mask_token, dec.pos_embed, ids_restore32, B, L, nk, Dd, x, (nF + L) * Dd, nF)
     tapes = []
+    swin = getattr(dec, 'arch', 'plain') == 'swin'
     for blk in dec.blocks:
-        x, bt = block_fwd(blk, x, None, dec.heads, blk.norm1.eps)
+        if swin:
+            x, bt = swin_block_fwd(blk, x, nF)
+        else:
+            x, bt = block_fwd(blk, x, None, dec.heads, blk.norm1.eps)
         tapes.append(bt)
     # decoder_norm + pred on the patch rows only (x[:, nF:]) — the LN reads them through the batch stride
     D_ = Dd
@@ -1096,8 +1100,12 @@ def decoder_bwd(dec, t, dpred_b, ids_keep32, B):
                       g.view(-1)[nF * Dd:], (nF + L) * Dd, 0, None, 0, gb.view(-1)[nF * Dd:], (nF + L) * Dd,
                       None, 0, 0, None, 0, None, 0, gbuf(dec.norm.weight), gbuf(dec.norm.bias))
     _ready(dec.norm.weight, dec.norm.bias)
+    swin = getattr(dec, 'arch', 'plain') == 'swin'
     for blk, bt in zip(reversed(list(dec.blocks)), reversed(t['tapes'])):
-        g, gb, _ = block_bwd(blk, bt, g, gb)
+        if swin:
+            g, gb = swin_block_bwd(blk, bt, g, gb)
+        else:
+            g, gb, _ = block_bwd(blk, bt, g, gb)
     d_emb = _e((B * nk, Dd), BF16, dev)
     d_embf = _e((B * nF, Dd), BF16, dev)
     ops.rows_gather_cast(g, (nF + L) * Dd, nF, ids_keep32, B, nk, Dd, d_emb)
@@ -1107,6 +1115,86 @@ def decoder_bwd(dec, t, dpred_b, ids_keep32, B):
     dx_b = lin_bwd(dec.embed, d_emb, t['x_b'], B * nk, final=False)
     dxf_b = lin_bwd(dec.embed, d_embf, t['xf_b'], B * nF)
     return dx_b, dxf_b
+
+
+# ------------------------------------------------------------------------------------------------
+# Swin decoder block (models/swin.py:160-209 with x_fusion given, models/avmae.py:174-176)
+# ------------------------------------------------------------------------------------------------
+LOG2E = 1.4426950408889634
+
+
+def swin_block_fwd(blk, x, nF):
+    """x fp32 [B, nF + L, D] = [fusion rows | token rows] (the decoder's layout).  Every window attends over its A tokens
+    and ALL nF fusion tokens with the relative-position bias (+ shift mask) on the A x A corner; the fusion rows of the
+    result are the mean over the windows.  Returns (x_out fp32 [B, nF + L, D], tape)."""
+    B, R, D = x.shape
+    L, dev = R - nF, x.device
+    heads, nW = blk.num_heads, blk.num_windows
+    A = blk.attn.window_area
+    N, hd, M, Mw = A + nF, D // heads, B * R, B * nW * (A + nF)
+    h1, _, st1 = ln_fwd(blk.norm1, None, x, B)
+    seq = _e((Mw, D), BF16, dev)
+    ops.window_unfold(h1, blk.rows32, B, nW, A, nF, L, D, 1.0, seq)                        # roll + window_partition + cat (:172-185)
+    qkv = lin_fwd(blk.attn.qkv, seq, Mw, out_bf16=True)                                    # [Mw, 3D]
+    nb = nW if blk.attn_mask is not None else 1
+    ld = (N + 31) // 32 * 32
+    bias = _e((nb, heads, N, ld), F32, dev)                                                # rebuilt per step: the table is a parameter
+    ops.relpos_bias_build(blk.attn.relative_position_bias_table, blk.index32, blk.attn_mask, nb, heads, A, N, ld,
+                          1.0 if PRECISION == 'fp32' else LOG2E, bias)
+    o = _e((Mw, D), BF16, dev)
+    lse = _e((B * nW, heads, N), F32, dev)
+    ops.hold(qkv)
+    es = qkv.element_size()
+    ops.attn_bias_fwd(qkv.data_ptr(), qkv.data_ptr() + es * D, qkv.data_ptr() + es * 2 * D, o, lse, B * nW, heads, N, N, hd, hd,
+                      N * 3 * D, 3 * D, N * 3 * D, 3 * D, N * 3 * D, 3 * D, N * D, D, blk.attn.scale, bias, nb, ld)
+    t = lin_fwd(blk.attn.proj, o, Mw)                                                      # fp32 [Mw, D]
+    x1 = _e((B, R, D), F32, dev)
+    ops.window_fold(t, blk.inv32, x, B, nW, A, nF, L, D, 1.0 / nW, x1)                     # window_reverse + roll back + mean (:191-201)
+    h2, _, st2 = ln_fwd(blk.norm2, None, x1, B)
+    Hd = blk.mlp.fc1.weight.shape[0]
+    z = _e((M, Hd), BF16, dev)
+    u = lin_fwd(blk.mlp.fc1, h2, M, act=1, out_bf16=True, C2=z, c2_mode=4)
+    x2 = _res_add(blk.mlp.fc2, u, M, x1, B, R, D, None).view(B, R, D)
+    tape = dict(x=x, nF=nF, h1=h1, st1=st1, seq=seq, qkv=qkv, bias=bias, nb=nb, ld=ld, o=o, lse=lse, x1=x1, h2=h2, st2=st2, z=z, u=u)
+    return x2, tape
+
+
+def swin_block_bwd(blk, t, g2, g2b=None):
+    """g2 fp32 [B, nF + L, D] -> (dx fp32, dx bf16 twin)."""
+    x, nF = t['x'], t['nF']
+    B, R, D = x.shape
+    L, dev = R - nF, x.device
+    heads, nW = blk.num_heads, blk.num_windows
+    A = blk.attn.window_area
+    N, hd, M, Mw = A + nF, D // heads, B * R, B * nW * (A + nF)
+    if g2b is None:
+        g2b = to_bf16(g2.view(M, D))
+    dz = lin_bwd(blk.mlp.fc2, g2b, t['u'], M, gelu_aux=t['z'])
+    dh2 = lin_bwd(blk.mlp.fc1, dz, t['h2'], M)
+    g1 = _e((B, R, D), F32, dev)
+    ln_bwd(blk.norm2, None, t['x1'], B, t['st2'], dy_bf16=dh2, dx1=g1, res1=g2)
+    dt = _e((Mw, D), BF16, dev)
+    ops.window_unfold(g1, blk.rows32, B, nW, A, nF, L, D, 1.0 / nW, dt)                    # backward of the fold (mean -> 1 / nW)
+    do = lin_bwd(blk.attn.proj, dt, t['o'], Mw)
+    dqkv = _e((Mw, 3 * D), BF16, dev)
+    dS = _e((B * nW, heads, N, t['ld']), F32, dev)
+    qkv = t['qkv']
+    ops.hold(qkv, dqkv)
+    es = qkv.element_size()
+    ops.attn_bias_bwd(qkv.data_ptr(), qkv.data_ptr() + es * D, qkv.data_ptr() + es * 2 * D, t['o'], do, t['lse'],
+                      torch.empty_like(t['lse']), dqkv.data_ptr(), dqkv.data_ptr() + es * D, dqkv.data_ptr() + es * 2 * D,
+                      B * nW, heads, N, N, hd, hd, N * 3 * D, 3 * D, N * 3 * D, 3 * D, N * 3 * D, 3 * D, N * D, D, N * D, D,
+                      N * 3 * D, 3 * D, N * 3 * D, 3 * D, N * 3 * D, 3 * D, blk.attn.scale, t['bias'], t['nb'], t['ld'], dS)
+    table = blk.attn.relative_position_bias_table
+    ops.relpos_bias_bwd(dS, blk.index32, B * nW, heads, A, N, t['ld'], table.shape[0], gbuf(table))
+    _ready(table)
+    dseq = lin_bwd(blk.attn.qkv, dqkv, t['seq'], Mw, dx_bf16=False)                        # fp32 [Mw, D]
+    dh1 = _e((M, D), F32, dev)
+    ops.window_fold(dseq, blk.inv32, None, B, nW, A, nF, L, D, 1.0, dh1)                   # backward of the unfold (repeat -> sum)
+    dx = _e((B, R, D), F32, dev)
+    dxb = _e((M, D), BF16, dev)
+    ln_bwd(blk.norm1, None, x, B, t['st1'], dy_f32=dh1, dx1=dx, res1=g1, dx1_bf16=dxb)
+    return dx, dxb
 
 
 # ------------------------------------------------------------------------------------------------

@@ -5,18 +5,20 @@ import torch
 from torch import nn
 
 from ..util.pos_embed import get_2d_sincos_pos_embed
+from .swin import SwinTransformerBlock
 from .vits import Block, init_linear_and_norm
 
 
 class AVMAE(nn.Module):
-    """Same ctor / attribute names / state-dict keys as models/avmae.py:9-90 (decoder_arch 'plain')."""
+    """Same ctor / attribute names / state-dict keys as models/avmae.py:9-90 (decoder_arch 'plain' or 'swin')."""
     def __init__(self, encoder, encoder_dim,
                  image_decoder_arch='plain', image_decoder_depth=8, image_mask_ratio=0.75, image_norm_loss=False,
                  audio_decoder_arch='plain', audio_decoder_depth=8, audio_mask_ratio=0.8, audio_norm_loss=False,
                  decoder_dim=512, num_heads=16, mlp_ratio=4., norm_layer=nn.LayerNorm):
         super().__init__()
-        if image_decoder_arch != 'plain' or audio_decoder_arch != 'plain':
-            raise NotImplementedError("only decoder_arch='plain' (the default in configs/deepavfusion.yaml) is on the gfx950 path")
+        for a in (image_decoder_arch, audio_decoder_arch):
+            if a not in ('plain', 'swin'):
+                raise ValueError(f"decoder_arch {a!r}: 'plain' | 'swin' (models/avmae.py:37, 67)")
         self.image_mask_ratio, self.image_norm_loss = image_mask_ratio, image_norm_loss
         self.audio_mask_ratio, self.audio_norm_loss = audio_mask_ratio, audio_norm_loss
         self.decoder_dim, self.decoder_heads = decoder_dim, num_heads
@@ -24,14 +26,19 @@ class AVMAE(nn.Module):
         self.encoder = encoder
         self.image_gs, self.audio_gs = encoder.image.patch_embed.grid_size, encoder.audio.patch_embed.grid_size
         self.image_ps, self.audio_ps = encoder.image.patch_embed.patch_size, encoder.audio.patch_embed.patch_size
-        for mod, gs, ps, cin, depth in (('audio', self.audio_gs, self.audio_ps, 1, audio_decoder_depth),
-                                        ('image', self.image_gs, self.image_ps, 3, image_decoder_depth)):
+        for mod, gs, ps, cin, depth, arch in (('audio', self.audio_gs, self.audio_ps, 1, audio_decoder_depth, audio_decoder_arch),
+                                              ('image', self.image_gs, self.image_ps, 3, image_decoder_depth, image_decoder_arch)):
             setattr(self, f'{mod}_decoder_embed', nn.Linear(encoder_dim, decoder_dim, bias=True))
             setattr(self, f'{mod}_decoder_mask_token', nn.Parameter(torch.zeros(1, 1, decoder_dim)))
             # trainable although initialised from the sin-cos table (no requires_grad=False in models/avmae.py:34,64)
             setattr(self, f'{mod}_decoder_pos_embed', nn.Parameter(torch.zeros(1, gs[0] * gs[1], decoder_dim)))
-            setattr(self, f'{mod}_decoder_blocks', nn.ModuleList([
-                Block(decoder_dim, num_heads, mlp_ratio, qkv_bias=True, norm_layer=norm_layer) for _ in range(depth)]))
+            if arch == 'swin':          # models/avmae.py:37-51, 67-81: window 4, odd blocks shifted by 2
+                blocks = [SwinTransformerBlock(dim=decoder_dim, input_resolution=gs, window_size=4, shift_size=(index % 2) * 2,
+                                               num_heads=num_heads, mlp_ratio=mlp_ratio, drop=0.0, attn_drop=0.0, drop_path=0.0,
+                                               norm_layer=norm_layer) for index in range(depth)]
+            else:
+                blocks = [Block(decoder_dim, num_heads, mlp_ratio, qkv_bias=True, norm_layer=norm_layer) for _ in range(depth)]
+            setattr(self, f'{mod}_decoder_blocks', nn.ModuleList(blocks))
             setattr(self, f'{mod}_decoder_norm', norm_layer(decoder_dim))
             setattr(self, f'{mod}_decoder_pred', nn.Linear(decoder_dim, ps[0] * ps[1] * cin, bias=True))
         self.initialize_weights()
@@ -48,7 +55,8 @@ class AVMAE(nn.Module):
     def decoder(self, modality):
         g = lambda s: getattr(self, f'{modality}_decoder_{s}')
         return types.SimpleNamespace(embed=g('embed'), mask_token=g('mask_token'), pos_embed=g('pos_embed'), blocks=g('blocks'),
-                                     norm=g('norm'), pred=g('pred'), heads=self.decoder_heads)
+                                     norm=g('norm'), pred=g('pred'), heads=self.decoder_heads,
+                                     arch=getattr(self, f'{modality}_decoder_arch'))
 
     def random_masking(self, N, L, mask_ratio, device, noise=None):
         """models/avmae.py:120-142 -> (ids_keep, mask, ids_restore); ``noise`` may be injected for tests."""

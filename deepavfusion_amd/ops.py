@@ -184,6 +184,48 @@ def attn_fwd(q_ptr, k_ptr, v_ptr, O, LSE, B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_b
                                 v_bs, v_rs, o_bs, o_rs, float(scale), _stream()), 'dav_attn_fwd')
 
 
+def attn_bias_fwd(q_ptr, k_ptr, v_ptr, O, LSE, B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, scale,
+                  bias, bias_nb, bias_ld):
+    """attn_fwd with an additive logit bias [bias_nb, H, Nq, bias_ld] (bf16 path: log2 units; fp32 path: natural units)."""
+    lib = _lib.load()
+    fn, name = (lib.dav_attn_bias_fwd_f32, 'dav_attn_bias_fwd_f32') if O.dtype == F32 else (lib.dav_attn_bias_fwd, 'dav_attn_bias_fwd')
+    _lib.check(fn(q_ptr, k_ptr, v_ptr, _ptr(O), _ptr(LSE), B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs,
+                  float(scale), _ptr(bias), bias_nb, bias_ld, _stream()), name)
+
+
+def attn_bias_bwd(q_ptr, k_ptr, v_ptr, O, dO, LSE, Delta, dq_ptr, dk_ptr, dv_ptr, B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs,
+                  v_bs, v_rs, o_bs, o_rs, do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, scale, bias, bias_nb, bias_ld,
+                  dS, part=3):
+    """attn_bwd with the bias of the forward; dS [B, H, Nq, bias_ld] fp32 receives the gradient of the biased logits."""
+    lib = _lib.load()
+    fn, name = (lib.dav_attn_bias_bwd_f32, 'dav_attn_bias_bwd_f32') if O.dtype == F32 else (lib.dav_attn_bias_bwd, 'dav_attn_bias_bwd')
+    _lib.check(fn(q_ptr, k_ptr, v_ptr, _ptr(O), _ptr(dO), _ptr(LSE), _ptr(Delta), dq_ptr, dk_ptr, dv_ptr, B, H, Nq, Nk, dqk, dv,
+                  q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs,
+                  float(scale), _ptr(bias), bias_nb, bias_ld, _ptr(dS), part, _stream()), name)
+
+
+def window_unfold(src, rows32, B, nW, A, nF, L, Cc, fusion_scale, out):
+    """[B, nF + L, C] rows -> [B * nW, A + nF, C] window sequences (see dav_window_unfold)."""
+    _lib.check(_lib.load().dav_window_unfold(_ptr(src), int(src.dtype == BF16), _ptr(rows32), B, nW, A, nF, L, Cc, float(fusion_scale),
+                                             _ptr(out), int(out.dtype == BF16), _stream()), 'dav_window_unfold')
+
+
+def window_fold(t, inv32, res, B, nW, A, nF, L, Cc, fusion_scale, out):
+    """[B * nW, A + nF, C] fp32 sequences (+ res) -> [B, nF + L, C] fp32 rows (see dav_window_fold)."""
+    _lib.check(_lib.load().dav_window_fold(_ptr(t), _ptr(inv32), _ptr(res), B, nW, A, nF, L, Cc, float(fusion_scale), _ptr(out),
+                                           _stream()), 'dav_window_fold')
+
+
+def relpos_bias_build(table, index32, mask, nb, H, A, N, ld, mul, out):
+    _lib.check(_lib.load().dav_relpos_bias_build(_ptr(table), _ptr(index32), _ptr(mask), nb, H, A, N, ld, float(mul), _ptr(out),
+                                                 _stream()), 'dav_relpos_bias_build')
+
+
+def relpos_bias_bwd(dS, index32, Bw, H, A, N, ld, T, dtable):
+    _lib.check(_lib.load().dav_relpos_bias_bwd(_ptr(dS), _ptr(index32), Bw, H, A, N, ld, T, _ptr(dtable), _stream()),
+               'dav_relpos_bias_bwd')
+
+
 def attn_bwd(q_ptr, k_ptr, v_ptr, O, dO, LSE, Delta, dq_ptr, dk_ptr, dv_ptr, B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs,
              v_bs, v_rs, o_bs, o_rs, do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, scale, part=3):
     """part 1: dQ (+ Delta) kernel only, 2: dK/dV kernel only (after part 1), 3: both."""

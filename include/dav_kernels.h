@@ -112,6 +112,40 @@ int dav_attn_bwd_part(const void* Q, const void* K, const void* V, const void* O
                  int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, long do_bs, int do_rs, long dq_bs, int dq_rs, long dk_bs,
                  int dk_rs, long dv_bs, int dv_rs, float scale, int part, hipStream_t stream);
 
+/* Window attention of the Swin decoder blocks (models/swin.py:55-87; decoder_arch == 'swin', models/avmae.py:37-51): the same
+ * kernels with an additive logit bias.  bias [bias_nb][H][Nq][bias_ld] fp32 in LOG2 units (natural value x log2 e), zero
+ * padded to bias_ld >= Nk rounded up to 32; batch element b uses table b % bias_nb (the shift mask differs per window,
+ * :75-78).  Backward: dS [B][H][Nq][bias_ld] (optional) receives the gradient of the biased logits in natural units — what
+ * dav_relpos_bias_bwd reduces into the relative-position table's gradient. */
+int dav_attn_bias_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int Nq, int Nk, int dqk,
+                      int dv, long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, float scale,
+                      const float* bias, int bias_nb, int bias_ld, hipStream_t stream);
+int dav_attn_bias_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, float* Delta,
+                      void* dQ, void* dK, void* dV, int B, int H, int Nq, int Nk, int dqk, int dv, long q_bs, int q_rs, long k_bs,
+                      int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, long do_bs, int do_rs, long dq_bs, int dq_rs, long dk_bs,
+                      int dk_rs, long dv_bs, int dv_rs, float scale, const float* bias, int bias_nb, int bias_ld, float* dS,
+                      int part, hipStream_t stream);
+
+/* ---- Swin decoder data movers (csrc/swin.hip) --------------------------------------------- */
+/* A decoder activation is [B][nF fusion rows | L = nW * A token rows][C]; a window sequence is [A window tokens | nF fusion
+ * tokens], B * nW of them.  rows[w * A + i] = token (0-based, within the L token rows) at slot i of window w after the cyclic
+ * shift (torch.roll + timm window_partition, models/swin.py:172-179); inv = its inverse permutation.
+ * dav_window_unfold: sequences <- rows (the fusion rows repeated per window and scaled by fusion_scale; models/swin.py:183-185;
+ *   with fusion_scale = 1 / nW also the backward of the fold's mean).  src fp32 or bf16, out bf16 or fp32.
+ * dav_window_fold: rows <- sequences (+ res): token rows through inv (window_reverse + roll back, :191-197), fusion rows =
+ *   fusion_scale x the sum over the windows (1 / nW: the mean of :199; 1: the backward of the unfold's repeat). */
+int dav_window_unfold(const void* src, int src_is_bf16, const int* rows, int B, int nW, int A, int nF, int L, int C,
+                      float fusion_scale, void* out, int out_is_bf16, hipStream_t stream);
+int dav_window_fold(const float* t, const int* inv, const float* res, int B, int nW, int A, int nF, int L, int C,
+                    float fusion_scale, float* out, hipStream_t stream);
+/* out[w][h][q][k] = mul * (table[index[q * A + k]][h] + mask[w][q][k]) for q, k < A, 0 elsewhere ([nb][H][N][ld]; mask NULL
+ * for unshifted blocks, then nb = 1): models/swin.py:49-53 + :66-78 (the reference pads both with zeros to the N = A + nF
+ * sequence).  dav_relpos_bias_bwd: dtable[e][h] += sum over the Bw sequences and the (q, k) with index == e of dS. */
+int dav_relpos_bias_build(const float* table, const int* index, const float* mask, int nb, int H, int A, int N, int ld, float mul,
+                          float* out, hipStream_t stream);
+int dav_relpos_bias_bwd(const float* dS, const int* index, int Bw, int H, int A, int N, int ld, int T, float* dtable,
+                        hipStream_t stream);
+
 /* ---- LayerNorm ---------------------------------------------------------------------------- */
 /* nn.LayerNorm over D on rows taken from two fp32 sources per batch element (r0 rows of x0, then r1
  * rows of x1; r1 may be 0): folds torch.cat((x_fusion, x_mod), 1) of models/deepavfusion.py:104-105
@@ -221,6 +255,15 @@ int dav_attn_bwd_f32(const float* Q, const float* K, const float* V, const float
                      float* Delta, float* dQ, float* dK, float* dV, int B, int H, int Nq, int Nk, int dqk, int dv, long q_bs,
                      int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, long do_bs, int do_rs, long dq_bs,
                      int dq_rs, long dk_bs, int dk_rs, long dv_bs, int dv_rs, float scale, int part, hipStream_t stream);
+/* fp32 twins of dav_attn_bias_fwd / dav_attn_bias_bwd; bias in NATURAL units here, bias_ld >= Nk */
+int dav_attn_bias_fwd_f32(const float* Q, const float* K, const float* V, float* O, float* LSE, int B, int H, int Nq, int Nk,
+                          int dqk, int dv, long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs,
+                          float scale, const float* bias, int bias_nb, int bias_ld, hipStream_t stream);
+int dav_attn_bias_bwd_f32(const float* Q, const float* K, const float* V, const float* O, const float* dO, const float* LSE,
+                          float* Delta, float* dQ, float* dK, float* dV, int B, int H, int Nq, int Nk, int dqk, int dv, long q_bs,
+                          int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, long do_bs, int do_rs,
+                          long dq_bs, int dq_rs, long dk_bs, int dk_rs, long dv_bs, int dv_rs, float scale, const float* bias,
+                          int bias_nb, int bias_ld, float* dS, int part, hipStream_t stream);
 int dav_patch_gather_f32(const float* img, int B, int C, int T, int H, int W, int pt, const int* ids_keep32, int nk, float* A,
                          hipStream_t stream);
 int dav_rows_gather_f32(const float* x, long x_bs, int row_off, const int* ids32, int B, int n, int D, float* out, long out_bs,

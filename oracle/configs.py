@@ -30,6 +30,7 @@ CONFIGS = {
                        fusion_attn_ratio=0.25, fusion_num_heads=3),
     'base': PathConfig(),
     'base_m75': PathConfig(audio_mask_ratio=0.75),
+    'base_swin': PathConfig(image_size=(256, 256), decoder_arch='swin'),      # 16 x 16 image tokens: a multiple of the 4 x 4 window
     'base_token': PathConfig(fusion_arch='token'),
     'base_dense': PathConfig(fusion_arch='dense_mmi'),      # 63 x 49 = 3087 (audio, image) pairs per sample
     'base_as': PathConfig(fusion_mlp_ratio=4.0, fusion_attn_ratio=1.0),

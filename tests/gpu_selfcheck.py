@@ -250,6 +250,85 @@ def attention():
 
 
 @check
+def window_attention():
+    """Swin decoder kernels (models/swin.py): attention with the relative-position bias + shift mask on the A x A corner of
+    [A window tokens | nF fusion tokens] sequences (bias table per window, b % nb), its dS output and the table gradient
+    reduced from it, and the unfold / fold row movers — against plain torch."""
+    LOG2E = 1.4426950408889634
+    for (B, nW, H, A, nF, d, masked) in [(2, 4, 2, 16, 9, 32, True), (3, 6, 2, 16, 9, 32, False), (2, 20, 16, 16, 32, 32, True),
+                                          (1, 1, 2, 16, 3, 32, False), (2, 4, 2, 16, 16, 64, True)]:
+        N, D = A + nF, H * d
+        ld = (N + 31) // 32 * 32
+        win = int(A ** 0.5)
+        T = (2 * win - 1) ** 2
+        table = rnd(T, H, seed=71, scale=0.7)
+        coords = torch.stack(torch.meshgrid(torch.arange(win), torch.arange(win), indexing='ij')).flatten(1)
+        relc = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0) + (win - 1)
+        index = (relc[..., 0] * (2 * win - 1) + relc[..., 1]).to(dev)
+        index32 = index.reshape(-1).to(torch.int32)
+        mask = None
+        if masked:
+            mask = torch.where(rnd(nW, A, A, seed=72) > 0.3, torch.full((nW, A, A), -100.0, device=dev), torch.zeros(nW, A, A, device=dev))
+            mask[:, torch.arange(A), torch.arange(A)] = 0.0            # a row never masks itself
+        nb = nW if masked else 1
+        bias2 = torch.empty(nb, H, N, ld, device=dev)
+        ops.relpos_bias_build(table, index32, mask, nb, H, A, N, ld, LOG2E, bias2)
+        full = torch.zeros(nb, H, N, N, device=dev)
+        full[:, :, :A, :A] = table[index.reshape(-1)].view(A, A, H).permute(2, 0, 1)[None] + (mask[:, None] if masked else 0.0)
+        report(f'relpos_bias_build nW{nW} H{H} N{N}', rel(bias2[..., :N] / LOG2E, full) + (float(bias2[..., N:].abs().max()) if ld > N else 0.0), 1e-6)
+        buf = rnd(B * nW, N, 3, H, d, dtype=BF16, seed=73)
+        q = buf[:, :, 0].permute(0, 2, 1, 3).float().requires_grad_(True)
+        k = buf[:, :, 1].permute(0, 2, 1, 3).float().requires_grad_(True)
+        v = buf[:, :, 2].permute(0, 2, 1, 3).float().requires_grad_(True)
+        scale = d ** -0.5
+        logits = (q @ k.transpose(-2, -1)) * scale + full.repeat(B * nW // nb, 1, 1, 1)
+        logits.retain_grad()
+        ref = logits.softmax(-1) @ v
+        O = torch.empty(B * nW * N, D, device=dev, dtype=BF16)
+        LSE = torch.empty(B * nW, H, N, device=dev)
+        st = (N * 3 * D, 3 * D) * 3
+        p0 = buf.data_ptr()
+        ops.attn_bias_fwd(p0, p0 + 2 * D, p0 + 4 * D, O, LSE, B * nW, H, N, N, d, d, *st, N * D, D, scale, bias2, nb, ld)
+        tag = f'window attn B{B} nW{nW} H{H} N{N} d{d} mask{int(masked)}'
+        report(tag + ' fwd', rel(O.view(B * nW, N, H, d).permute(0, 2, 1, 3), ref), 1e-2)
+        report(tag + ' lse', rel(LSE, torch.logsumexp(logits, -1)), 1e-4)
+        dO = rnd(B * nW * N, D, dtype=BF16, seed=74)
+        ref.backward(dO.view(B * nW, N, H, d).permute(0, 2, 1, 3).float())
+        dbuf = torch.zeros_like(buf)
+        dS = torch.zeros(B * nW, H, N, ld, device=dev)
+        d0 = dbuf.data_ptr()
+        ops.attn_bias_bwd(p0, p0 + 2 * D, p0 + 4 * D, O, dO, LSE, torch.empty_like(LSE), d0, d0 + 2 * D, d0 + 4 * D, B * nW, H, N, N, d, d,
+                          *st, N * D, D, N * D, D, *st, scale, bias2, nb, ld, dS)
+        report(tag + ' dq', rel(dbuf[:, :, 0].permute(0, 2, 1, 3), q.grad), 2e-2)
+        report(tag + ' dk', rel(dbuf[:, :, 1].permute(0, 2, 1, 3), k.grad), 2e-2)
+        report(tag + ' dv', rel(dbuf[:, :, 2].permute(0, 2, 1, 3), v.grad), 2e-2)
+        report(tag + ' dS', rel(dS[..., :N], logits.grad), 2e-2)
+        dtab = torch.zeros(T, H, device=dev)
+        ops.relpos_bias_bwd(dS, index32, B * nW, H, A, N, ld, T, dtab)
+        want = torch.zeros(T, H, device=dev)
+        want.index_add_(0, index.reshape(-1), dS[:, :, :A, :A].sum(0).permute(1, 2, 0).reshape(A * A, H))
+        report(tag + ' dtable (from the kernel dS)', rel(dtab, want), 1e-5)
+        # ---- row movers: [B, nF + L, C] <-> [B * nW, A + nF, C] through a random token permutation
+        L, C = nW * A, 96
+        rows = torch.randperm(L, generator=torch.Generator().manual_seed(5)).to(dev)
+        inv = torch.empty_like(rows); inv[rows] = torch.arange(L, device=dev)
+        x = rnd(B, nF + L, C, seed=75)
+        seq = torch.empty(B * nW * N, C, device=dev, dtype=BF16)
+        ops.window_unfold(x, rows.to(torch.int32), B, nW, A, nF, L, C, 0.5, seq)
+        want = torch.cat([x[:, nF:][:, rows].reshape(B * nW, A, C), (0.5 * x[:, None, :nF]).expand(B, nW, nF, C).reshape(B * nW, nF, C)], 1)
+        report(f'window_unfold nW{nW} nF{nF}', rel(seq.view(B * nW, N, C), want), 4e-3)
+        t = rnd(B * nW * N, C, seed=76)
+        res = rnd(B, nF + L, C, seed=77)
+        out = torch.empty(B, nF + L, C, device=dev)
+        ops.window_fold(t, inv.to(torch.int32), res, B, nW, A, nF, L, C, 1.0 / nW, out)
+        tv = t.view(B, nW, N, C)
+        tok = torch.empty(B, L, C, device=dev)
+        tok[:, rows] = tv[:, :, :A].reshape(B, L, C)
+        want = res + torch.cat([tv[:, :, A:].mean(1), tok], 1)
+        report(f'window_fold nW{nW} nF{nF}', rel(out, want), 1e-6)
+
+
+@check
 def layernorm():
     for (B, r0, r1, D) in [(3, 4, 9, 128), (2, 0, 81, 768), (64, 32, 49, 768), (2, 0, 228, 512), (3, 5, 0, 192), (2, 3, 3, 1024)]:
         x0 = rnd(B, max(r0, 1), D, seed=31)[:, :r0].contiguous() if r0 else None

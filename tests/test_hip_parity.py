@@ -34,14 +34,14 @@ def _build(name):
 ZERO_GRADS = ('attn.k.bias',)      # factorised block; the kv.bias of the token / dense blocks has a live v half
 
 
-@pytest.mark.parametrize('name', ['micro', 'tiny', 'micro_token', 'micro_dense'])
+@pytest.mark.parametrize('name', ['micro', 'tiny', 'micro_token', 'micro_dense', 'micro_swin'])
 def test_end_to_end_vs_oracle_and_golden(golden, name):
     g = golden(f'e2e_{name}')
     model, sd, cfg, O = _build(name)
     image, audio, ni, na = O.synthetic_batch(cfg, int(g['B']), seed=int(g['seed']))
     out = model(image.cuda(), audio.cuda(), torch.from_numpy(ni).cuda(), torch.from_numpy(na).cuda())
     (out[0] + out[1]).backward()
-    sdo = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in sd.items()}
+    sdo = {k: v.clone().requires_grad_(k not in O.FROZEN and not O.is_buffer(k)) for k, v in sd.items()}
     li, la, pi, pa, aux = O.avmae_forward(sdo, cfg, image, audio, ni, na)
     (li + la).backward()
     for k in ('image_ids_keep', 'image_mask', 'image_ids_restore', 'audio_ids_keep', 'audio_mask', 'audio_ids_restore'):
@@ -72,7 +72,8 @@ def test_end_to_end_vs_oracle_and_golden(golden, name):
     assert abs(tot - float(g['grad_norm_total'])) < 5e-3 * float(g['grad_norm_total'])
 
 
-@pytest.mark.parametrize('name,batch', [('micro', 2), ('micro', 64), ('tiny', 2), ('micro_token', 2), ('micro_dense', 2)])
+@pytest.mark.parametrize('name,batch', [('micro', 2), ('micro', 64), ('tiny', 2), ('micro_token', 2), ('micro_dense', 2), ('micro_swin', 2),
+                                        ('micro_swin', 5)])
 def test_end_to_end_fp32(golden, name, batch):
     """The WHOLE hand-written forward + backward in fp32 (engine.set_precision('fp32'): the fp32-operand twins of every
     kernel, csrc/f32_path.hip) against the fp32 oracle and the reference's own fixture numbers at 1e-4 — what bf16's 2e-2
@@ -86,7 +87,7 @@ def test_end_to_end_fp32(golden, name, batch):
         image, audio, ni, na = O.synthetic_batch(cfg, batch, seed=int(g['seed']) if same_as_fixture else 91)
         out = model(image.cuda(), audio.cuda(), torch.from_numpy(ni).cuda(), torch.from_numpy(na).cuda())
         (out[0] + out[1]).backward()
-        sdo = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in sd.items()}
+        sdo = {k: v.clone().requires_grad_(k not in O.FROZEN and not O.is_buffer(k)) for k, v in sd.items()}
         li, la, pi, pa, aux = O.avmae_forward(sdo, cfg, image, audio, ni, na)
         (li + la).backward()
         TOL = 1e-4
@@ -125,7 +126,7 @@ def test_batch64_grouped_wgrad_path_vs_oracle():
     image, audio, ni, na = O.synthetic_batch(cfg, 64, seed=77)
     out = model(image.cuda(), audio.cuda(), torch.from_numpy(ni).cuda(), torch.from_numpy(na).cuda())
     (out[0] + out[1]).backward()
-    sdo = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in sd.items()}
+    sdo = {k: v.clone().requires_grad_(k not in O.FROZEN and not O.is_buffer(k)) for k, v in sd.items()}
     li, la, pi, pa, aux = O.avmae_forward(sdo, cfg, image, audio, ni, na)
     (li + la).backward()
     assert abs(float(out[0]) - float(li)) <= LOSS_RTOL * float(li) and abs(float(out[1]) - float(la)) <= LOSS_RTOL * float(la)
@@ -149,7 +150,7 @@ def test_batch1_vs_oracle():
     image, audio, ni, na = O.synthetic_batch(cfg, 1, seed=78)
     out = model(image.cuda(), audio.cuda(), torch.from_numpy(ni).cuda(), torch.from_numpy(na).cuda())
     (out[0] + out[1]).backward()
-    sdo = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in sd.items()}
+    sdo = {k: v.clone().requires_grad_(k not in O.FROZEN and not O.is_buffer(k)) for k, v in sd.items()}
     li, la, pi, pa, aux = O.avmae_forward(sdo, cfg, image, audio, ni, na)
     (li + la).backward()
     assert abs(float(out[0]) - float(li)) <= LOSS_RTOL * float(li) and abs(float(out[1]) - float(la)) <= LOSS_RTOL * float(la)
@@ -206,7 +207,7 @@ def test_video_earlyfusion_vs_oracle_and_golden(golden):
     w, loss = _probe((xv, xa, xf), int(g['seed']) + 1)
     assert abs(float(loss) - float(g['loss_probe'])) <= 5e-3 * abs(float(g['loss_probe']))
     loss.backward()
-    sdo = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in sd.items()}
+    sdo = {k: v.clone().requires_grad_(k not in O.FROZEN and not O.is_buffer(k)) for k, v in sd.items()}
     ov = O.video_earlyfusion_forward(sdo, cfg, video, audio)
     sum((t * wi).sum() for t, wi in zip(ov, w)).backward()
     _check_video_grads(model, sdo)
@@ -239,7 +240,7 @@ def test_video_earlyfusion_fp32(golden):
             assert rel(got, g[key]) < 1e-4, key
         w, loss = _probe(outs, int(g['seed']) + 1)
         loss.backward()
-        sdo = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in sd.items()}
+        sdo = {k: v.clone().requires_grad_(k not in O.FROZEN and not O.is_buffer(k)) for k, v in sd.items()}
         ov = O.video_earlyfusion_forward(sdo, cfg, video, audio)
         sum((t * wi).sum() for t, wi in zip(ov, w)).backward()
         g_all = sum(float(v.grad.double().norm()) ** 2 for v in sdo.values() if v.grad is not None) ** 0.5
@@ -263,7 +264,7 @@ def test_video_long_sequences_vs_oracle():
     outs = model(video.cuda(), audio.cuda())
     w, loss = _probe(outs, 35)
     loss.backward()
-    sdo = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in sd.items()}
+    sdo = {k: v.clone().requires_grad_(k not in O.FROZEN and not O.is_buffer(k)) for k, v in sd.items()}
     ov = O.video_earlyfusion_forward(sdo, cfg, video, audio)
     ref = sum((t * wi).sum() for t, wi in zip(ov, w))
     ref.backward()
@@ -281,7 +282,7 @@ def test_baseline_config_video_base_vs_oracle():
     outs = model(video.cuda(), audio.cuda())
     w, loss = _probe(outs, 45)
     loss.backward()
-    sdo = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in sd.items()}
+    sdo = {k: v.clone().requires_grad_(k not in O.FROZEN and not O.is_buffer(k)) for k, v in sd.items()}
     ov = O.video_earlyfusion_forward(sdo, cfg, video, audio)
     ref = sum((t * wi).sum() for t, wi in zip(ov, w))
     ref.backward()
@@ -412,6 +413,31 @@ def test_cross_attention_module_forward_backward(golden):
         if k.startswith('cross_attention.gw.') and not k.endswith(('kv.bias',)):
             p = dict(ca.named_parameters())[k[len('cross_attention.gw.'):]]
             assert rel(p.grad, g[k]) < GRAD_TOL, k
+
+
+def test_swin_block_module_forward_backward():
+    """models/swin.py:160-209 as a module call (the reference's SwinTransformerBlock is callable on its own): a shifted block
+    of the micro_swin image decoder, outputs, input gradients and the relative-position table's gradient vs the oracle."""
+    model, sd, cfg, O = _build('micro_swin')
+    blk = model.image_decoder_blocks[1]                      # odd block: shifted by 2, with the window mask
+    assert blk.shift_size == 2 and blk.attn_mask is not None
+    B, L, nF, C = 3, cfg.image_grid[0] * cfg.image_grid[1], sum(cfg.fusion_tkns), cfg.decoder_dim
+    g = torch.Generator().manual_seed(3)
+    x0, f0 = torch.randn(B, L, C, generator=g), torch.randn(B, nF, C, generator=g)
+    gy, gf = torch.randn(B, L, C, generator=g), torch.randn(B, nF, C, generator=g)
+    x, xf = x0.cuda().requires_grad_(True), f0.cuda().requires_grad_(True)
+    y, yf = blk(x, xf)
+    ((y * gy.cuda()).sum() + (yf * gf.cuda()).sum()).backward()
+    pre = 'image_decoder_blocks.1'
+    sdo = {k: v.clone().requires_grad_(not O.is_buffer(k)) for k, v in sd.items() if k.startswith(pre)}
+    xo, fo = x0.clone().requires_grad_(True), f0.clone().requires_grad_(True)
+    yo, yfo = O.swin_block(xo, fo, sdo, pre, cfg.decoder_heads, cfg.image_grid, 1, cfg.dec_eps)
+    ((yo * gy).sum() + (yfo * gf).sum()).backward()
+    assert rel(y, yo) < ACT_TOL and rel(yf, yfo) < ACT_TOL
+    assert rel(x.grad, xo.grad) < GRAD_TOL and rel(xf.grad, fo.grad) < GRAD_TOL
+    for n in ('attn.relative_position_bias_table', 'attn.qkv.weight', 'mlp.fc2.bias', 'norm1.weight'):
+        got = dict(blk.named_parameters())[n].grad
+        assert rel(got, sdo[f'{pre}.{n}'].grad) < GRAD_TOL, n
 
 
 def test_trainer_step_semantics(golden):
@@ -752,7 +778,7 @@ def test_random_path_configurations_vs_oracle():
     assert ran >= 6 and not bad, bad[:8]
 
 
-@pytest.mark.parametrize('name,batch', [('base', 4), ('base_as', 2), ('large', 2)])
+@pytest.mark.parametrize('name,batch', [('base', 4), ('base_as', 2), ('large', 2), ('base_swin', 2)])
 def test_baseline_config_shapes_vs_oracle(name, batch):
     """BASELINE.json configs[1] (ViT-B, attn_ratio 0.25 / mlp_ratio 1.0: the bench workload's model), configs[2] (ViT-B,
     AudioSet-style fusion widths: attn_ratio 1.0, mlp_ratio 4.0) and configs[3] (ViT-L) at their real widths and depths, at
@@ -761,7 +787,7 @@ def test_baseline_config_shapes_vs_oracle(name, batch):
     image, audio, ni, na = O.synthetic_batch(cfg, batch, seed=25)
     out = model(image.cuda(), audio.cuda(), torch.from_numpy(ni).cuda(), torch.from_numpy(na).cuda())
     (out[0] + out[1]).backward()
-    sdo = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in sd.items()}
+    sdo = {k: v.clone().requires_grad_(k not in O.FROZEN and not O.is_buffer(k)) for k, v in sd.items()}
     li, la, pi, pa, aux = O.avmae_forward(sdo, cfg, image, audio, ni, na)
     (li + la).backward()
     for k in ('image_ids_keep', 'audio_ids_keep', 'image_ids_restore', 'audio_ids_restore'):
