@@ -1171,6 +1171,7 @@ void nt2_issue_auto(const void* const* params_in, int n, hipStream_t stream) {
     case 46: nt2_issue<128, 256, 2, 4, 2, BT, 32>(params, n, stream); break;
     case 3: nt2_issue<128, 128, 2, 4, 2, BT, 64>(params, n, stream); break;
     case 8: nt2_issue<128, 64, 2, 2, 2, BT, 64>(params, n, stream); break;
+    case 7: nt2_issue<64, 64, 2, 2, 4, BT, 64>(params, n, stream); break;
     default: nt2_issue<64, 64, 2, 2, 2, BT, 64>(params, n, stream); break;
   }
 }
@@ -1475,7 +1476,11 @@ RowMap mk(const int* m) { return m ? RowMap{m[0], m[1], m[2]} : RowMap{0, 0, 0};
 int nt_auto_config_tiles(long t128, bool narrow) {
   // measured on MI355X over the ViT-B step's shapes (tools/gemm_bench.py): occupancy beats pipeline depth,
   // so 2-stage rings everywhere; 8 waves on 128x128 when there are enough tiles to fill 2 blocks per CU.
-  if (narrow || t128 < 200) return 5;         // 64x64, 4 waves
+  // 64x64, 4 waves, FOUR-stage ring: these launches are a few dozen tiles alone on the GPU (the fusion block's projections)
+  // whose weights were last touched a step ago — three k-steps of prefetch cover the HBM miss a two-stage ring exposes at
+  // every k-step (in-step 15 us vs 7 us with warm operands); DAV_NT_SMALL=5 restores the two-stage ring (A/B: -0.1 ms per step)
+  static const int small_cfg = getenv("DAV_NT_SMALL") ? atoi(getenv("DAV_NT_SMALL")) : 7;
+  if (narrow || t128 < 200) return small_cfg == 5 ? 5 : 7;
   if (t128 < 400) return 8;                   // 128x64, 4 waves
   return 3;                                   // 128x128, 8 waves (2 x 4)
 }
@@ -1513,7 +1518,7 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
   const bool vec_ok = glds_ok && (N & 3) == 0 && (ldc & 3) == 0 && (!res || (ldres & 3) == 0) && (!C2 || (ldc2 & 3) == 0) &&
                       (!aux || (ldaux & 3) == 0) && !(((uintptr_t)C | (uintptr_t)C2 | (uintptr_t)res) & 15) && !((uintptr_t)aux & 7);
   int cfg = variant >> 4;
-  const bool groupable_cfg = cfg == 0 || cfg == 3 || cfg == 5 || cfg == 8 || cfg == 43 || cfg == 44 || cfg == 45 || cfg == 46;
+  const bool groupable_cfg = cfg == 0 || cfg == 3 || cfg == 5 || cfg == 7 || cfg == 8 || cfg == 43 || cfg == 44 || cfg == 45 || cfg == 46;
   p.force_cfg = cfg;
   if (vec_ok && groupable_cfg && !(variant & 15) && davb::recording()) {
     // batched: the tile configuration is chosen when the group is issued, from the tile count of the whole group
@@ -1543,6 +1548,7 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
       case 45: launch_nt2<256, 128, 4, 2, 2, true, 32>(p, stream); break;
       case 46: launch_nt2<128, 256, 2, 4, 2, true, 32>(p, stream); break;
       case 8: launch_nt2<128, 64, 2, 2, 2, true>(p, stream); break;
+      case 7: launch_nt2<64, 64, 2, 2, 4, true>(p, stream); break;
       default: launch_nt2<64, 64, 2, 2, 2, true>(p, stream); break;
     }
     return dav_launch_status();
