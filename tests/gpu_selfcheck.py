@@ -90,6 +90,31 @@ def gemm_nt():
             C = torch.empty(M, N, device=dev)
             ops.gemm_nt(A, Bm, M, N, K, bias=bias, res=res, ldres=N, C_out=C, variant=cfg << 4)
             report(f'gemm_nt {M}x{N}x{K} cfg{cfg}', rel(C, ref), 1e-4)
+    # the big-tile / deep-ring configurations of round 2 (43 / 45 = 256x128, 44 / 46 = 128x256 on 32-deep rings, 7 = 64x64 on
+    # four stages) with every epilogue kind the step gives them: staged bf16 output, the SPLIT staged epilogue with a GELU' twin,
+    # multiply by aux, fp32 + residual; forward form and b_kn (32-deep stages in b_kn mode are new)
+    for (M, N, K) in [(2100, 1024, 512), (1000, 768, 192), (300, 512, 64)]:
+        A = rnd(M, K, dtype=BF16, seed=31)
+        W_nk, W_kn = rnd(N, K, dtype=BF16, scale=0.05, seed=32), rnd(K, N, dtype=BF16, scale=0.05, seed=33)
+        bias, res, aux = rnd(N, seed=34), rnd(M, N, seed=35), rnd(M, N, dtype=BF16, seed=36)
+        for cfg in (43, 44, 45, 46, 7, 8, 3):
+            for bt in (0, 1):
+                Wm, kw = (W_kn, dict(ldb=N)) if bt else (W_nk, {})
+                base = A.float() @ (W_kn.float() if bt else W_nk.float().t())
+                var = (cfg << 4) | (bt << 12)
+                tag = f'gemm_nt {M}x{N}x{K} cfg{cfg} b_kn{bt}'
+                U, D = torch.empty(M, N, device=dev, dtype=BF16), torch.empty(M, N, device=dev, dtype=BF16)
+                ops.gemm_nt(A, Wm, M, N, K, bias=bias, act=1, C_out=U, c_bf16=True, C2=D, ldc2=N, c2_mode=4, variant=var, **kw)
+                xg = (base + bias).clone().requires_grad_(True)
+                torch.nn.functional.gelu(xg).sum().backward()
+                report(tag + ' gelu (staged)', rel(U, torch.nn.functional.gelu(base + bias)), 6e-3)
+                report(tag + " gelu' twin (staged)", float((D.float() - xg.grad).abs().max()), 5e-3)
+                G = torch.empty(M, N, device=dev, dtype=BF16)
+                ops.gemm_nt(A, Wm, M, N, K, act=3, aux=aux, ldaux=N, C_out=G, c_bf16=True, variant=var, **kw)
+                report(tag + ' act3 bf16', rel(G, base * aux.float()), 6e-3)
+                C = torch.empty(M, N, device=dev)
+                ops.gemm_nt(A, Wm, M, N, K, bias=bias, res=res, ldres=N, C_out=C, variant=var, **kw)
+                report(tag + ' fp32 + res', rel(C, base + bias + res), 1e-4)
     # act 2 (multiply by gelu'(aux)) and row maps
     M, N, K = 3 * 7, 128, 64
     Bsz, rpb, tot = 3, 7, 11

@@ -144,3 +144,49 @@ def test_batched_grouped_launches_equal_individual_launches():
     for c, r in zip(again, single):
         assert torch.equal(c, r)
     assert torch.equal(tail, single[0] + single[0])
+
+
+def test_tuned_table_picks_the_configuration_and_results_do_not_change():
+    """dav_nt_tune_set: a recorded group whose signature is in the table is issued with the table's tile configuration (seen in
+    the library's own issue log), any other group by the rules — and the numbers are the same either way."""
+    import ctypes as C
+    import torch
+    from deepavfusion_amd import _lib, engine as E, ops
+    lib = _lib.load()
+    dev = 'cuda'
+    torch.manual_seed(0)
+    probs = [(1536, 1024, 256), (2048, 1024, 256)]
+    ops_in = [(torch.randn(M, K, device=dev).bfloat16(), (torch.randn(N, K, device=dev) * 0.05).bfloat16(),
+               torch.empty(M, N, device=dev, dtype=torch.bfloat16)) for (M, N, K) in probs]
+
+    def run():
+        ops.nt_issue_log(True)
+        with E.batch() as bt:
+            for (M, N, K), (A, W, Cc) in zip(probs, ops_in):
+                bt.lane()
+                ops.gemm_nt(A, W, M, N, K, C_out=Cc, c_bf16=True)
+        log = ops.nt_issue_log(with_flags=True)
+        ops.nt_issue_log(False)
+        torch.cuda.synchronize()
+        return log, [c.clone() for _, _, c in ops_in]
+    try:
+        assert lib.dav_nt_tune_set(None, 0) == 0
+        log0, out0 = run()
+        assert len(log0) == 1 and len(log0[0][2]) == 2                  # ONE grouped launch of both problems
+        rule_cfg, flags = log0[0][0], log0[0][3]
+        want = 46 if rule_cfg != 46 else 44
+        blob = [want, 0, 2]
+        for (M, N, K), f in zip(probs, flags):
+            blob += [M, N, K, f]
+        assert lib.dav_nt_tune_set((C.c_int * len(blob))(*blob), len(blob)) == 1
+        log1, out1 = run()
+        assert log1[0][0] == want
+        for a, b in zip(out0, out1):
+            assert torch.equal(a, b)                                    # same k order per element: bit-identical
+        # a different group (other M) is not in the table -> the rule's choice again
+        ops_in[0] = (torch.randn(1664, 256, device=dev).bfloat16(), ops_in[0][1], torch.empty(1664, 1024, device=dev, dtype=torch.bfloat16))
+        probs[0] = (1664, 1024, 256)
+        log2, _ = run()
+        assert log2[0][0] == rule_cfg
+    finally:
+        _lib.load_nt_tuning(_lib.NT_TUNING_PATH)
