@@ -54,6 +54,13 @@ __device__ __forceinline__ void ln_fwd_body(const LNFwd& p, const int vbid, cons
   const int lane = threadIdx.x & 63;
   const int gw = (vbid * blockDim.x + threadIdx.x) >> 6, nwaves = (vgrid * blockDim.x) >> 6;
   const int R = p.s0.rows + p.s1.rows, rows = p.B * R, nch = p.D >> 2;
+  float4 gmv[MAXC], btv[MAXC];          // the affine parameters are the same for every row of the wave: read once
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = lane + 64 * i;
+    gmv[i] = c < nch ? reinterpret_cast<const float4*>(p.gamma)[c] : float4{0.f, 0.f, 0.f, 0.f};
+    btv[i] = c < nch ? reinterpret_cast<const float4*>(p.beta)[c] : float4{0.f, 0.f, 0.f, 0.f};
+  }
   for (int row = gw; row < rows; row += nwaves) {
     const int b = row / R, j = row % R;
     const float* x = j < p.s0.rows ? p.s0.x + b * p.s0.bs + (long)j * p.D : p.s1.x + b * p.s1.bs + (long)(j - p.s0.rows) * p.D;
@@ -83,8 +90,7 @@ __device__ __forceinline__ void ln_fwd_body(const LNFwd& p, const int vbid, cons
     for (int i = 0; i < MAXC; ++i) {
       const int c = lane + 64 * i;
       if (c < nch) {
-        const float4 gm = reinterpret_cast<const float4*>(p.gamma)[c];
-        const float4 bt = reinterpret_cast<const float4*>(p.beta)[c];
+        const float4 gm = gmv[i], bt = btv[i];
         float4 o;
         o.x = (v[i].x - mean) * rstd * gm.x + bt.x;
         o.y = (v[i].y - mean) * rstd * gm.y + bt.y;
@@ -129,9 +135,13 @@ __device__ __forceinline__ void ln_bwd_body(const LNBwd& p, const int vbid, cons
   const int lane = threadIdx.x & 63;
   const int gw = (vbid * blockDim.x + threadIdx.x) >> 6, nwaves = (vgrid * blockDim.x) >> 6;
   const int R = p.s0.rows + p.s1.rows, rows = p.B * R, nch = p.D >> 2;
-  float4 dg[MAXC], db[MAXC];
+  float4 dg[MAXC], db[MAXC], gmv[MAXC];
 #pragma unroll
-  for (int i = 0; i < MAXC; ++i) { dg[i] = float4{0.f, 0.f, 0.f, 0.f}; db[i] = float4{0.f, 0.f, 0.f, 0.f}; }
+  for (int i = 0; i < MAXC; ++i) {
+    dg[i] = float4{0.f, 0.f, 0.f, 0.f}; db[i] = float4{0.f, 0.f, 0.f, 0.f};
+    const int c = lane + 64 * i;
+    gmv[i] = c < nch ? reinterpret_cast<const float4*>(p.gamma)[c] : float4{0.f, 0.f, 0.f, 0.f};      // same for every row: read once
+  }
 
   for (int row = gw; row < rows; row += nwaves) {
     const int b = row / R, j = row % R;
@@ -140,12 +150,16 @@ __device__ __forceinline__ void ln_bwd_body(const LNBwd& p, const int vbid, cons
     const float* x = seg0 ? p.s0.x + b * p.s0.bs + (long)jj * p.D : p.s1.x + b * p.s1.bs + (long)jj * p.D;
     const LNDst& d = seg0 ? p.d0 : p.d1;
     const float mean = p.mean[row], rstd = p.rstd[row];
-    float4 xh[MAXC], gy[MAXC];
+    float4 xh[MAXC], gy[MAXC], rv[MAXC];
     float s1 = 0.f, s2 = 0.f;
+    // the residual-gradient row is fetched together with x / dy (one memory latency per row instead of two: the second pass
+    // would otherwise issue its loads only after the two wave reductions)
+    const float* rr = (d.dx && d.res) ? d.res + b * d.res_bs + (long)jj * p.D : nullptr;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
       const int c = lane + 64 * i;
       if (c < nch) {
+        rv[i] = rr ? reinterpret_cast<const float4*>(rr)[c] : float4{0.f, 0.f, 0.f, 0.f};
         const float4 xv = reinterpret_cast<const float4*>(x)[c];
         float4 dyv = float4{0.f, 0.f, 0.f, 0.f};
         if (p.dy) {
@@ -157,7 +171,7 @@ __device__ __forceinline__ void ln_bwd_body(const LNBwd& p, const int vbid, cons
           const float4 t = reinterpret_cast<const float4*>(p.dy32 + (long)row * p.D)[c];
           dyv.x += t.x; dyv.y += t.y; dyv.z += t.z; dyv.w += t.w;
         }
-        const float4 gm = reinterpret_cast<const float4*>(p.gamma)[c];
+        const float4 gm = gmv[i];
         xh[i].x = (xv.x - mean) * rstd; xh[i].y = (xv.y - mean) * rstd;
         xh[i].z = (xv.z - mean) * rstd; xh[i].w = (xv.w - mean) * rstd;
         dg[i].x += dyv.x * xh[i].x; dg[i].y += dyv.y * xh[i].y; dg[i].z += dyv.z * xh[i].z; dg[i].w += dyv.w * xh[i].w;
@@ -171,7 +185,6 @@ __device__ __forceinline__ void ln_bwd_body(const LNBwd& p, const int vbid, cons
     s2 = wave_sum(s2) / p.D;
     if (d.dx == nullptr) continue;   // caller does not need this segment's input gradient
     float* dxr = d.dx + b * d.bs + (long)jj * p.D;
-    const float* rr = d.res ? d.res + b * d.res_bs + (long)jj * p.D : nullptr;
     bf16_t* br = d.dx_bf16 ? d.dx_bf16 + b * d.bf_bs + (long)jj * p.D : nullptr;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
@@ -182,7 +195,7 @@ __device__ __forceinline__ void ln_bwd_body(const LNBwd& p, const int vbid, cons
         o.y = rstd * (gy[i].y - s1 - xh[i].y * s2);
         o.z = rstd * (gy[i].z - s1 - xh[i].z * s2);
         o.w = rstd * (gy[i].w - s1 - xh[i].w * s2);
-        if (rr) { const float4 t = reinterpret_cast<const float4*>(rr)[c]; o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+        o.x += rv[i].x; o.y += rv[i].y; o.z += rv[i].z; o.w += rv[i].w;
         if (d.accumulate) { const float4 t = reinterpret_cast<const float4*>(dxr)[c]; o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
         reinterpret_cast<float4*>(dxr)[c] = o;
         if (br) { uint2 w; w.x = pack2bf(o.x, o.y); w.y = pack2bf(o.z, o.w); reinterpret_cast<uint2*>(br)[c] = w; }
