@@ -34,10 +34,10 @@ def _streams(dev):
     return main, sa, sf
 
 
-def _batched():
-    """Launch batching (engine.batch, csrc/batch.h) for the paired tower blocks / decoders; DAV_BATCH=0 restores one HIP
-    stream per tower instead."""
-    return os.environ.get('DAV_BATCH', '1') != '0' and E.PRECISION == 'bf16'
+def _batched(rows):
+    """Launch batching (engine.batch, csrc/batch.h) with the paired tower blocks / decoders as LANES of one batch, or one HIP
+    stream per tower: engine.lanes_for (DAV_BATCH = 1 / 0 force either; default: by the step's size)."""
+    return E.lanes_for(rows)
 
 
 def _f32c(x):
@@ -86,7 +86,7 @@ def encoder_fwd(enc, image, audio, ik32, ak32, want_f32=False, collect_embs=Fals
     Hi, Ha, Hf = vis.num_heads, enc.audio.num_heads, enc.fusion_num_heads
     layers, embs = [], []
     main, sa, sf = _streams(image.device)
-    batched = _batched()
+    batched = _batched(B * (x_i.shape[1] + x_f.shape[1]))          # rows of the (smaller) visual tower's blocks
     for l, (bi, ba, fb) in enumerate(zip(vis.blocks, enc.audio.blocks, enc.fusion_blocks)):
         # the reference draws in call order: visual block (attn, mlp), audio block, fusion block (:104-106)
         dpi, dpa = drop_path_scales(enc, bi, B, image.device, f'visual.{l}'), drop_path_scales(enc, ba, B, image.device, f'audio.{l}')
@@ -97,8 +97,14 @@ def encoder_fwd(enc, image, audio, ik32, ak32, want_f32=False, collect_embs=Fals
             # ONE launch batch per layer, three lanes — image block, audio block, fusion block (all read the layer inputs
             # only, models/deepavfusion.py:104-107): LayerNorms / GEMMs / attentions of equal rank go out as grouped grids
             # on one stream.  (hipGraph branches of this weight start ~150 us late on MI355X)
-            lane_f = fb is not None and E.fusion_block_batchable(fb, dpf)
-            if fb is not None and not lane_f:
+            lane_f = fb is not None and E.fusion_block_batchable(fb, dpf) and not E.FUSION_ON_STREAM
+            if fb is not None and E.FUSION_ON_STREAM:
+                # mixed schedule: the fusion block's ~11 small dependent steps run on their own stream (its independent launches
+                # still grouped per region) BESIDE the two tower lanes, which then need no idle steps
+                sf.wait_stream(main)
+                with torch.cuda.stream(sf):
+                    n_f, tf = E.fusion_block_fwd(fb, x_f, x_i, x_a, Hf, enc.num_fusion, dpf)
+            elif fb is not None and not lane_f:
                 n_f, tf = E.fusion_block_fwd(fb, x_f, x_i, x_a, Hf, enc.num_fusion, dpf)      # reads the layer INPUT x_i / x_a (:106-107)
             idle = E.FUSION_IDLE_FWD if lane_f else 0
             with E.batch() as bt:
@@ -109,6 +115,8 @@ def encoder_fwd(enc, image, audio, ik32, ak32, want_f32=False, collect_embs=Fals
                 if lane_f:
                     bt.lane()
                     n_f, tf = E.fusion_block_fwd(fb, x_f, x_i, x_a, Hf, enc.num_fusion, dpf)
+            if fb is not None and E.FUSION_ON_STREAM:
+                main.wait_stream(sf)
             if fb is not None:
                 x_f = n_f
             x_i, x_a = n_i, n_a
@@ -132,7 +140,7 @@ def encoder_fwd(enc, image, audio, ik32, ak32, want_f32=False, collect_embs=Fals
     xi_b, xi32, st_i = E.ln_fwd(vis.norm, None, x_i, B, want_f32=want_f32)
     xa_b, xa32, st_a = E.ln_fwd(enc.audio.norm, None, x_a, B, want_f32=want_f32)
     xf_b, xf32, st_f = E.ln_fwd(enc.fusion_norm, None, x_f, B, want_f32=want_f32)
-    tape = dict(t_pi=t_pi, t_pa=t_pa, layers=layers, x_i=x_i, x_a=x_a, x_f=x_f, st_i=st_i, st_a=st_a, st_f=st_f, B=B)
+    tape = dict(t_pi=t_pi, t_pa=t_pa, layers=layers, x_i=x_i, x_a=x_a, x_f=x_f, st_i=st_i, st_a=st_a, st_f=st_f, B=B, lanes=batched)
     return (xi_b, xa_b, xf_b), (xi32, xa32, xf32), embs, tape
 
 
@@ -160,7 +168,7 @@ def _encoder_bwd(enc, t, dxi_b, dxa_b, dxf_b, dxi32, dxa32, dxf32, layer_cb=None
     g_f, g_fb = final_norm(enc.fusion_norm, t['x_f'], t['st_f'], dxf_b, dxf32)
     blocks = list(zip(vis.blocks, enc.audio.blocks, enc.fusion_blocks))
     main, sa, sf = _streams(dev)
-    batched = _batched()
+    batched = t['lanes']                  # the schedule the forward of this step chose
     for l, ((bi, ba, fb), (ti, ta, tf)) in reversed(list(enumerate(zip(blocks, t['layers'])))):
         # Memory lifetime across streams: the gradients entering this layer were allocated on one stream (main for the
         # final norms, the fusion / audio stream further down) and are READ by kernels of another.  Dropping the last
@@ -173,8 +181,12 @@ def _encoder_bwd(enc, t, dxi_b, dxa_b, dxf_b, dxi32, dxa32, dxf32, layer_cb=None
             # whole backward.  The towers' last kernel — the norm1 backward — accumulates into the buffers the fusion
             # block's backward produces, so it forms a second (two-lane) batch behind the first.
             dx_f = dx_i = dx_a = None
-            lane_f = fb is not None and E.fusion_block_batchable(fb, tf.get('dp'))
-            if fb is not None and not lane_f:
+            lane_f = fb is not None and E.fusion_block_batchable(fb, tf.get('dp')) and not E.FUSION_ON_STREAM
+            if fb is not None and E.FUSION_ON_STREAM:
+                sf.wait_stream(main)
+                with torch.cuda.stream(sf):
+                    dx_f, dx_i, dx_a = E.fusion_block_bwd(fb, tf, g_f, g_fb)
+            elif fb is not None and not lane_f:
                 dx_f, dx_i, dx_a = E.fusion_block_bwd(fb, tf, g_f, g_fb)
             idle = E.FUSION_IDLE_BWD if lane_f else 0
             with E.batch() as bt:
@@ -186,6 +198,8 @@ def _encoder_bwd(enc, t, dxi_b, dxa_b, dxf_b, dxi32, dxa32, dxf32, layer_cb=None
                     bt.lane()
                     dx_f, dx_i, dx_a = E.fusion_block_bwd(fb, tf, g_f, g_fb)
             acc = 1 if fb is not None else 0
+            if fb is not None and E.FUSION_ON_STREAM:
+                main.wait_stream(sf)          # the norm1 backwards accumulate into the buffers the fusion block's backward wrote
             with E.batch() as bt:
                 bt.lane()
                 g_i, g_ib, dxf_i = E.block_bwd_tail(bi, ti, st_i, dx_fus=dx_f, dx_fus_acc=acc, dx_mod=dx_i, dx_mod_acc=acc)
@@ -382,7 +396,8 @@ def avmae_fwd(model, image, audio, noise_i, noise_a):
     nF = enc.fusion_tokens.shape[1]
     dec_i, dec_a = model.decoder('image'), model.decoder('audio')
     main, sa, _ = _streams(image.device)
-    if _batched():
+    lanes = t_enc['lanes']            # (the decoders as lanes beside stream-scheduled encoder layers measured 0.4 ms slower)
+    if lanes:
         with E.batch() as bt:                 # the two MAE decoders (models/avmae.py:147-180) in lockstep
             bt.lane()
             pred_i, t_di = E.decoder_fwd(dec_i, xi_b, xf_b, ir32, B, nki, nF)
@@ -398,7 +413,7 @@ def avmae_fwd(model, image, audio, noise_i, noise_a):
         pred_i, t_di = E.decoder_fwd(dec_i, xi_b, xf_b, ir32, B, nki, nF)
         loss_i, t_li = E.loss_fwd(image, pred_i, im, model.image_norm_loss)
         main.wait_stream(sa)
-    tape = dict(image=image, audio=audio, im=im, am=am, ik32=ik32, ak32=ak32, t_enc=t_enc, t_di=t_di, t_da=t_da, t_li=t_li,
+    tape = dict(image=image, audio=audio, im=im, am=am, ik32=ik32, ak32=ak32, dec_lanes=lanes, t_enc=t_enc, t_di=t_di, t_da=t_da, t_li=t_li,
                 t_la=t_la, pred_i=pred_i, pred_a=pred_a, B=B)
     aux = dict(image_ids_keep=ik, image_mask=im, image_ids_restore=ir, audio_ids_keep=ak, audio_mask=am, audio_ids_restore=ar)
     return (loss_i, loss_a, pred_i, pred_a), tape, aux
@@ -408,7 +423,7 @@ def avmae_bwd(model, t, g_li, g_la, g_pi=None, g_pa=None, layer_cb=None):
     B = t['B']
     dec_i, dec_a = model.decoder('image'), model.decoder('audio')
     main, sa, _ = _streams(t['image'].device)
-    if _batched():
+    if t['dec_lanes']:
         dpi = E.loss_bwd(t['image'], t['pred_i'], t['im'], t['t_li'], g_li)
         dpa = E.loss_bwd(t['audio'], t['pred_a'], t['am'], t['t_la'], g_la)
         if g_pi is not None:

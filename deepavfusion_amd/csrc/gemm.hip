@@ -1476,11 +1476,12 @@ RowMap mk(const int* m) { return m ? RowMap{m[0], m[1], m[2]} : RowMap{0, 0, 0};
 int nt_auto_config_tiles(long t128, bool narrow) {
   // measured on MI355X over the ViT-B step's shapes (tools/gemm_bench.py): occupancy beats pipeline depth,
   // so 2-stage rings everywhere; 8 waves on 128x128 when there are enough tiles to fill 2 blocks per CU.
-  // 64x64, 4 waves, FOUR-stage ring: these launches are a few dozen tiles alone on the GPU (the fusion block's projections)
-  // whose weights were last touched a step ago — three k-steps of prefetch cover the HBM miss a two-stage ring exposes at
-  // every k-step (in-step 15 us vs 7 us with warm operands); DAV_NT_SMALL=5 restores the two-stage ring (A/B: -0.1 ms per step)
+  // 64x64, 4 waves.  A few dozen tiles alone on the GPU (the fusion block's projections: weights last touched a step ago)
+  // get the FOUR-stage ring — three k-steps of prefetch cover the HBM miss a two-stage ring exposes at every k-step (15 us in
+  // the step vs 7 us with warm operands); from ~250 tiles of 64x64 on the 64 KB ring costs occupancy instead (3136x768x3072
+  // alone: 40.5 vs 32.7 us).  DAV_NT_SMALL=5 forces the two-stage ring.
   static const int small_cfg = getenv("DAV_NT_SMALL") ? atoi(getenv("DAV_NT_SMALL")) : 7;
-  if (narrow || t128 < 200) return small_cfg == 5 ? 5 : 7;
+  if (narrow || t128 < 200) return (small_cfg == 5 || t128 > 64) ? 5 : 7;
   if (t128 < 400) return 8;                   // 128x64, 4 waves
   return 3;                                   // 128x128, 8 waves (2 x 4)
 }

@@ -63,10 +63,47 @@ def _ready(*params):
 # and the audio tower block of a layer (models/deepavfusion.py:104-105), the two decoders (models/avmae.py:147-180), the
 # two aggregation cross-attentions of a fusion block.  ``batch(auto_lanes=True)``: every launch inside is independent of
 # the others.  Only library launches may touch live buffers inside a batch (torch ops would run BEFORE the recorded
-# kernels).  Nested use joins the outer batch (lane() then has no effect).  DAV_BATCH=0 turns batching off.
+# kernels).  Nested use joins the outer batch (lane() then has no effect).  DAV_BATCH=0 turns batching off (BATCH_POLICY below).
 # ------------------------------------------------------------------------------------------------
 _BATCH = None
 BATCH_STATS = [0, 0]          # launches recorded / issued since the last reset (diagnostics, tests)
+
+# Schedules of the independent chains of a step (image block | audio block | fusion block of a layer; the two decoders):
+#   streams   one HIP stream per chain (parallel hipGraph branches), launch batching only INSIDE a chain: regions of independent
+#             launches (the fusion block's projections / cross-attentions / LayerNorms) and the layer's grouped weight gradients.
+#   lanes     the two tower blocks (the two decoders) as LANES of one launch batch on the main stream — equal-rank kernels merged
+#             into grouped grids — with the fusion block on its own stream beside them (DAV_FUSION_STREAM=0: as a third lane
+#             of the batch, the towers idling through its extra steps: everything on ONE queue).
+# BATCH_POLICY 'auto' (default): lanes from LANE_MIN_ROWS rows (B x tokens per tower block) upwards, streams below;
+# 'on' (DAV_BATCH=1): lanes always; 'off' (DAV_BATCH=0): streams and no launch batching at all.
+# Same-box A/B (tools/ab_env.sh; ViT-B B = 64 / ViT-B B = 32 / ViT-L B = 32, ms per step): streams 29.0-29.3 / 22.2 / 46.8-47.5,
+# lanes + fusion stream 29.5-29.8 / 24.3 / 48.0, three lanes on one queue 29.7-30.2 / 26.2 / 52.0, 'off' 31.0 / 24.2 / 49.0-49.5.
+# The merged tower grids are ~10 % faster than their parts and keep the big GEMM launches at 1400+ tiles; what the single queue
+# lost was the fusion block's ~11 small dependent steps, 4-8 of them alone on the GPU per layer.  At the
+# bench size the stream schedule is another 0.2-0.4 ms faster than lanes + fusion stream, but its per-tower launches are the
+# less efficient kernels (0.23 vs 0.255 of the MFMA peak in isolation): lanes stay the choice there; below ~4096 rows the
+# towers' launches are too small to fill the GPU either way and concurrency wins clearly.
+BATCH_POLICY = {'1': 'on', '0': 'off'}.get(os.environ.get('DAV_BATCH', ''), 'auto')
+LANE_MIN_ROWS = int(os.environ.get('DAV_LANE_MIN_ROWS', '4096'))
+FUSION_ON_STREAM = os.environ.get('DAV_FUSION_STREAM', '1') != '0'
+
+
+def set_batch_policy(policy: str):
+    """'on' | 'off' | 'auto' (see BATCH_POLICY); tests use it to run one model under both schedules."""
+    global BATCH_POLICY
+    assert policy in ('on', 'off', 'auto')
+    BATCH_POLICY = policy
+
+
+def batching_allowed() -> bool:
+    return BATCH_POLICY != 'off' and PRECISION == 'bf16'
+
+
+def lanes_for(rows: int) -> bool:
+    """Should the independent chains of a step with ``rows`` = B x (tokens per tower) go out as lanes of one batch?"""
+    if not batching_allowed():
+        return False
+    return BATCH_POLICY == 'on' or rows >= LANE_MIN_ROWS
 
 
 class batch:
@@ -77,7 +114,7 @@ class batch:
 
     def __enter__(self):
         global _BATCH
-        if _BATCH is None and os.environ.get('DAV_BATCH', '1') != '0' and PRECISION == 'bf16':
+        if _BATCH is None and batching_allowed():
             ops.batch_begin(self.auto_lanes)
             _BATCH = self
             self.active = True
@@ -212,7 +249,7 @@ class region:
         self.own = None
         if _BATCH is not None:
             ops.batch_region(True)
-        elif os.environ.get('DAV_BATCH', '1') != '0' and PRECISION == 'bf16':
+        elif batching_allowed():
             self.own = batch(auto_lanes=True)
             self.own.__enter__()
         return self

@@ -72,6 +72,38 @@ def test_end_to_end_vs_oracle_and_golden(golden, name):
     assert abs(tot - float(g['grad_norm_total'])) < 5e-3 * float(g['grad_norm_total'])
 
 
+def test_lane_batched_and_stream_schedules_agree():
+    """engine.BATCH_POLICY: the towers / decoders of a step as lanes of one launch batch ('on'), one HIP stream per tower with
+    only regions batched (what 'auto' picks at this size) and no batching at all ('off') are three SCHEDULES of the same
+    kernels — losses, predictions and every gradient must agree to rounding (grouped launches are bit-identical to individual
+    ones; only the order of fp32 accumulation into shared gradient buffers may differ)."""
+    from deepavfusion_amd import engine as E
+    results = {}
+    try:
+        for policy in ('on', 'auto', 'off'):
+            E.set_batch_policy(policy)
+            model, sd, cfg, O = _build('micro')
+            image, audio, ni, na = O.synthetic_batch(cfg, 3, seed=21)
+            E.BATCH_STATS[0] = E.BATCH_STATS[1] = 0
+            out = model(image.cuda(), audio.cuda(), torch.from_numpy(ni).cuda(), torch.from_numpy(na).cuda())
+            (out[0] + out[1]).backward()
+            torch.cuda.synchronize()
+            results[policy] = (float(out[0]), float(out[1]), out[2].detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None},
+                               tuple(E.BATCH_STATS))
+    finally:
+        E.set_batch_policy({'1': 'on', '0': 'off'}.get(os.environ.get('DAV_BATCH', ''), 'auto'))
+    assert results['off'][4] == (0, 0)                                   # nothing recorded without batching
+    assert results['on'][4][0] > results['auto'][4][0] > 0               # lanes record more launches than regions alone
+    ref = results['on']
+    for policy in ('auto', 'off'):
+        got = results[policy]
+        assert abs(got[0] - ref[0]) <= 1e-6 * abs(ref[0]) and abs(got[1] - ref[1]) <= 1e-6 * abs(ref[1])
+        assert rel(got[2], ref[2]) < 1e-6
+        assert set(got[3]) == set(ref[3])
+        for n, g in ref[3].items():
+            assert rel(got[3][n], g) < 1e-5, (policy, n)
+
+
 @pytest.mark.parametrize('name,batch', [('micro', 2), ('micro', 64), ('tiny', 2), ('micro_token', 2), ('micro_dense', 2), ('micro_swin', 2),
                                         ('micro_swin', 5)])
 def test_end_to_end_fp32(golden, name, batch):
