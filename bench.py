@@ -270,7 +270,7 @@ def main():
         if os.path.exists(tf):
             rec = json.load(open(tf)).get(f'{a.config}_b{B}', {})
             traffic = rec.get('hbm_bytes_per_launch')
-        result['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_nt2_grouped_kernel, the launches of >= 400 tile equivalents with the tile configuration the step gives each (128x128 dominant; 128x256 / 256x128 / 128x64 per the rules and the tuned table): forward + b_kn dgrad, grouped launches',
+        result['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_nt2_kernel / gemm_nt2_grouped_kernel, the launches of >= 400 tile equivalents exactly as the step issues them (default stream schedule: one launch per tower GEMM), each with its tile configuration (128x128 dominant; 128x256 per the rules / tuned table): forward + b_kn dgrad',
                               'launches_by_config': {str(c): sum(1 for cc, _b, _p in big if cc == c) for c in sorted({cc for cc, _b, _p in big})},
                               'achieved': round(ach, 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                               'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': traffic,
@@ -279,6 +279,40 @@ def main():
                               'launches_per_step': len(big), 'problems_per_step': sum(len(pr) for _c, _b, pr in big),
                               'avg_launch_us': round(total_ms * 1e3 / len(big), 2),
                               'avg_gflop_per_launch': round(fl / len(big) / 1e9, 3)}
+        # the same kernel in the LANES schedule (engine.BATCH_POLICY 'on', three lanes on one queue: the towers' and the fusion
+        # block's equal-rank GEMMs merged into one grid): what the kernel reaches with 1400-2400 tiles per launch — reported
+        # beside the as-issued figure because the default stream schedule (faster end to end) launches per tower.
+        if world == 1 and E.BATCH_POLICY != 'on' and not a.roofline_only:
+            prev_policy, prev_fs = E.BATCH_POLICY, E.FUSION_ON_STREAM
+            try:
+                E.set_batch_policy('on')
+                E.FUSION_ON_STREAM = False
+                ops.nt_issue_log(True)
+                eager_step()
+                lane_log = ops.nt_issue_log()
+                ops.nt_issue_log(False)
+            finally:
+                E.set_batch_policy(prev_policy)
+                E.FUSION_ON_STREAM = prev_fs
+            big2 = [(c, bt, probs) for (c, bt, probs) in lane_log if t128(probs) >= BIG_LAUNCH_TILES]
+            for _c, bt, probs in big2:
+                for (M, N, K) in probs:
+                    if (M, N, K, bt) not in bufs:
+                        Bm = (torch.randn(K, N, device=dev) * 0.05).bfloat16() if bt else (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+                        bufs[(M, N, K, bt)] = (torch.randn(M, K, device=dev).bfloat16(), Bm, torch.empty(M, N, device=dev, dtype=torch.bfloat16))
+
+            def replay_lanes():
+                for c, bt, probs in big2:
+                    with E.batch(auto_lanes=True):
+                        for (M, N, K) in probs:
+                            A, Bm, C = bufs[(M, N, K, bt)]
+                            ops.gemm_nt(A, Bm, M, N, K, ldb=N if bt else K, C_out=C, c_bf16=True, variant=(c << 4) | (bt << 12))
+            ms2 = time_replay(replay_lanes, reps)
+            fl2 = sum(2.0 * M * N * K for _c, _b, probs in big2 for (M, N, K) in probs)
+            result['roofline']['lanes_schedule'] = {'what': "the same GEMMs as the launches of DAV_BATCH=1 DAV_FUSION_STREAM=0 (towers + fusion block merged per step)",
+                                                    'achieved': round(fl2 / (ms2 * 1e-3) / 1e12, 1),
+                                                    'frac': round(fl2 / (ms2 * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                                                    'launches_per_step': len(big2), 'avg_launch_us': round(ms2 * 1e3 / len(big2), 2)}
         del bufs
     # ---- weight-gradient kernel (gemm_tn_grouped_kernel<128,2,4>): the step's grouped launches, one per layer / decoder pair
     if tn_log and not a.no_roofline:

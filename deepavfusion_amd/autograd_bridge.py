@@ -396,7 +396,7 @@ def avmae_fwd(model, image, audio, noise_i, noise_a):
     nF = enc.fusion_tokens.shape[1]
     dec_i, dec_a = model.decoder('image'), model.decoder('audio')
     main, sa, _ = _streams(image.device)
-    lanes = t_enc['lanes']            # (the decoders as lanes beside stream-scheduled encoder layers measured 0.4 ms slower)
+    lanes = t_enc['lanes'] and os.environ.get('DAV_DEC_STREAMS', '0') != '1'      # the two decoders follow the encoder's schedule
     if lanes:
         with E.batch() as bt:                 # the two MAE decoders (models/avmae.py:147-180) in lockstep
             bt.lane()

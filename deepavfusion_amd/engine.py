@@ -73,18 +73,21 @@ BATCH_STATS = [0, 0]          # launches recorded / issued since the last reset 
 #             launches (the fusion block's projections / cross-attentions / LayerNorms) and the layer's grouped weight gradients.
 #   lanes     the two tower blocks (the two decoders) as LANES of one launch batch on the main stream — equal-rank kernels merged
 #             into grouped grids — with the fusion block on its own stream beside them (DAV_FUSION_STREAM=0: as a third lane
-#             of the batch, the towers idling through its extra steps: everything on ONE queue).
-# BATCH_POLICY 'auto' (default): lanes from LANE_MIN_ROWS rows (B x tokens per tower block) upwards, streams below;
-# 'on' (DAV_BATCH=1): lanes always; 'off' (DAV_BATCH=0): streams and no launch batching at all.
-# Same-box A/B (tools/ab_env.sh; ViT-B B = 64 / ViT-B B = 32 / ViT-L B = 32, ms per step): streams 29.0-29.3 / 22.2 / 46.8-47.5,
-# lanes + fusion stream 29.5-29.8 / 24.3 / 48.0, three lanes on one queue 29.7-30.2 / 26.2 / 52.0, 'off' 31.0 / 24.2 / 49.0-49.5.
-# The merged tower grids are ~10 % faster than their parts and keep the big GEMM launches at 1400+ tiles; what the single queue
-# lost was the fusion block's ~11 small dependent steps, 4-8 of them alone on the GPU per layer.  At the
-# bench size the stream schedule is another 0.2-0.4 ms faster than lanes + fusion stream, but its per-tower launches are the
-# less efficient kernels (0.23 vs 0.255 of the MFMA peak in isolation): lanes stay the choice there; below ~4096 rows the
-# towers' launches are too small to fill the GPU either way and concurrency wins clearly.
+#             of the batch, the towers idling through its extra steps: everything on ONE queue; DAV_DEC_STREAMS=1: the decoders
+#             on two streams all the same).
+# BATCH_POLICY 'auto' (default): streams, unless DAV_LANE_MIN_ROWS=n asks for lanes from n rows (B x tokens per tower block)
+# upwards; 'on' (DAV_BATCH=1): lanes always; 'off' (DAV_BATCH=0): streams and no launch batching at all.
+# Same-box A/B (tools/ab_env.sh; ms per step at ViT-B B = 64 / ViT-B B = 32 / ViT-L B = 32):
+#   streams                                  28.8-28.9 / 22.2 / 46.8-47.5
+#   lanes + fusion stream, decoders streams  29.1-29.2
+#   lanes + fusion stream                    29.5-29.8 / 24.3 / 48.0
+#   three lanes on one queue                 30.0-30.2 / 26.2 / 52.0      (the default of the first half of round 2)
+#   'off'                                    31.0 / 24.2 / 49.0-49.5      (round 1's schedule)
+# The merged tower grids are ~10 % faster than their parts in isolation (0.256 vs 0.233 of the MFMA peak for the big GEMM
+# launches), but on one queue the fusion block's ~11 small dependent steps run alone on the GPU (4-8 per layer, DESIGN.md
+# section 4), and concurrent streams also fill each other's launch tails — once the regions are batched that is worth more.
 BATCH_POLICY = {'1': 'on', '0': 'off'}.get(os.environ.get('DAV_BATCH', ''), 'auto')
-LANE_MIN_ROWS = int(os.environ.get('DAV_LANE_MIN_ROWS', '4096'))
+LANE_MIN_ROWS = int(os.environ.get('DAV_LANE_MIN_ROWS', str(1 << 30)))
 FUSION_ON_STREAM = os.environ.get('DAV_FUSION_STREAM', '1') != '0'
 
 
