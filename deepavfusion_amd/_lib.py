@@ -119,7 +119,7 @@ def load():
     return lib
 
 
-NT_TUNING_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuning', 'nt_gfx950.json')
+NT_TUNING_PATH = os.environ.get('DAV_NT_TUNE_FILE') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuning', 'nt_gfx950.json')
 
 
 def load_nt_tuning(path):
