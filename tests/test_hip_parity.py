@@ -567,13 +567,14 @@ def test_trainer_and_loss_curve_fp32(golden):
         E.set_precision('bf16')
 
 
-def test_graphed_step_equals_eager_step():
+@pytest.mark.parametrize('name', ['micro', 'micro_swin'])
+def test_graphed_step_equals_eager_step(name):
     from deepavfusion_amd.util import lr_sched
     from deepavfusion_amd.util.flat import FlatAdamW
     from deepavfusion_amd.util.misc import GraphedStep, Trainer
     losses = []
     for graphed in (False, True):
-        model, sd, cfg, O = _build('micro')
+        model, sd, cfg, O = _build(name)
         nd = [n for n, p in model.named_parameters() if 'bias' in n or 'norm' in n]
         groups = lr_sched.param_groups_pretrained(model, 0.05, no_weight_decay_list=nd, image_pt='', audio_pt='')
         opt = FlatAdamW(groups, lr=2e-3, betas=(0.9, 0.95), model=model)
