@@ -1403,11 +1403,14 @@ __device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, 
       for (int i = 0; i < FM; ++i) af[i] = tn2_frag<RB>(Ab, kk * 32, wm * WTN + i * 16, lane);
 #pragma unroll
       for (int j = 0; j < FN; ++j) bfr[j] = tn2_frag<RB>(Bb, kk * 32, wn * WTK + j * 16, lane);
+      // operands swapped (B fragment first): the 16 x 16 block comes out TRANSPOSED — lane (fr, fg) holds C[n = fr][k = 4 fg .. + 3],
+      // four consecutive columns of one row — so the read-modify-write of the gradient tile is one 16-byte access per lane and
+      // fragment instead of four scalar ones (as the NT kernels' epilogue)
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
       if (do_bias) {
 #pragma unroll
         for (int i = 0; i < FM; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones.v, accb[i], 0, 0, 0);
@@ -1420,25 +1423,33 @@ __device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, 
   // read-modify-write when accumulating)
   const bool atomic = p.splits > 1 && !p.debug_plain_store;
 #pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = n0 + wm * WTN + i * 16 + fg * 4 + r;
-      if (n >= p.N) continue;
+  for (int i = 0; i < FM; ++i) {
+    const int n = n0 + wm * WTN + i * 16 + fr;
+    if (n < p.N) {
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
-        const int k = k0 + wn * WTK + j * 16 + fr;
-        if (k >= p.K) continue;
+        const int k = k0 + wn * WTK + j * 16 + fg * 4;
+        if (k >= p.K) continue;                           // K is a multiple of 8: the four columns are in or out together
         float* c = p.C + (long)n * p.ldc + k;
-        if (atomic) unsafeAtomicAdd(c, acc[i][j][r]);
-        else if (p.beta) *c += acc[i][j][r];
-        else *c = acc[i][j][r];
-      }
-      if (do_bias && fr == 0) {
-        if (p.splits > 1) unsafeAtomicAdd(p.bias_grad + n, accb[i][r]);
-        else p.bias_grad[n] += accb[i][r];
+        if (atomic) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) unsafeAtomicAdd(c + r, acc[i][j][r]);
+        } else {
+          float4 v = float4{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+          if (p.beta) { const float4 o = *reinterpret_cast<const float4*>(c); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+          *reinterpret_cast<float4*>(c) = v;
+        }
       }
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                         // the bias-gradient accumulators keep the untransposed layout
+      const int nb = n0 + wm * WTN + i * 16 + fg * 4 + r;
+      if (do_bias && fr == 0 && nb < p.N) {
+        if (p.splits > 1) unsafeAtomicAdd(p.bias_grad + nb, accb[i][r]);
+        else p.bias_grad[nb] += accb[i][r];
+      }
+    }
+  }
 }
 
 template <int T, int WM_, int WN_>
@@ -1673,7 +1684,7 @@ extern "C" int dav_gemm_tn_grouped_bf16(const DavTnProblem* probs, int count, hi
   for (int i = 0; i < count; ++i) {
     const DavTnProblem& q = probs[i];
     if (q.Mc <= 0 || (q.Mc & 63) || q.N <= 0 || q.K <= 0 || (q.N & 7) || (q.K & 7) || (q.lda & 7) || (q.ldb & 7)) return DAV_ERR_SHAPE;
-    if (((uintptr_t)q.A | (uintptr_t)q.B) & 15) return DAV_ERR_ALIGN;
+    if (((uintptr_t)q.A | (uintptr_t)q.B | (uintptr_t)q.C) & 15 || (q.ldc & 3)) return DAV_ERR_ALIGN;      // 16-byte gradient accesses
     total_tiles += (long)((q.N + 127) / 128) * ((q.K + 127) / 128);
   }
   // aim at ~4 workgroups of 8 waves per CU-slot pair (1024 blocks) but keep >= 8 k-steps of 64 rows per split
@@ -1711,7 +1722,7 @@ extern "C" int dav_gemm_tn_bf16(const void* A, const void* B, int Mc, int N, int
   variant &= ~256;
   const int steps = (Mc + 63) / 64;
   const int cfg = variant >> 4;           // 0 auto, 1 = 128x128 tiles, 2 = 64x64 tiles (benchmark knob)
-  if (!(variant & 15) && (Mc & 63) == 0 && (beta || cfg)) {
+  if (!(variant & 15) && (Mc & 63) == 0 && (beta || cfg) && !(ldc & 3) && !((uintptr_t)C & 15)) {      // (16-byte gradient accesses)
     const int t128 = ((N + 127) / 128) * ((K + 127) / 128), t64 = ((N + 63) / 64) * ((K + 63) / 64);
     const bool big = cfg ? cfg == 1 : (Mc >= 20000 && t128 >= 48);   // 64x64 tiles win except on the longest contractions
     const int tiles = big ? t128 : t64;
