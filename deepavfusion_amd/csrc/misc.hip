@@ -359,8 +359,9 @@ __global__ __launch_bounds__(1024) void sumsq_final_kernel(const float* partial,
 // step-dependent bias corrections are read from device memory so a captured graph can be replayed.
 // Segments start on 64-element boundaries (FlatParams.ALIGN), so a lane's 4 consecutive elements share one segment and
 // every access is a 16-byte one; n is a multiple of 4.
-__global__ __launch_bounds__(256) void adamw_flat_kernel(float* p, float* g, float* m, float* v, bf16_t* p_bf16, long n,
-                                                         const long* seg_end, const float* hyper, int nseg, float beta1,
+__global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                         float* __restrict__ v, bf16_t* __restrict__ p_bf16, long n,
+                                                         const long* __restrict__ seg_end, const float* __restrict__ hyper, int nseg, float beta1,
                                                          float beta2, float eps, const float* bias_corr, float grad_scale,
                                                          float* sumsq_out, int zero_grad) {
   constexpr long CHUNK = 256 * 4 * 4;     // contiguous elements per workgroup iteration: 4 float4 per lane
