@@ -343,65 +343,92 @@ template <int FM, int FN, int WTM, int WTN>
 __device__ __forceinline__ void nt_epilogue_t(const NTParams& p, f32x4 (&acc)[FM][FN], int m0, int n0, int wm, int wn, int lane) {
   if (p.debug & 2) return;
   const int fr = lane & 15, fg = lane >> 4;
+  // Every global READ of the epilogue (bias, residual, aux) is requested for a batch of fragments (2 x FN, or FN for the
+  // 64-wide wave tiles) before the first one is used: written fragment by fragment the compiler has to wait for each load
+  // right where it stands (a store to C may alias the next residual), i.e. one memory latency per read — sixteen of them in
+  // a row for an fp32 + residual tile, about as long as a K = 768 k-loop.
+  float4 bv[FN];
+  bool nok[FN];
 #pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const int m = m0 + wm * WTM + i * 16 + fr;
-    if (m >= p.M) continue;
-    const long crow = p.C ? map_row(m, p.cmap) : 0;
-    long rrow = 0;
-    if (p.res) rrow = p.res_rows ? (long)p.res_rows[m] : map_row(m, p.rmap);
+  for (int j = 0; j < FN; ++j) {
+    const int n = n0 + wn * WTN + j * 16 + fg * 4;
+    nok[j] = n < p.N;
+    bv[j] = (p.bias && nok[j]) ? *reinterpret_cast<const float4*>(p.bias + n) : float4{0.f, 0.f, 0.f, 0.f};
+  }
+  constexpr int IH = (FM >= 2 && FN <= 2) ? 2 : 1;          // fragment rows per batch (about 40 registers of staging)
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int n = n0 + wn * WTN + j * 16 + fg * 4;
-      if (n >= p.N) continue;
-      float4 v;
-      v.x = acc[i][j][0] * p.alpha; v.y = acc[i][j][1] * p.alpha; v.z = acc[i][j][2] * p.alpha; v.w = acc[i][j][3] * p.alpha;
-      if (p.bias) {
-        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+  for (int i0 = 0; i0 < FM; i0 += IH) {
+    float4 rv[IH][FN];
+    uint2 av[IH][FN];
+    long crow[IH], rrow[IH];
+    bool mok[IH];
+#pragma unroll
+    for (int ii = 0; ii < IH; ++ii) {
+      const int m = m0 + wm * WTM + (i0 + ii) * 16 + fr;
+      mok[ii] = m < p.M;
+      const int mc = mok[ii] ? m : p.M - 1;
+      crow[ii] = p.C ? map_row(mc, p.cmap) : 0;
+      rrow[ii] = p.res ? (p.res_rows ? (long)p.res_rows[mc] : map_row(mc, p.rmap)) : 0;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int n = n0 + wn * WTN + j * 16 + fg * 4;
+        const bool ok = mok[ii] && nok[j];
+        rv[ii][j] = (p.res && ok) ? *reinterpret_cast<const float4*>(p.res + rrow[ii] * p.ldres + n) : float4{0.f, 0.f, 0.f, 0.f};
+        av[ii][j] = ((p.act == 2 || p.act == 3) && ok) ? *reinterpret_cast<const uint2*>(p.aux + (long)mc * p.ldaux + n) : uint2{0, 0};
       }
-      if (p.debug & 1) { if (v.x == 123.456f) reinterpret_cast<float*>(p.C)[0] = v.y; continue; }
-      if (p.c2_mode == 1) {
-        uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
-        *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
-      }
-      if (p.act == 1) {
-        float4 d;
-        gelu_pair_f(v.x, v.x, d.x); gelu_pair_f(v.y, v.y, d.y); gelu_pair_f(v.z, v.z, d.z); gelu_pair_f(v.w, v.w, d.w);
-        if (p.c2_mode == 4) {          // bf16 twin = GELU'(pre-activation): the fc2 input gradient only multiplies by it
-          uint2 w; w.x = pack2bf(d.x, d.y); w.y = pack2bf(d.z, d.w);
+    }
+#pragma unroll
+    for (int ii = 0; ii < IH; ++ii) {
+      const int i = i0 + ii;
+      const int m = m0 + wm * WTM + i * 16 + fr;
+      if (!mok[ii]) continue;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int n = n0 + wn * WTN + j * 16 + fg * 4;
+        if (!nok[j]) continue;
+        float4 v;
+        v.x = acc[i][j][0] * p.alpha + bv[j].x; v.y = acc[i][j][1] * p.alpha + bv[j].y;
+        v.z = acc[i][j][2] * p.alpha + bv[j].z; v.w = acc[i][j][3] * p.alpha + bv[j].w;
+        if (p.debug & 1) { if (v.x == 123.456f) reinterpret_cast<float*>(p.C)[0] = v.y; continue; }
+        if (p.c2_mode == 1) {
+          uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
           *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
         }
-      } else if (p.act == 2) {
-        const uint2 a = *reinterpret_cast<const uint2*>(p.aux + (long)m * p.ldaux + n);
-        v.x *= gelu_grad_f(__uint_as_float(a.x << 16)); v.y *= gelu_grad_f(__uint_as_float(a.x & 0xffff0000u));
-        v.z *= gelu_grad_f(__uint_as_float(a.y << 16)); v.w *= gelu_grad_f(__uint_as_float(a.y & 0xffff0000u));
-      } else if (p.act == 3) {
-        const uint2 a = *reinterpret_cast<const uint2*>(p.aux + (long)m * p.ldaux + n);
-        v.x *= __uint_as_float(a.x << 16); v.y *= __uint_as_float(a.x & 0xffff0000u);
-        v.z *= __uint_as_float(a.y << 16); v.w *= __uint_as_float(a.y & 0xffff0000u);
-      }
-      if (p.c2_mode == 2) {
-        uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
-        *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
-      }
-      if (p.res) {
-        const float4 t = *reinterpret_cast<const float4*>(p.res + rrow * p.ldres + n);
-        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-      }
-      if (p.C) {
-        if (p.c_bf16) {
-          uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
-          *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + crow * p.ldc + n) = w;
-        } else {
-          float4* c = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + crow * p.ldc + n);
-          if (p.beta) { const float4 o = *c; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-          *c = v;
+        if (p.act == 1) {
+          float4 d;
+          gelu_pair_f(v.x, v.x, d.x); gelu_pair_f(v.y, v.y, d.y); gelu_pair_f(v.z, v.z, d.z); gelu_pair_f(v.w, v.w, d.w);
+          if (p.c2_mode == 4) {          // bf16 twin = GELU'(pre-activation): the fc2 input gradient only multiplies by it
+            uint2 w; w.x = pack2bf(d.x, d.y); w.y = pack2bf(d.z, d.w);
+            *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
+          }
+        } else if (p.act == 2) {
+          const uint2 a = av[ii][j];
+          v.x *= gelu_grad_f(__uint_as_float(a.x << 16)); v.y *= gelu_grad_f(__uint_as_float(a.x & 0xffff0000u));
+          v.z *= gelu_grad_f(__uint_as_float(a.y << 16)); v.w *= gelu_grad_f(__uint_as_float(a.y & 0xffff0000u));
+        } else if (p.act == 3) {
+          const uint2 a = av[ii][j];
+          v.x *= __uint_as_float(a.x << 16); v.y *= __uint_as_float(a.x & 0xffff0000u);
+          v.z *= __uint_as_float(a.y << 16); v.w *= __uint_as_float(a.y & 0xffff0000u);
         }
-      }
-      if (p.c2_mode == 3) {
-        uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
-        *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
+        if (p.c2_mode == 2) {
+          uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
+          *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
+        }
+        if (p.res) { const float4 t = rv[ii][j]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+        if (p.C) {
+          if (p.c_bf16) {
+            uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + crow[ii] * p.ldc + n) = w;
+          } else {
+            float4* c = reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + crow[ii] * p.ldc + n);
+            if (p.beta) { const float4 o = *c; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }      // (accumulating GEMMs are the fusion block's small ones)
+            *c = v;
+          }
+        }
+        if (p.c2_mode == 3) {
+          uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
+          *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
+        }
       }
     }
   }
@@ -433,8 +460,27 @@ __device__ __forceinline__ void nt_epilogue_s(const NTParams& p, f32x4 (&acc)[FM
   const int fr = lane & 15, fg = lane >> 4;
   char* img2 = SPLIT ? lds : lds + BM * RB;
   uint2 w2r[SPLIT ? FM : 1][SPLIT ? FN : 1];
+  // all global reads of the elementwise part (bias per fragment column, aux per fragment) go out before the first use: one
+  // memory latency per tile instead of one per fragment (see nt_epilogue_t)
+  float4 bv[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int n = n0 + wn * WTN + j * 16 + fg * 4;
+    bv[j] = (p.bias && n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : float4{0.f, 0.f, 0.f, 0.f};
+  }
+  constexpr int AH = FN <= 2 ? FM : 1;       // fragment rows whose aux reads are in flight together (8-16 registers)
+  uint2 av[AH][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
+    if (i % AH == 0) {
+#pragma unroll
+      for (int ii = 0; ii < AH; ++ii)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int m = m0 + wm * WTM + (i + ii) * 16 + fr, n = n0 + wn * WTN + j * 16 + fg * 4;
+          av[ii][j] = ((p.act == 2 || p.act == 3) && i + ii < FM && m < p.M && n < p.N) ? *reinterpret_cast<const uint2*>(p.aux + (long)m * p.ldaux + n) : uint2{0, 0};
+        }
+    }
     const int ml = wm * WTM + i * 16 + fr;
     const int m = m0 + ml;
 #pragma unroll
@@ -442,12 +488,9 @@ __device__ __forceinline__ void nt_epilogue_s(const NTParams& p, f32x4 (&acc)[FM
       const int nl = wn * WTN + j * 16 + fg * 4;
       const int n = n0 + nl;
       float4 v;
-      v.x = acc[i][j][0] * p.alpha; v.y = acc[i][j][1] * p.alpha; v.z = acc[i][j][2] * p.alpha; v.w = acc[i][j][3] * p.alpha;
       const bool ok = m < p.M && n < p.N;
-      if (p.bias && ok) {
-        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-      }
+      v.x = acc[i][j][0] * p.alpha + bv[j].x; v.y = acc[i][j][1] * p.alpha + bv[j].y;
+      v.z = acc[i][j][2] * p.alpha + bv[j].z; v.w = acc[i][j][3] * p.alpha + bv[j].w;
       uint2 w2 = uint2{0, 0};
       if (p.c2_mode == 1) { w2.x = pack2bf(v.x, v.y); w2.y = pack2bf(v.z, v.w); }
       if (p.act == 1) {
@@ -455,7 +498,7 @@ __device__ __forceinline__ void nt_epilogue_s(const NTParams& p, f32x4 (&acc)[FM
         gelu_pair_f(v.x, v.x, d.x); gelu_pair_f(v.y, v.y, d.y); gelu_pair_f(v.z, v.z, d.z); gelu_pair_f(v.w, v.w, d.w);
         if (p.c2_mode == 4) { w2.x = pack2bf(d.x, d.y); w2.y = pack2bf(d.z, d.w); }
       } else if ((p.act == 2 || p.act == 3) && ok) {
-        const uint2 a = *reinterpret_cast<const uint2*>(p.aux + (long)m * p.ldaux + n);
+        const uint2 a = av[i % AH][j];
         float4 g;
         g.x = __uint_as_float(a.x << 16); g.y = __uint_as_float(a.x & 0xffff0000u);
         g.z = __uint_as_float(a.y << 16); g.w = __uint_as_float(a.y & 0xffff0000u);
@@ -968,7 +1011,7 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(NTParams p) {
 }
 // PIPE: two 512-thread workgroups per CU = 4 waves per SIMD -> at most 128 VGPRs (2nd launch-bounds argument = waves per SIMD)
 template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK = 64, int PIPE = 0>
-__global__ __launch_bounds__(WM_* WN_ * 64, PIPE ? 4 : 1) void gemm_nt2_kernel(NTParams p) {
+__global__ __launch_bounds__(WM_* WN_ * 64, (PIPE || (WM_ * WN_ == 8 && BM * BN > 128 * 128)) ? 4 : 1) void gemm_nt2_kernel(NTParams p) {
   nt2_body<BM, BN, WM_, WN_, STAGES, BT, BK, false, PIPE>(p, blockIdx.x);
 }
 
@@ -984,7 +1027,7 @@ struct NTGroup {
 };
 
 template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK = 64, int PIPE = 0>
-__global__ __launch_bounds__(WM_* WN_ * 64, PIPE ? 4 : 1) void gemm_nt2_grouped_kernel(const NTGroup g) {
+__global__ __launch_bounds__(WM_* WN_ * 64, (PIPE || (WM_ * WN_ == 8 && BM * BN > 128 * 128)) ? 4 : 1) void gemm_nt2_grouped_kernel(const NTGroup g) {
   int pi = 0;
   while (pi + 1 < g.count && (int)blockIdx.x >= g.first_block[pi + 1]) ++pi;
   nt2_body<BM, BN, WM_, WN_, STAGES, BT, BK, false, PIPE>(g.prob[pi], (int)blockIdx.x - g.first_block[pi]);
