@@ -85,6 +85,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     force_dist = os.environ.get('DAV_FORCE_DIST', '0') == '1'      # test hook: 1-rank RCCL group on a single GPU
+    # stdout carries exactly ONE line, the result: anything a library prints there meanwhile (RCCL's version banner at
+    # communicator creation does) is sent to stderr instead; the JSON goes to the saved descriptor at the end
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     if world > 1 or force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
@@ -404,7 +409,8 @@ def main():
     except Exception:
         pass
     sys.stderr.flush()
-    print(json.dumps(result), flush=True)
+    sys.stdout.flush()
+    os.write(result_fd, (json.dumps(result) + '\n').encode())
     return 0
 
 
