@@ -319,7 +319,7 @@ def main():
                                                     'frac': round(fl2 / (ms2 * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
                                                     'launches_per_step': len(big2), 'avg_launch_us': round(ms2 * 1e3 / len(big2), 2)}
         del bufs
-    # ---- weight-gradient kernel (gemm_tn_grouped_kernel<128,2,4>): the step's grouped launches, one per layer / decoder pair
+    # ---- weight-gradient kernel (gemm_tn_grouped_kernel<128,4,2>): the step's grouped launches, one per layer / decoder pair
     if tn_log and not a.no_roofline:
         tbufs = {}
         for probs in tn_log:
@@ -335,7 +335,7 @@ def main():
         uniq = [list(dict.fromkeys(probs)) for probs in tn_log]      # one buffer set per shape: equal shapes of a launch would race on C
         ms_tn = time_replay(replay_tn, reps)
         fl_tn = sum(2.0 * Mc * N * K for probs in uniq for (Mc, N, K) in probs)
-        result['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'gemm_tn_grouped_kernel<128,2,4> (all weight gradients of a layer / of both decoders per launch)',
+        result['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'gemm_tn_grouped_kernel<128,4,2> (all weight gradients of a layer / of both decoders per launch)',
                                     'achieved': round(fl_tn / (ms_tn * 1e-3) / 1e12, 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                     'frac': round(fl_tn / (ms_tn * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
                                     'launches_per_step': len(tn_log), 'avg_launch_us': round(ms_tn * 1e3 / len(tn_log), 1),

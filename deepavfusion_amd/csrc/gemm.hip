@@ -1380,24 +1380,26 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TNParams p) {
 // tr-read fragments, bias gradient as one extra MFMA against a fragment of ones, split-K with fp32
 // atomics into the live gradient.
 // ------------------------------------------------------------------------------------------------
-template <int T, int WM_, int WN_>
+template <int T, int WM_, int WN_, int RS = 64, int NST = 2>
 __device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, const int split_idx) {
+  // RS contraction rows per ring stage, NST stages (NST - 1 stages of loads in flight while one is consumed)
   constexpr int NT = WM_ * WN_ * 64, RB = T * 2, CPRW = T / 8;      // 16-byte chunks per tile row
-  constexpr int TILE_BYTES = 64 * RB, STAGE_BYTES = 2 * TILE_BYTES;
-  constexpr int CH = 64 * CPRW / NT;                                // chunks per thread per operand
+  constexpr int TILE_BYTES = RS * RB, STAGE_BYTES = 2 * TILE_BYTES;
+  constexpr int CH = RS * CPRW / NT;                                // chunks per thread per operand
   constexpr int WTN = T / WM_, WTK = T / WN_, FM = WTN / 16, FN = WTK / 16;
-  static_assert(64 * CPRW % NT == 0, "tile/threads mismatch");
+  static_assert(RS * CPRW % NT == 0 && (RS == 32 || RS == 64) && NST >= 2, "tile/threads mismatch");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN_, wn = wave % WN_;
   const int tiles_k = (p.K + T - 1) / T;
   const int bn = tile_idx / tiles_k, bk = tile_idx % tiles_k;
   const int n0 = bn * T, k0 = bk * T;
-  const int steps_total = p.Mc >> 6;
+  const int steps_total = p.Mc >> 6;                                // the split of the contraction is in 64-row units
   const int steps_per = (steps_total + p.splits - 1) / p.splits;
-  const int s_begin = split_idx * steps_per;
+  int s_begin = split_idx * steps_per;
   int s_end = s_begin + steps_per; s_end = s_end < steps_total ? s_end : steps_total;
   if (s_begin >= s_end) return;
+  s_begin *= 64 / RS; s_end *= 64 / RS;                             // ... the ring's steps in RS-row units
 
   int a_col[CH], b_col[CH], rowi[CH];
 #pragma unroll
@@ -1412,7 +1414,7 @@ __device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, 
     char* st = smem + stage * STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-      const int m = (s << 6) + rowi[i];
+      const int m = s * RS + rowi[i];
       __builtin_amdgcn_global_load_lds(GLB_PTR(void, p.A + map_row(m, p.amap) * p.lda + a_col[i]),
                                        LDS_PTR(void, st + (wave * 64 + NT * i) * 16), 16, 0, 0);
       __builtin_amdgcn_global_load_lds(GLB_PTR(void, p.B + map_row(m, p.bmap) * p.ldb + b_col[i]),
@@ -1431,16 +1433,21 @@ __device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, 
   union { uint32_t w[4]; bf16x8 v; } ones;
   ones.w[0] = ones.w[1] = ones.w[2] = ones.w[3] = 0x3f803f80u;
 
-  dma_tile(s_begin, 0);
+#pragma unroll
+  for (int st = 0; st < NST - 1; ++st)
+    if (s_begin + st < s_end) dma_tile(s_begin + st, st);
+  int stage = 0;
   for (int s = s_begin; s < s_end; ++s) {
-    const int stage = (s - s_begin) & 1;
-    wait_vmcnt<0>();
+    // the loads of step s must have landed; those of the NST - 2 steps after it may still be in flight (each step is 2 CH loads
+    // per wave) — once the tail stops issuing, drain everything
+    if (NST > 2 && s + NST - 2 < s_end) wait_vmcnt<(NST - 2) * 2 * CH>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    if (s + 1 < s_end) dma_tile(s + 1, stage ^ 1);
+    if (s + NST - 1 < s_end) dma_tile(s + NST - 1, stage == 0 ? NST - 1 : stage - 1);      // the stage step s - 1 has just released
     const char* Ab = smem + stage * STAGE_BYTES;
     const char* Bb = Ab + TILE_BYTES;
+    stage = stage + 1 == NST ? 0 : stage + 1;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < RS / 32; ++kk) {
       bf16x8 af[FM], bfr[FN];
 #pragma unroll
       for (int i = 0; i < FM; ++i) af[i] = tn2_frag<RB>(Ab, kk * 32, wm * WTN + i * 16, lane);
@@ -1509,14 +1516,14 @@ struct TNGroup {
   int count;
 };
 
-template <int T, int WM_, int WN_>
-__global__ __launch_bounds__(WM_* WN_ * 64) void gemm_tn_grouped_kernel(const TNGroup g) {
+template <int T, int WM_, int WN_, int RS = 64, int NST = 2, int MINW = 1>
+__global__ __launch_bounds__(WM_* WN_ * 64, MINW) void gemm_tn_grouped_kernel(const TNGroup g) {
   int pi = 0;
   while (pi + 1 < g.count && (int)blockIdx.x >= g.first_block[pi + 1]) ++pi;
   const TNParams& p = g.prob[pi];
   const int local = blockIdx.x - g.first_block[pi];
   const int tiles = ((p.N + T - 1) / T) * ((p.K + T - 1) / T);
-  tn2_body<T, WM_, WN_>(p, local % tiles, local / tiles);
+  tn2_body<T, WM_, WN_, RS, NST>(p, local % tiles, local / tiles);
 }
 
 template <int T, int WM_, int WN_>
@@ -1749,7 +1756,9 @@ extern "C" int dav_gemm_tn_grouped_bf16(const DavTnProblem* probs, int count, hi
   }
   g.first_block[count] = first;
   g.count = count;
-  DAV_LAUNCH((gemm_tn_grouped_kernel<128, 2, 4>), dim3(first), dim3(512), (size_t)2 * 2 * 64 * 128 * 2, stream, g);
+  // 4 x 2 waves (32 x 64 wave tiles): +1 % over 2 x 4 in the step; thinner or deeper rings (32-row stages x 3 / 4, 64-row x 3),
+  // 4-wave workgroups and three workgroups per CU were all measured slower (profiles/r02_tn_ring_variants.txt)
+  DAV_LAUNCH((gemm_tn_grouped_kernel<128, 4, 2>), dim3(first), dim3(512), (size_t)2 * 2 * 64 * 128 * 2, stream, g);
   return dav_launch_status();
 }
 

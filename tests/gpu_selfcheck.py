@@ -523,6 +523,10 @@ def misc_kernels():
 def main():
     flt = sys.argv[1] if len(sys.argv) > 1 else ''
     print('device:', torch.cuda.get_device_name(0), flush=True)
+    for kv in os.environ.get('DAV_TUNE', '').split(','):      # same launch-geometry knobs as bench.py (e.g. DAV_TUNE=4:1)
+        if ':' in kv:
+            from deepavfusion_amd import _lib
+            _lib.check(_lib.load().dav_tune(int(kv.split(':')[0]), int(kv.split(':')[1])), 'dav_tune')
     for fn in (gemm_nt, gemm_tn, attention, layernorm, masking, misc_kernels, patch_gather3d):
         if flt in fn.__name__:
             fn()
