@@ -35,7 +35,7 @@ calls = {}
 for r in csv.DictReader(open(os.path.join(d, f'{pre}_roofline_kernel_stats.csv'))):
     calls[fam(r['Name'])] = calls.get(fam(r['Name']), 0) + int(r['Calls'])
 F, W = load(os.path.join(d, f'{pre}_pmc_FETCH_SIZE.txt')), load(os.path.join(d, f'{pre}_pmc_WRITE_SIZE.txt'))
-big = re.compile(r'^void gemm_nt2(_grouped)?_kernel<(128, 128, 2, 4|128, 256, 2, 4|256, 128, 4, 2)')
+big = re.compile(r'^void gemm_nt2(_grouped)?_kernel<(128, 128, 4, 2|128, 128, 2, 4|128, 256, 2, 4|256, 128, 4, 2)')
 fams = [k for k in F if big.match(k) and k in W and calls.get(k, 0) > 0]
 tot = sum(calls[k] for k in fams)
 fetch = sum(calls[k] * F[k] for k in fams) / tot
