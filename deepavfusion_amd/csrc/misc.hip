@@ -359,7 +359,6 @@ __global__ __launch_bounds__(1024) void sumsq_final_kernel(const float* partial,
 // step-dependent bias corrections are read from device memory so a captured graph can be replayed.
 // Segments start on 64-element boundaries (FlatParams.ALIGN), so a lane's 4 consecutive elements share one segment and
 // every access is a 16-byte one; n is a multiple of 4.
-template <bool STREAM>
 __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                          float* __restrict__ v, bf16_t* __restrict__ p_bf16, long n,
                                                          const long* __restrict__ seg_end, const float* __restrict__ hyper, int nseg, float beta1,
@@ -381,19 +380,10 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
       while (s + 1 < nseg && i >= seg_end[s]) ++s;
       const float lr = hyper[2 * s], wd = hyper[2 * s + 1];
       const float decay = 1.f - lr * wd, step = lr / bc1;
-      // every operand is touched once per step: with STREAM the accesses are marked non-temporal (no reuse to keep in L2 / MALL)
-      auto ld = [](const float* q) {
-        if (STREAM) { const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q)); return float4{t[0], t[1], t[2], t[3]}; }
-        return *reinterpret_cast<const float4*>(q);
-      };
-      auto st = [](float* q, const float4 t) {
-        if (STREAM) __builtin_nontemporal_store(f32x4{t.x, t.y, t.z, t.w}, reinterpret_cast<f32x4*>(q));
-        else *reinterpret_cast<float4*>(q) = t;
-      };
-      const float4 gr = ld(g + i);
-      float4 pi = ld(p + i);
-      float4 mi = ld(m + i);
-      float4 vi = ld(v + i);
+      const float4 gr = *reinterpret_cast<const float4*>(g + i);
+      float4 pi = *reinterpret_cast<const float4*>(p + i);
+      float4 mi = *reinterpret_cast<const float4*>(m + i);
+      float4 vi = *reinterpret_cast<const float4*>(v + i);
       ss += gr.x * gr.x + gr.y * gr.y + gr.z * gr.z + gr.w * gr.w;
       const float gx = gr.x * grad_scale, gy = gr.y * grad_scale, gz = gr.z * grad_scale, gw = gr.w * grad_scale;
       mi.x = beta1 * mi.x + ob1 * gx; mi.y = beta1 * mi.y + ob1 * gy; mi.z = beta1 * mi.z + ob1 * gz; mi.w = beta1 * mi.w + ob1 * gw;
@@ -403,14 +393,14 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
       pi.y = pi.y * decay - step * mi.y / (sqrtf(vi.y) / bc2_sqrt + eps);
       pi.z = pi.z * decay - step * mi.z / (sqrtf(vi.z) / bc2_sqrt + eps);
       pi.w = pi.w * decay - step * mi.w / (sqrtf(vi.w) / bc2_sqrt + eps);
-      st(p + i, pi);
-      st(m + i, mi);
-      st(v + i, vi);
+      *reinterpret_cast<float4*>(p + i) = pi;
+      *reinterpret_cast<float4*>(m + i) = mi;
+      *reinterpret_cast<float4*>(v + i) = vi;
       if (p_bf16) {
         uint2 w; w.x = pack2bf(pi.x, pi.y); w.y = pack2bf(pi.z, pi.w);
         *reinterpret_cast<uint2*>(p_bf16 + i) = w;
       }
-      if (zero_grad) st(g + i, float4{0.f, 0.f, 0.f, 0.f});
+      if (zero_grad) *reinterpret_cast<float4*>(g + i) = float4{0.f, 0.f, 0.f, 0.f};
     }
   }
   if (sumsq_out) {                        // one atomic per workgroup (<= 16384 distinct-time adds on one word)
@@ -576,12 +566,7 @@ extern "C" int dav_adamw_flat(float* p, float* g, float* m, float* v, void* p_bf
   if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15 || ((uintptr_t)p_bf16 & 7)) return DAV_ERR_ALIGN;
   if (sumsq_out) HIP_CHECK_RET(hipMemsetAsync(sumsq_out, 0, sizeof(float), stream));
   long g2 = (n + 4095) / 4096; g2 = g2 > 16384 ? 16384 : g2;
-  static const bool streaming = [] { const char* e = getenv("DAV_ADAMW_STREAM"); return e && e[0] == '1'; }();
-  if (streaming)
-    DAV_LAUNCH(adamw_flat_kernel<true>, dim3((int)g2), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, n, seg_end, hyper, nseg,
-               beta1, beta2, eps, bias_corr, grad_scale, sumsq_out, zero_grad);
-  else
-    DAV_LAUNCH(adamw_flat_kernel<false>, dim3((int)g2), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, n, seg_end, hyper, nseg,
-               beta1, beta2, eps, bias_corr, grad_scale, sumsq_out, zero_grad);
+  DAV_LAUNCH(adamw_flat_kernel, dim3((int)g2), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, n, seg_end, hyper, nseg,
+                     beta1, beta2, eps, bias_corr, grad_scale, sumsq_out, zero_grad);
   return dav_launch_status();
 }
