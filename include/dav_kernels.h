@@ -11,7 +11,10 @@
  *    the library never allocates, frees or keeps a pointer past return;
  *  - all work is enqueued on `stream`; no host synchronisation, no host callbacks; safe to call from
  *    several host threads on distinct streams, and inside hipGraph stream capture;
- *  - return 0 on success, a negative DAV_ERR_* code otherwise (never aborts);
+ *  - return 0 on success, a negative DAV_ERR_* code otherwise (never aborts).  Arguments are validated BEFORE any HIP call:
+ *    empty input (a size of 0) is a bad shape (-1) for every kernel entry point, an unsupported dtype combination -2, a
+ *    workspace that is too small -3, a HIP launch failure -4 (text: dav_last_error_string), a misaligned pointer or stride
+ *    -5; a refused call has enqueued nothing (tests/test_cabi_and_host.py checks every entry point, without a GPU);
  *  - "bf16" buffers are raw uint16 bfloat16; index tensors are int64 where the reference exposes
  *    them (ids_keep / ids_restore) with int32 twins for in-kernel use; row strides are in elements.
  *  - a "row map" is an int[3] {rows_per_batch, batch_stride_rows, row_offset} (NULL = identity):

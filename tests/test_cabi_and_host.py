@@ -230,3 +230,69 @@ def test_nt_tuning_table_loads_and_rejects_malformed_blobs():
     finally:
         del os.environ['DAV_NT_TUNE']
     assert _lib.load_nt_tuning(_lib.NT_TUNING_PATH) == n        # back to the shipped table for the rest of the session
+
+
+def _zero_args(argtypes):
+    import ctypes as C
+    return [None if t is C.c_void_p else t(0) for t in argtypes]
+
+
+def test_every_entry_point_rejects_empty_input_with_the_documented_code():
+    """Error contract of include/dav_kernels.h: argument validation comes before any HIP call and answers with a negative
+    code (never abort / never undefined behaviour).  Empty input — every size 0, every pointer NULL — is a bad shape for each
+    kernel entry point; the call returns before a launch, so this runs without a GPU."""
+    from deepavfusion_amd import _lib
+    lib = _lib.load()
+    host_only = {'dav_abi_version', 'dav_last_error_string', 'dav_tune', 'dav_nt_issue_log', 'dav_nt_tune_set', 'dav_batch_begin',
+                 'dav_batch_lane', 'dav_batch_region', 'dav_batch_skip', 'dav_batch_suspend', 'dav_batch_end', 'dav_batch_abort',
+                 'dav_batch_stats', 'dav_layernorm_bwd_workspace_bytes', 'dav_l2norm_workspace_bytes'}
+    kernels = sorted(set(_lib.SIGNATURES) - host_only)
+    assert len(kernels) >= 40
+    for name in kernels:
+        rc = getattr(lib, name)(*_zero_args(_lib.SIGNATURES[name]))
+        assert rc == -1, f'{name}(empty input) returned {rc}, expected DAV_ERR_SHAPE (-1)'
+    # the launch batcher refuses calls outside a batch the same way
+    for name in ('dav_batch_lane', 'dav_batch_end'):
+        assert getattr(lib, name)() == -1
+    assert lib.dav_batch_region(1) == -1 and lib.dav_batch_skip(1) == -1
+    assert lib.dav_tune(99, 0) == -1
+
+
+def test_error_codes_for_dtype_alignment_and_workspace():
+    """-2 unsupported dtype combination, -3 workspace too small, -5 misaligned pointer / stride: each from a call whose sizes
+    are valid, whose pointers are never dereferenced (validation returns first) — the conventions block of include/dav_kernels.h."""
+    import ctypes as C
+    from deepavfusion_amd import _lib
+    lib = _lib.load()
+    p = lambda v: C.c_void_p(v)
+    S = _lib.SIGNATURES
+
+    def call(name, **over):
+        args = _zero_args(S[name])
+        for k, v in over.items():
+            args[int(k[1:])] = v
+        return getattr(lib, name)(*args)
+    # dav_gemm_nt_bf16(A, B, M, N, K, lda, ldb, ..., C @16, ldc, c_is_bf16 @18, ..., beta @23): accumulate into a bf16 output
+    nt = dict(a0=p(4096), a1=p(8192), a2=C.c_int(128), a3=C.c_int(128), a4=C.c_int(64), a5=C.c_int(64), a6=C.c_int(64),
+              a16=p(12288), a17=C.c_int(128))
+    assert call('dav_gemm_nt_bf16', **nt, a18=C.c_int(1), a23=C.c_int(1)) == -2
+    assert call('dav_gemm_nt_bf16', **{**nt, 'a0': p(4096 + 8)}) == -5                    # A not 16-byte aligned
+    assert call('dav_gemm_nt_bf16', **{**nt, 'a5': C.c_int(60)}) == -1                    # lda not a multiple of 8
+    # dav_gemm_tn_bf16(A, B, Mc, N, K, lda, ldb, ...)
+    assert call('dav_gemm_tn_bf16', a0=p(4096 + 2), a1=p(8192), a2=C.c_int(64), a3=C.c_int(8), a4=C.c_int(8), a5=C.c_int(8), a6=C.c_int(8)) == -5
+    # dav_l2norm(x, n, scale, out, workspace, workspace_bytes, stream)
+    assert call('dav_l2norm', a0=p(4096), a1=C.c_long(1024), a3=p(8192), a4=p(12288), a5=C.c_size_t(16)) == -3
+    assert lib.dav_l2norm_workspace_bytes(1024) >= 4096
+    # dav_adamw_flat(p, g, m, v, p_bf16, n, seg_end, hyper, nseg, ...)
+    assert call('dav_adamw_flat', a0=p(4096 + 4), a1=p(8192), a2=p(12288), a3=p(16384), a5=C.c_long(1024), a8=C.c_int(1)) == -5
+    assert call('dav_adamw_flat', a0=p(4096), a1=p(8192), a2=p(12288), a3=p(16384), a5=C.c_long(1022), a8=C.c_int(1)) == -1   # n % 4
+    # dav_layernorm_bwd: workspace given but too small for (rows, D)
+    need = lib.dav_layernorm_bwd_workspace_bytes(4 * 7, 64)
+    assert need > 0
+    ln = S['dav_layernorm_bwd']
+    args = _zero_args(ln)
+    args[2], args[6], args[7] = C.c_int(7), C.c_int(4), C.c_int(64)            # r0, B, D
+    args[8] = p(4096)                                                          # dy_bf16
+    args[-3], args[-2] = p(8192), C.c_size_t(need - 1)                         # workspace, workspace_bytes
+    assert lib.dav_layernorm_bwd(*args) == -3
+    assert _lib.ERRORS[-2] and _lib.ERRORS[-3] and _lib.ERRORS[-5]
