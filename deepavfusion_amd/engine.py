@@ -1069,6 +1069,17 @@ def patch_embed_fwd(vit, img, ids_keep32):
     D = vit.embed_dim
     clip = img.dim() == 5
     pt = pe.patch_size[0] if clip else 1
+    if not clip:      # timm PatchEmbed.forward asserts the exact input size (the kernels would index a different grid)
+        H, W = img.shape[2], img.shape[3]
+        assert H == pe.img_size[0], f"Input image height ({H}) doesn't match model ({pe.img_size[0]})."
+        assert W == pe.img_size[1], f"Input image width ({W}) doesn't match model ({pe.img_size[1]})."
+    else:             # PatchEmbed3D has no check of its own: a clip of another size fails at `+ pos_embed` (models/video_vits.py:229-232)
+        got = (img.shape[2] // pt) * (img.shape[3] // 16) * (img.shape[4] // 16)
+        if tuple(img.shape[2:]) != tuple(pe.input_size):
+            raise RuntimeError(f'The size of tensor a ({got}) must match the size of tensor b ({L}) at non-singleton dimension 1')
+    if C != pe.proj.weight.shape[1]:
+        raise RuntimeError(f'Given groups=1, weight of size {list(pe.proj.weight.shape)}, expected input{list(img.shape)} to have '
+                           f'{pe.proj.weight.shape[1]} channels, but got {C} channels instead')
     if clip and nk != L:
         raise RuntimeError(f'The size of tensor a ({nk}) must match the size of tensor b ({L}) at non-singleton dimension 1')
     K = C * pt * 256

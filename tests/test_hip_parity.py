@@ -438,6 +438,13 @@ def test_encoder_forward_api(golden):
         assert rel(xi, g['encoder_full.x_image']) < ACT_TOL and rel(xa, g['encoder_full.x_audio']) < ACT_TOL and rel(xf, g['encoder_full.x_fusion']) < ACT_TOL
         tok = enc.image.prepare_patch_tokens(img, ids)
         assert rel(tok, g['prepare.out']) < 5e-3
+    # input-size errors as timm's PatchEmbed raises them (SURVEY 8(b) conventions), and the path is usable afterwards
+    with pytest.raises(AssertionError, match="doesn't match model"):
+        enc.image.prepare_patch_tokens(img[:, :, :-16], ids)
+    with pytest.raises(AssertionError, match="Input image width"):
+        model(img, aud[..., :-16])
+    with pytest.raises(RuntimeError, match='channels'):
+        model(img[:, :1], aud)
     # gradients flow through the stand-alone encoder node as well
     model.zero_grad()
     xi, xa, xf = enc(img, aud, ids, ids_a)
