@@ -43,7 +43,7 @@ struct NTParams {
   bf16_t* C2; int ldc2; int c2_mode;   // second bf16 output [M, ldc2]: 1 pre-activation, 2 post-activation/pre-residual, 3 final value
   int beta;                      // C (fp32) += result
   float alpha;
-  int debug;                     // timing experiments only (DAV_NT_DEBUG): 1 = epilogue without global stores, 2 = no epilogue
+  int debug;                     // timing experiments only (DAV_NT_DEBUG): 1 = epilogue without global stores, 2 = no epilogue, 4 = no fragment reads / MFMAs
   int force_cfg;                 // host side only: tile configuration asked for explicitly (0 = chosen per group at issue time)
 };
 
@@ -55,7 +55,7 @@ struct TNParams {
   int beta;                           // 0: overwrite (only legal with splits == 1), 1: accumulate
   int splits;                         // split of the contraction over blockIdx.y (atomic accumulate)
   float* bias_grad;                   // optional: column sums of A accumulated into [N]
-  int debug_plain_store;              // timing experiments only (variant bit 8): plain stores instead of atomics
+  int debug_plain_store;              // timing experiments only: 1 (variant bit 8) plain stores instead of atomics; DAV_TN_DEBUG: 2 no epilogue, 4 no reads / MFMAs
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -752,6 +752,7 @@ __device__ __forceinline__ void nt2_body(const NTParams& p, int bid) {
     if (PROF) { const long long t = __builtin_readcyclecounter(); pt[2] += t - tk0; tk0 = t; }
     const char* Ab = smem + (kt % STAGES) * STAGE_BYTES;
     const char* Bb = Ab + A_BYTES;
+    if (p.debug & 4) continue;             // timing experiment: the global -> LDS stream alone
 #pragma unroll
     for (int kk = 0; kk < BK / 32; ++kk) {
       bf16x8 af[FM], bfr[FN];
@@ -1446,6 +1447,7 @@ __device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, 
     const char* Ab = smem + stage * STAGE_BYTES;
     const char* Bb = Ab + TILE_BYTES;
     stage = stage + 1 == NST ? 0 : stage + 1;
+    if (p.debug_plain_store & 4) continue;      // timing experiment (DAV_TN_DEBUG): the global -> LDS stream alone
 #pragma unroll
     for (int kk = 0; kk < RS / 32; ++kk) {
       bf16x8 af[FM], bfr[FN];
@@ -1468,37 +1470,60 @@ __device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, 
     }
   }
 
+  if (p.debug_plain_store & 2) return;          // timing experiment: no epilogue
   const int fr = lane & 15, fg = lane >> 4;
   // splits > 1: partial sums meet through fp32 atomics; splits == 1: this workgroup owns the tile (plain
   // read-modify-write when accumulating)
-  const bool atomic = p.splits > 1 && !p.debug_plain_store;
+  const bool atomic = p.splits > 1 && !(p.debug_plain_store & 1);
+  if (atomic) {
 #pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const int n = n0 + wm * WTN + i * 16 + fr;
-    if (n < p.N) {
+    for (int i = 0; i < FM; ++i) {
+      const int n = n0 + wm * WTN + i * 16 + fr;
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         const int k = k0 + wn * WTK + j * 16 + fg * 4;
-        if (k >= p.K) continue;                           // K is a multiple of 8: the four columns are in or out together
+        if (n >= p.N || k >= p.K) continue;               // K is a multiple of 8: the four columns are in or out together
         float* c = p.C + (long)n * p.ldc + k;
-        if (atomic) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) unsafeAtomicAdd(c + r, acc[i][j][r]);
-        } else {
-          float4 v = float4{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-          if (p.beta) { const float4 o = *reinterpret_cast<const float4*>(c); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-          *reinterpret_cast<float4*>(c) = v;
+        for (int r = 0; r < 4; ++r) unsafeAtomicAdd(c + r, acc[i][j][r]);
+      }
+    }
+  } else {
+    // the tile's old values are fetched in ONE batch (FM * FN independent 16-byte loads in flight) before the first store: a
+    // load -> add -> store chain per fragment is one exposed memory latency each (8 per wave, 25 % of the kernel's time)
+    float4 old[FM][FN];
+    if (p.beta) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int n = n0 + wm * WTN + i * 16 + fr;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int k = k0 + wn * WTK + j * 16 + fg * 4;
+          old[i][j] = (n < p.N && k < p.K) ? *reinterpret_cast<const float4*>(p.C + (long)n * p.ldc + k) : float4{0.f, 0.f, 0.f, 0.f};
         }
       }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {                         // the bias-gradient accumulators keep the untransposed layout
-      const int nb = n0 + wm * WTN + i * 16 + fg * 4 + r;
-      if (do_bias && fr == 0 && nb < p.N) {
-        if (p.splits > 1) unsafeAtomicAdd(p.bias_grad + nb, accb[i][r]);
-        else p.bias_grad[nb] += accb[i][r];
+    for (int i = 0; i < FM; ++i) {
+      const int n = n0 + wm * WTN + i * 16 + fr;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int k = k0 + wn * WTK + j * 16 + fg * 4;
+        if (n >= p.N || k >= p.K) continue;
+        float4 v = float4{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        if (p.beta) { v.x += old[i][j].x; v.y += old[i][j].y; v.z += old[i][j].z; v.w += old[i][j].w; }
+        *reinterpret_cast<float4*>(p.C + (long)n * p.ldc + k) = v;
       }
     }
+  }
+  if (do_bias && fr == 0) {                               // the bias-gradient accumulators keep the untransposed layout; one
+#pragma unroll                                            // contribution per element and launch: a no-return atomic costs no latency
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nb = n0 + wm * WTN + i * 16 + fg * 4 + r;
+        if (nb < p.N) unsafeAtomicAdd(p.bias_grad + nb, accb[i][r]);
+      }
   }
 }
 
@@ -1651,6 +1676,7 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
       case 2: launch_nt2<128, 128, 2, 2, 3>(p, stream); return dav_launch_status();
       case 3: launch_nt2<128, 128, 4, 2, 2>(p, stream); return dav_launch_status();
       case 4: launch_nt2<128, 128, 2, 4, 3>(p, stream); return dav_launch_status();
+      case 48: launch_nt2<128, 128, 4, 2, 4>(p, stream); return dav_launch_status();      // 4 x 32 KB ring, one workgroup per CU (in-flight depth experiment)
       case 5: launch_nt2<64, 64, 2, 2, 2>(p, stream); return dav_launch_status();
       case 6: launch_nt2<64, 64, 2, 2, 3>(p, stream); return dav_launch_status();
       case 7: launch_nt2<64, 64, 2, 2, 4>(p, stream); return dav_launch_status();
@@ -1745,7 +1771,8 @@ extern "C" int dav_gemm_tn_grouped_bf16(const DavTnProblem* probs, int count, hi
     p.A = (const bf16_t*)q.A; p.B = (const bf16_t*)q.B; p.Mc = q.Mc; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = q.ldb;
     p.amap = RowMap{q.a_rowmap[0], q.a_rowmap[1], q.a_rowmap[2]};
     p.bmap = RowMap{q.b_rowmap[0], q.b_rowmap[1], q.b_rowmap[2]};
-    p.C = q.C; p.ldc = q.ldc; p.beta = 1; p.bias_grad = q.bias_grad; p.debug_plain_store = 0;
+    static const int tn_debug = getenv("DAV_TN_DEBUG") ? atoi(getenv("DAV_TN_DEBUG")) & 6 : 0;
+    p.C = q.C; p.ldc = q.ldc; p.beta = 1; p.bias_grad = q.bias_grad; p.debug_plain_store = tn_debug;
     const int tiles = ((q.N + 127) / 128) * ((q.K + 127) / 128), steps = q.Mc >> 6;
     int splits = (int)((1024 + total_tiles - 1) / total_tiles);
     const int max_splits = steps / 8 > 0 ? steps / 8 : 1;
