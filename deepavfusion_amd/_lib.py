@@ -81,7 +81,7 @@ SIGNATURES = {
     'dav_batch_end': [],
     'dav_batch_abort': [],
     'dav_batch_stats': [_p, _p],
-    'dav_adamw_flat': [_p, _p, _p, _p, _p, _l, _p, _p, _i, _f, _f, _f, _p, _f, _p, _i, _p],
+    'dav_adamw_flat': [_p, _p, _p, _p, _p, _l, _p, _p, _i, _f, _f, _f, _p, _f, _p, _i, _p, _p],
 }
 
 class DavLnReduce(C.Structure):
@@ -91,7 +91,7 @@ class DavLnReduce(C.Structure):
 class DavTnProblem(C.Structure):
     _fields_ = [('A', C.c_void_p), ('B', C.c_void_p), ('C', C.c_void_p), ('bias_grad', C.c_void_p),
                 ('Mc', C.c_int), ('N', C.c_int), ('K', C.c_int), ('lda', C.c_int), ('ldb', C.c_int), ('ldc', C.c_int),
-                ('a_rowmap', C.c_int * 3), ('b_rowmap', C.c_int * 3)]
+                ('a_rowmap', C.c_int * 3), ('b_rowmap', C.c_int * 3), ('flags', C.c_int)]
 
 
 ERRORS = {-1: 'bad shape', -2: 'unsupported dtype', -3: 'insufficient workspace', -4: 'HIP error', -5: 'misaligned pointer/stride'}

@@ -1772,11 +1772,12 @@ extern "C" int dav_gemm_tn_grouped_bf16(const DavTnProblem* probs, int count, hi
     p.amap = RowMap{q.a_rowmap[0], q.a_rowmap[1], q.a_rowmap[2]};
     p.bmap = RowMap{q.b_rowmap[0], q.b_rowmap[1], q.b_rowmap[2]};
     static const int tn_debug = getenv("DAV_TN_DEBUG") ? atoi(getenv("DAV_TN_DEBUG")) & 6 : 0;
-    p.C = q.C; p.ldc = q.ldc; p.beta = 1; p.bias_grad = q.bias_grad; p.debug_plain_store = tn_debug;
+    p.C = q.C; p.ldc = q.ldc; p.beta = (q.flags & 1) ? 0 : 1; p.bias_grad = q.bias_grad; p.debug_plain_store = tn_debug;
     const int tiles = ((q.N + 127) / 128) * ((q.K + 127) / 128), steps = q.Mc >> 6;
     int splits = (int)((1024 + total_tiles - 1) / total_tiles);
     const int max_splits = steps / 8 > 0 ? steps / 8 : 1;
     if (splits > max_splits) splits = max_splits;
+    if (q.flags & 1) splits = 1;                         // a written (not accumulated) tile has one owner
     p.splits = splits;
     g.first_block[i] = first;
     first += tiles * splits;

@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
                                                          float* __restrict__ v, bf16_t* __restrict__ p_bf16, long n,
                                                          const long* __restrict__ seg_end, const float* __restrict__ hyper, int nseg, float beta1,
                                                          float beta2, float eps, const float* bias_corr, float grad_scale,
-                                                         float* sumsq_out, int zero_grad) {
+                                                         float* sumsq_out, int zero_grad, const unsigned char* __restrict__ keep_grad) {
   constexpr long CHUNK = 256 * 4 * 4;     // contiguous elements per workgroup iteration: 4 float4 per lane
   __shared__ float sw[4];
   const float bc1 = bias_corr[0], bc2_sqrt = bias_corr[1];
@@ -379,6 +379,7 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
       if (i >= n) break;
       while (s + 1 < nseg && i >= seg_end[s]) ++s;
       const float lr = hyper[2 * s], wd = hyper[2 * s + 1];
+      const bool fill = zero_grad && !(keep_grad && keep_grad[s]);      // (fetched with the segment's hyper-parameters)
       const float decay = 1.f - lr * wd, step = lr / bc1;
       const float4 gr = *reinterpret_cast<const float4*>(g + i);
       float4 pi = *reinterpret_cast<const float4*>(p + i);
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
         uint2 w; w.x = pack2bf(pi.x, pi.y); w.y = pack2bf(pi.z, pi.w);
         *reinterpret_cast<uint2*>(p_bf16 + i) = w;
       }
-      if (zero_grad) *reinterpret_cast<float4*>(g + i) = float4{0.f, 0.f, 0.f, 0.f};
+      if (fill) *reinterpret_cast<float4*>(g + i) = float4{0.f, 0.f, 0.f, 0.f};
     }
   }
   if (sumsq_out) {                        // one atomic per workgroup (<= 16384 distinct-time adds on one word)
@@ -561,12 +562,12 @@ extern "C" int dav_l2norm(const float* x, long n, float scale, float* out, void*
 
 extern "C" int dav_adamw_flat(float* p, float* g, float* m, float* v, void* p_bf16, long n, const long* seg_end,
                               const float* hyper, int nseg, float beta1, float beta2, float eps, const float* bias_corr,
-                              float grad_scale, float* sumsq_out, int zero_grad, hipStream_t stream) {
+                              float grad_scale, float* sumsq_out, int zero_grad, const unsigned char* keep_grad, hipStream_t stream) {
   if (n <= 0 || nseg <= 0 || (n & 3)) return DAV_ERR_SHAPE;
   if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15 || ((uintptr_t)p_bf16 & 7)) return DAV_ERR_ALIGN;
   if (sumsq_out) HIP_CHECK_RET(hipMemsetAsync(sumsq_out, 0, sizeof(float), stream));
   long g2 = (n + 4095) / 4096; g2 = g2 > 16384 ? 16384 : g2;
   DAV_LAUNCH(adamw_flat_kernel, dim3((int)g2), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, n, seg_end, hyper, nseg,
-                     beta1, beta2, eps, bias_corr, grad_scale, sumsq_out, zero_grad);
+                     beta1, beta2, eps, bias_corr, grad_scale, sumsq_out, zero_grad, keep_grad);
   return dav_launch_status();
 }

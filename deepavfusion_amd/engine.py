@@ -291,6 +291,29 @@ class deferred_wgrads:
         _DEFERRED, _DEFERRED_LN = self.prev
 
 
+# ------------------------------------------------------------------------------------------------
+# Written (not accumulated) first contributions.  A captured step (util.misc.GraphedStep) knows that every gradient is consumed
+# and re-initialised by the fused AdamW pass at its end, so the FIRST weight-gradient GEMM into a Linear weight may write its
+# tile instead of read-modify-writing it, and AdamW need not zero-fill that weight's gradient: the gradient tiles' fp32 reads
+# (a burst at the end of every tile, 25 % of the weight-gradient kernel) and 4 of AdamW's 34 bytes per parameter go away.
+# Only full-weight problems of the grouped launches qualify; a weight that saw an immediate (un-deferred) contribution earlier
+# in the step, or whose problem covers a column block only, keeps the accumulate / zero-fill pair.
+# ------------------------------------------------------------------------------------------------
+_OVERWRITE = None          # None: off;  dict(written=set of C addresses, touched=set of C addresses, params=set of id(weight))
+
+
+def wgrad_overwrite_begin():
+    global _OVERWRITE
+    _OVERWRITE = dict(written=set(), touched=set(), params={})
+
+
+def wgrad_overwrite_end():
+    """-> the weights (parameters) whose gradient the step wrote instead of accumulating."""
+    global _OVERWRITE
+    st, _OVERWRITE = _OVERWRITE, None
+    return list(st['params'].values()) if st else []
+
+
 def flush_wgrads():
     """Launch the queued weight-gradient problems on the current stream (their operands must be complete on it)."""
     if _DEFERRED_LN:
@@ -315,6 +338,15 @@ def flush_wgrads():
         # longest contractions first: tiles are dispatched in list order as workgroup slots free up, and a tile's run time is
         # proportional to its contraction length (49 .. 95 k-steps in one launch) — the short ones fill the tail
         now.sort(key=lambda pr: -pr['Mc'])
+        if _OVERWRITE is not None:
+            for pr in now:
+                key = pr['C'].data_ptr()
+                pr['overwrite'] = bool(pr.get('weight') is not None and key not in _OVERWRITE['written'] and key not in _OVERWRITE['touched'])
+                _OVERWRITE['written'].add(key)
+                if pr.get('weight') is None:                       # a column block: the weight as a whole stays on accumulate / zero-fill
+                    _OVERWRITE['touched'].add(pr.get('gbase', key))
+                if pr['overwrite']:
+                    _OVERWRITE['params'][id(pr['weight'])] = pr['weight']
         ops.gemm_tn_grouped(now)
         for pr in now:
             _ready(*pr['ready'])
@@ -434,8 +466,12 @@ def lin_bwd(lin, dy, a, M, *, dy_rowmap=None, a_rowmap=None, lda=None, need_dx=T
         # weight gradients are off the dependency chain: queue them and launch ONE grouped GEMM per layer
         _DEFERRED.append(dict(A=dy, B=a, Mc=M, N=N, K=K, C=Cw, lda=N, ldb=lda if lda is not None else K, ldc=Kfull,
                               a_rowmap=dy_rowmap, b_rowmap=a_rowmap, bias_grad=gb,
-                              ready=(lin.weight, lin.bias) if final else ()))
+                              ready=(lin.weight, lin.bias) if final else (),
+                              gbase=gwv.data_ptr(),
+                              weight=lin.weight if (w_col_off == 0 and K == Kfull) else None))      # full weight: may be written
         return dx
+    if _OVERWRITE is not None:
+        _OVERWRITE['touched'].add(gwv.data_ptr())
     if sw is None:
         ops.gemm_tn(dy, a, M, N, K, Cw, lda=N, ldb=lda if lda is not None else K, ldc=Kfull, a_rowmap=dy_rowmap,
                     b_rowmap=a_rowmap, beta=1, bias_grad=gb)

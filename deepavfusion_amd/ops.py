@@ -155,12 +155,14 @@ def gemm_tn(A, B, Mc, N, K, C_out, *, lda=None, ldb=None, ldc=None, a_rowmap=Non
 
 
 def gemm_tn_grouped(problems):
-    """problems: list of dicts(A, B, Mc, N, K, C, lda, ldb, ldc, a_rowmap, b_rowmap, bias_grad); see dav_gemm_tn_grouped_bf16."""
+    """problems: list of dicts(A, B, Mc, N, K, C, lda, ldb, ldc, a_rowmap, b_rowmap, bias_grad[, overwrite]); see
+    dav_gemm_tn_grouped_bf16 (overwrite: C is written instead of accumulated, DavTnProblem.flags bit 0)."""
     lib = _lib.load()
     if problems and problems[0]['A'].dtype == F32:      # fp32 path: one launch per problem
         for d in problems:
             gemm_tn(d['A'], d['B'], d['Mc'], d['N'], d['K'], d['C'], lda=d['lda'], ldb=d['ldb'], ldc=d['ldc'],
-                    a_rowmap=d.get('a_rowmap'), b_rowmap=d.get('b_rowmap'), beta=1, bias_grad=d.get('bias_grad'))
+                    a_rowmap=d.get('a_rowmap'), b_rowmap=d.get('b_rowmap'), beta=0 if d.get('overwrite') else 1,
+                    bias_grad=d.get('bias_grad'))
         return
     for i in range(0, len(problems), 32):
         chunk = problems[i:i + 32]
@@ -170,6 +172,7 @@ def gemm_tn_grouped(problems):
             q.Mc, q.N, q.K, q.lda, q.ldb, q.ldc = d['Mc'], d['N'], d['K'], d['lda'], d['ldb'], d['ldc']
             q.a_rowmap[:] = d.get('a_rowmap') or (0, 0, 0)
             q.b_rowmap[:] = d.get('b_rowmap') or (0, 0, 0)
+            q.flags = 1 if d.get('overwrite') else 0
         _lib.check(lib.dav_gemm_tn_grouped_bf16(arr, len(chunk), _stream()), 'dav_gemm_tn_grouped_bf16')
 
 
@@ -404,11 +407,12 @@ def l2norm(x_flat, out, workspace, scale=1.0):
 
 
 def adamw_flat(p, g, m, v, p_bf16, seg_end, hyper, nseg, beta1, beta2, eps, bias_corr, grad_scale=1.0, sumsq_out=None,
-               zero_grad=False):
+               zero_grad=False, keep_grad=None):
+    """keep_grad: uint8 [nseg] or None — segments whose gradient is NOT zero-filled by zero_grad (see dav_adamw_flat)."""
     lib = _lib.load()
     _lib.check(lib.dav_adamw_flat(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(p_bf16), p.numel(), _ptr(seg_end), _ptr(hyper), nseg,
                                   float(beta1), float(beta2), float(eps), _ptr(bias_corr), float(grad_scale), _ptr(sumsq_out),
-                                  int(zero_grad), _stream()), 'dav_adamw_flat')
+                                  int(zero_grad), _ptr(keep_grad), _stream()), 'dav_adamw_flat')
 
 
 def rows_axpy(res, y, scale, B, rows, D, out):

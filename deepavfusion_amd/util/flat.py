@@ -52,6 +52,9 @@ class FlatParams:
 
     def zero_grad(self):
         self.flat_g.zero_()
+        self.stale = False
+
+    stale = False      # True while gradients a captured step kept (not zero-filled) are lying in flat_g
 
     def grad_norm(self, scale: float = 1.0) -> torch.Tensor:
         """Global L2 norm of all gradients (util/misc.py:151-163) as a device scalar; no host sync."""
@@ -92,6 +95,9 @@ class FlatAdamW(torch.optim.Optimizer):
         self._gidx = torch.tensor([self._group_of[id(p)] for p in self.flat.params], dtype=torch.long)
         self.step_count = 0
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        # one byte per parameter: 1 = the fused pass does not zero-fill this gradient (its next value will be written, not
+        # accumulated: engine.wgrad_overwrite_begin / util.misc.GraphedStep).  All zero unless a captured step sets it.
+        self.keep_grad = torch.zeros(n, dtype=torch.uint8, device=dev)
         for p, o in zip(self.flat.params, self.flat.offsets):    # torch-compatible per-parameter state (views)
             self.state[p] = dict(step=torch.tensor(0.), exp_avg=self.exp_avg[o:o + p.numel()].view(p.shape),
                                  exp_avg_sq=self.exp_avg_sq[o:o + p.numel()].view(p.shape))
@@ -132,7 +138,8 @@ class FlatAdamW(torch.optim.Optimizer):
         f = self.flat
         ops.adamw_flat(f.flat_p, f.flat_g, self.exp_avg, self.exp_avg_sq, self.flat_bf16, f.seg_end, self._hyper, len(f.params),
                        b1, b2, self.defaults['eps'], self._bc, grad_scale,
-                       sumsq_out=self.sumsq if fused_norm_and_zero else None, zero_grad=fused_norm_and_zero)
+                       sumsq_out=self.sumsq if fused_norm_and_zero else None, zero_grad=fused_norm_and_zero,
+                       keep_grad=self.keep_grad if fused_norm_and_zero else None)
         engine.invalidate_weight_cache(f.params)      # fp32 masters changed behind torch's back
 
     @torch.no_grad()

@@ -81,6 +81,8 @@ class Trainer:
         return get_grad_norm_(self.model_without_ddp.parameters()) / max(self.accums, 1)
 
     def backward(self, loss, create_graph=False):
+        if self.flat is not None and self.flat.stale and self.accums == 0:      # eager step after replays of a captured one
+            self.flat.zero_grad()
         loss.backward(create_graph=create_graph)
         self.accums += 1
         if self.distributed:
@@ -214,11 +216,14 @@ class GraphedStep:
         self.opt.flat.zero_grad()            # the AdamW pass leaves the gradients zeroed for the next replay
         with torch.cuda.stream(cap):
             self.graphs[0].capture_begin(capture_error_mode=CAPTURE_MODE)
+            if os.environ.get('DAV_WGRAD_OVERWRITE', '1') != '0':
+                engine.wgrad_overwrite_begin()       # first weight-gradient GEMM into a Linear weight writes its tile (see engine)
             # every derived bf16 copy (casts of un-mirrored weights, TRANSPOSED copies) must be re-derived INSIDE the graph:
             # copies left over from the warm-up passes would otherwise be read, stale, by every replay
             engine.invalidate_weight_cache(self.model.parameters())
             engine.refresh_weight_cache(self.model)
             self.loss_image, self.loss_audio = self._fwd_bwd(layer_cb)
+            kept = {id(p) for p in engine.wgrad_overwrite_end()}
             if not self.dist_active:
                 self.opt.launch_step(fused_norm_and_zero=True)      # AdamW + sum(g^2) + zero_grad in one pass
                 self.grad_norm = self.opt.sumsq.sqrt()
@@ -237,6 +242,9 @@ class GraphedStep:
             self.bucket_sched[-1] += [bi for bi in range(len(self.reducer.buckets)) if bi not in done]
         engine.set_grad_ready_hook(saved_hook)
         self.opt.flat.zero_grad()
+        # the captured AdamW pass reads this table at replay time: gradients the captured backward WRITES are not zero-filled
+        self.opt.keep_grad.copy_(torch.tensor([1 if id(p) in kept else 0 for p in self.opt.flat.params], dtype=torch.uint8))
+        self.kept_params = len(kept)
 
     def _fwd_bwd(self, layer_cb):
         """Forward + hand-written backward straight on the engine (no autograd), unit upstream gradients."""
@@ -261,6 +269,7 @@ class GraphedStep:
         if self.opt_graph is not None:
             self.reducer.finish()
             self.opt_graph.replay()
+        self.opt.flat.stale = self.kept_params > 0
         self.tr.n_steps += 1
         return self.loss_image, self.loss_audio, self.grad_norm
 

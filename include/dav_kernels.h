@@ -92,6 +92,9 @@ typedef struct DavTnProblem {
   float* C; float* bias_grad;         /* fp32 [N, K] (ldc), fp32 [N] or NULL; both accumulated */
   int Mc, N, K, lda, ldb, ldc;
   int a_rowmap[3], b_rowmap[3];
+  int flags;                          /* bit 0: C is WRITTEN, its old contents ignored (the first contribution to a gradient
+                                         that the optimizer pass did not zero-fill, see dav_adamw_flat keep_grad); bias_grad
+                                         is accumulated regardless.  Such a problem is never split over the contraction. */
 } DavTnProblem;
 int dav_gemm_tn_grouped_bf16(const DavTnProblem* problems, int count, hipStream_t stream);
 
@@ -220,11 +223,13 @@ int dav_l2norm(const float* x, long n, float scale, float* out, void* workspace,
  * per-segment {lr, weight_decay}; bias_corr = {1-beta1^t, sqrt(1-beta2^t)} in device memory.  The same pass can
  * (a) accumulate sum(g^2) of the unscaled gradients into *sumsq_out (zeroed first; the grad norm of
  * util/misc.py:151-163 is its square root), (b) rewrite the bf16 weight mirror p_bf16, (c) zero the gradients
- * (Trainer.zero_grad) — one trip over the buffers instead of three.  All accesses are 16-byte ones: the buffers must be
+ * (Trainer.zero_grad) — one trip over the buffers instead of three.  keep_grad (NULL or one byte per segment): segments
+ * with a non-zero byte are NOT zero-filled — their next gradient will be written, not accumulated (DavTnProblem.flags bit 0),
+ * which saves the fill here and the read there.  All accesses are 16-byte ones: the buffers must be
  * 16-byte aligned (p_bf16 8-byte), n and every seg_end a multiple of 4 (FlatParams aligns segments to 64 elements). */
 int dav_adamw_flat(float* p, float* g, float* m, float* v, void* p_bf16, long n, const long* seg_end, const float* hyper,
                    int nseg, float beta1, float beta2, float eps, const float* bias_corr, float grad_scale, float* sumsq_out,
-                   int zero_grad, hipStream_t stream);
+                   int zero_grad, const unsigned char* keep_grad, hipStream_t stream);
 
 /* ---- log-mel front-end (csrc/mel.hip) ------------------------------ */
 /* out[b, m, t] = log10(mel_m(|STFT_t(wave[b])|^2) + eps): the reference's audio transform

@@ -181,6 +181,21 @@ def gemm_tn():
             report(f'gemm_tn grouped #{i} bias', rel(bg, rb), 2e-4)
     ops.gemm_tn_grouped(probs[:2])        # small group -> split-K atomics path
     report('gemm_tn grouped split acc', rel(refs[0][0], 2 * refs[0][1] - 0.25), 2e-4)
+    # written (not accumulated) tiles: DavTnProblem.flags bit 0 — old contents (NaN here) are ignored, the bias gradient still
+    # accumulates, never split over the contraction (a small group would otherwise take the atomics path); mixed with an accumulating problem
+    for group in (probs[:2], probs):
+        for i, pr in enumerate(group):
+            pr['overwrite'] = i != 1
+            pr['C'].fill_(float('nan') if pr['overwrite'] else 0.25)
+            if pr['bias_grad'] is not None:
+                pr['bias_grad'].fill_(0.5)
+        ops.gemm_tn_grouped(group)
+        for i, (C, rc, bg, rb) in enumerate(refs[:len(group)]):
+            report(f'gemm_tn grouped[{len(group)}] #{i} {"written" if i != 1 else "accumulated"}', rel(C, rc - (0.25 if i != 1 else 0.0)), 2e-4)
+            if bg is not None:
+                report(f'gemm_tn grouped[{len(group)}] #{i} bias', rel(bg, rb), 2e-4)
+    for pr in probs:
+        pr.pop('overwrite')
     # row maps + ldc sub-block
     Bsz, rpb, tot, N, K = 3, 5, 9, 64, 128
     Af, Bf = rnd(Bsz * tot, N, dtype=BF16, seed=13), rnd(Bsz * tot, K, dtype=BF16, seed=14)
@@ -513,9 +528,11 @@ def misc_kernels():
         bc = torch.tensor([1 - 0.9 ** step, math.sqrt(1 - 0.95 ** step)], device=dev)
         gcur = (g0 * step).clone()
         ssq = torch.zeros(1, device=dev)
-        ops.adamw_flat(p, gcur, m, v, pb, seg, hyper, 2, 0.9, 0.95, 1e-8, bc, sumsq_out=ssq, zero_grad=True)
+        keep = torch.tensor([0, 1 if step == 2 else 0], device=dev, dtype=torch.uint8)      # step 2: the second segment's gradient is kept
+        ops.adamw_flat(p, gcur, m, v, pb, seg, hyper, 2, 0.9, 0.95, 1e-8, bc, sumsq_out=ssq, zero_grad=True, keep_grad=keep)
         report(f'adamw fused sumsq step{step}', abs(float(ssq) - float((g0 * step).double().pow(2).sum())) / float((g0 * step).double().pow(2).sum()), 1e-5)
-        report(f'adamw fused zero_grad step{step}', float(gcur.abs().max()), 0.0)
+        report(f'adamw fused zero_grad step{step}', float(gcur[:40000].abs().max()), 0.0)
+        report(f'adamw fused zero_grad / keep_grad step{step}', float((gcur[40000:] - (g0 * step)[40000:] * (step == 2)).abs().max()), 0.0)
     report('adamw_flat vs torch.optim.AdamW', rel(p, pr.detach()), 1e-6)
     report('adamw bf16 mirror', rel(pb, p), 4e-3)
 

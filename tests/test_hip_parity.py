@@ -641,6 +641,49 @@ def test_graphed_step_equals_eager_step(name):
     assert abs(losses[0][-1] - losses[1][-1]) < 0.15 * losses[0][0]
 
 
+def test_written_first_gradients_equal_accumulated_ones(monkeypatch):
+    """The captured step writes (instead of accumulating) the first weight-gradient GEMM into a Linear weight and skips that
+    gradient's zero-fill in AdamW (engine.wgrad_overwrite_begin, DavTnProblem.flags, dav_adamw_flat keep_grad).  Same seeds with
+    the switch off must give the same parameters — including across an eager step in between, which finds kept (stale)
+    gradients in the flat buffer and has to clear them first."""
+    from deepavfusion_amd.util import lr_sched
+    from deepavfusion_amd.util.flat import FlatAdamW
+    from deepavfusion_amd.util.misc import GraphedStep, Trainer
+    finals, losses, kept = [], [], []
+    for mode in ('1', '0'):
+        monkeypatch.setenv('DAV_WGRAD_OVERWRITE', mode)
+        model, sd, cfg, O = _build('micro')
+        nd = [n for n, p in model.named_parameters() if 'bias' in n or 'norm' in n]
+        groups = lr_sched.param_groups_pretrained(model, 0.05, no_weight_decay_list=nd, image_pt='', audio_pt='')
+        opt = FlatAdamW(groups, lr=1e-3, betas=(0.9, 0.95), model=model)
+        tr = Trainer(model, optimizer=opt, accum_iter=1)
+        image, audio, _, _ = O.structured_batch(cfg, 64, seed=3)
+        image, audio = image.cuda(), audio.cuda()
+        torch.manual_seed(77)
+        gs = GraphedStep(tr, image.shape, audio.shape)
+        kept.append(gs.kept_params)
+        run = []
+        for s in range(6):
+            torch.manual_seed(500 + s)
+            if s == 3:                                            # an eager step between replays
+                li, la = tr.model(image, audio)[:2]
+                tr.step(li + la)
+            else:
+                li, la, gn = gs(image, audio)
+            run.append(float(li) + float(la))
+        torch.cuda.synchronize()
+        finals.append(opt.flat.flat_p.clone())
+        losses.append(run)
+    n_linear = sum(1 for n, p in model.named_parameters() if p.ndim == 2 and p.requires_grad)
+    assert kept[0] > n_linear // 2 and kept[1] == 0, (kept, n_linear)
+    assert all(np.isfinite(losses[0])) and losses[0][-1] < losses[0][0]
+    for a, b in zip(*losses):
+        assert abs(a - b) <= 1e-5 * abs(b), losses
+    # not bit-equal: a written tile is never split over the contraction, an accumulated one may be (fp32 atomics), and AdamW turns
+    # rounding noise on exactly-zero gradients (key biases) into lr-sized steps; a LOST contribution would show at >= 4e-3
+    assert rel(finals[0], finals[1]) < 2e-4
+
+
 def test_segmented_graph_step_matches_single_graph_and_schedules_every_bucket():
     """The multi-GPU form of the step (3 graph segments + per-segment gradient buckets) must compute the same step as
     the single graph, and its capture-time bucket schedule must cover every bucket once, decoders first."""
