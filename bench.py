@@ -339,7 +339,7 @@ def main():
                                     'achieved': round(fl_tn / (ms_tn * 1e-3) / 1e12, 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                     'frac': round(fl_tn / (ms_tn * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
                                     'launches_per_step': len(tn_log), 'avg_launch_us': round(ms_tn * 1e3 / len(tn_log), 1),
-                                    'note': 'replay holds one problem per distinct shape of each launch (equal shapes would share the output buffer)'}
+                                    'note': 'replay holds one problem per distinct shape of each launch (equal shapes would share the output buffer); it accumulates into the gradient tiles as the eager step does — the captured step WRITES the first contribution to a Linear weight (no tile read), so this figure is the conservative one'}
         del tbufs
     # ---- attention family (isolated replays of the step's shapes; in the step equal-rank calls of both towers are one grid)
     if attn_log and not a.no_roofline:
