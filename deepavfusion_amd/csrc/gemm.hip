@@ -551,6 +551,59 @@ __device__ __forceinline__ void nt_epilogue_s(const NTParams& p, f32x4 (&acc)[FM
   }
 }
 
+// PIPE == 2: two extra LOADER waves per workgroup issue every global -> LDS piece of the ring; the WM_ x WN_ compute waves only wait
+// at the per-step barrier, read fragments and issue MFMAs.  A wave that issues LDS-DMA pieces is blocked by the vector-memory path's
+// back-pressure for ~700 cycles per k-step (profiles/r02_gemm_phase_profile.txt), and in-order issue puts its MFMAs behind that
+// stall: with the roles split the stall overlaps the other waves' MFMAs (step = max(stream, compute) instead of their sum).
+template <int BM, int BN, int NTC, bool BT, int BK, int NL>
+__device__ __forceinline__ void nt2_loader(const NTParams& p, int m0, int n0, int nk, char* smem) {
+  constexpr int ARB = BK * 2, ACPR = BK / 8, A_CH = BM * ACPR / NL, B_CH = BN * ACPR / NL;      // NL loader threads
+  constexpr int A_BYTES = BM * ARB, STAGE_BYTES = (BM + BN) * ARB, BRB = BN * 2, BCPR = BN / 8;
+  static_assert(BK == 64 && BM * ACPR % NL == 0 && BN * ACPR % NL == 0, "loader tile");
+  const int ltid = threadIdx.x - NTC, lw = __builtin_amdgcn_readfirstlane(ltid >> 6);
+  auto rswz = [](int row) { return (row >> 1) & 7; };
+  const bf16_t* a_src[A_CH];
+  const bf16_t* b_src[B_CH];
+#pragma unroll
+  for (int i = 0; i < A_CH; ++i) {
+    const int c = ltid + NL * i, row = c / ACPR, ls = (c % ACPR) ^ rswz(row);
+    int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;
+    a_src[i] = p.A + map_row(gm, p.amap) * p.lda + ls * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < B_CH; ++i) {
+    const int c = ltid + NL * i;
+    if (!BT) {
+      const int row = c / ACPR, ls = (c % ACPR) ^ rswz(row);
+      int gn = n0 + row; gn = gn < p.N ? gn : p.N - 1;
+      b_src[i] = p.B + (long)gn * p.ldb + ls * 8;
+    } else {
+      const int row = c / BCPR, pc = c % BCPR;
+      const int lc = (((pc >> 1) ^ tn2_swz<BRB>(row)) << 1) | (pc & 1);
+      int gc = n0 + lc * 8; gc = gc < p.N ? gc : p.N - 8;
+      b_src[i] = p.B + (long)row * p.ldb + gc;
+    }
+  }
+  auto dma_tile = [&](int kt) {
+    const int k0 = kt * BK;
+    char* st = smem + (kt & 1) * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(void, a_src[i] + k0), LDS_PTR(void, st + (lw * 64 + NL * i) * 16), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(void, BT ? b_src[i] + (long)k0 * p.ldb : b_src[i] + k0),
+                                       LDS_PTR(void, st + A_BYTES + (lw * 64 + NL * i) * 16), 16, 0, 0);
+  };
+  dma_tile(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    wait_vmcnt<0>();                       // tile kt has landed
+    __builtin_amdgcn_s_barrier();          // ... and the compute waves are done with tile kt - 1: its stage is free
+    if (kt + 1 < nk) dma_tile(kt + 1);
+  }
+  // the loaders leave here; the barriers of the epilogue count the surviving (compute) waves only
+}
+
 template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK, bool PROF = false, int PIPE = 0>
 __device__ __forceinline__ void nt2_body(const NTParams& p, int bid) {
   // PROF (tile configuration 30, tools/gemm_phase_prof.py only): per-wave shader-cycle sums of the k-loop phases —
@@ -591,13 +644,19 @@ __device__ __forceinline__ void nt2_body(const NTParams& p, int bid) {
     bn = pnl * wn_ + rem % wp;
   }
   const int m0 = bm * BM, n0 = bn * BN;
+  if constexpr (PIPE >= 2) {
+    if (wave >= WM_ * WN_) {                 // PIPE loader waves (two-stage ring of 64-deep stages only)
+      nt2_loader<BM, BN, NT, BT, BK, PIPE * 64>(p, m0, n0, p.K / BK, smem);
+      return;
+    }
+  }
   // 16-byte-slot XOR swizzle of the row-major tiles: 128-byte rows (BK 64) / 64-byte rows (BK 32)
   auto rswz = [](int row) { return BK == 64 ? ((row >> 1) & 7) : ((0 - (row >> 2)) & 3); };
 
   const bf16_t* a_src[A_CH];
   const bf16_t* b_src[B_CH];
 #pragma unroll
-  for (int i = 0; i < A_CH; ++i) {
+  for (int i = 0; i < (PIPE >= 2 ? 0 : A_CH); ++i) {
     const int c = tid + NT * i, row = c / ACPR, ls = (c % ACPR) ^ rswz(row);
     int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;
     a_src[i] = p.A + map_row(gm, p.amap) * p.lda + ls * 8;
@@ -606,7 +665,7 @@ __device__ __forceinline__ void nt2_body(const NTParams& p, int bid) {
   // [64 k rows][BN cols] (BN*2-byte rows) read back with the transposing ds_read_b64_tr_b16.
   constexpr int BRB = BN * 2, BCPR = BN / 8;
 #pragma unroll
-  for (int i = 0; i < B_CH; ++i) {
+  for (int i = 0; i < (PIPE >= 2 ? 0 : B_CH); ++i) {
     const int c = tid + NT * i;
     if (!BT) {
       const int row = c / ACPR, ls = (c % ACPR) ^ rswz(row);
@@ -638,9 +697,11 @@ __device__ __forceinline__ void nt2_body(const NTParams& p, int bid) {
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / BK;
+  if (PIPE < 2) {
 #pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s)
-    if (s < nk) dma_tile(s);
+    for (int s = 0; s < STAGES - 1; ++s)
+      if (s < nk) dma_tile(s);
+  }
 
   const int fr = lane & 15, fg = lane >> 4;
   if (PROF) { const long long t = __builtin_readcyclecounter(); pt[4] = t - tk0; tk0 = t; }
@@ -742,13 +803,14 @@ __device__ __forceinline__ void nt2_body(const NTParams& p, int bid) {
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt must have landed; up to STAGES-2 younger tiles may stay in flight
     const int younger = nk - 1 - kt;
-    if (STAGES >= 3 && younger >= STAGES - 2) wait_vmcnt<(STAGES - 2) * LPT>();
+    if (PIPE >= 2) {}                      // the loader waves wait for their pieces (nt2_loader); here only the barrier
+    else if (STAGES >= 3 && younger >= STAGES - 2) wait_vmcnt<(STAGES - 2) * LPT>();
     else if (STAGES >= 4 && younger == 1) wait_vmcnt<LPT>();
     else wait_vmcnt<0>();
     if (PROF) { const long long t = __builtin_readcyclecounter(); pt[0] += t - tk0; tk0 = t; }
     __builtin_amdgcn_s_barrier();          // everyone's pieces of tile kt are in LDS; stage (kt-1)%STAGES is free
     if (PROF) { const long long t = __builtin_readcyclecounter(); pt[1] += t - tk0; tk0 = t; }
-    if (kt + STAGES - 1 < nk) dma_tile(kt + STAGES - 1);
+    if (PIPE < 2 && kt + STAGES - 1 < nk) dma_tile(kt + STAGES - 1);
     if (PROF) { const long long t = __builtin_readcyclecounter(); pt[2] += t - tk0; tk0 = t; }
     const char* Ab = smem + (kt % STAGES) * STAGE_BYTES;
     const char* Bb = Ab + A_BYTES;
@@ -1012,7 +1074,7 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(NTParams p) {
 }
 // PIPE: two 512-thread workgroups per CU = 4 waves per SIMD -> at most 128 VGPRs (2nd launch-bounds argument = waves per SIMD)
 template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK = 64, int PIPE = 0>
-__global__ __launch_bounds__(WM_* WN_ * 64, (PIPE || (WM_ * WN_ == 8 && BM * BN > 128 * 128)) ? 4 : 1) void gemm_nt2_kernel(NTParams p) {
+__global__ __launch_bounds__((WM_* WN_ + (PIPE >= 2 ? PIPE : 0)) * 64, PIPE == 4 ? 6 : PIPE == 2 ? 5 : ((PIPE || (WM_ * WN_ == 8 && BM * BN > 128 * 128)) ? 4 : 1)) void gemm_nt2_kernel(NTParams p) {
   nt2_body<BM, BN, WM_, WN_, STAGES, BT, BK, false, PIPE>(p, blockIdx.x);
 }
 
@@ -1028,7 +1090,7 @@ struct NTGroup {
 };
 
 template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK = 64, int PIPE = 0>
-__global__ __launch_bounds__(WM_* WN_ * 64, (PIPE || (WM_ * WN_ == 8 && BM * BN > 128 * 128)) ? 4 : 1) void gemm_nt2_grouped_kernel(const NTGroup g) {
+__global__ __launch_bounds__((WM_* WN_ + (PIPE >= 2 ? PIPE : 0)) * 64, PIPE == 4 ? 6 : PIPE == 2 ? 5 : ((PIPE || (WM_ * WN_ == 8 && BM * BN > 128 * 128)) ? 4 : 1)) void gemm_nt2_grouped_kernel(const NTGroup g) {
   int pi = 0;
   while (pi + 1 < g.count && (int)blockIdx.x >= g.first_block[pi + 1]) ++pi;
   nt2_body<BM, BN, WM_, WN_, STAGES, BT, BK, false, PIPE>(g.prob[pi], (int)blockIdx.x - g.first_block[pi]);
@@ -1092,7 +1154,7 @@ void launch_nt3(const NTParams& p, hipStream_t stream) {
 // launches n >= 1 recorded problems of this tile configuration (davb::GroupFn)
 template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK, int PIPE = 0>
 void nt2_issue(const void* const* params, int n, hipStream_t stream) {
-  constexpr int NT = WM_ * WN_ * 64;
+  constexpr int NT = (WM_ * WN_ + (PIPE >= 2 ? PIPE : 0)) * 64;      // + the loader waves
   constexpr size_t lds = nt2_lds_bytes<BM, BN, WM_, WN_, STAGES, BT, BK>();
   auto kern = gemm_nt2_kernel<BM, BN, WM_, WN_, STAGES, BT, BK, PIPE>;
   auto gkern = gemm_nt2_grouped_kernel<BM, BN, WM_, WN_, STAGES, BT, BK, PIPE>;
@@ -1213,6 +1275,8 @@ void nt2_issue_auto(const void* const* params_in, int n, hipStream_t stream) {
     case 45: nt2_issue<256, 128, 4, 2, 2, BT, 32>(params, n, stream); break;
     case 43: nt2_issue<256, 128, 4, 2, 3, BT, 32>(params, n, stream); break;      // (43 / 46: tools/mix_sweep.py candidates)
     case 46: nt2_issue<128, 256, 2, 4, 2, BT, 32>(params, n, stream); break;
+    case 50: nt2_issue<128, 128, 4, 2, 2, BT, 64, 2>(params, n, stream); break;      // + two loader waves
+    case 51: nt2_issue<128, 128, 4, 2, 2, BT, 64, 4>(params, n, stream); break;      // + four
     case 3: nt2_issue<128, 128, 4, 2, 2, BT, 64>(params, n, stream); break;      // 4 x 2 waves (32 x 64 wave tiles): +0.8 % over 2 x 4 in the step
     case 8: nt2_issue<128, 64, 2, 2, 2, BT, 64>(params, n, stream); break;
     case 7: nt2_issue<64, 64, 2, 2, 4, BT, 64>(params, n, stream); break;
@@ -1606,7 +1670,7 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
   const bool vec_ok = glds_ok && (N & 3) == 0 && (ldc & 3) == 0 && (!res || (ldres & 3) == 0) && (!C2 || (ldc2 & 3) == 0) &&
                       (!aux || (ldaux & 3) == 0) && !(((uintptr_t)C | (uintptr_t)C2 | (uintptr_t)res) & 15) && !((uintptr_t)aux & 7);
   int cfg = variant >> 4;
-  const bool groupable_cfg = cfg == 0 || cfg == 3 || cfg == 5 || cfg == 7 || cfg == 8 || cfg == 43 || cfg == 44 || cfg == 45 || cfg == 46;
+  const bool groupable_cfg = cfg == 0 || cfg == 3 || cfg == 5 || cfg == 7 || cfg == 8 || cfg == 50 || cfg == 51 || cfg == 43 || cfg == 44 || cfg == 45 || cfg == 46;
   p.force_cfg = cfg;
   if (vec_ok && groupable_cfg && !(variant & 15) && davb::recording()) {
     // batched: the tile configuration is chosen when the group is issued, from the tile count of the whole group
@@ -1626,6 +1690,8 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
       if (cfg == 3 && K <= 512 && !(N & 255) && N >= 1024 && (long)((M + 127) / 128) * (N / 256) >= 512 && nt_wide_on()) cfg = 44;     // as nt2_issue_auto
     }
     switch (cfg) {
+      case 50: launch_nt2<128, 128, 4, 2, 2, true, 64, 2>(p, stream); break;
+      case 51: launch_nt2<128, 128, 4, 2, 2, true, 64, 4>(p, stream); break;
       case 3: launch_nt2<128, 128, 4, 2, 2, true>(p, stream); break;
       case 31: launch_nt2<128, 128, 2, 4, 2, true, 64, 1>(p, stream); break;
       case 32: launch_nt3<true>(p, stream); break;
@@ -1674,6 +1740,8 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
       }
       case 1: launch_nt2<128, 128, 2, 2, 2>(p, stream); return dav_launch_status();
       case 2: launch_nt2<128, 128, 2, 2, 3>(p, stream); return dav_launch_status();
+      case 50: launch_nt2<128, 128, 4, 2, 2, false, 64, 2>(p, stream); return dav_launch_status();
+      case 51: launch_nt2<128, 128, 4, 2, 2, false, 64, 4>(p, stream); return dav_launch_status();
       case 3: launch_nt2<128, 128, 4, 2, 2>(p, stream); return dav_launch_status();
       case 4: launch_nt2<128, 128, 2, 4, 3>(p, stream); return dav_launch_status();
       case 48: launch_nt2<128, 128, 4, 2, 4>(p, stream); return dav_launch_status();      // 4 x 32 KB ring, one workgroup per CU (in-flight depth experiment)
