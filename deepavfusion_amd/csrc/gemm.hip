@@ -1240,6 +1240,7 @@ static int nt_tuned_lookup(bool bt, const void* const* params, int n) {
 }
 
 // DAV_NT_WIDE=0 switches the 128 x 256 configuration off (A/B timing of the same box)
+static bool nt_ld_on() { static const bool on = [] { const char* e = getenv("DAV_NT_LD"); return e && e[0] == '1'; }(); return on; }
 static bool nt_wide_on() { static const bool on = [] { const char* e = getenv("DAV_NT_WIDE"); return !(e && e[0] == '0'); }(); return on; }
 
 // Recorded with the tile configuration left open: chosen at issue time from the tile count of the WHOLE group.
@@ -1269,6 +1270,7 @@ void nt2_issue_auto(const void* const* params_in, int n, hipStream_t stream) {
   if (forced) cfg = forced;
   else if (tuned) cfg = tuned;
   else if (cfg == 3 && wide && t256 >= 512 && nt_wide_on()) cfg = 44;
+  if (cfg == 3 && nt_ld_on()) cfg = 51;
   nt_log_issue(cfg, BT, params, n);
   switch (cfg) {
     case 44: nt2_issue<128, 256, 2, 4, 3, BT, 32>(params, n, stream); break;
@@ -1689,6 +1691,7 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
       cfg = nt_auto_config(M, N, K);
       if (cfg == 3 && K <= 512 && !(N & 255) && N >= 1024 && (long)((M + 127) / 128) * (N / 256) >= 512 && nt_wide_on()) cfg = 44;     // as nt2_issue_auto
     }
+    if (cfg == 3 && nt_ld_on()) cfg = 51;
     switch (cfg) {
       case 50: launch_nt2<128, 128, 4, 2, 2, true, 64, 2>(p, stream); break;
       case 51: launch_nt2<128, 128, 4, 2, 2, true, 64, 4>(p, stream); break;
@@ -1712,6 +1715,7 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
       cfg = nt_auto_config(M, N, K);
       if (cfg == 3 && K <= 512 && !(N & 255) && N >= 1024 && (long)((M + 127) / 128) * (N / 256) >= 512 && nt_wide_on()) cfg = 44;     // as nt2_issue_auto
     }
+    if (cfg == 3 && nt_ld_on()) cfg = 51;
     switch (cfg) {
       case 30: {      // phase profile of the dominant configuration (see nt2_body); res_rows carries the int64 output buffer
         if (res) return DAV_ERR_SHAPE;
