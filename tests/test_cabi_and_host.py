@@ -296,3 +296,45 @@ def test_error_codes_for_dtype_alignment_and_workspace():
     args[-3], args[-2] = p(8192), C.c_size_t(need - 1)                         # workspace, workspace_bytes
     assert lib.dav_layernorm_bwd(*args) == -3
     assert _lib.ERRORS[-2] and _lib.ERRORS[-3] and _lib.ERRORS[-5]
+
+
+def test_written_first_contribution_bookkeeping(monkeypatch):
+    """engine.flush_wgrads under wgrad_overwrite_begin(): which queued weight-gradient problems may WRITE their tile
+    (DavTnProblem.flags bit 0) — pure host logic, the grouped launch is intercepted."""
+    from deepavfusion_amd import engine as E, ops
+    launches = []
+    monkeypatch.setattr(ops, 'gemm_tn_grouped', lambda probs: launches.append([dict(p) for p in probs]))
+    lin = [torch.nn.Linear(8, 8) for _ in range(5)]
+    g = [torch.zeros(8, 8) for _ in range(5)]
+
+    def prob(i, mc, full=True, col=0):
+        C = g[i] if col == 0 else g[i].view(-1)[col:]
+        return dict(A=None, B=None, Mc=mc, N=8, K=8 if full else 4, C=C, lda=8, ldb=8, ldc=8, bias_grad=None, ready=(),
+                    gbase=g[i].data_ptr(), weight=lin[i].weight if full else None)
+    with E.deferred_wgrads():
+        E.wgrad_overwrite_begin()
+        E._OVERWRITE['touched'].add(g[3].data_ptr())               # weight 3 got an immediate (un-deferred) contribution earlier
+        E._DEFERRED.extend([prob(0, 128), prob(1, 64), prob(1, 192),    # weight 1 twice (decoder_embed: tokens and fusion tokens)
+                            prob(2, 64, full=False), prob(2, 64, full=False, col=4),      # weight 2 as two column blocks (pair path)
+                            prob(3, 64), prob(4, 256)])
+        E.flush_wgrads()
+        E._DEFERRED.append(prob(4, 64))                            # a later flush into weight 4: accumulates
+        E.flush_wgrads()
+        kept = E.wgrad_overwrite_end()
+    assert E._OVERWRITE is None
+    flat = [(p['C'].data_ptr(), p['Mc'], bool(p.get('overwrite'))) for l in launches for p in l]
+    assert len(launches) == 3 and [len(l) for l in launches] == [6, 1, 1]          # the second problem of weight 1 cannot share a launch
+    assert [p['Mc'] for p in launches[0]] == sorted((p['Mc'] for p in launches[0]), reverse=True)   # longest contraction first
+    ow = {(ptr, mc): o for ptr, mc, o in flat}
+    assert ow[(g[0].data_ptr(), 128)] and ow[(g[4].data_ptr(), 256)]              # first full-weight contribution: written
+    assert ow[(g[1].data_ptr(), 64)] != ow[(g[1].data_ptr(), 192)]                 # exactly one of the two problems of weight 1 writes ...
+    assert launches[1][0]['C'].data_ptr() == g[1].data_ptr() and not launches[1][0].get('overwrite')   # ... the one issued first
+    assert not any(o for ptr, mc, o in flat if ptr in (g[2].data_ptr(), g[2].view(-1)[4:].data_ptr()))   # column blocks accumulate
+    assert not ow[(g[3].data_ptr(), 64)]                                           # touched before: accumulates
+    assert not ow[(g[4].data_ptr(), 64)]                                           # second flush into a written weight: accumulates
+    assert {id(p) for p in kept} == {id(lin[0].weight), id(lin[1].weight), id(lin[4].weight)}
+    # outside a captured step nothing is ever written
+    launches.clear()
+    with E.deferred_wgrads():
+        E._DEFERRED.append(prob(0, 64))
+    assert launches and not launches[0][0].get('overwrite')
