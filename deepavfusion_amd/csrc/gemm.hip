@@ -551,6 +551,8 @@ __device__ __forceinline__ void nt_epilogue_s(const NTParams& p, f32x4 (&acc)[FM
   }
 }
 
+#include "gemm_nt256.h"
+
 // PIPE == 2: two extra LOADER waves per workgroup issue every global -> LDS piece of the ring; the WM_ x WN_ compute waves only wait
 // at the per-step barrier, read fragments and issue MFMAs.  A wave that issues LDS-DMA pieces is blocked by the vector-memory path's
 // back-pressure for ~700 cycles per k-step (profiles/r02_gemm_phase_profile.txt), and in-order issue puts its MFMAs behind that
@@ -1103,6 +1105,58 @@ constexpr size_t nt2_lds_bytes() {
   return ring > epi ? ring : epi;
 }
 
+template <bool BT, int EK>
+__global__ __launch_bounds__(512) void gemm_nt256_grouped_kernel(const NTGroup g) {
+  int pi = 0;
+  while (pi + 1 < g.count && (int)blockIdx.x >= g.first_block[pi + 1]) ++pi;
+  nt256_body<BT, EK>(g.prob[pi], (int)blockIdx.x - g.first_block[pi]);
+}
+
+// 256 x 256 tiles (configuration 60): n >= 1 recorded problems (davb::GroupFn).  One kernel form (problem table by value, also
+// for a single problem); the epilogue specialisation is the kind all problems of the launch share, else the generic one.
+template <bool BT, int EK>
+void nt256_launch(const NTGroup& g, int grid, hipStream_t stream) {
+  static bool big = false;
+  if (!big) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt256_grouped_kernel<BT, EK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    big = true;
+  }
+  DAV_LAUNCH_NOW((gemm_nt256_grouped_kernel<BT, EK>), dim3(grid), dim3(512), NT256_LDS, stream, g);
+}
+template <bool BT>
+void nt256_issue(const void* const* params, int n, hipStream_t stream) {
+  for (int base = 0; base < n; base += NT_GROUP_MAX) {
+    const int cnt = n - base < NT_GROUP_MAX ? n - base : NT_GROUP_MAX;
+    NTGroup g;
+    int first = 0, kind = -1;
+    for (int i = 0; i < cnt; ++i) {
+      g.prob[i] = *(const NTParams*)params[base + i];
+      g.first_block[i] = first;
+      const int tiles = ((g.prob[i].M + 255) / 256) * ((g.prob[i].N + 255) / 256);
+      first += cnt == 1 ? tiles : (tiles + 7) & ~7;
+      const int k = nt256_kind(g.prob[i]);
+      kind = (kind < 0 || kind == k) ? k : 0;
+    }
+    g.first_block[cnt] = first;
+    g.count = cnt;
+    switch (kind) {
+      case 1: nt256_launch<BT, 1>(g, first, stream); break;
+      case 2: nt256_launch<BT, 2>(g, first, stream); break;
+      case 3: nt256_launch<BT, 3>(g, first, stream); break;
+      default: nt256_launch<BT, 0>(g, first, stream); break;
+    }
+  }
+}
+template <bool BT>
+void launch_nt256(const NTParams& p, hipStream_t stream) {
+  if (davb::recording()) {
+    davb::push_typed(nt256_issue<BT>, &p, sizeof(p), stream);
+    return;
+  }
+  const void* one = &p;
+  nt256_issue<BT>(&one, 1, stream);
+}
+
 template <bool BT>
 __global__ __launch_bounds__(512) void gemm_nt3_grouped_kernel(const NTGroup g) {
   int pi = 0;
@@ -1241,6 +1295,13 @@ static int nt_tuned_lookup(bool bt, const void* const* params, int n) {
 
 // DAV_NT_WIDE=0 switches the 128 x 256 configuration off (A/B timing of the same box)
 static bool nt_ld_on() { static const bool on = [] { const char* e = getenv("DAV_NT_LD"); return e && e[0] == '1'; }(); return on; }
+// 256 x 256 tiles (configuration 60).  The rule is OFF by default (DAV_NT256=1 switches it on): alone on the GPU the configuration is
+// 7-25 % faster than 128 x 128 / 128 x 256 on every wide shape of the step, warm or cold operands, but the step gets 0.25 ms SLOWER with
+// it in every schedule (same-box alternation, profiles/r03_nt256_instep_ab.txt) — a workgroup that owns 128 KB of LDS keeps the
+// other streams' kernels off its CU.  When on: the group must hold DAV_NT256_TILES tiles (default 150) and every problem must be at least DAV_NT256_N columns wide (default 1024)
+static bool nt256_on() { static const bool on = [] { const char* e = getenv("DAV_NT256"); return e && e[0] == '1'; }(); return on; }
+static long nt256_min_tiles() { static const long v = getenv("DAV_NT256_TILES") ? atol(getenv("DAV_NT256_TILES")) : 150; return v; }
+static int nt256_min_n() { static const int v = getenv("DAV_NT256_N") ? atoi(getenv("DAV_NT256_N")) : 1024; return v; }
 static bool nt_wide_on() { static const bool on = [] { const char* e = getenv("DAV_NT_WIDE"); return !(e && e[0] == '0'); }(); return on; }
 
 // Recorded with the tile configuration left open: chosen at issue time from the tile count of the WHOLE group.
@@ -1250,11 +1311,14 @@ void nt2_issue_auto(const void* const* params_in, int n, hipStream_t stream) {
   std::vector<const void*> sorted(params_in, params_in + n);
   std::stable_sort(sorted.begin(), sorted.end(), [](const void* a, const void* b) { return ((const NTParams*)a)->K > ((const NTParams*)b)->K; });
   const void* const* params = sorted.data();
-  long t128 = 0, t256 = 0;
+  long t128 = 0, t256 = 0, t256sq = 0;
   bool wide = true;
   bool narrow = true;
+  bool all256 = true;                                     // every problem can go through the 256 x 256 body and is wide enough for it
   for (int i = 0; i < n; ++i) {
     const NTParams& p = *(const NTParams*)params[i];
+    t256sq += (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+    all256 = all256 && nt256_ok(p) && p.N >= nt256_min_n();
     t128 += (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     t256 += (long)((p.M + 127) / 128) * ((p.N + 255) / 256);
     narrow = narrow && p.N <= 64;
@@ -1271,8 +1335,27 @@ void nt2_issue_auto(const void* const* params_in, int n, hipStream_t stream) {
   else if (tuned) cfg = tuned;
   else if (cfg == 3 && wide && t256 >= 512 && nt_wide_on()) cfg = 44;
   if (cfg == 3 && nt_ld_on()) cfg = 51;
+  if (!forced && !tuned && nt256_on() && t256sq >= nt256_min_tiles() && all256) cfg = 60;
+  if (!forced && !tuned && nt256_on() && !all256 && n > 1) {
+    // mixed group (the towers' GEMMs with the fusion block's narrow projections riding along): the problems the 256 x 256 body
+    // can take go out as one launch of their own when they fill the chip, the rest by the rules
+    std::vector<const void*> wide_p, rest_p;
+    long tw = 0;
+    for (int i = 0; i < n; ++i) {
+      const NTParams& p = *(const NTParams*)params[i];
+      if (nt256_ok(p) && p.N >= nt256_min_n()) { wide_p.push_back(params[i]); tw += (long)((p.M + 255) / 256) * ((p.N + 255) / 256); }
+      else rest_p.push_back(params[i]);
+    }
+    if (tw >= nt256_min_tiles() && !rest_p.empty()) {
+      nt2_issue_auto<BT>(wide_p.data(), (int)wide_p.size(), stream);
+      nt2_issue_auto<BT>(rest_p.data(), (int)rest_p.size(), stream);
+      return;
+    }
+  }
+  if (cfg == 60 && !all256) cfg = 3;                     // (an explicit or tuned 60 on a group the 256 x 256 body cannot take)
   nt_log_issue(cfg, BT, params, n);
   switch (cfg) {
+    case 60: nt256_issue<BT>(params, n, stream); break;
     case 44: nt2_issue<128, 256, 2, 4, 3, BT, 32>(params, n, stream); break;
     case 45: nt2_issue<256, 128, 4, 2, 2, BT, 32>(params, n, stream); break;
     case 43: nt2_issue<256, 128, 4, 2, 3, BT, 32>(params, n, stream); break;      // (43 / 46: tools/mix_sweep.py candidates)
@@ -1632,7 +1715,7 @@ int nt_auto_config_tiles(long t128, bool narrow) {
   // get the FOUR-stage ring — three k-steps of prefetch cover the HBM miss a two-stage ring exposes at every k-step (15 us in
   // the step vs 7 us with warm operands); from ~250 tiles of 64x64 on the 64 KB ring costs occupancy instead (3136x768x3072
   // alone: 40.5 vs 32.7 us).  DAV_NT_SMALL=5 forces the two-stage ring.
-  static const int small_cfg = getenv("DAV_NT_SMALL") ? atoi(getenv("DAV_NT_SMALL")) : 7;
+  static const int small_cfg = getenv("DAV_NT_SMALL") ? atoi(getenv("DAV_NT_SMALL")) : 5;      // round 3, stream schedule: the two-stage ring is -0.18 ms per step (same-box alternation); 7 = the four-stage ring
   static const int t5 = getenv("DAV_NT_T5") ? atoi(getenv("DAV_NT_T5")) : 200, t8 = getenv("DAV_NT_T8") ? atoi(getenv("DAV_NT_T8")) : 400;
   if (narrow || t128 < t5) return (small_cfg == 5 || t128 > 64) ? 5 : 7;
   if (t128 < t8) return 8;                   // 128x64, 4 waves
@@ -1672,7 +1755,7 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
   const bool vec_ok = glds_ok && (N & 3) == 0 && (ldc & 3) == 0 && (!res || (ldres & 3) == 0) && (!C2 || (ldc2 & 3) == 0) &&
                       (!aux || (ldaux & 3) == 0) && !(((uintptr_t)C | (uintptr_t)C2 | (uintptr_t)res) & 15) && !((uintptr_t)aux & 7);
   int cfg = variant >> 4;
-  const bool groupable_cfg = cfg == 0 || cfg == 3 || cfg == 5 || cfg == 7 || cfg == 8 || cfg == 50 || cfg == 51 || cfg == 43 || cfg == 44 || cfg == 45 || cfg == 46;
+  const bool groupable_cfg = cfg == 0 || cfg == 60 || cfg == 3 || cfg == 5 || cfg == 7 || cfg == 8 || cfg == 50 || cfg == 51 || cfg == 43 || cfg == 44 || cfg == 45 || cfg == 46;
   p.force_cfg = cfg;
   if (vec_ok && groupable_cfg && !(variant & 15) && davb::recording()) {
     // batched: the tile configuration is chosen when the group is issued, from the tile count of the whole group
@@ -1680,19 +1763,18 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
     return DAV_OK;
   }
   if (vec_ok && cfg == 0 && !(variant & 15)) {
+    // not recording, configuration left open: the same choice (rules, tuned table, issue log) as a recorded group of one
     const void* one = &p;
-    int c = nt_auto_config(M, N, K);
-    if (c == 3 && K <= 512 && !(N & 255) && N >= 1024 && (long)((M + 127) / 128) * (N / 256) >= 512 && nt_wide_on()) c = 44;
-    nt_log_issue(c, b_kn != 0, &one, 1);
+    if (b_kn) nt2_issue_auto<true>(&one, 1, stream); else nt2_issue_auto<false>(&one, 1, stream);
+    return dav_launch_status();
   }
   if (b_kn) {
     if (!vec_ok) return DAV_ERR_SHAPE;
-    if (cfg == 0) {
-      cfg = nt_auto_config(M, N, K);
-      if (cfg == 3 && K <= 512 && !(N & 255) && N >= 1024 && (long)((M + 127) / 128) * (N / 256) >= 512 && nt_wide_on()) cfg = 44;     // as nt2_issue_auto
-    }
+    if (cfg == 0) cfg = nt_auto_config(M, N, K);       // (only reached with the variant bits set; the open choice returned above)
     if (cfg == 3 && nt_ld_on()) cfg = 51;
+    if (cfg == 60 && !nt256_ok(p)) return DAV_ERR_SHAPE;
     switch (cfg) {
+      case 60: launch_nt256<true>(p, stream); break;
       case 50: launch_nt2<128, 128, 4, 2, 2, true, 64, 2>(p, stream); break;
       case 51: launch_nt2<128, 128, 4, 2, 2, true, 64, 4>(p, stream); break;
       case 3: launch_nt2<128, 128, 4, 2, 2, true>(p, stream); break;
@@ -1711,12 +1793,11 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
     return dav_launch_status();
   }
   if (vec_ok && !(variant & 15)) {
-    if (cfg == 0) {
-      cfg = nt_auto_config(M, N, K);
-      if (cfg == 3 && K <= 512 && !(N & 255) && N >= 1024 && (long)((M + 127) / 128) * (N / 256) >= 512 && nt_wide_on()) cfg = 44;     // as nt2_issue_auto
-    }
+    if (cfg == 0) cfg = nt_auto_config(M, N, K);
     if (cfg == 3 && nt_ld_on()) cfg = 51;
+    if (cfg == 60 && !nt256_ok(p)) return DAV_ERR_SHAPE;
     switch (cfg) {
+      case 60: launch_nt256<false>(p, stream); return dav_launch_status();
       case 30: {      // phase profile of the dominant configuration (see nt2_body); res_rows carries the int64 output buffer
         if (res) return DAV_ERR_SHAPE;
         const int grid = ((M + 127) / 128) * ((N + 127) / 128);
@@ -1796,7 +1877,7 @@ extern "C" int dav_nt_tune_set(const int* blob, int n_ints) {
     if (i + 3 > n_ints) return DAV_ERR_SHAPE;
     const int cfg = blob[i], bt = blob[i + 1], n = blob[i + 2];
     if (n <= 0 || i + 3 + 4 * n > n_ints) return DAV_ERR_SHAPE;
-    if (!(cfg == 3 || cfg == 5 || cfg == 8 || cfg == 43 || cfg == 44 || cfg == 45 || cfg == 46)) return DAV_ERR_SHAPE;
+    if (!(cfg == 60 || cfg == 3 || cfg == 5 || cfg == 8 || cfg == 43 || cfg == 44 || cfg == 45 || cfg == 46)) return DAV_ERR_SHAPE;
     std::vector<std::array<int, 4>> v(n);
     for (int j = 0; j < n; ++j) v[j] = {blob[i + 3 + 4 * j], blob[i + 4 + 4 * j], blob[i + 5 + 4 * j], blob[i + 6 + 4 * j]};
     std::sort(v.begin(), v.end());

@@ -86,7 +86,7 @@ def gemm_nt():
         A, Bm = rnd(M, K, dtype=BF16, seed=1), rnd(N, K, dtype=BF16, scale=0.05, seed=2)
         bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
         ref = A.float() @ Bm.float().t() + bias + res
-        for cfg in (1, 3, 5, 8, 13, 15, 16, 17, 18, 19, 20, 21, 22):
+        for cfg in (1, 3, 5, 8, 13, 15, 16, 17, 18, 19, 20, 21, 22, 60):
             C = torch.empty(M, N, device=dev)
             ops.gemm_nt(A, Bm, M, N, K, bias=bias, res=res, ldres=N, C_out=C, variant=cfg << 4)
             report(f'gemm_nt {M}x{N}x{K} cfg{cfg}', rel(C, ref), 1e-4)
@@ -115,6 +115,51 @@ def gemm_nt():
                 C = torch.empty(M, N, device=dev)
                 ops.gemm_nt(A, Wm, M, N, K, bias=bias, res=res, ldres=N, C_out=C, variant=var, **kw)
                 report(tag + ' fp32 + res', rel(C, base + bias + res), 1e-4)
+    # 256 x 256 tiles (configuration 60, csrc/gemm_nt256.h; K % 128 == 0): every epilogue kind in both operand modes, ragged M / N
+    # edges (tiles of 256 on 2100 / 1000 / 300 rows, 200 .. 2304 columns), a K of a single pair of K-tiles, row maps, grouped form
+    for (M, N, K) in [(2100, 1024, 512), (1000, 768, 256), (300, 512, 128), (5184, 2304, 768), (517, 200, 384)]:
+        A = rnd(M, K, dtype=BF16, seed=41)
+        W_nk, W_kn = rnd(N, K, dtype=BF16, scale=0.05, seed=42), rnd(K, N, dtype=BF16, scale=0.05, seed=43)
+        bias, res, aux = rnd(N, seed=44), rnd(M, N, seed=45), rnd(M, N, dtype=BF16, seed=46)
+        for bt in (0, 1):
+            Wm, kw = (W_kn, dict(ldb=N)) if bt else (W_nk, {})
+            base = A.float() @ (W_kn.float() if bt else W_nk.float().t())
+            var = (60 << 4) | (bt << 12)
+            tag = f'gemm_nt {M}x{N}x{K} cfg60 b_kn{bt}'
+            U, D = torch.empty(M, N, device=dev, dtype=BF16), torch.empty(M, N, device=dev, dtype=BF16)
+            ops.gemm_nt(A, Wm, M, N, K, bias=bias, act=1, C_out=U, c_bf16=True, C2=D, ldc2=N, c2_mode=4, variant=var, **kw)
+            xg = (base + bias).clone().requires_grad_(True)
+            torch.nn.functional.gelu(xg).sum().backward()
+            report(tag + ' gelu', rel(U, torch.nn.functional.gelu(base + bias)), 6e-3)
+            report(tag + " gelu' twin", float((D.float() - xg.grad).abs().max()), 5e-3)
+            Z = torch.empty(M, N, device=dev, dtype=BF16)
+            ops.gemm_nt(A, Wm, M, N, K, bias=bias, act=1, C_out=U, c_bf16=True, C2=Z, ldc2=N, c2_mode=1, variant=var, **kw)
+            report(tag + ' preact twin', rel(Z, base + bias), 6e-3)
+            G = torch.empty(M, N, device=dev, dtype=BF16)
+            ops.gemm_nt(A, Wm, M, N, K, act=3, aux=aux, ldaux=N, C_out=G, c_bf16=True, variant=var, **kw)
+            report(tag + ' act3 bf16', rel(G, base * aux.float()), 6e-3)
+            xa = aux.float().requires_grad_(True)
+            torch.nn.functional.gelu(xa).sum().backward()
+            ops.gemm_nt(A, Wm, M, N, K, act=2, aux=aux, ldaux=N, C_out=G, c_bf16=True, alpha=0.5, variant=var, **kw)
+            report(tag + ' act2 bf16 alpha', rel(G, 0.5 * base * xa.grad), 6e-3)
+            C = torch.full((M, N), 0.25, device=dev)
+            T = torch.empty(M, N, device=dev, dtype=BF16)
+            ops.gemm_nt(A, Wm, M, N, K, bias=bias, res=res, ldres=N, C_out=C, beta=1, C2=T, ldc2=N, c2_mode=3, variant=var, **kw)
+            report(tag + ' fp32 + res + beta', rel(C, base + bias + res + 0.25), 1e-4)
+            report(tag + ' final twin', rel(T, base + bias + res + 0.25), 6e-3)
+            P = torch.full((M, N), 7.0, device=dev, dtype=BF16)
+            ops.gemm_nt(A, Wm, M, N, K, C_out=P, c_bf16=True, variant=var, **kw)
+            report(tag + ' plain bf16', rel(P, base), 6e-3)
+    # (row maps: A rows 4.. of every batch, C rows 1..)
+    Bsz, rpb, tot, N, K = 5, 70, 90, 512, 256
+    M = Bsz * rpb
+    Afull, Bm = rnd(Bsz * tot, K, dtype=BF16, seed=47), rnd(N, K, dtype=BF16, scale=0.1, seed=48)
+    Asub = Afull.view(Bsz, tot, K)[:, 4:4 + rpb, :].reshape(M, K)
+    Cfull = torch.zeros(Bsz * tot, N, device=dev, dtype=BF16)
+    ops.gemm_nt(Afull, Bm, M, N, K, a_rowmap=(rpb, tot, 4), C_out=Cfull, c_bf16=True, c_rowmap=(rpb, tot, 1), variant=60 << 4)
+    ref_full = torch.zeros(Bsz, tot, N, device=dev)
+    ref_full[:, 1:1 + rpb] = (Asub.float() @ Bm.float().t()).view(Bsz, rpb, N)
+    report('gemm_nt cfg60 rowmaps', rel(Cfull, ref_full.view(-1, N)), 6e-3)
     # act 2 (multiply by gelu'(aux)) and row maps
     M, N, K = 3 * 7, 128, 64
     Bsz, rpb, tot = 3, 7, 11

@@ -52,11 +52,30 @@ def main():
     for (M, N, K, cnt) in shapes:
         A = torch.randn(M, K if kind in ('nt', 'kn') else N, device=dev).bfloat16()
         Bm = (torch.randn(N if kind == 'nt' else (K if kind == 'kn' else M), K if kind != 'kn' else N, device=dev) * 0.05).bfloat16()
+        if os.environ.get('GEMM_BENCH_UNIFORM') == '1':      # full-range uniform operands (what tools/micro/gemm256.hip times): the GEMMs are power-bound, the fill matters
+            A = (torch.rand_like(A.float()) * 2 - 1).bfloat16()
+            Bm = (torch.rand_like(Bm.float()) * 2 - 1).bfloat16()
+        rot = int(os.environ.get('GEMM_BENCH_ROTATE', '0'))      # > 0: that many operand / output sets used in turn (cold operands, as in the step)
+        if rot > 0 and kind in ('nt', 'kn'):
+            As = [A.clone() for _ in range(rot)]
+            Bs = [Bm.clone() for _ in range(rot)]
+            Cs = [torch.empty(M, N, device=dev, dtype=torch.bfloat16) for _ in range(rot)]
         row = f'{M:>7}x{N:>5}x{K:>5} {cnt:>4} '
         fl = 2.0 * M * N * K
         totfl += fl * cnt
         for v in variants:
-            if kind == 'nt':
+            if rot > 0 and kind in ('nt', 'kn'):
+                it = [0]
+
+                def fn():
+                    i = it[0] % rot
+                    it[0] += 1
+                    if kind == 'nt':
+                        ops.gemm_nt(As[i], Bs[i], M, N, K, C_out=Cs[i], c_bf16=True, variant=v)
+                    else:
+                        ops.gemm_nt(As[i], Bs[i], M, N, K, ldb=N, C_out=Cs[i], c_bf16=True, variant=v | (1 << 12))
+                us = timeit(fn, reps=2 * rot)
+            elif kind == 'nt':
                 C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
                 us = timeit(lambda: ops.gemm_nt(A, Bm, M, N, K, C_out=C, c_bf16=True, variant=v))
             elif kind == 'kn':
