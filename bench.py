@@ -59,6 +59,25 @@ def necessary_fwd_flops_per_pair(cfg):
     return f
 
 
+def _spawn_ranks(n):
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -80,8 +99,10 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if a.gpus > 1 and world == 1:
-        print('bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)', file=sys.stderr)
-        return 2
+        # Plain `python bench.py --gpus N` (no torch.distributed.run around it): this process starts the N ranks itself, as
+        # fresh child processes, BEFORE it has made any GPU call (it never does), waits for them and forwards rank 0's
+        # one JSON line.  Never re-exec a process that has initialised the GPU.
+        return _spawn_ranks(a.gpus)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     force_dist = os.environ.get('DAV_FORCE_DIST', '0') == '1'      # test hook: 1-rank RCCL group on a single GPU

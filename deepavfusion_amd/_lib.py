@@ -17,6 +17,8 @@ LIB_PATH = os.path.join(_HERE, 'libdavfusion_hip.so')
 
 _p, _i, _l, _f, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 
+ABI_VERSION = 2      # DAV_ABI_VERSION of include/dav_kernels.h this package was written against (struct layouts, signatures)
+
 # name -> argtypes (must match include/dav_kernels.h)
 SIGNATURES = {
     'dav_abi_version': [],
@@ -81,7 +83,8 @@ SIGNATURES = {
     'dav_batch_end': [],
     'dav_batch_abort': [],
     'dav_batch_stats': [_p, _p],
-    'dav_adamw_flat': [_p, _p, _p, _p, _p, _l, _p, _p, _i, _f, _f, _f, _p, _f, _p, _i, _p, _p],
+    'dav_adamw_flat': [_p, _p, _p, _p, _p, _l, _p, _p, _i, _f, _f, _f, _p, _f, _p, _i, _p, _p, _p],
+    'dav_step_guard': [_p, _p, _p, _f, _f, _p, _p, _p],
 }
 
 class DavLnReduce(C.Structure):
@@ -112,7 +115,7 @@ def load():
         fn = getattr(lib, name)           # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = _sz if name.endswith('workspace_bytes') else (C.c_char_p if name == 'dav_last_error_string' else _i)
-    if lib.dav_abi_version() != 1:
+    if lib.dav_abi_version() != ABI_VERSION:
         raise RuntimeError('libdavfusion_hip.so ABI version mismatch')
     _lib = lib
     load_nt_tuning(NT_TUNING_PATH)

@@ -1939,7 +1939,10 @@ extern "C" int dav_gemm_tn_grouped_bf16(const DavTnProblem* probs, int count, hi
   g.count = count;
   // 4 x 2 waves (32 x 64 wave tiles): +1 % over 2 x 4 in the step; thinner or deeper rings (32-row stages x 3 / 4, 64-row x 3),
   // 4-wave workgroups and three workgroups per CU were all measured slower (profiles/r02_tn_ring_variants.txt)
-  DAV_LAUNCH((gemm_tn_grouped_kernel<128, 4, 2>), dim3(first), dim3(512), (size_t)2 * 2 * 64 * 128 * 2, stream, g);
+  // (by-value copy in an AUTOMATIC: a launch recorded inside dav_batch_begin .. dav_batch_end captures its arguments with [=],
+  // which does not copy objects of static storage — two recorded grouped calls would both run with the last table)
+  const TNGroup gl = g;
+  DAV_LAUNCH((gemm_tn_grouped_kernel<128, 4, 2>), dim3(first), dim3(512), (size_t)2 * 2 * 64 * 128 * 2, stream, gl);
   return dav_launch_status();
 }
 

@@ -404,7 +404,8 @@ extern "C" int dav_layernorm_bwd_reduce_grouped(const DavLnReduce* items, int co
   }
   g.first_block[count] = first;
   g.count = count;
-  DAV_LAUNCH(ln_bwd_reduce_grouped_kernel, dim3(first), dim3(1024), 0, stream, g);
+  const LNReduceGroup gl = g;      // automatic copy: a recorded launch captures by [=], which does not copy static storage (see gemm.hip)
+  DAV_LAUNCH(ln_bwd_reduce_grouped_kernel, dim3(first), dim3(1024), 0, stream, gl);
   return dav_launch_status();
 }
 

@@ -363,11 +363,18 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
                                                          float* __restrict__ v, bf16_t* __restrict__ p_bf16, long n,
                                                          const long* __restrict__ seg_end, const float* __restrict__ hyper, int nseg, float beta1,
                                                          float beta2, float eps, const float* bias_corr, float grad_scale,
-                                                         float* sumsq_out, int zero_grad, const unsigned char* __restrict__ keep_grad) {
+                                                         float* sumsq_out, int zero_grad, const unsigned char* __restrict__ keep_grad,
+                                                         const float* __restrict__ gscale_dev) {
   constexpr long CHUNK = 256 * 4 * 4;     // contiguous elements per workgroup iteration: 4 float4 per lane
   __shared__ float sw[4];
   const float bc1 = bias_corr[0], bc2_sqrt = bias_corr[1];
   const float ob1 = 1.f - beta1, ob2 = 1.f - beta2;
+  // device-side step guard (dav_step_guard): the multiplier a captured step cannot know at capture time — min(1, clip / norm) —
+  // and 0 for "non-finite loss or gradient norm: leave parameters and moments alone" (the reference raises before its
+  // optimizer step, train.py:166-167; a replayed graph cannot, so the update is skipped and the host raises when it looks)
+  const float gsd = gscale_dev ? gscale_dev[0] : 1.f;
+  const bool skip = gscale_dev != nullptr && !(gsd > 0.f);
+  grad_scale *= skip ? 0.f : gsd;
   float ss = 0.f;                         // sum of squared (unscaled) gradients seen by this thread
   for (long base = (long)blockIdx.x * CHUNK; base < n; base += (long)gridDim.x * CHUNK) {
     long i = base + threadIdx.x * 4;
@@ -382,6 +389,11 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
       const bool fill = zero_grad && !(keep_grad && keep_grad[s]);      // (fetched with the segment's hyper-parameters)
       const float decay = 1.f - lr * wd, step = lr / bc1;
       const float4 gr = *reinterpret_cast<const float4*>(g + i);
+      if (skip) {
+        ss += gr.x * gr.x + gr.y * gr.y + gr.z * gr.z + gr.w * gr.w;
+        if (fill) *reinterpret_cast<float4*>(g + i) = float4{0.f, 0.f, 0.f, 0.f};
+        continue;
+      }
       float4 pi = *reinterpret_cast<const float4*>(p + i);
       float4 mi = *reinterpret_cast<const float4*>(m + i);
       float4 vi = *reinterpret_cast<const float4*>(v + i);
@@ -410,6 +422,23 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
     __syncthreads();
     if (threadIdx.x == 0) unsafeAtomicAdd(sumsq_out, sw[0] + sw[1] + sw[2] + sw[3]);
   }
+}
+
+// one thread: the scale of this step's update, see adamw_flat_kernel
+__global__ void step_guard_kernel(const float* loss_a, const float* loss_b, const float* gnorm, float clip, float grad_scale,
+                                  float* out_scale, int* bad_count) {
+  float s = 1.f;
+  if (gnorm) {
+    const float norm = gnorm[0] * grad_scale;
+    if (!isfinite(norm)) s = 0.f;
+    else if (clip > 0.f) s = fminf(1.f, clip / (norm + 1e-6f));
+  }
+  float l = 0.f;
+  if (loss_a) l += loss_a[0];
+  if (loss_b) l += loss_b[0];
+  if (!isfinite(l)) s = 0.f;
+  out_scale[0] = s;
+  if (s == 0.f && bad_count) bad_count[0] += 1;
 }
 
 int wave_grid(long rows) {
@@ -560,14 +589,22 @@ extern "C" int dav_l2norm(const float* x, long n, float scale, float* out, void*
   return dav_launch_status();
 }
 
+extern "C" int dav_step_guard(const float* loss_a, const float* loss_b, const float* gnorm, float clip, float grad_scale,
+                              float* out_scale, int* bad_count, hipStream_t stream) {
+  if (!out_scale) return DAV_ERR_SHAPE;
+  DAV_LAUNCH(step_guard_kernel, dim3(1), dim3(1), 0, stream, loss_a, loss_b, gnorm, clip, grad_scale, out_scale, bad_count);
+  return dav_launch_status();
+}
+
 extern "C" int dav_adamw_flat(float* p, float* g, float* m, float* v, void* p_bf16, long n, const long* seg_end,
                               const float* hyper, int nseg, float beta1, float beta2, float eps, const float* bias_corr,
-                              float grad_scale, float* sumsq_out, int zero_grad, const unsigned char* keep_grad, hipStream_t stream) {
+                              float grad_scale, float* sumsq_out, int zero_grad, const unsigned char* keep_grad,
+                              const float* gscale_dev, hipStream_t stream) {
   if (n <= 0 || nseg <= 0 || (n & 3)) return DAV_ERR_SHAPE;
   if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15 || ((uintptr_t)p_bf16 & 7)) return DAV_ERR_ALIGN;
   if (sumsq_out) HIP_CHECK_RET(hipMemsetAsync(sumsq_out, 0, sizeof(float), stream));
   long g2 = (n + 4095) / 4096; g2 = g2 > 16384 ? 16384 : g2;
   DAV_LAUNCH(adamw_flat_kernel, dim3((int)g2), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, n, seg_end, hyper, nseg,
-                     beta1, beta2, eps, bias_corr, grad_scale, sumsq_out, zero_grad, keep_grad);
+                     beta1, beta2, eps, bias_corr, grad_scale, sumsq_out, zero_grad, keep_grad, gscale_dev);
   return dav_launch_status();
 }

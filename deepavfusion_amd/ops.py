@@ -407,12 +407,20 @@ def l2norm(x_flat, out, workspace, scale=1.0):
 
 
 def adamw_flat(p, g, m, v, p_bf16, seg_end, hyper, nseg, beta1, beta2, eps, bias_corr, grad_scale=1.0, sumsq_out=None,
-               zero_grad=False, keep_grad=None):
-    """keep_grad: uint8 [nseg] or None — segments whose gradient is NOT zero-filled by zero_grad (see dav_adamw_flat)."""
+               zero_grad=False, keep_grad=None, gscale_dev=None):
+    """keep_grad: uint8 [nseg] or None — segments whose gradient is NOT zero-filled by zero_grad (see dav_adamw_flat).
+    gscale_dev: float32 [1] device scalar from ``step_guard`` (clip factor; 0 = skip the update) or None."""
     lib = _lib.load()
     _lib.check(lib.dav_adamw_flat(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(p_bf16), p.numel(), _ptr(seg_end), _ptr(hyper), nseg,
                                   float(beta1), float(beta2), float(eps), _ptr(bias_corr), float(grad_scale), _ptr(sumsq_out),
-                                  int(zero_grad), _ptr(keep_grad), _stream()), 'dav_adamw_flat')
+                                  int(zero_grad), _ptr(keep_grad), _ptr(gscale_dev), _stream()), 'dav_adamw_flat')
+
+
+def step_guard(loss_a, loss_b, gnorm, clip, grad_scale, out_scale, bad_count):
+    """Device-side replacement of train.py:166-167 / util/misc.py:118-120 for a captured step (dav_step_guard)."""
+    lib = _lib.load()
+    _lib.check(lib.dav_step_guard(_ptr(loss_a), _ptr(loss_b), _ptr(gnorm), float(clip if clip else 0.0), float(grad_scale),
+                                  _ptr(out_scale), _ptr(bad_count), _stream()), 'dav_step_guard')
 
 
 def rows_axpy(res, y, scale, B, rows, D, out):

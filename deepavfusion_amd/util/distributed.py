@@ -92,7 +92,12 @@ def init_distributed_mode(local_rank, args, log_fn=None):
         spawned = bool(env.spawned)
     except (AttributeError, KeyError):
         spawned = False
-    env.distributed = ngpus > 0 and (env_world > 1 or (spawned and env.world_size * max(ngpus, 1) > 1))
+    # ranks per node of a spawned launch = env.ngpu (what train.py / the reference's launcher.py spawned), NOT the number of
+    # visible devices: env.ngpu = 2 on an 8-GPU host would otherwise wait for six ranks nobody started
+    per_node = int(_cfg_get(env, 'ngpu') or ngpus or 1) if spawned else ngpus
+    if spawned and per_node > ngpus:
+        raise RuntimeError(f'env.ngpu = {per_node} but only {ngpus} device(s) are visible')
+    env.distributed = ngpus > 0 and (env_world > 1 or (spawned and env.world_size * max(per_node, 1) > 1))
     if not env.distributed:
         setup_for_distributed(is_master=True, log_fn=log_fn)
         env.world_size, env.rank = 1, 0
@@ -106,8 +111,8 @@ def init_distributed_mode(local_rank, args, log_fn=None):
         local_rank = int(os.environ.get('LOCAL_RANK', local_rank))
         url = 'env://'
     else:
-        env.world_size = ngpus * env.world_size
-        env.rank = env.rank * ngpus + local_rank
+        env.world_size = per_node * env.world_size
+        env.rank = env.rank * per_node + local_rank
         url = env.dist_url
     torch.cuda.set_device(local_rank)
     dist.init_process_group(backend='nccl', init_method=url, world_size=env.world_size, rank=env.rank,

@@ -131,15 +131,19 @@ class FlatAdamW(torch.optim.Optimizer):
         for st in self.state.values():
             st['step'] += 1
 
-    def launch_step(self, grad_scale: float = 1.0, fused_norm_and_zero: bool = False):
+    def launch_step(self, grad_scale: float = 1.0, fused_norm_and_zero: bool = False, keep_grad=None, gscale_dev=None):
         """Device side of a step: one kernel over all parameters (capturable).  With ``fused_norm_and_zero`` the same
-        pass also leaves sum(g^2) in ``self.sumsq`` (grad norm = sqrt) and zeroes the gradients."""
+        pass also leaves sum(g^2) in ``self.sumsq`` (grad norm = sqrt) and zeroes the gradients — except those of the
+        parameters flagged in ``keep_grad`` (uint8 per parameter; every captured step owns its table, default: this
+        optimizer's all-zero one).  ``gscale_dev``: device scalar of ``ops.step_guard`` (clip factor, 0 = skip)."""
         b1, b2 = self.defaults['betas']
         f = self.flat
+        if keep_grad is None:
+            keep_grad = self.keep_grad
         ops.adamw_flat(f.flat_p, f.flat_g, self.exp_avg, self.exp_avg_sq, self.flat_bf16, f.seg_end, self._hyper, len(f.params),
                        b1, b2, self.defaults['eps'], self._bc, grad_scale,
                        sumsq_out=self.sumsq if fused_norm_and_zero else None, zero_grad=fused_norm_and_zero,
-                       keep_grad=self.keep_grad if fused_norm_and_zero else None)
+                       keep_grad=keep_grad if fused_norm_and_zero else None, gscale_dev=gscale_dev)
         engine.invalidate_weight_cache(f.params)      # fp32 masters changed behind torch's back
 
     @torch.no_grad()

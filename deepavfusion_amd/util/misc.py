@@ -18,7 +18,7 @@ import os
 
 import torch
 
-from .. import engine
+from .. import engine, ops
 from . import distributed as dist_utils
 from .flat import FlatAdamW
 
@@ -153,8 +153,13 @@ class GraphedStep:
     completed (known from capture time) are all-reduced on the comm stream, i.e. overlapped with the next segment;
     grad norm + AdamW form a last graph behind the final reduction.  Collectives themselves are never captured."""
 
-    def __init__(self, trainer: Trainer, image_shape, audio_shape, warmup: int = 2, segments: int = 0):
+    def __init__(self, trainer: Trainer, image_shape, audio_shape, warmup: int = 2, segments: int = 0, clip_grad=None):
+        """``clip_grad``: max global gradient norm (``opt.clip_grad``; util/misc.py:118-120) — the norm is then taken in a
+        pass of its own in front of AdamW and the factor min(1, clip / (norm + 1e-6)) reaches the update as a device scalar.
+        Always on: the non-finite guard of train.py:166-167 — a step whose loss (or, with clipping, gradient norm) is not
+        finite leaves parameters and moments untouched; ``check()`` raises on the host when it is convenient to look."""
         assert trainer.accum_iter == 1 and isinstance(trainer.optimizer, FlatAdamW)
+        self.clip_grad = float(clip_grad) if clip_grad else None
         from .. import autograd_bridge as bridge
         self.bridge = bridge
         self.tr = trainer
@@ -214,26 +219,45 @@ class GraphedStep:
         cap = torch.cuda.Stream()
         cap.wait_stream(torch.cuda.current_stream())
         self.opt.flat.zero_grad()            # the AdamW pass leaves the gradients zeroed for the next replay
+        # per captured step (several GraphedSteps may share one optimizer): which gradients its backward WRITES (not zero-filled
+        # by its AdamW pass), the device scalar its update is scaled by, and how many of its replays were skipped
+        self.keep_grad = torch.zeros_like(self.opt.keep_grad)
+        self.step_scale = torch.ones(1, dtype=torch.float32, device=dev)
+        self.bad_steps = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._presq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._presq_ws = torch.zeros(1024, dtype=torch.float32, device=dev)
+
+        def optimizer_pass():
+            gnorm = None
+            if self.clip_grad is not None:       # the clip factor needs the norm BEFORE the update: one extra read of the gradients
+                ops.l2norm(self.opt.flat.flat_g, self._presq, self._presq_ws, 1.0)
+                gnorm = self._presq
+            ops.step_guard(self.loss_image, self.loss_audio, gnorm, self.clip_grad, 1.0, self.step_scale, self.bad_steps)
+            self.opt.launch_step(fused_norm_and_zero=True, keep_grad=self.keep_grad, gscale_dev=self.step_scale)      # AdamW + sum(g^2) + zero_grad in one pass
+            self.grad_norm = self.opt.sumsq.sqrt()
+        kept = set()
         with torch.cuda.stream(cap):
             self.graphs[0].capture_begin(capture_error_mode=CAPTURE_MODE)
-            if os.environ.get('DAV_WGRAD_OVERWRITE', '1') != '0':
-                engine.wgrad_overwrite_begin()       # first weight-gradient GEMM into a Linear weight writes its tile (see engine)
-            # every derived bf16 copy (casts of un-mirrored weights, TRANSPOSED copies) must be re-derived INSIDE the graph:
-            # copies left over from the warm-up passes would otherwise be read, stale, by every replay
-            engine.invalidate_weight_cache(self.model.parameters())
-            engine.refresh_weight_cache(self.model)
-            self.loss_image, self.loss_audio = self._fwd_bwd(layer_cb)
-            kept = {id(p) for p in engine.wgrad_overwrite_end()}
+            try:
+                if os.environ.get('DAV_WGRAD_OVERWRITE', '1') != '0':
+                    engine.wgrad_overwrite_begin()       # first weight-gradient GEMM into a Linear weight writes its tile (see engine)
+                # every derived bf16 copy (casts of un-mirrored weights, TRANSPOSED copies) must be re-derived INSIDE the graph:
+                # copies left over from the warm-up passes would otherwise be read, stale, by every replay
+                engine.invalidate_weight_cache(self.model.parameters())
+                engine.refresh_weight_cache(self.model)
+                self.loss_image, self.loss_audio = self._fwd_bwd(layer_cb)
+            finally:
+                # (also on an exception: a write-first mode left on would make later EAGER backwards overwrite instead of
+                # accumulate the first contribution to every Linear weight's gradient)
+                kept = {id(p) for p in engine.wgrad_overwrite_end()}
             if not self.dist_active:
-                self.opt.launch_step(fused_norm_and_zero=True)      # AdamW + sum(g^2) + zero_grad in one pass
-                self.grad_norm = self.opt.sumsq.sqrt()
+                optimizer_pass()
             self.graphs[seg[0]].capture_end()
             self.opt_graph = None
             if self.dist_active:
                 self.opt_graph = torch.cuda.CUDAGraph()
                 self.opt_graph.capture_begin(pool=self.graphs[0].pool(), capture_error_mode=CAPTURE_MODE)
-                self.opt.launch_step(fused_norm_and_zero=True)
-                self.grad_norm = self.opt.sumsq.sqrt()
+                optimizer_pass()
                 self.opt_graph.capture_end()
         torch.cuda.current_stream().wait_stream(cap)
         torch.cuda.synchronize()
@@ -243,8 +267,16 @@ class GraphedStep:
         engine.set_grad_ready_hook(saved_hook)
         self.opt.flat.zero_grad()
         # the captured AdamW pass reads this table at replay time: gradients the captured backward WRITES are not zero-filled
-        self.opt.keep_grad.copy_(torch.tensor([1 if id(p) in kept else 0 for p in self.opt.flat.params], dtype=torch.uint8))
+        self.keep_grad.copy_(torch.tensor([1 if id(p) in kept else 0 for p in self.opt.flat.params], dtype=torch.uint8))
         self.kept_params = len(kept)
+
+    def check(self):
+        """Host side of the non-finite guard (one device read: call it where the loss is read anyway, e.g. every
+        ``print_freq`` steps).  Raises like train.py:166-167 if any replay since construction was skipped."""
+        n = int(self.bad_steps.item())
+        if n:
+            raise RuntimeError(f'Loss is {float(self.loss_image + self.loss_audio)}, stopping training '
+                               f'({n} captured step(s) had a non-finite loss or gradient norm; their updates were skipped)')
 
     def _fwd_bwd(self, layer_cb):
         """Forward + hand-written backward straight on the engine (no autograd), unit upstream gradients."""

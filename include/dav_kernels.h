@@ -37,7 +37,7 @@ typedef struct ihipStream_t* hipStream_t;
 extern "C" {
 #endif
 
-#define DAV_ABI_VERSION 1
+#define DAV_ABI_VERSION 2   /* 2: DavTnProblem.flags, dav_adamw_flat keep_grad + gscale_dev, dav_step_guard */
 int dav_abi_version(void);
 /* text of the last HIP error latched by a kernel launch of the calling thread (diagnostics) */
 const char* dav_last_error_string(void);
@@ -226,10 +226,21 @@ int dav_l2norm(const float* x, long n, float scale, float* out, void* workspace,
  * (Trainer.zero_grad) — one trip over the buffers instead of three.  keep_grad (NULL or one byte per segment): segments
  * with a non-zero byte are NOT zero-filled — their next gradient will be written, not accumulated (DavTnProblem.flags bit 0),
  * which saves the fill here and the read there.  All accesses are 16-byte ones: the buffers must be
- * 16-byte aligned (p_bf16 8-byte), n and every seg_end a multiple of 4 (FlatParams aligns segments to 64 elements). */
+ * 16-byte aligned (p_bf16 8-byte), n and every seg_end a multiple of 4 (FlatParams aligns segments to 64 elements).
+ * gscale_dev (optional): device scalar from dav_step_guard, see there. */
 int dav_adamw_flat(float* p, float* g, float* m, float* v, void* p_bf16, long n, const long* seg_end, const float* hyper,
                    int nseg, float beta1, float beta2, float eps, const float* bias_corr, float grad_scale, float* sumsq_out,
-                   int zero_grad, const unsigned char* keep_grad, hipStream_t stream);
+                   int zero_grad, const unsigned char* keep_grad, const float* gscale_dev, hipStream_t stream);
+
+/* Device-side guard of a captured (hipGraph) step, replaces the host checks of train.py:166-167 (non-finite loss aborts before the
+ * optimizer step) and util/misc.py:118-120 (clip_grad_norm_) that a replayed graph cannot run:
+ *   out_scale[0] = 0                                    if loss_a + loss_b (either may be NULL) or gnorm[0] is not finite,
+ *                = min(1, clip / (gnorm[0] * grad_scale + 1e-6))   if gnorm != NULL (the global gradient norm, dav_l2norm) and
+ *                                                                   clip > 0,   = 1 otherwise;
+ * bad_count[0] (optional) is incremented when the scale is 0.  dav_adamw_flat(gscale_dev = out_scale) multiplies the gradients
+ * by it and, when it is 0, leaves parameters, moments and the bf16 mirror untouched (gradients are still zero-filled). */
+int dav_step_guard(const float* loss_a, const float* loss_b, const float* gnorm, float clip, float grad_scale, float* out_scale,
+                   int* bad_count, hipStream_t stream);
 
 /* ---- log-mel front-end (csrc/mel.hip) ------------------------------ */
 /* out[b, m, t] = log10(mel_m(|STFT_t(wave[b])|^2) + eps): the reference's audio transform

@@ -580,6 +580,36 @@ def misc_kernels():
         report(f'adamw fused zero_grad / keep_grad step{step}', float((gcur[40000:] - (g0 * step)[40000:] * (step == 2)).abs().max()), 0.0)
     report('adamw_flat vs torch.optim.AdamW', rel(p, pr.detach()), 1e-6)
     report('adamw bf16 mirror', rel(pb, p), 4e-3)
+    # device-side step guard (dav_step_guard + dav_adamw_flat gscale_dev): clip factor as a device scalar == the same factor as
+    # a host argument, bit for bit; scale 0 (non-finite loss / norm) leaves parameters, moments and mirror untouched, still
+    # zero-fills the gradients and still reports sum(g^2)
+    bc = torch.tensor([1 - 0.9 ** 4, math.sqrt(1 - 0.95 ** 4)], device=dev)
+    one, nan, inf = torch.tensor([2.5], device=dev), torch.tensor([float('nan')], device=dev), torch.tensor([float('inf')], device=dev)
+    gn, ws = torch.empty(1, device=dev), torch.empty(1024, device=dev)
+    ops.l2norm(g0, gn, ws, 1.0)
+    sc, bad = torch.empty(1, device=dev), torch.zeros(1, device=dev, dtype=torch.int32)
+    clip = 0.25 * float(gn)
+    ops.step_guard(one, one, gn, clip, 1.0, sc, bad)
+    report('step_guard clip factor', abs(float(sc) - clip / (float(gn) + 1e-6)), 1e-7)
+    ops.step_guard(one, None, gn, 10.0 * float(gn), 1.0, sc, bad)
+    report('step_guard no clipping below the limit', abs(float(sc) - 1.0), 0.0)
+    ops.step_guard(one, one, None, 0.0, 1.0, sc, bad)
+    report('step_guard plain', abs(float(sc) - 1.0) + float(bad), 0.0)
+    for tag, (la, lb, nrm) in dict(nan_loss=(nan, one, None), inf_loss=(one, inf, gn), nan_norm=(one, one, nan)).items():
+        bad.zero_()
+        ops.step_guard(la, lb, nrm, 1.0, 1.0, sc, bad)
+        report(f'step_guard {tag} -> 0', abs(float(sc)) + abs(int(bad) - 1), 0.0)
+    ops.step_guard(one, one, gn, clip, 1.0, sc, bad)
+    pa, ma, va, pba, ga = p.clone(), m.clone(), v.clone(), pb.clone(), g0.clone()
+    pc, mc, vc, pbc, gc = p.clone(), m.clone(), v.clone(), pb.clone(), g0.clone()
+    ops.adamw_flat(pa, ga, ma, va, pba, seg, hyper, 2, 0.9, 0.95, 1e-8, bc, grad_scale=float(sc))
+    ops.adamw_flat(pc, gc, mc, vc, pbc, seg, hyper, 2, 0.9, 0.95, 1e-8, bc, gscale_dev=sc)
+    report('adamw gscale_dev == grad_scale (bit-equal)', float((pa != pc).sum() + (ma != mc).sum() + (va != vc).sum()), 0.0)
+    sc.zero_()
+    pz, mz, vz, pbz, gz, ssq = p.clone(), m.clone(), v.clone(), pb.clone(), g0.clone(), torch.zeros(1, device=dev)
+    ops.adamw_flat(pz, gz, mz, vz, pbz, seg, hyper, 2, 0.9, 0.95, 1e-8, bc, sumsq_out=ssq, zero_grad=True, gscale_dev=sc)
+    report('adamw skipped step: p, m, v, mirror untouched', float((pz != p).sum() + (mz != m).sum() + (vz != v).sum() + (pbz != pb).sum()), 0.0)
+    report('adamw skipped step: gradients zero-filled, sumsq reported', float(gz.abs().max()) + abs(float(ssq) / float(g0.double().pow(2).sum()) - 1.0), 1e-5)
 
 
 def main():

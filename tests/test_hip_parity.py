@@ -684,6 +684,72 @@ def test_written_first_gradients_equal_accumulated_ones(monkeypatch):
     assert rel(finals[0], finals[1]) < 2e-4
 
 
+def test_captured_step_guards_non_finite_loss_and_clips():
+    """Reference train.py:166-167 (a non-finite loss aborts BEFORE the optimizer step) and util/misc.py:118-120 (clip_grad) inside
+    the captured step: a replay with a NaN in its input leaves parameters, both moments and the bf16 mirror bit-identical,
+    ``check()`` raises on the host, the next clean replay trains on; a clip far above the norm changes nothing
+    and the reported norm is the UNclipped one; two captured steps on one optimizer keep their own keep-gradient tables."""
+    from deepavfusion_amd.util import lr_sched
+    from deepavfusion_amd.util.flat import FlatAdamW
+    from deepavfusion_amd.util.misc import GraphedStep, Trainer
+
+    def make(clip):
+        model, sd, cfg, O = _build('micro')
+        nd = [n for n, p in model.named_parameters() if 'bias' in n or 'norm' in n]
+        groups = lr_sched.param_groups_pretrained(model, 0.05, no_weight_decay_list=nd, image_pt='', audio_pt='')
+        opt = FlatAdamW(groups, lr=1e-3, betas=(0.9, 0.95), model=model)
+        tr = Trainer(model, optimizer=opt, accum_iter=1)
+        image, audio, _, _ = O.structured_batch(cfg, 64, seed=3)
+        image, audio = image.cuda(), audio.cuda()
+        torch.manual_seed(77)
+        return opt, GraphedStep(tr, image.shape, audio.shape, clip_grad=clip), image, audio
+
+    # ---- non-finite guard
+    opt, gs, image, audio = make(None)
+    torch.manual_seed(1)
+    gs(image, audio)
+    torch.cuda.synchronize()
+    gs.check()
+    snap = [t.clone() for t in (opt.flat.flat_p, opt.exp_avg, opt.exp_avg_sq, opt.flat_bf16)]
+    bad = image.clone()
+    bad[3, 1, 5, 7] = float('nan')
+    li, la, gn = gs(bad, audio)
+    torch.cuda.synchronize()
+    assert not np.isfinite(float(li) + float(la))
+    for a, b in zip(snap, (opt.flat.flat_p, opt.exp_avg, opt.exp_avg_sq, opt.flat_bf16)):
+        assert torch.equal(a, b)
+    assert int(gs.bad_steps) == 1 and float(gs.step_scale) == 0.0
+    with pytest.raises(RuntimeError, match='stopping training'):
+        gs.check()
+    li, la, gn = gs(image, audio)                                # the gradients of the skipped step were cleared: training continues
+    torch.cuda.synchronize()
+    assert np.isfinite(float(li) + float(la)) and np.isfinite(float(gn)) and float(gs.step_scale) == 1.0
+    assert not torch.equal(snap[0], opt.flat.flat_p)
+    # ---- clipping: far above the norm == no clipping; below the norm: the factor min(1, clip / norm)
+    finals, norms = [], []
+    for clip in (None, 1e9):
+        opt, gs, image, audio = make(clip)
+        for s in range(3):
+            torch.manual_seed(500 + s)
+            li, la, gn = gs(image, audio)
+        torch.cuda.synchronize()
+        finals.append(opt.flat.flat_p.clone())
+        norms.append(float(gn))
+    # (same arithmetic — a factor of exactly 1.0 — but not bit-equal between two runs: split weight-gradient tiles meet through fp32 atomics)
+    assert rel(finals[0], finals[1]) < 2e-4 and abs(norms[0] - norms[1]) < 1e-4 * norms[1]
+    opt, gs, image, audio = make(0.5 * norms[0])
+    for s in range(3):
+        torch.manual_seed(500 + s)
+        li, la, gn = gs(image, audio)
+    torch.cuda.synchronize()
+    assert abs(float(gs.step_scale) - 0.5 * norms[0] / (float(gn) + 1e-6)) < 1e-6 and 0.2 < float(gs.step_scale) < 1.0
+    assert abs(float(gn) - norms[0]) < 0.2 * norms[0]            # the norm reported is the unclipped one
+    # ---- a second captured step on the same optimizer owns its keep-gradient table (ADVICE round 2)
+    gs2 = GraphedStep(gs.tr, image.shape, audio.shape)
+    assert gs2.keep_grad.data_ptr() != gs.keep_grad.data_ptr() and gs.keep_grad.data_ptr() != opt.keep_grad.data_ptr()
+    assert int(opt.keep_grad.sum()) == 0 and int(gs.keep_grad.sum()) == gs.kept_params
+
+
 def test_segmented_graph_step_matches_single_graph_and_schedules_every_bucket():
     """The multi-GPU form of the step (3 graph segments + per-segment gradient buckets) must compute the same step as
     the single graph, and its capture-time bucket schedule must cover every bucket once, decoders first."""

@@ -143,11 +143,9 @@ def main_worker(local_rank, args):
                                         save_freq=args.log.save_freq)
     start_epoch = ckpt.resume()[0] if args.opt.resume else 0
     graphed = None
-    if args.opt.get('graph', False) and args.opt.clip_grad is not None:
-        print('opt.clip_grad is set: the captured step does not clip, running eager launches instead (opt.graph ignored)')
-    elif args.opt.get('graph', False) and args.opt.accum_iter == 1:
+    if args.opt.get('graph', False) and args.opt.accum_iter == 1:
         B = args.opt.batch_size
-        graphed = misc_utils.GraphedStep(trainer, (B, 3, *image_size), (B, 1, *audio_size))
+        graphed = misc_utils.GraphedStep(trainer, (B, 3, *image_size), (B, 1, *audio_size), clip_grad=args.opt.clip_grad)
 
     frontend = None
     if gpu_frontend:
@@ -186,6 +184,8 @@ def train_one_epoch(loader, trainer, epoch, device, args, graphed=None, frontend
             grad_norm, amp_scale = trainer.step(loss, clip_grad=args.opt.clip_grad)
         seen += image.shape[0]
         if step % args.log.print_freq == 0 and trainer.accums == 0:
+            if graphed is not None:
+                graphed.check()                     # a captured step with a non-finite loss skipped its update on the device
             if not math.isfinite(float(loss)):
                 raise RuntimeError(f'Loss is {float(loss)}, stopping training')
             print(f'[Train][Ep-{epoch}/{args.opt.epochs}] step {step}/{len(loader)}  loss {float(loss):.4f}  '
@@ -209,6 +209,15 @@ def main(argv):
     if under_torchrun or ngpu <= 1:
         return main_worker(int(os.environ.get('LOCAL_RANK', '0')), cfg)
     cfg.env.spawned = True
+    # launcher.py:80-86 of the reference: every job gets its own rendezvous (file:// under the job's output directory) so that two
+    # jobs on one host do not meet on a fixed port; a dist_url given explicitly (multi-node: the same one on every node) is kept
+    if not cfg.env.get('dist_url') or str(cfg.env.dist_url) == 'tcp://127.0.0.1:50000':
+        jd = os.path.join(str(cfg.get('output_dir', 'checkpoints')), str(cfg.get('job_name', 'job')))
+        os.makedirs(jd, exist_ok=True)
+        url_file = os.path.join(os.path.abspath(jd), f'.dist_{os.getpid()}')
+        if os.path.exists(url_file):
+            os.remove(url_file)
+        cfg.env.dist_url = 'file://' + url_file
     import torch.multiprocessing as mp
     mp.spawn(_spawned_worker, args=(_to_plain(cfg),), nprocs=ngpu)       # children start before anything touches the GPU here
 
