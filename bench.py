@@ -98,6 +98,10 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('DAV_BENCH_SPAWN_DRY') == '1' and world > 1:      # CPU test hook of the rank spawner below: no GPU call, report and leave
+        if rank == 0:
+            print(json.dumps({'dry': True, 'world': world, 'rank': rank, 'master': os.environ.get('MASTER_ADDR'), 'port': int(os.environ.get('MASTER_PORT', '0')), 'argv_gpus': a.gpus}))
+        return 0
     if a.gpus > 1 and world == 1:
         # Plain `python bench.py --gpus N` (no torch.distributed.run around it): this process starts the N ranks itself, as
         # fresh child processes, BEFORE it has made any GPU call (it never does), waits for them and forwards rank 0's

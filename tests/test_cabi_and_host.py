@@ -338,3 +338,21 @@ def test_written_first_contribution_bookkeeping(monkeypatch):
     with E.deferred_wgrads():
         E._DEFERRED.append(prob(0, 64))
     assert launches and not launches[0][0].get('overwrite')
+
+
+def test_bench_starts_its_own_ranks_when_launched_plainly():
+    """`python bench.py --gpus N` without torch.distributed.run around it (missing #1): the process starts N
+    fresh children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, before any GPU call, and forwards rank 0's one line."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, DAV_BENCH_SPAWN_DRY='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '4', '--steps', '3'], env=env, capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d['dry'] and d['world'] == 4 and d['rank'] == 0 and d['master'] == '127.0.0.1' and d['port'] > 0 and d['argv_gpus'] == 4

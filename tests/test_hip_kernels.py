@@ -190,3 +190,37 @@ def test_tuned_table_picks_the_configuration_and_results_do_not_change():
         assert log2[0][0] == rule_cfg
     finally:
         _lib.load_nt_tuning(_lib.NT_TUNING_PATH)
+
+
+def test_two_grouped_weight_gradient_launches_recorded_in_one_batch():
+    """dav_gemm_tn_grouped_bf16 staged its problem table in static storage and a recorded launch captured
+    it by reference — two grouped calls inside one dav_batch_begin .. dav_batch_end both ran with the LAST table.  Each must
+    keep its own: the results equal the two launches issued one by one."""
+    import torch
+
+    from deepavfusion_amd import ops
+    dev, bf = 'cuda', torch.bfloat16
+    g = torch.Generator(device=dev).manual_seed(5)
+
+    def problem(Mc, N, K):
+        A = torch.randn(Mc, N, device=dev, generator=g).to(bf)
+        B = torch.randn(Mc, K, device=dev, generator=g).to(bf)
+        return dict(A=A, B=B, Mc=Mc, N=N, K=K, C=None, lda=N, ldb=K, ldc=K, a_rowmap=None, b_rowmap=None, bias_grad=None)
+    sets = [[problem(256, 128, 192), problem(320, 64, 128)], [problem(192, 256, 64), problem(128, 192, 320), problem(64, 128, 128)]]
+    outs = {}
+    for mode in ('single', 'batched'):
+        for ps in sets:
+            for d in ps:
+                d['C'] = torch.zeros(d['N'], d['K'], device=dev)
+        if mode == 'batched':
+            ops.batch_begin()
+        for ps in sets:
+            ops.gemm_tn_grouped(ps)
+        if mode == 'batched':
+            ops.batch_end()
+        torch.cuda.synchronize()
+        outs[mode] = [d['C'].clone() for ps in sets for d in ps]
+    for a, b, d in zip(outs['single'], outs['batched'], [d for ps in sets for d in ps]):
+        ref = d['A'].float().t() @ d['B'].float()
+        assert float((a - ref).norm() / ref.norm()) < 1e-5
+        assert torch.equal(a, b)
