@@ -552,6 +552,7 @@ __device__ __forceinline__ void nt_epilogue_s(const NTParams& p, f32x4 (&acc)[FM
 }
 
 #include "gemm_nt256.h"
+#include "gemm_tn256.h"
 
 // PIPE == 2: two extra LOADER waves per workgroup issue every global -> LDS piece of the ring; the WM_ x WN_ compute waves only wait
 // at the per-step barrier, read fragments and issue MFMAs.  A wave that issues LDS-DMA pieces is blocked by the vector-memory path's
@@ -1915,6 +1916,35 @@ extern "C" int dav_gemm_tn_grouped_bf16(const DavTnProblem* probs, int count, hi
     if (q.Mc <= 0 || (q.Mc & 63) || q.N <= 0 || q.K <= 0 || (q.N & 7) || (q.K & 7) || (q.lda & 7) || (q.ldb & 7)) return DAV_ERR_SHAPE;
     if (((uintptr_t)q.A | (uintptr_t)q.B | (uintptr_t)q.C) & 15 || (q.ldc & 3)) return DAV_ERR_ALIGN;      // 16-byte gradient accesses
     total_tiles += (long)((q.N + 127) / 128) * ((q.K + 127) / 128);
+  }
+  // 256 x 256 persistent form (csrc/gemm_tn256.h; DAV_TN256=0 restores the 128 x 128 tiles): one slice of the K-tile-pair
+  // sequence per workgroup
+  static const bool tn256 = [] { const char* e = getenv("DAV_TN256"); return !(e && e[0] == '0'); }();
+  static const long tn256_min = getenv("DAV_TN256_MIN") ? atol(getenv("DAV_TN256_MIN")) : 512;      // K-tile pairs below which the old kernel runs
+  if (tn256) {
+    TN256Group g2;
+    long units = 0;
+    for (int i = 0; i < count; ++i) {
+      const DavTnProblem& q = probs[i];
+      TNParams& p = g2.prob[i];
+      p.A = (const bf16_t*)q.A; p.B = (const bf16_t*)q.B; p.Mc = q.Mc; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = q.ldb;
+      p.amap = RowMap{q.a_rowmap[0], q.a_rowmap[1], q.a_rowmap[2]};
+      p.bmap = RowMap{q.b_rowmap[0], q.b_rowmap[1], q.b_rowmap[2]};
+      static const int tn256_debug = getenv("DAV_TN256_DEBUG") ? atoi(getenv("DAV_TN256_DEBUG")) : 0;
+      p.C = q.C; p.ldc = q.ldc; p.beta = (q.flags & 1) ? 0 : 1; p.bias_grad = q.bias_grad; p.debug_plain_store = tn256_debug; p.splits = 1;
+      g2.first_unit[i] = (int)units;
+      units += (long)((q.N + 255) / 256) * ((q.K + 255) / 256) * (((q.Mc >> 6) + 1) >> 1);
+    }
+    if (units >= tn256_min && units < (1l << 30)) {
+      g2.first_unit[count] = (int)units;
+      g2.count = count;
+      long G = units / 4;                                  // at least four K-tile pairs per workgroup
+      G = G > 256 ? 256 : (G < 8 ? 8 : (G & ~7l));
+      static bool big = false;
+      if (!big) { (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); big = true; }
+      DAV_LAUNCH(gemm_tn256_kernel, dim3((int)G), dim3(512), NT256_LDS, stream, g2);
+      return dav_launch_status();
+    }
   }
   // aim at ~4 workgroups of 8 waves per CU-slot pair (1024 blocks) but keep >= 8 k-steps of 64 rows per split
   int first = 0;

@@ -224,3 +224,15 @@ def test_two_grouped_weight_gradient_launches_recorded_in_one_batch():
         ref = d['A'].float().t() @ d['B'].float()
         assert float((a - ref).norm() / ref.norm()) < 1e-5
         assert torch.equal(a, b)
+
+
+def test_tn256_weight_gradient_kernel_matches_reference():
+    """csrc/gemm_tn256.h (256 x 256 persistent stream-K weight-gradient kernel, default off: DAV_TN256=1): the whole gemm_tn
+    family of checks in a fresh process with the switch on — whole and split tiles, odd K-tile counts (zero padding), written
+    tiles (never split), row maps, bias gradients."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, 'tests'); import gpu_selfcheck as sc; sc.gemm_tn(); "
+            "bad = [r for r in sc.RESULTS if not r[3]]; print(len(sc.RESULTS), 'checks', len(bad), 'bad', bad[:5]); sys.exit(1 if bad or not sc.RESULTS else 0)")
+    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, DAV_TN256='1', DAV_TN256_MIN='64'), cwd=ROOT, capture_output=True, timeout=600)
+    assert r.returncode == 0, (r.stdout.decode()[-3000:], r.stderr.decode()[-2000:])
