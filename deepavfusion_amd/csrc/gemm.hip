@@ -1917,9 +1917,12 @@ extern "C" int dav_gemm_tn_grouped_bf16(const DavTnProblem* probs, int count, hi
     if (((uintptr_t)q.A | (uintptr_t)q.B | (uintptr_t)q.C) & 15 || (q.ldc & 3)) return DAV_ERR_ALIGN;      // 16-byte gradient accesses
     total_tiles += (long)((q.N + 127) / 128) * ((q.K + 127) / 128);
   }
-  // 256 x 256 persistent form (csrc/gemm_tn256.h; DAV_TN256=0 restores the 128 x 128 tiles): one slice of the K-tile-pair
-  // sequence per workgroup
-  static const bool tn256 = [] { const char* e = getenv("DAV_TN256"); return !(e && e[0] == '0'); }();
+  // 256 x 256 persistent form (csrc/gemm_tn256.h): one slice of the K-tile-pair sequence per workgroup.  OFF by default
+  // (DAV_TN256=1 switches it on): bit-correct, but measured slower than the 128 x 128 tiles on the step's launches
+  // (profiles/r03_tn256_group_bench.txt): its k-loop alone reaches 673-733 TF against 580-635 for the old kernel INCLUDING its
+  // epilogue — the weight gradients are bound by re-streaming their operands from MALL / HBM, which a wider tile only halves —
+  // and the fp32 atomics of the split tiles (one dword per lane and instruction) cost 440-900 us per launch.
+  static const bool tn256 = [] { const char* e = getenv("DAV_TN256"); return e && e[0] == '1'; }();
   static const long tn256_min = getenv("DAV_TN256_MIN") ? atol(getenv("DAV_TN256_MIN")) : 512;      // K-tile pairs below which the old kernel runs
   if (tn256) {
     TN256Group g2;
