@@ -22,6 +22,7 @@ ABI_VERSION = 2      # DAV_ABI_VERSION of include/dav_kernels.h this package was
 # name -> argtypes (must match include/dav_kernels.h)
 SIGNATURES = {
     'dav_abi_version': [],
+    'dav_build_flags': [],
     'dav_last_error_string': [],
     'dav_tune': [_i, _i],
     'dav_gemm_nt_bf16': [_p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _f, _i, _p],

@@ -869,9 +869,11 @@ __device__ __forceinline__ void nt2_body(const NTParams& p, int bid) {
   else nt_epilogue_t<FM, FN, WTM, WTN>(p, acc, m0, n0, wm, wn, lane);
 }
 
+#ifdef DAV_EXPERIMENTAL
 __global__ __launch_bounds__(512) void gemm_nt2_prof_kernel(NTParams p) {
   nt2_body<128, 128, 2, 4, 2, false, 64, true>(p, blockIdx.x);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // NT kernel, third generation ("staggered halves"): 256 x 128 tile, 8 waves of 64 x 64, six 24 KB ring stages of
@@ -1295,7 +1297,7 @@ static int nt_tuned_lookup(bool bt, const void* const* params, int n) {
 }
 
 // DAV_NT_WIDE=0 switches the 128 x 256 configuration off (A/B timing of the same box)
-static bool nt_ld_on() { static const bool on = [] { const char* e = getenv("DAV_NT_LD"); return e && e[0] == '1'; }(); return on; }
+[[maybe_unused]] static bool nt_ld_on() { static const bool on = [] { const char* e = getenv("DAV_NT_LD"); return e && e[0] == '1'; }(); return on; }
 // 256 x 256 tiles (configuration 60).  The rule is OFF by default (DAV_NT256=1 switches it on): alone on the GPU the configuration is
 // 7-25 % faster than 128 x 128 / 128 x 256 on every wide shape of the step, warm or cold operands, but the step gets 0.25 ms SLOWER with
 // it in every schedule (same-box alternation, profiles/r03_nt256_instep_ab.txt) — a workgroup that owns 128 KB of LDS keeps the
@@ -1335,7 +1337,9 @@ void nt2_issue_auto(const void* const* params_in, int n, hipStream_t stream) {
   if (forced) cfg = forced;
   else if (tuned) cfg = tuned;
   else if (cfg == 3 && wide && t256 >= 512 && nt_wide_on()) cfg = 44;
+#ifdef DAV_EXPERIMENTAL
   if (cfg == 3 && nt_ld_on()) cfg = 51;
+#endif
   if (!forced && !tuned && nt256_on() && t256sq >= nt256_min_tiles() && all256) cfg = 60;
   if (!forced && !tuned && nt256_on() && !all256 && n > 1) {
     // mixed group (the towers' GEMMs with the fusion block's narrow projections riding along): the problems the 256 x 256 body
@@ -1361,8 +1365,10 @@ void nt2_issue_auto(const void* const* params_in, int n, hipStream_t stream) {
     case 45: nt2_issue<256, 128, 4, 2, 2, BT, 32>(params, n, stream); break;
     case 43: nt2_issue<256, 128, 4, 2, 3, BT, 32>(params, n, stream); break;      // (43 / 46: tools/mix_sweep.py candidates)
     case 46: nt2_issue<128, 256, 2, 4, 2, BT, 32>(params, n, stream); break;
+#ifdef DAV_EXPERIMENTAL
     case 50: nt2_issue<128, 128, 4, 2, 2, BT, 64, 2>(params, n, stream); break;      // + two loader waves
     case 51: nt2_issue<128, 128, 4, 2, 2, BT, 64, 4>(params, n, stream); break;      // + four
+#endif
     case 3: nt2_issue<128, 128, 4, 2, 2, BT, 64>(params, n, stream); break;      // 4 x 2 waves (32 x 64 wave tiles): +0.8 % over 2 x 4 in the step
     case 8: nt2_issue<128, 64, 2, 2, 2, BT, 64>(params, n, stream); break;
     case 7: nt2_issue<64, 64, 2, 2, 4, BT, 64>(params, n, stream); break;
@@ -1772,24 +1778,29 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
   if (b_kn) {
     if (!vec_ok) return DAV_ERR_SHAPE;
     if (cfg == 0) cfg = nt_auto_config(M, N, K);       // (only reached with the variant bits set; the open choice returned above)
+#ifdef DAV_EXPERIMENTAL
     if (cfg == 3 && nt_ld_on()) cfg = 51;
+#endif
     if (cfg == 60 && !nt256_ok(p)) return DAV_ERR_SHAPE;
     switch (cfg) {
       case 60: launch_nt256<true>(p, stream); break;
-      case 50: launch_nt2<128, 128, 4, 2, 2, true, 64, 2>(p, stream); break;
-      case 51: launch_nt2<128, 128, 4, 2, 2, true, 64, 4>(p, stream); break;
       case 3: launch_nt2<128, 128, 4, 2, 2, true>(p, stream); break;
-      case 31: launch_nt2<128, 128, 2, 4, 2, true, 64, 1>(p, stream); break;
-      case 32: launch_nt3<true>(p, stream); break;
-      case 40: launch_nt2<256, 128, 4, 4, 3, true>(p, stream); break;      // 16 waves, one workgroup per CU, 3 x 48 KB ring
-      case 41: launch_nt2<128, 256, 4, 4, 3, true>(p, stream); break;
       case 44: launch_nt2<128, 256, 2, 4, 3, true, 32>(p, stream); break;
       case 43: launch_nt2<256, 128, 4, 2, 3, true, 32>(p, stream); break;
       case 45: launch_nt2<256, 128, 4, 2, 2, true, 32>(p, stream); break;
       case 46: launch_nt2<128, 256, 2, 4, 2, true, 32>(p, stream); break;
+#ifdef DAV_EXPERIMENTAL      // measured and rejected configurations: kept for the tools that reproduce the measurements
+      case 50: launch_nt2<128, 128, 4, 2, 2, true, 64, 2>(p, stream); break;
+      case 51: launch_nt2<128, 128, 4, 2, 2, true, 64, 4>(p, stream); break;
+      case 31: launch_nt2<128, 128, 2, 4, 2, true, 64, 1>(p, stream); break;
+      case 32: launch_nt3<true>(p, stream); break;
+      case 40: launch_nt2<256, 128, 4, 4, 3, true>(p, stream); break;      // 16 waves, one workgroup per CU, 3 x 48 KB ring
+      case 41: launch_nt2<128, 256, 4, 4, 3, true>(p, stream); break;
+#endif
       case 8: launch_nt2<128, 64, 2, 2, 2, true>(p, stream); break;
       case 7: launch_nt2<64, 64, 2, 2, 4, true>(p, stream); break;
-      default: launch_nt2<64, 64, 2, 2, 2, true>(p, stream); break;
+      case 5: launch_nt2<64, 64, 2, 2, 2, true>(p, stream); break;
+      default: return DAV_ERR_SHAPE;          // a configuration this build does not contain (-DDAV_EXPERIMENTAL builds the rejected ones)
     }
     return dav_launch_status();
   }
@@ -1799,6 +1810,15 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
     if (cfg == 60 && !nt256_ok(p)) return DAV_ERR_SHAPE;
     switch (cfg) {
       case 60: launch_nt256<false>(p, stream); return dav_launch_status();
+      case 3: launch_nt2<128, 128, 4, 2, 2>(p, stream); return dav_launch_status();
+      case 5: launch_nt2<64, 64, 2, 2, 2>(p, stream); return dav_launch_status();
+      case 7: launch_nt2<64, 64, 2, 2, 4>(p, stream); return dav_launch_status();
+      case 8: launch_nt2<128, 64, 2, 2, 2>(p, stream); return dav_launch_status();
+      case 43: launch_nt2<256, 128, 4, 2, 3, false, 32>(p, stream); return dav_launch_status();   // 8 waves of 64x64, 3 x 24 KB ring, two workgroups per CU
+      case 44: launch_nt2<128, 256, 2, 4, 3, false, 32>(p, stream); return dav_launch_status();
+      case 45: launch_nt2<256, 128, 4, 2, 2, false, 32>(p, stream); return dav_launch_status();
+      case 46: launch_nt2<128, 256, 2, 4, 2, false, 32>(p, stream); return dav_launch_status();
+#ifdef DAV_EXPERIMENTAL      // measured and rejected configurations: kept for the tools that reproduce the measurements
       case 30: {      // phase profile of the dominant configuration (see nt2_body); res_rows carries the int64 output buffer
         if (res) return DAV_ERR_SHAPE;
         const int grid = ((M + 127) / 128) * ((N + 127) / 128);
@@ -1810,10 +1830,6 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
       case 40: launch_nt2<256, 128, 4, 4, 3>(p, stream); return dav_launch_status();   // 16 waves, one workgroup per CU, 3 x 48 KB ring
       case 41: launch_nt2<128, 256, 4, 4, 3>(p, stream); return dav_launch_status();
       case 42: launch_nt2<256, 128, 4, 4, 2>(p, stream); return dav_launch_status();
-      case 43: launch_nt2<256, 128, 4, 2, 3, false, 32>(p, stream); return dav_launch_status();   // 8 waves of 64x64, 3 x 24 KB ring, two workgroups per CU
-      case 44: launch_nt2<128, 256, 2, 4, 3, false, 32>(p, stream); return dav_launch_status();
-      case 45: launch_nt2<256, 128, 4, 2, 2, false, 32>(p, stream); return dav_launch_status();
-      case 46: launch_nt2<128, 256, 2, 4, 2, false, 32>(p, stream); return dav_launch_status();
       case 33: case 34: case 35: case 36: case 37: {      // phase profile of the staggered-halves kernel (+ ablations 1..4); res_rows = int64 output
         if (res) return DAV_ERR_SHAPE;
         const int grid = ((M + 255) / 256) * ((N + 127) / 128);
@@ -1828,13 +1844,9 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
       case 2: launch_nt2<128, 128, 2, 2, 3>(p, stream); return dav_launch_status();
       case 50: launch_nt2<128, 128, 4, 2, 2, false, 64, 2>(p, stream); return dav_launch_status();
       case 51: launch_nt2<128, 128, 4, 2, 2, false, 64, 4>(p, stream); return dav_launch_status();
-      case 3: launch_nt2<128, 128, 4, 2, 2>(p, stream); return dav_launch_status();
       case 4: launch_nt2<128, 128, 2, 4, 3>(p, stream); return dav_launch_status();
       case 48: launch_nt2<128, 128, 4, 2, 4>(p, stream); return dav_launch_status();      // 4 x 32 KB ring, one workgroup per CU (in-flight depth experiment)
-      case 5: launch_nt2<64, 64, 2, 2, 2>(p, stream); return dav_launch_status();
       case 6: launch_nt2<64, 64, 2, 2, 3>(p, stream); return dav_launch_status();
-      case 7: launch_nt2<64, 64, 2, 2, 4>(p, stream); return dav_launch_status();
-      case 8: launch_nt2<128, 64, 2, 2, 2>(p, stream); return dav_launch_status();
       case 9: launch_nt2<128, 64, 2, 2, 3>(p, stream); return dav_launch_status();
       case 10: launch_nt2<128, 64, 4, 1, 3>(p, stream); return dav_launch_status();
       case 11: launch_nt2<64, 128, 2, 2, 3>(p, stream); return dav_launch_status();
@@ -1849,7 +1861,9 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
       case 20: launch_nt2<128, 128, 2, 4, 2, false, 32>(p, stream); return dav_launch_status();   // 8 waves, 32 KB
       case 21: launch_nt2<128, 128, 2, 4, 3, false, 32>(p, stream); return dav_launch_status();
       case 22: launch_nt2<128, 128, 2, 4, 4, false, 32>(p, stream); return dav_launch_status();   // 64 KB, 1.5 steps of lookahead
-      default: break;
+#endif
+      case 0: break;
+      default: return DAV_ERR_SHAPE;          // a configuration this build does not contain (-DDAV_EXPERIMENTAL builds the rejected ones)
     }
   }
   const bool use_glds = glds_ok && !(variant & 1);

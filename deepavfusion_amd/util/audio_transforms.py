@@ -29,12 +29,18 @@ class Compose(torch.nn.Module):
 
 
 class RandomVol(torch.nn.Module):
-    """util/audio_transforms.py:8-17: one random gain in dB per call, then clamp to [-1, 1]."""
+    """util/audio_transforms.py:8-17: a random gain in dB, then clamp to [-1, 1].  The reference applies this transform per
+    SAMPLE inside the dataset (one draw per call on a [channels, samples] waveform); on a batch [B, samples] (the GPU front-end
+    of this package) every sample therefore gets its own draw."""
     def __init__(self, gain=(-6, 6)):
         super().__init__()
         self.gain = gain
 
     def forward(self, waveform):
+        if waveform.dim() >= 2 and waveform.shape[0] > 1:        # a batch: one gain per sample, as per-sample calls would draw
+            g = torch.tensor([random.uniform(self.gain[0], self.gain[1]) for _ in range(waveform.shape[0])],
+                             dtype=waveform.dtype, device=waveform.device).view(-1, *([1] * (waveform.dim() - 1)))
+            return torch.clamp(waveform * torch.pow(10.0, g / 20.0), -1, 1)
         g = random.uniform(self.gain[0], self.gain[1])
         return torch.clamp(waveform * (10.0 ** (g / 20.0)), -1, 1)
 

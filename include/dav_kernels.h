@@ -39,6 +39,7 @@ extern "C" {
 
 #define DAV_ABI_VERSION 2   /* 2: DavTnProblem.flags, dav_adamw_flat keep_grad + gscale_dev, dav_step_guard */
 int dav_abi_version(void);
+int dav_build_flags(void);   /* bit 0: experimental build (make EXPERIMENTAL=1): the rejected GEMM tile configurations exist */
 /* text of the last HIP error latched by a kernel launch of the calling thread (diagnostics) */
 const char* dav_last_error_string(void);
 /* launch-geometry knobs for tuning experiments (1: LayerNorm-backward waves per workgroup {2,4,8}; 2: its grid cap;

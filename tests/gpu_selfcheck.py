@@ -86,7 +86,8 @@ def gemm_nt():
         A, Bm = rnd(M, K, dtype=BF16, seed=1), rnd(N, K, dtype=BF16, scale=0.05, seed=2)
         bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
         ref = A.float() @ Bm.float().t() + bias + res
-        for cfg in (1, 3, 5, 8, 13, 15, 16, 17, 18, 19, 20, 21, 22, 60):
+        experimental = (1, 13, 15, 16, 17, 18, 19, 20, 21, 22) if ops._lib.load().dav_build_flags() & 1 else ()      # make EXPERIMENTAL=1
+        for cfg in (3, 5, 7, 8, 60) + experimental:
             C = torch.empty(M, N, device=dev)
             ops.gemm_nt(A, Bm, M, N, K, bias=bias, res=res, ldres=N, C_out=C, variant=cfg << 4)
             report(f'gemm_nt {M}x{N}x{K} cfg{cfg}', rel(C, ref), 1e-4)

@@ -61,6 +61,14 @@ def test_pad_randomvol_and_other_geometries():
     ratio = (v.cpu() / short)[short.abs() > 1e-3]
     inside = ratio[(v.cpu().abs() < 1.0)[short.abs() > 1e-3]]
     assert float(inside.max() - inside.min()) < 1e-5 and 0.5 <= float(inside.mean()) <= 2.0      # one gain in [-6, 6] dB
+    # a batch gets one gain PER SAMPLE (the reference applies the transform per sample inside its dataset)
+    wb = (0.05 * torch.randn(6, 4000)).clamp(-1, 1)
+    vb = aT.RandomVol()(wb.cuda()).cpu()
+    gains = [float((vb[i] / wb[i])[wb[i].abs() > 1e-3].median()) for i in range(6)]
+    for i in range(6):
+        r = (vb[i] / wb[i])[wb[i].abs() > 1e-3]
+        assert float(r.max() - r.min()) < 1e-4 and 0.5 <= gains[i] <= 2.0
+    assert max(gains) - min(gains) > 1e-3
     # another rate / mel count (8 kHz, 64 mels): n_fft 400, hop 125
     w8 = (0.3 * torch.randn(3, 12000)).clamp(-1, 1)
     _check(aT.LogMelSpectrogram(sample_rate=8000, n_mels=64).cuda()(w8.cuda()), A.log_mel(w8, 8000, 64))
