@@ -243,7 +243,7 @@ def test_every_entry_point_rejects_empty_input_with_the_documented_code():
     kernel entry point; the call returns before a launch, so this runs without a GPU."""
     from deepavfusion_amd import _lib
     lib = _lib.load()
-    host_only = {'dav_abi_version', 'dav_last_error_string', 'dav_tune', 'dav_nt_issue_log', 'dav_nt_tune_set', 'dav_batch_begin',
+    host_only = {'dav_abi_version', 'dav_build_flags', 'dav_last_error_string', 'dav_tune', 'dav_nt_issue_log', 'dav_nt_tune_set', 'dav_batch_begin',
                  'dav_batch_lane', 'dav_batch_region', 'dav_batch_skip', 'dav_batch_suspend', 'dav_batch_end', 'dav_batch_abort',
                  'dav_batch_stats', 'dav_layernorm_bwd_workspace_bytes', 'dav_l2norm_workspace_bytes'}
     kernels = sorted(set(_lib.SIGNATURES) - host_only)
