@@ -43,6 +43,7 @@ struct AttnParams {
   long dq_bs, dk_bs, dv_bs;
   int dq_rs, dk_rs, dv_rs;
   int debug;          // DAV_ATTN_DEBUG ablations (timing experiments only): 1 = no tile loop, 2 = no staging
+  int pair;           // narrow heads: adjacent heads on the same XCD (pair_heads); DAV_ATTN_PAIR=0 switches it off
   // additive score bias (window attention, models/swin.py:66-80): bias[b % bias_nb][h][q][0 .. bias_ld) in LOG2 units (already
   // multiplied by log2 e), bias_ld = Nk rounded up to 32 with zero padding; dS (backward, optional): gradient of the biased
   // logits [B][H][Nq][bias_ld] in natural units, what the relative-position table's gradient is reduced from
@@ -666,10 +667,19 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
   }
 }
 
+// Head pairing for narrow heads (round 3): with d = 32 a head's K / V / Q rows are 64-byte pieces of the fused qkv rows — every
+// 128-byte line is wanted by the workgroups of heads 2j and 2j+1.  Workgroup x runs on XCD x % 8, so neighbours in x never share
+// an L2; this permutation of the linear (batch, head) index puts heads 2j and 2j+1 on ids x and x + 8 — the same XCD, dispatched
+// back to back — and the second request of a line meets the first in that XCD's L2.  A bijection on [0, n) for n % 16 == 0.
+__device__ __forceinline__ int pair_heads(int x, int n) {
+  if (n & 15) return x;
+  return (((x >> 4) << 3) + (x & 7)) * 2 + ((x >> 3) & 1);
+}
+
 // ---- kernels: one grid per problem, or (resident variants) several problems in one grid (batch.h) ------------------
 template <int DQK, int DV, bool CHUNKED, int QT>
 __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
-  attn_fwd_body<DQK, DV, CHUNKED, QT>(p, blockIdx.x, blockIdx.y);
+  attn_fwd_body<DQK, DV, CHUNKED, QT>(p, (DQK <= 32 && p.pair) ? pair_heads(blockIdx.x, gridDim.x) : (int)blockIdx.x, blockIdx.y);
 }
 // own tiles per wave in the RESIDENT backward kernels.  Two tiles per wave halve the LDS fragment traffic per MFMA; measured
 // on the decoders' d = 32, 228 / 352-row problems it changes nothing (73.5 / 131 us vs 73.3 / 126 us): those kernels are bound
@@ -678,11 +688,11 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
 template <int DQK, int DV> constexpr int bwd_tiles() { return 1; }
 template <int DQK, int DV, bool CHUNKED>
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
-  attn_bwd_dq_body<DQK, DV, CHUNKED, CHUNKED ? 1 : bwd_tiles<DQK, DV>()>(p, blockIdx.x, blockIdx.y);
+  attn_bwd_dq_body<DQK, DV, CHUNKED, CHUNKED ? 1 : bwd_tiles<DQK, DV>()>(p, (DQK <= 32 && p.pair) ? pair_heads(blockIdx.x, gridDim.x) : (int)blockIdx.x, blockIdx.y);
 }
 template <int DQK, int DV, bool CHUNKED>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
-  attn_bwd_dkv_body<DQK, DV, CHUNKED, CHUNKED ? 1 : bwd_tiles<DQK, DV>()>(p, blockIdx.x, blockIdx.y);
+  attn_bwd_dkv_body<DQK, DV, CHUNKED, CHUNKED ? 1 : bwd_tiles<DQK, DV>()>(p, (DQK <= 32 && p.pair) ? pair_heads(blockIdx.x, gridDim.x) : (int)blockIdx.x, blockIdx.y);
 }
 
 constexpr int ATTN_GROUP_MAX = 8;
@@ -697,7 +707,8 @@ template <int DQK, int DV, int WHICH>
 __global__ __launch_bounds__(512) void attn_grouped_kernel(const AttnGroup g) {
   int pi = 0;
   while (pi + 1 < g.count && (int)blockIdx.x >= g.first_block[pi + 1]) ++pi;
-  const int bh = (int)blockIdx.x - g.first_block[pi];
+  int bh = (int)blockIdx.x - g.first_block[pi];
+  if (DQK <= 32 && g.prob[pi].pair && !(g.first_block[pi] & 7)) bh = pair_heads(bh, g.first_block[pi + 1] - g.first_block[pi]);
   if (WHICH == 0) attn_fwd_body<DQK, DV, false, 1>(g.prob[pi], bh, 0);
   else if (WHICH == 1) attn_bwd_dq_body<DQK, DV, false, bwd_tiles<DQK, DV>()>(g.prob[pi], bh, 0);
   else attn_bwd_dkv_body<DQK, DV, false, bwd_tiles<DQK, DV>()>(g.prob[pi], bh, 0);
@@ -872,6 +883,7 @@ extern "C" int dav_attn_bias_fwd(const void* Q, const void* K, const void* V, vo
   if (!bias_ok(bias, bias_nb, bias_ld, nullptr, B, Nk)) return DAV_ERR_SHAPE;
   AttnParams p = {};
   p.debug = attn_debug();
+  { static const int pr = [] { const char* e = getenv("DAV_ATTN_PAIR"); return e ? atoi(e) : 1; }(); p.pair = pr; }
   p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (bf16_t*)O; p.LSE = LSE;
   p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.q_bs = q_bs; p.k_bs = k_bs; p.v_bs = v_bs; p.o_bs = o_bs;
   p.q_rs = q_rs; p.k_rs = k_rs; p.v_rs = v_rs; p.o_rs = o_rs; p.scale = scale;
@@ -910,6 +922,7 @@ extern "C" int dav_attn_bias_bwd(const void* Q, const void* K, const void* V, co
   if (!bias_ok(bias, bias_nb, bias_ld, dS, B, Nk)) return DAV_ERR_SHAPE;
   AttnParams p = {};
   p.debug = attn_debug();
+  { static const int pr = [] { const char* e = getenv("DAV_ATTN_PAIR"); return e ? atoi(e) : 1; }(); p.pair = pr; }
   p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.Of = (const bf16_t*)O; p.O = nullptr;
   p.dO = (const bf16_t*)dO; p.LSE = const_cast<float*>(LSE); p.Delta = Delta;
   p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV;
