@@ -90,10 +90,25 @@ class Trainer:
         return self.grad_norm_tensor().item(), self.get_scale()
 
     def step(self, loss, create_graph=False, clip_grad=None, skip_grad=None):
-        """util/misc.py:96-136 (skip_grad's backup/restore path is not on the pre-training path)."""
+        """util/misc.py:96-136.  ``skip_grad`` (util/misc.py:81-104, never enabled by train.py): the gradients accumulated so far
+        are set aside, this micro-step's gradients are taken alone, and if their norm exceeds ``skip_grad`` they are dropped and
+        the micro-step is not counted; then the set-aside gradients are added back.  (One device-to-device copy of the flat
+        gradient buffer per call: this is a safety option, not a fast path.)"""
         if skip_grad is not None:
-            raise NotImplementedError('skip_grad is never enabled by train.py')
-        norm, scale = self.backward(loss, create_graph=create_graph)
+            if self.flat is None:
+                raise NotImplementedError('skip_grad needs the flat gradient buffer (FlatAdamW)')
+            if self.flat.stale and self.accums == 0:         # kept gradients of a replayed captured step: nothing of value in the buffer
+                self.flat.zero_grad()
+            backup = self.flat.flat_g.clone()
+            self.flat.flat_g.zero_()
+            norm, scale = self.backward(loss, create_graph=create_graph)
+            if norm > skip_grad:
+                self.flat.flat_g.zero_()
+                self.accums -= 1
+            self.flat.flat_g.add_(backup)
+            del backup
+        else:
+            norm, scale = self.backward(loss, create_graph=create_graph)
         if self.accums == self.accum_iter:
             gscale = 1.0 / self.accum_iter if self.accum_iter > 1 else 1.0
             if clip_grad is not None:

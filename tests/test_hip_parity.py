@@ -684,6 +684,37 @@ def test_written_first_gradients_equal_accumulated_ones(monkeypatch):
     assert rel(finals[0], finals[1]) < 2e-4
 
 
+def test_trainer_skip_grad_drops_an_outlier_micro_step():
+    """util/misc.py:81-104: with ``skip_grad`` a micro-step whose own gradient norm exceeds the limit is dropped — the gradients
+    accumulated before it survive, the step counter of the accumulation does not advance — and a normal one is kept."""
+    from deepavfusion_amd.util import lr_sched
+    from deepavfusion_amd.util.flat import FlatAdamW
+    from deepavfusion_amd.util.misc import Trainer
+    model, sd, cfg, O = _build('micro')
+    nd = [n for n, p in model.named_parameters() if 'bias' in n or 'norm' in n]
+    groups = lr_sched.param_groups_pretrained(model, 0.05, no_weight_decay_list=nd, image_pt='', audio_pt='')
+    opt = FlatAdamW(groups, lr=1e-3, betas=(0.9, 0.95), model=model)
+    tr = Trainer(model, optimizer=opt, accum_iter=3)
+    image, audio, ni, na = O.synthetic_batch(cfg, 4, seed=8)
+    batch = (image.cuda(), audio.cuda(), torch.from_numpy(ni).cuda(), torch.from_numpy(na).cuda())
+
+    def loss(scale=1.0):
+        li, la = tr.model(*batch)[:2]
+        return (li + la) * scale
+    n1, _ = tr.step(loss(), skip_grad=1e9)                      # kept
+    g1 = opt.flat.flat_g.clone()
+    assert tr.accums == 1 and float(g1.norm()) > 0
+    n2, _ = tr.step(loss(1e4), skip_grad=10.0 * n1)             # an outlier: dropped, the first micro-step's gradients survive
+    assert tr.accums == 1 and n2 > 10.0 * n1
+    assert torch.equal(opt.flat.flat_g, g1)
+    n3, _ = tr.step(loss(), skip_grad=1e9)                      # kept: the sum of two equal micro-steps
+    assert tr.accums == 2
+    assert rel(opt.flat.flat_g, 2.0 * g1) < 1e-5
+    p0 = opt.flat.flat_p.clone()
+    tr.step(loss(), skip_grad=1e9)                              # third kept micro-step: the optimizer steps, gradients are cleared
+    assert tr.accums == 0 and int(tr.n_steps) == 1 and not torch.equal(p0, opt.flat.flat_p) and float(opt.flat.flat_g.abs().max()) == 0.0
+
+
 def test_captured_step_guards_non_finite_loss_and_clips():
     """Reference train.py:166-167 (a non-finite loss aborts BEFORE the optimizer step) and util/misc.py:118-120 (clip_grad) inside
     the captured step: a replay with a NaN in its input leaves parameters, both moments and the bf16 mirror bit-identical,
