@@ -1043,10 +1043,17 @@ def test_baseline_config_shapes_vs_oracle(name, batch):
     small batches (the oracle needs seconds of host time): masking indices, losses and every gradient.  ``base-64`` is the
     bench workload itself (B = 64 per GPU: the tile configurations, the tuned table and the grouped weight-gradient launches
     of the timed step are live; the oracle takes about a minute of host time)."""
+    from deepavfusion_amd import ops
     model, sd, cfg, O = _build(name)
     image, audio, ni, na = O.synthetic_batch(cfg, batch, seed=25)
+    ops.nt_issue_log(True)
     out = model(image.cuda(), audio.cuda(), torch.from_numpy(ni).cuda(), torch.from_numpy(na).cuda())
     (out[0] + out[1]).backward()
+    issued = ops.nt_issue_log()
+    ops.nt_issue_log(False)
+    if os.environ.get('DAV_TEST_EXPECT_NT256'):       # (the 256 x 256 variant below: the opt-in body must really have run)
+        n60 = sum(1 for e in issued if e[0] == 60)
+        assert n60 >= int(os.environ['DAV_TEST_EXPECT_NT256']), (n60, sorted({e[0] for e in issued}))
     sdo = {k: v.clone().requires_grad_(k not in O.FROZEN and not O.is_buffer(k)) for k, v in sd.items()}
     li, la, pi, pa, aux = O.avmae_forward(sdo, cfg, image, audio, ni, na)
     (li + la).backward()
@@ -1064,6 +1071,22 @@ def test_baseline_config_shapes_vs_oracle(name, batch):
         rels.append(d / max(float(ref.norm()), 1e-30))
         assert d <= GRAD_TOL * float(ref.norm()) + 1e-4 * g_all, (n, d, float(ref.norm()))
     assert np.median(rels) < ACT_TOL
+
+
+@pytest.mark.timeout(600)
+def test_bench_workload_with_the_opt_in_256_tile_kernels_vs_oracle():
+    """The 256 x 256 NT body (configuration 60, DAV_NT256=1) and the persistent 256 x 256 weight-gradient kernel (DAV_TN256=1)
+    are off by default (slower inside the step) but shipped: the bench workload at B = 64 with both switched
+    on, as a fresh process (the switches are read once per process), against the oracle at the same tolerances — and the
+    launch log must show that configuration 60 really carried launches."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DAV_NT256='1', DAV_NT256_N='512', DAV_NT256_TILES='64', DAV_NT_TUNE='0', DAV_TN256='1', DAV_TN256_MIN='64',
+               DAV_TEST_EXPECT_NT256='8')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider',
+                        '-k', 'test_baseline_config_shapes_vs_oracle and base-64'], cwd=root, env=env, capture_output=True, text=True, timeout=580)
+    assert r.returncode == 0 and '1 passed' in r.stdout, (r.stdout[-3000:], r.stderr[-1500:])
 
 
 def test_load_state_dict_after_optimizer_refreshes_the_bf16_mirror():
