@@ -1548,8 +1548,11 @@ __device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN_, wn = wave % WN_;
-  const int tiles_k = (p.K + T - 1) / T;
-  const int bn = tile_idx / tiles_k, bk = tile_idx % tiles_k;
+  const int tiles_k = (p.K + T - 1) / T, tiles_n = (p.N + T - 1) / T;
+  // consecutive tile ids walk the SHORTER side of the tile grid first: a run of ids (what one XCD owns, see the grouped kernel)
+  // then covers a few whole rows / columns of it and touches few distinct operand panels
+  const bool k_minor = tiles_k <= tiles_n;
+  const int bn = k_minor ? tile_idx / tiles_k : tile_idx % tiles_n, bk = k_minor ? tile_idx % tiles_k : tile_idx / tiles_n;
   const int n0 = bn * T, k0 = bk * T;
   const int steps_total = p.Mc >> 6;                                // the split of the contraction is in 64-row units
   const int steps_per = (steps_total + p.splits - 1) / p.splits;
@@ -1695,6 +1698,7 @@ struct TNGroup {
   TNParams prob[TN_GROUP_MAX];
   int first_block[TN_GROUP_MAX + 1];
   int count;
+  int xcd_runs;                       // 1: every XCD owns one contiguous run of each problem's (split, tile) units
 };
 
 template <int T, int WM_, int WN_, int RS = 64, int NST = 2, int MINW = 1>
@@ -1704,7 +1708,17 @@ __global__ __launch_bounds__(WM_* WN_ * 64, MINW) void gemm_tn_grouped_kernel(co
   const TNParams& p = g.prob[pi];
   const int local = blockIdx.x - g.first_block[pi];
   const int tiles = ((p.N + T - 1) / T) * ((p.K + T - 1) / T);
-  tn2_body<T, WM_, WN_, RS, NST>(p, local % tiles, local / tiles);
+  int unit = local;
+  if (g.xcd_runs) {
+    // workgroup ids go round the 8 XCDs (private L2s): the ids with the same residue form one XCD's share of this problem.  Give
+    // that share a contiguous run of units — a few whole rows / columns of the tile grid, streaming the contraction side by
+    // side — so that the XCD pulls few distinct operand panels through the fabric instead of nearly all of them
+    // (profiles/r03_step_traffic.txt: the weight gradients fetched 33 GB per step, 6 x their operands)
+    const int total = g.first_block[pi + 1] - g.first_block[pi];
+    const int r = local & 7, j = local >> 3, q = total >> 3, rem = total & 7;
+    unit = r * q + (r < rem ? r : rem) + j;
+  }
+  tn2_body<T, WM_, WN_, RS, NST>(p, unit % tiles, unit / tiles);
 }
 
 template <int T, int WM_, int WN_>
@@ -1984,6 +1998,11 @@ extern "C" int dav_gemm_tn_grouped_bf16(const DavTnProblem* probs, int count, hi
   }
   g.first_block[count] = first;
   g.count = count;
+  // (round 3: -21 % memory-side fetch, -5 % kernel time, -0.2 ms per step on two boxes.  Cutting the WHOLE launch's unit sequence
+  // into eight equal-work ranges, one per XCD, took the fetch down 3 x (33.5 -> 11.5 GB per step) and the kernel time UP 6 %: the
+  // weight gradients are not bound by fabric traffic — profiles/r03_step_traffic.txt)
+  static const int xcd_runs = getenv("DAV_TN_XCD") ? atoi(getenv("DAV_TN_XCD")) != 0 : 1;
+  g.xcd_runs = xcd_runs;
   // 4 x 2 waves (32 x 64 wave tiles): +1 % over 2 x 4 in the step; thinner or deeper rings (32-row stages x 3 / 4, 64-row x 3),
   // 4-wave workgroups and three workgroups per CU were all measured slower (profiles/r02_tn_ring_variants.txt)
   // (by-value copy in an AUTOMATIC: a launch recorded inside dav_batch_begin .. dav_batch_end captures its arguments with [=],
