@@ -171,13 +171,17 @@ constexpr int ATTN_CHUNK = 256;
 
 // cross-lane max over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) with the gfx950 row/half swaps
 // instead of two LDS-pipe ds_bpermute round trips
+// The scores come out of MFMAs (never signalling NaNs); fmaxf() would still quiet every operand first (a v_max x, x each, IEEE
+// mode) — 21 instructions for the maximum of a lane's 8 scores and its cross-lane part where 10 do.
+__device__ __forceinline__ float max_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float max3_raw(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float rows_max(float x) {
   const unsigned u = __float_as_uint(x);
   auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);     // {x.r0,x.r0,x.r2,x.r2}, {x.r1,x.r1,x.r3,x.r3}
-  const float y = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const float y = max_raw(__uint_as_float(a[0]), __uint_as_float(a[1]));
   const unsigned v = __float_as_uint(y);
   auto c = __builtin_amdgcn_permlane32_swap(v, v, false, false);     // {y.lo,y.lo}, {y.hi,y.hi}
-  return fmaxf(__uint_as_float(c[0]), __uint_as_float(c[1]));
+  return max_raw(__uint_as_float(c[0]), __uint_as_float(c[1]));
 }
 
 template <int DQK, int DV, bool CHUNKED, int QT>
@@ -205,6 +209,16 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, const int bh,
   const int nqt = p.debug == 1 ? 0 : (p.Nq + 15) >> 4;
   const float sl2 = p.scale * 1.44269504088896341f;
   const float mul = p.bias ? 1.f : sl2;        // with a bias the scores are scaled when it is added
+  // MFMA_SUM (measured, off): the row sums by one more MFMA against a block of ones instead of 8 adds per lane and key step — the
+  // sums are then those of the bf16-ROUNDED probabilities (LSE off by 1-3e-4) for -5 % on the decoder shapes
+  constexpr bool MFMA_SUM = false;
+  bf16x8 ones;                         // 8 x bf16 1.0 in four registers the compiler cannot fold back into one (it would rebuild the quad per key step)
+  {
+    union { uint32_t w[4]; bf16x8 v; } o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("v_mov_b32 %0, 0x3f803f80" : "=v"(o.w[i]));
+    ones = o.v;
+  }
   uint32_t ka0[KS], va0[VC];           // this lane's fragment addresses at key row 0
 #pragma unroll
   for (int kk = 0; kk < KS; ++kk) ka0[kk] = lds_addr(Ks) + frag_off<KRB>(fr, kk, g);
@@ -217,7 +231,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, const int bh,
     bool qok[QT];
     bf16x8 qf[QT][KS];
     float m[QT], lsum[QT];             // m: reference max in the log2 domain
-    f32x4 oacc[QT][VC];
+    f32x4 oacc[QT][VC], lacc[QT];      // lacc (MFMA_SUM): the row sums as one more "value column" of ones through the MFMA pipe
 #pragma unroll
     for (int u = 0; u < QT; ++u) {
       const int q = (qt + u) * 16 + fr;
@@ -225,7 +239,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, const int bh,
       const bf16_t* qrow = p.Q + b * p.q_bs + (long)(qok[u] ? q : p.Nq - 1) * p.q_rs + h * DQK;
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) qf[u][kk] = gfrag(qrow, kk * 32 + 8 * g, kk * 32 + 8 * g < DQK);
-      m[u] = -1e30f; lsum[u] = 0.f;
+      m[u] = -1e30f; lsum[u] = 0.f; lacc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < VC; ++c) oacc[u][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -290,8 +304,10 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, const int bh,
         bf16x8 pf[QT];
 #pragma unroll
         for (int u = 0; u < QT; ++u) {
-          float mx = fmaxf(fmaxf(fmaxf(st[u][0][0], st[u][0][1]), fmaxf(st[u][0][2], st[u][0][3])),
-                           fmaxf(fmaxf(st[u][1][0], st[u][1][1]), fmaxf(st[u][1][2], st[u][1][3])));
+          float mx = max3_raw(st[u][0][0], st[u][0][1], st[u][0][2]);
+          mx = max3_raw(mx, st[u][0][3], st[u][1][0]);
+          mx = max3_raw(mx, st[u][1][1], st[u][1][2]);
+          mx = max_raw(mx, st[u][1][3]);
           mx = rows_max(mx) * mul;       // log2 domain (scale * log2(e) > 0 commutes with max)
           // deferred rescale: keep the reference max while no row's tile max exceeds it by more than 2^8 — the
           // probabilities then stay <= 256 (bf16 keeps its relative precision), O and the row sum need no multiply
@@ -300,6 +316,10 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, const int bh,
             const float alpha = __builtin_amdgcn_exp2f(m[u] - mn);
             m[u] = mn;
             lsum[u] *= alpha;
+            if constexpr (MFMA_SUM) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) lacc[u][r] *= alpha;
+            }
 #pragma unroll
             for (int c = 0; c < VC; ++c)
 #pragma unroll
@@ -311,10 +331,11 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, const int bh,
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               st[u][t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[u][t][r], mul, -m[u]));    // v_exp_f32 is 2^x
-              ps += st[u][t][r];
+              if constexpr (!MFMA_SUM) ps += st[u][t][r];
             }
           lsum[u] += ps;
           pf[u] = pack8(st[u][0], st[u][1]);
+          if constexpr (MFMA_SUM) lacc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[u], lacc[u], 0, 0, 0);
         }
 #pragma unroll
         for (int c = 0; c < VC; ++c)
@@ -330,8 +351,8 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, const int bh,
 #pragma unroll
     for (int u = 0; u < QT; ++u) {
       float l = lsum[u];
-      l += __shfl_xor(l, 16, 64);
-      l += __shfl_xor(l, 32, 64);
+      if constexpr (MFMA_SUM) l = lacc[u][0];
+      else { l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64); }
       const float inv = 1.f / l;
       const int q = (qt + u) * 16 + fr;
       if (qok[u]) {
