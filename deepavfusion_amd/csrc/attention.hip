@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <vector>
 
+#include <type_traits>
 #include "common.h"
 #include "dav_kernels.h"
 
@@ -448,6 +449,10 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
 #pragma unroll
     for (int c = 0; c < QC; ++c) kta[c] = lds_addr(Ks) + frag_tr_off<KRB>(c * 16, lane);
     // no key mask: the padded key rows of the K tile are zero, so whatever dS they get multiplies zeros in dQ = dS.K
+    // (two copies of the key loop, picked once per walk: the path's own case — no bias, no dS output — carries no zero bias to
+    // subtract the LSE from and no 64-bit score-row addresses; decided inside the loop the compiler kept both alive per step)
+    auto key_loop = [&](auto plain_c) {
+    constexpr bool PLAIN = decltype(plain_c)::value;
     for (int k0 = c0; k0 < cend; k0 += 32) {
       f32x4 st[QT][2], dp[QT][2];
 #pragma unroll
@@ -470,6 +475,14 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
         }
 #pragma unroll
         for (int u = 0; u < QT; ++u) {
+          if constexpr (PLAIN) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(st[u][t][r], sl2, -lse2[u]));
+              st[u][t][r] = pr * (dp[u][t][r] - delta[u]);     // dS^T
+            }
+            continue;
+          }
           float4 bv = float4{0.f, 0.f, 0.f, 0.f};
           const int q = (qt + u) * 16 + fr;
           const long srow = (((long)b * p.H + h) * p.Nq + (q < p.Nq ? q : p.Nq - 1)) * p.bias_ld + k0 + t * 16 + 4 * g;
@@ -499,6 +512,8 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
 #pragma unroll
       for (int c = 0; c < QC; ++c) kta[c] += 32 * KRB;
     }
+    };
+    if (!p.bias && !p.dS) key_loop(std::true_type{}); else key_loop(std::false_type{});
     }
 #pragma unroll
     for (int u = 0; u < QT; ++u) {
@@ -594,6 +609,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
 #pragma unroll
     for (int c = 0; c < QC; ++c) qta[c] = lds_addr(Qs) + frag_tr_off<QRB>(c * 16, lane);
     uint32_t la = lds_addr(lse_s) + 16 * g, da = lds_addr(del_s) + 16 * g;     // this lane's four query rows' statistics
+    auto query_loop = [&](auto plain_c) {          // (as in the dQ kernel: the no-bias copy of the loop is picked once per walk)
+    constexpr bool PLAIN = decltype(plain_c)::value;
     for (int qa = c0; qa < cend; qa += 32) {
       f32x4 s[KT][2], dp[KT][2];
 #pragma unroll
@@ -617,6 +634,15 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
         }
 #pragma unroll
         for (int u = 0; u < KT; ++u) {
+          if constexpr (PLAIN) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][t][r], sl2, -lse4[r]));
+              s[u][t][r] = pr;                                 // P[q][key]
+              dp[u][t][r] = pr * (dp[u][t][r] - del4[r]);      // dS[q][key]
+            }
+            continue;
+          }
           float bb[4] = {0.f, 0.f, 0.f, 0.f};
           if (p.bias) {                                      // bias[q][this lane's key]: four query rows, one column
             const int key = (kt + u) * 16 + fr, kc = key < p.Nk ? key : p.Nk - 1;
@@ -662,6 +688,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
       for (int c = 0; c < QC; ++c) qta[c] += 32 * QRB;
       la += 128; da += 128;
     }
+    };
+    if (!p.bias) query_loop(std::true_type{}); else query_loop(std::false_type{});
     }
 #pragma unroll
     for (int u = 0; u < KT; ++u) {

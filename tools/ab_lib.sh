@@ -1,0 +1,12 @@
+#!/bin/bash
+# same-box comparison of two builds of the library: tools/ab_lib.sh old.so new.so  (alternating, bench --steps 40; restores new.so)
+L=deepavfusion_amd/libdavfusion_hip.so
+for i in 1 2 3; do
+for S in "$1" "$2"; do
+cp $S $L
+timeout 300 python bench.py --no-cpu-baseline --steps 40 > gpurun_out/abl.json 2> gpurun_out/abl.err
+python -c "
+import json; d=json.load(open('gpurun_out/abl.json')); print('$S |', d['value'], d['ms_per_step'])"
+done
+done
+cp "$2" $L
