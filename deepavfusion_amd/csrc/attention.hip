@@ -739,8 +739,9 @@ template <int DQK, int DV, bool CHUNKED>
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
   attn_bwd_dq_body<DQK, DV, CHUNKED, CHUNKED ? 1 : bwd_tiles<DQK, DV>()>(p, (DQK <= 32 && p.pair) ? pair_heads(blockIdx.x, gridDim.x) : (int)blockIdx.x, blockIdx.y);
 }
+// (narrow heads: 4 waves per SIMD = two 8-wave workgroups per CU — at 130 registers only ONE fitted, 2 waves per SIMD under a VALU-bound loop)
 template <int DQK, int DV, bool CHUNKED>
-__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(AttnParams p) {
+__global__ __launch_bounds__(512, (DQK <= 32 && DV <= 32) ? 4 : 1) void attn_bwd_dkv_kernel(AttnParams p) {
   attn_bwd_dkv_body<DQK, DV, CHUNKED, CHUNKED ? 1 : bwd_tiles<DQK, DV>()>(p, (DQK <= 32 && p.pair) ? pair_heads(blockIdx.x, gridDim.x) : (int)blockIdx.x, blockIdx.y);
 }
 
