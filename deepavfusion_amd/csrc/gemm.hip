@@ -1546,6 +1546,7 @@ __device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, 
   constexpr int WTN = T / WM_, WTK = T / WN_, FM = WTN / 16, FN = WTK / 16;
   static_assert(RS * CPRW % NT == 0 && (RS == 32 || RS == 64) && NST >= 2, "tile/threads mismatch");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int dbg = p.debug_plain_store;                              // (a register: read through p inside the loop it was a scalar load + wait per stage)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN_, wn = wave % WN_;
   const int tiles_k = (p.K + T - 1) / T, tiles_n = (p.N + T - 1) / T;
@@ -1561,24 +1562,46 @@ __device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, 
   if (s_begin >= s_end) return;
   s_begin *= 64 / RS; s_end *= 64 / RS;                             // ... the ring's steps in RS-row units
 
-  int a_col[CH], b_col[CH], rowi[CH];
+  // Source pointers of this thread's chunks, carried from stage to stage (the stages are issued in contraction order): one 64-bit
+  // add per chunk and stage.  Re-deriving them per stage (row map division, two 32-bit multiplies and a 64-bit multiply-add per
+  // chunk, all quarter rate) was ~100 VALU cycles per chunk against the 256 MFMA cycles of a wave's whole stage.
+  const bf16_t* ap[CH]; const bf16_t* bp[CH];
+  int ar[CH], br[CH];                                      // row index inside the row map's period
 #pragma unroll
   for (int i = 0; i < CH; ++i) {
     const int c = tid + NT * i, row = c / CPRW, pc = c % CPRW;
     const int lc = (((pc >> 1) ^ tn2_swz<RB>(row)) << 1) | (pc & 1);
     int ac = n0 + lc * 8; ac = ac < p.N ? ac : p.N - 8;     // out-of-range output columns: any valid data (discarded)
     int bc = k0 + lc * 8; bc = bc < p.K ? bc : p.K - 8;
-    a_col[i] = ac; b_col[i] = bc; rowi[i] = row;
+    const int m = s_begin * RS + row;
+    ap[i] = p.A + map_row(m, p.amap) * p.lda + ac;
+    bp[i] = p.B + map_row(m, p.bmap) * p.ldb + bc;
+    ar[i] = p.amap.rpb > 0 ? m % p.amap.rpb : 0;
+    br[i] = p.bmap.rpb > 0 ? m % p.bmap.rpb : 0;
   }
-  auto dma_tile = [&](int s, int stage) {
+  const long a_step = (long)RS * p.lda, b_step = (long)RS * p.ldb;
+  const long a_wrap = (long)(p.amap.bs - p.amap.rpb) * p.lda, b_wrap = (long)(p.bmap.bs - p.bmap.rpb) * p.ldb;
+  auto dma_tile = [&](int stage) {                         // the next RS contraction rows
     char* st = smem + stage * STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-      const int m = s * RS + rowi[i];
-      __builtin_amdgcn_global_load_lds(GLB_PTR(void, p.A + map_row(m, p.amap) * p.lda + a_col[i]),
-                                       LDS_PTR(void, st + (wave * 64 + NT * i) * 16), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(GLB_PTR(void, p.B + map_row(m, p.bmap) * p.ldb + b_col[i]),
-                                       LDS_PTR(void, st + TILE_BYTES + (wave * 64 + NT * i) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(void, ap[i]), LDS_PTR(void, st + (wave * 64 + NT * i) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(void, bp[i]), LDS_PTR(void, st + TILE_BYTES + (wave * 64 + NT * i) * 16), 16, 0, 0);
+      ap[i] += a_step; bp[i] += b_step;
+    }
+    if (p.amap.rpb > 0) {                                  // (uniform) a mapped operand: period boundaries crossed by this advance
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        ar[i] += RS;
+        while (ar[i] >= p.amap.rpb) { ar[i] -= p.amap.rpb; ap[i] += a_wrap; }
+      }
+    }
+    if (p.bmap.rpb > 0) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        br[i] += RS;
+        while (br[i] >= p.bmap.rpb) { br[i] -= p.bmap.rpb; bp[i] += b_wrap; }
+      }
     }
   };
 
@@ -1595,18 +1618,18 @@ __device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, 
 
 #pragma unroll
   for (int st = 0; st < NST - 1; ++st)
-    if (s_begin + st < s_end) dma_tile(s_begin + st, st);
+    if (s_begin + st < s_end) dma_tile(st);
   int stage = 0;
   for (int s = s_begin; s < s_end; ++s) {
     // the loads of step s must have landed; those of the NST - 2 steps after it may still be in flight (each step is 2 CH loads
     // per wave) — once the tail stops issuing, drain everything
     if (NST > 2 && s + NST - 2 < s_end) wait_vmcnt<(NST - 2) * 2 * CH>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    if (s + NST - 1 < s_end) dma_tile(s + NST - 1, stage == 0 ? NST - 1 : stage - 1);      // the stage step s - 1 has just released
+    if (s + NST - 1 < s_end) dma_tile(stage == 0 ? NST - 1 : stage - 1);      // the stage step s - 1 has just released
     const char* Ab = smem + stage * STAGE_BYTES;
     const char* Bb = Ab + TILE_BYTES;
     stage = stage + 1 == NST ? 0 : stage + 1;
-    if (p.debug_plain_store & 4) continue;      // timing experiment (DAV_TN_DEBUG): the global -> LDS stream alone
+    if (dbg & 4) continue;      // timing experiment (DAV_TN_DEBUG): the global -> LDS stream alone
 #pragma unroll
     for (int kk = 0; kk < RS / 32; ++kk) {
       bf16x8 af[FM], bfr[FN];
@@ -1629,11 +1652,11 @@ __device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, 
     }
   }
 
-  if (p.debug_plain_store & 2) return;          // timing experiment: no epilogue
+  if (dbg & 2) return;          // timing experiment: no epilogue
   const int fr = lane & 15, fg = lane >> 4;
   // splits > 1: partial sums meet through fp32 atomics; splits == 1: this workgroup owns the tile (plain
   // read-modify-write when accumulating)
-  const bool atomic = p.splits > 1 && !(p.debug_plain_store & 1);
+  const bool atomic = p.splits > 1 && !(dbg & 1);
   if (atomic) {
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
