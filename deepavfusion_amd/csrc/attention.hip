@@ -754,14 +754,17 @@ struct AttnGroup {
 // WHICH: 0 forward, 1 dQ, 2 dK/dV.  The workgroup size is the largest any problem of the group asks for: the
 // surplus waves of a smaller problem stage tiles and then find no tile of their own.
 template <int DQK, int DV, int WHICH>
-__global__ __launch_bounds__(512) void attn_grouped_kernel(const AttnGroup g) {
+__global__ __launch_bounds__(512, (WHICH == 2 && DQK <= 32 && DV <= 32) ? 4 : 1) void attn_grouped_kernel(const AttnGroup g) {
   int pi = 0;
   while (pi + 1 < g.count && (int)blockIdx.x >= g.first_block[pi + 1]) ++pi;
   int bh = (int)blockIdx.x - g.first_block[pi];
   if (DQK <= 32 && g.prob[pi].pair && !(g.first_block[pi] & 7)) bh = pair_heads(bh, g.first_block[pi + 1] - g.first_block[pi]);
-  if (WHICH == 0) attn_fwd_body<DQK, DV, false, 1>(g.prob[pi], bh, 0);
-  else if (WHICH == 1) attn_bwd_dq_body<DQK, DV, false, bwd_tiles<DQK, DV>()>(g.prob[pi], bh, 0);
-  else attn_bwd_dkv_body<DQK, DV, false, bwd_tiles<DQK, DV>()>(g.prob[pi], bh, 0);
+  // (a copy in registers: read through a reference into the by-value table, every field the loops use came back as a scalar load
+  // + wait per iteration — the "memory" clobbers of the staging waits forbid hoisting them)
+  const AttnParams p = g.prob[pi];
+  if (WHICH == 0) attn_fwd_body<DQK, DV, false, 1>(p, bh, 0);
+  else if (WHICH == 1) attn_bwd_dq_body<DQK, DV, false, bwd_tiles<DQK, DV>()>(p, bh, 0);
+  else attn_bwd_dkv_body<DQK, DV, false, bwd_tiles<DQK, DV>()>(p, bh, 0);
 }
 
 template <int DQK> constexpr int padqk() { return DQK < 32 ? 32 : DQK; }      // LDS columns of a q/k (or v/dO) row

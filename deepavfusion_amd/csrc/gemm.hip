@@ -615,6 +615,9 @@ __device__ __forceinline__ void nt2_body(const NTParams& p, int bid) {
   long long pt[6] = {0, 0, 0, 0, 0, 0};
   long long tk0 = 0, tstart = 0;
   if (PROF) tstart = tk0 = __builtin_readcyclecounter();
+  // (a register: in the grouped kernels p points into the by-value table in the kernarg segment, and read through p inside the
+  // k-loop this flag was a scalar load + s_waitcnt lgkmcnt(0) per k-step — the "memory" clobbers of the counted waits forbid hoisting it)
+  const bool dbg4 = (p.debug & 4) != 0;
   constexpr int NT = WM_ * WN_ * 64;
   constexpr int WTM = BM / WM_, WTN = BN / WN_, FM = WTM / 16, FN = WTN / 16;
   constexpr int ARB = BK * 2, ACPR = BK / 8;               // LDS row bytes / 16-byte chunks per row of A (and NT-mode B) tiles
@@ -817,7 +820,7 @@ __device__ __forceinline__ void nt2_body(const NTParams& p, int bid) {
     if (PROF) { const long long t = __builtin_readcyclecounter(); pt[2] += t - tk0; tk0 = t; }
     const char* Ab = smem + (kt % STAGES) * STAGE_BYTES;
     const char* Bb = Ab + A_BYTES;
-    if (p.debug & 4) continue;             // timing experiment: the global -> LDS stream alone
+    if (dbg4) continue;                    // timing experiment: the global -> LDS stream alone
 #pragma unroll
     for (int kk = 0; kk < BK / 32; ++kk) {
       bf16x8 af[FM], bfr[FN];

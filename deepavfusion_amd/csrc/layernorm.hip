@@ -123,7 +123,8 @@ template <int MAXC>
 __global__ __launch_bounds__(256) void ln_fwd_grouped_kernel(const LNFwdGroup g) {
   int pi = 0;
   while (pi + 1 < g.count && (int)blockIdx.x >= g.first_block[pi + 1]) ++pi;
-  ln_fwd_body<MAXC>(g.prob[pi], (int)blockIdx.x - g.first_block[pi], g.first_block[pi + 1] - g.first_block[pi]);
+  const LNFwd p = g.prob[pi];          // (registers, not a reference into the by-value table: no scalar reloads inside the row loop)
+  ln_fwd_body<MAXC>(p, (int)blockIdx.x - g.first_block[pi], g.first_block[pi + 1] - g.first_block[pi]);
 }
 
 // 8 waves per workgroup (512 workgroups -> 16 waves/CU in flight).  dgamma/dbeta: the waves of a workgroup combine their partial sums in LDS and write ONE partial row
@@ -238,7 +239,8 @@ template <int MAXC>
 __global__ __launch_bounds__(512) void ln_bwd_grouped_kernel(const LNBwdGroup g) {
   int pi = 0;
   while (pi + 1 < g.count && (int)blockIdx.x >= g.first_block[pi + 1]) ++pi;
-  ln_bwd_body<MAXC>(g.prob[pi], (int)blockIdx.x - g.first_block[pi], g.first_block[pi + 1] - g.first_block[pi]);
+  const LNBwd p = g.prob[pi];
+  ln_bwd_body<MAXC>(p, (int)blockIdx.x - g.first_block[pi], g.first_block[pi + 1] - g.first_block[pi]);
 }
 
 // 64 columns x 16 row-lanes per workgroup: every thread sums its share of the partial rows with 4 independent
