@@ -1082,7 +1082,9 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(NTParams p) {
 }
 // PIPE: two 512-thread workgroups per CU = 4 waves per SIMD -> at most 128 VGPRs (2nd launch-bounds argument = waves per SIMD)
 template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK = 64, int PIPE = 0>
-__global__ __launch_bounds__((WM_* WN_ + (PIPE >= 2 ? PIPE : 0)) * 64, PIPE == 4 ? 6 : PIPE == 2 ? 5 : ((PIPE || (WM_ * WN_ == 8 && BM * BN > 128 * 128)) ? 4 : 1)) void gemm_nt2_kernel(NTParams p) {
+// (4-wave tiles ask for >= 2 waves per SIMD: with one, the register budget is 512 = VGPRs + AGPRs, the compiler puts the accumulators
+// into AGPRs and copies all of them to VGPRs and back around every k-step — 32-64 v_accvgpr moves against 8-16 MFMAs)
+__global__ __launch_bounds__((WM_* WN_ + (PIPE >= 2 ? PIPE : 0)) * 64, PIPE == 4 ? 6 : PIPE == 2 ? 5 : ((PIPE || (WM_ * WN_ == 8 && BM * BN > 128 * 128)) ? 4 : (WM_ * WN_ <= 4 ? 2 : 1))) void gemm_nt2_kernel(NTParams p) {
   nt2_body<BM, BN, WM_, WN_, STAGES, BT, BK, false, PIPE>(p, blockIdx.x);
 }
 
@@ -1098,7 +1100,7 @@ struct NTGroup {
 };
 
 template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK = 64, int PIPE = 0>
-__global__ __launch_bounds__((WM_* WN_ + (PIPE >= 2 ? PIPE : 0)) * 64, PIPE == 4 ? 6 : PIPE == 2 ? 5 : ((PIPE || (WM_ * WN_ == 8 && BM * BN > 128 * 128)) ? 4 : 1)) void gemm_nt2_grouped_kernel(const NTGroup g) {
+__global__ __launch_bounds__((WM_* WN_ + (PIPE >= 2 ? PIPE : 0)) * 64, PIPE == 4 ? 6 : PIPE == 2 ? 5 : ((PIPE || (WM_ * WN_ == 8 && BM * BN > 128 * 128)) ? 4 : (WM_ * WN_ <= 4 ? 2 : 1))) void gemm_nt2_grouped_kernel(const NTGroup g) {
   int pi = 0;
   while (pi + 1 < g.count && (int)blockIdx.x >= g.first_block[pi + 1]) ++pi;
   nt2_body<BM, BN, WM_, WN_, STAGES, BT, BK, false, PIPE>(g.prob[pi], (int)blockIdx.x - g.first_block[pi]);
@@ -1713,7 +1715,7 @@ __device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, 
 }
 
 template <int T, int WM_, int WN_>
-__global__ __launch_bounds__(WM_* WN_ * 64) void gemm_tn2_kernel(TNParams p) {
+__global__ __launch_bounds__(WM_* WN_ * 64, WM_ * WN_ <= 4 ? 2 : 1) void gemm_tn2_kernel(TNParams p) {
   tn2_body<T, WM_, WN_>(p, blockIdx.x, blockIdx.y);
 }
 
