@@ -1765,7 +1765,7 @@ int nt_auto_config_tiles(long t128, bool narrow) {
   // the step vs 7 us with warm operands); from ~250 tiles of 64x64 on the 64 KB ring costs occupancy instead (3136x768x3072
   // alone: 40.5 vs 32.7 us).  DAV_NT_SMALL=5 forces the two-stage ring.
   static const int small_cfg = getenv("DAV_NT_SMALL") ? atoi(getenv("DAV_NT_SMALL")) : 5;      // round 3, stream schedule: the two-stage ring is -0.18 ms per step (same-box alternation); 7 = the four-stage ring
-  static const int t5 = getenv("DAV_NT_T5") ? atoi(getenv("DAV_NT_T5")) : 200, t8 = getenv("DAV_NT_T8") ? atoi(getenv("DAV_NT_T8")) : 400;
+  static const int t5 = getenv("DAV_NT_T5") ? atoi(getenv("DAV_NT_T5")) : 100, t8 = getenv("DAV_NT_T8") ? atoi(getenv("DAV_NT_T8")) : 400;
   if (narrow || t128 < t5) return (small_cfg == 5 || t128 > 64) ? 5 : 7;
   if (t128 < t8) return 8;                   // 128x64, 4 waves
   return 3;                                   // 128x128, 8 waves (2 x 4)
