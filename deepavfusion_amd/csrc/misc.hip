@@ -354,6 +354,17 @@ __global__ __launch_bounds__(1024) void sumsq_final_kernel(const float* partial,
   }
 }
 
+// streaming accesses of the optimizer pass: 30 bytes per parameter that nothing reads again before the next step — marked
+// non-temporal so that they do not push the backward's activations out of L2 / MALL when the pass runs beside it
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldnt4(const float* q) {
+  const nt_f4 t = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(q));
+  return float4{t[0], t[1], t[2], t[3]};
+}
+__device__ __forceinline__ void stnt4(float* q, const float4& x) {
+  nt_f4 t; t[0] = x.x; t[1] = x.y; t[2] = x.z; t[3] = x.w;
+  __builtin_nontemporal_store(t, reinterpret_cast<nt_f4*>(q));
+}
 // AdamW over flat buffers.  seg_* describe contiguous segments (param groups laid out back to back):
 // element i belongs to the segment s with seg_end[s-1] <= i < seg_end[s]; hyper[s] = {lr, weight_decay}.
 // step-dependent bias corrections are read from device memory so a captured graph can be replayed.
@@ -388,15 +399,15 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
       const float lr = hyper[2 * s], wd = hyper[2 * s + 1];
       const bool fill = zero_grad && !(keep_grad && keep_grad[s]);      // (fetched with the segment's hyper-parameters)
       const float decay = 1.f - lr * wd, step = lr / bc1;
-      const float4 gr = *reinterpret_cast<const float4*>(g + i);
+      const float4 gr = ldnt4(g + i);
       if (skip) {
         ss += gr.x * gr.x + gr.y * gr.y + gr.z * gr.z + gr.w * gr.w;
-        if (fill) *reinterpret_cast<float4*>(g + i) = float4{0.f, 0.f, 0.f, 0.f};
+        if (fill) stnt4(g + i, float4{0.f, 0.f, 0.f, 0.f});
         continue;
       }
-      float4 pi = *reinterpret_cast<const float4*>(p + i);
-      float4 mi = *reinterpret_cast<const float4*>(m + i);
-      float4 vi = *reinterpret_cast<const float4*>(v + i);
+      float4 pi = ldnt4(p + i);
+      float4 mi = ldnt4(m + i);
+      float4 vi = ldnt4(v + i);
       ss += gr.x * gr.x + gr.y * gr.y + gr.z * gr.z + gr.w * gr.w;
       const float gx = gr.x * grad_scale, gy = gr.y * grad_scale, gz = gr.z * grad_scale, gw = gr.w * grad_scale;
       mi.x = beta1 * mi.x + ob1 * gx; mi.y = beta1 * mi.y + ob1 * gy; mi.z = beta1 * mi.z + ob1 * gz; mi.w = beta1 * mi.w + ob1 * gw;
@@ -406,14 +417,14 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
       pi.y = pi.y * decay - step * mi.y / (sqrtf(vi.y) / bc2_sqrt + eps);
       pi.z = pi.z * decay - step * mi.z / (sqrtf(vi.z) / bc2_sqrt + eps);
       pi.w = pi.w * decay - step * mi.w / (sqrtf(vi.w) / bc2_sqrt + eps);
-      *reinterpret_cast<float4*>(p + i) = pi;
-      *reinterpret_cast<float4*>(m + i) = mi;
-      *reinterpret_cast<float4*>(v + i) = vi;
+      stnt4(p + i, pi);
+      stnt4(m + i, mi);
+      stnt4(v + i, vi);
       if (p_bf16) {
         uint2 w; w.x = pack2bf(pi.x, pi.y); w.y = pack2bf(pi.z, pi.w);
         *reinterpret_cast<uint2*>(p_bf16 + i) = w;
       }
-      if (fill) *reinterpret_cast<float4*>(g + i) = float4{0.f, 0.f, 0.f, 0.f};
+      if (fill) stnt4(g + i, float4{0.f, 0.f, 0.f, 0.f});
     }
   }
   if (sumsq_out) {                        // one atomic per workgroup (<= 16384 distinct-time adds on one word)

@@ -146,6 +146,26 @@ class FlatAdamW(torch.optim.Optimizer):
                        keep_grad=keep_grad if fused_norm_and_zero else None, gscale_dev=gscale_dev)
         engine.invalidate_weight_cache(f.params)      # fp32 masters changed behind torch's back
 
+    def make_range(self, first: int, last: int):
+        """Tables for an AdamW pass over the parameters first..last (inclusive, flat order) only: the segment ends relative to
+        the range's first element (the kernel indexes from the pointers it is given).  Allocates: call OUTSIDE graph capture."""
+        f = self.flat
+        lo, hi = f.offsets[first], int(f.seg_end[last])
+        return dict(first=first, n=last - first + 1, lo=lo, hi=hi, seg_end=(f.seg_end[first:last + 1] - lo).contiguous(),
+                    sumsq=torch.zeros(1, dtype=torch.float32, device=f.flat_p.device))
+
+    def launch_range(self, r, keep_grad=None, gscale_dev=None):
+        """The fused pass of ``launch_step(fused_norm_and_zero=True)`` over one ``make_range`` range (capturable): the same
+        element-wise update, sum(g^2) of the range left in ``r['sumsq']``.  util.misc.GraphedStep issues the ranges whose
+        gradients are final while the rest of the backward is still running."""
+        b1, b2 = self.defaults['betas']
+        f, lo, hi, a = self.flat, r['lo'], r['hi'], r['first']
+        if keep_grad is None:
+            keep_grad = self.keep_grad
+        ops.adamw_flat(f.flat_p[lo:hi], f.flat_g[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.flat_bf16[lo:hi],
+                       r['seg_end'], self._hyper[a:], r['n'], b1, b2, self.defaults['eps'], self._bc, 1.0,
+                       sumsq_out=r['sumsq'], zero_grad=True, keep_grad=keep_grad[a:], gscale_dev=gscale_dev)
+
     @torch.no_grad()
     def load_state_dict(self, state_dict):
         """Accepts what ``torch.optim.AdamW.state_dict()`` produces for the same parameter groups (the 'optimizer' entry

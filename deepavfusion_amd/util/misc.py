@@ -201,14 +201,58 @@ class GraphedStep:
         self.n_seg = len(self.cuts) + 1
         saved_hook = engine._GRAD_READY
         engine.set_grad_ready_hook(None)
+        # Early AdamW (one GPU, no clipping — the clip factor needs every gradient first, a data-parallel step its all-reduce):
+        # the update of a parameter needs nothing but that parameter's final gradient, so the ranges of the flat buffer whose
+        # gradients are complete at a few points of the backward (after the decoders, after encoder layers 9 / 6 / 3 / 1 by
+        # default: DAV_EARLY_ADAMW_CUTS) get their AdamW pass THERE, on a side stream, under the rest of the backward — instead
+        # of one 1.8 ms memory-bound kernel running alone at the end of the step.  Which parameters are final where is learnt
+        # from one of the warm-up passes (the engine reports every parameter once its gradient is complete).
+        self.early = (not self.dist_active and self.n_seg == 1 and self.clip_grad is None and os.environ.get('DAV_EARLY_ADAMW', '0') == '1')
+        cuts_env = os.environ.get('DAV_EARLY_ADAMW_CUTS', '')
+        self.early_cuts = ({int(c) for c in cuts_env.split(',') if c.strip()} if cuts_env
+                           else {depth} | {l for l in (9, 6, 3, 1) if l < depth}) if self.early else set()
+        index_of = {id(p): i for i, p in enumerate(self.opt.flat.params)}
+        learnt, fresh = {}, []                 # cut -> parameter indices whose gradients became final since the previous cut
+
+        def learn_ready(p):
+            i = index_of.get(id(p))
+            if i is not None:
+                fresh.append(i)
+
+        def learn_cb(l):
+            if l in self.early_cuts:
+                learnt[l] = sorted(set(fresh))
+                fresh.clear()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(warmup):
-                self._fwd_bwd(None)
+            for it in range(max(warmup, 1 if self.early else 0)):
+                if self.early and it == 0:
+                    engine.set_grad_ready_hook(learn_ready)
+                    self._fwd_bwd(learn_cb)
+                    engine.set_grad_ready_hook(None)
+                else:
+                    self._fwd_bwd(None)
                 self.opt.flat.zero_grad()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+
+        def as_ranges(idx):                    # consecutive parameter indices -> [first, last] ranges of the flat buffer
+            out = []
+            for i in idx:
+                if out and i == out[-1][1] + 1:
+                    out[-1][1] = i
+                else:
+                    out.append([i, i])
+            return [self.opt.make_range(a, b) for a, b in out]
+        taken = set()
+        self.early_ranges = {}
+        for l in sorted(learnt, reverse=True):     # (the backward meets the cuts in descending order)
+            idx = [i for i in learnt[l] if i not in taken]
+            taken.update(idx)
+            self.early_ranges[l] = as_ranges(idx)
+        self.late_ranges = as_ranges([i for i in range(len(self.opt.flat.params)) if i not in taken]) if self.early else []
+        self.opt_stream = torch.cuda.Stream() if self.early else None
 
         # ---- capture ------------------------------------------------------------------------------------------
         self.graphs = [torch.cuda.CUDAGraph() for _ in range(self.n_seg)]
@@ -216,7 +260,10 @@ class GraphedStep:
         seg = [0]
         pending = [len(b[2]) for b in self.reducer.buckets] if self.reducer is not None else []
 
+        final_now = set()
+
         def on_ready(p):
+            final_now.add(index_of.get(id(p)))
             if self.reducer is None:
                 return
             bi = self.reducer._bucket_of.get(id(p))
@@ -226,11 +273,30 @@ class GraphedStep:
                     self.bucket_sched[seg[0]].append(bi)
         engine.set_grad_ready_hook(on_ready)
 
+        guard_done = [False]
+
+        def guard():                          # the device scalar the update is scaled by (0 = skip): needs the losses only
+            if not guard_done[0]:
+                ops.step_guard(self.loss_image_dev, self.loss_audio_dev, None, None, 1.0, self.step_scale, self.bad_steps)
+                guard_done[0] = True
+
         def layer_cb(l):
             if l in self.cuts:
                 self.graphs[seg[0]].capture_end()
                 seg[0] += 1
                 self.graphs[seg[0]].capture_begin(pool=self.graphs[0].pool(), capture_error_mode=CAPTURE_MODE)
+            if self.early and self.early_ranges.get(l):
+                # every stream of the backward is joined at a layer boundary and the layer's weight gradients are launched on
+                # this stream (autograd_bridge.encoder_bwd): whatever was reported final is final in stream order here
+                for r in self.early_ranges[l]:
+                    missing = [i for i in range(r['first'], r['first'] + r['n']) if i not in final_now]
+                    assert not missing, ('gradients not final at cut', l, missing[:4])
+                cur = torch.cuda.current_stream()
+                self.opt_stream.wait_stream(cur)
+                with torch.cuda.stream(self.opt_stream):
+                    guard()
+                    for r in self.early_ranges[l]:
+                        self.opt.launch_range(r, keep_grad=self.keep_grad, gscale_dev=self.step_scale)
         cap = torch.cuda.Stream()
         cap.wait_stream(torch.cuda.current_stream())
         self.opt.flat.zero_grad()            # the AdamW pass leaves the gradients zeroed for the next replay
@@ -243,6 +309,15 @@ class GraphedStep:
         self._presq_ws = torch.zeros(1024, dtype=torch.float32, device=dev)
 
         def optimizer_pass():
+            if self.early:                       # what the backward did not take along: the first layers, the embeddings
+                torch.cuda.current_stream().wait_stream(self.opt_stream)
+                guard()
+                for r in self.late_ranges:
+                    self.opt.launch_range(r, keep_grad=self.keep_grad, gscale_dev=self.step_scale)
+                parts = [r['sumsq'] for rs in self.early_ranges.values() for r in rs] + [r['sumsq'] for r in self.late_ranges]
+                self.grad_norm = torch.cat(parts).sum().sqrt()
+                engine.invalidate_weight_cache(self.opt.flat.params)
+                return
             gnorm = None
             if self.clip_grad is not None:       # the clip factor needs the norm BEFORE the update: one extra read of the gradients
                 ops.l2norm(self.opt.flat.flat_g, self._presq, self._presq_ws, 1.0)
@@ -299,6 +374,7 @@ class GraphedStep:
         Li, La = self.model.image_gs[0] * self.model.image_gs[1], self.model.audio_gs[0] * self.model.audio_gs[1]
         noise_i, noise_a = torch.rand(B, Li, device=dev), torch.rand(B, La, device=dev)
         outs, tape, aux = self.bridge.avmae_fwd(self.model, self.image, self.audio, noise_i, noise_a)
+        self.loss_image_dev, self.loss_audio_dev = outs[0], outs[1]      # (the early AdamW passes' guard reads them inside the backward)
         one = torch.ones((), device=dev)
         self.bridge.avmae_bwd(self.model, tape, one, one, layer_cb=layer_cb)
         return outs[0], outs[1]

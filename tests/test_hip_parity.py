@@ -684,6 +684,47 @@ def test_written_first_gradients_equal_accumulated_ones(monkeypatch):
     assert rel(finals[0], finals[1]) < 2e-4
 
 
+def test_early_adamw_ranges_equal_the_single_pass(monkeypatch):
+    """DAV_EARLY_ADAMW=1 (opt-in, measured slower in the step: DESIGN.md section 4): the captured step runs AdamW on the ranges of
+    the flat buffer whose gradients are final at a few points of the backward, on a side stream, and on the rest at the end.
+    The update is element-wise: the same seeds must give the same parameters, moments, losses and gradient norm as the single
+    pass at the end — and every parameter must be covered exactly once."""
+    from deepavfusion_amd.util import lr_sched
+    from deepavfusion_amd.util.flat import FlatAdamW
+    from deepavfusion_amd.util.misc import GraphedStep, Trainer
+    finals, moments, losses, norms = [], [], [], []
+    for mode in ('0', '1'):
+        monkeypatch.setenv('DAV_EARLY_ADAMW', mode)
+        monkeypatch.setenv('DAV_EARLY_ADAMW_CUTS', '2,1')         # micro is 2 layers deep: after the decoders (2) and after layer 1
+        model, sd, cfg, O = _build('micro')
+        nd = [n for n, p in model.named_parameters() if 'bias' in n or 'norm' in n]
+        groups = lr_sched.param_groups_pretrained(model, 0.05, no_weight_decay_list=nd, image_pt='', audio_pt='')
+        opt = FlatAdamW(groups, lr=1e-3, betas=(0.9, 0.95), model=model)
+        tr = Trainer(model, optimizer=opt, accum_iter=1)
+        image, audio, _, _ = O.structured_batch(cfg, 64, seed=3)
+        image, audio = image.cuda(), audio.cuda()
+        torch.manual_seed(77)
+        gs = GraphedStep(tr, image.shape, audio.shape)
+        assert gs.early == (mode == '1')
+        if gs.early:
+            covered = sorted(i for rs in list(gs.early_ranges.values()) + [gs.late_ranges] for r in rs for i in range(r['first'], r['first'] + r['n']))
+            assert covered == list(range(len(opt.flat.params)))
+            assert sum(len(rs) for rs in gs.early_ranges.values()) >= 2 and sum(r['n'] for rs in gs.early_ranges.values() for r in rs) > len(covered) // 2
+        run = []
+        for s in range(5):
+            torch.manual_seed(500 + s)
+            li, la, gn = gs(image, audio)
+            run.append(float(li) + float(la))
+        torch.cuda.synchronize()
+        gs.check()
+        finals.append(opt.flat.flat_p.clone()); moments.append(opt.exp_avg_sq.clone()); losses.append(run); norms.append(float(gn))
+    assert all(np.isfinite(losses[1])) and losses[1][-1] < losses[1][0]
+    for a, b in zip(*losses):
+        assert abs(a - b) <= 1e-5 * abs(b), losses
+    assert abs(norms[0] - norms[1]) <= 1e-4 * norms[0], norms
+    assert rel(finals[1], finals[0]) < 2e-4 and rel(moments[1], moments[0]) < 2e-3      # (fp32 atomics in the bias gradients: not bit-equal)
+
+
 def test_trainer_skip_grad_drops_an_outlier_micro_step():
     """util/misc.py:81-104: with ``skip_grad`` a micro-step whose own gradient norm exceeds the limit is dropped — the gradients
     accumulated before it survive, the step counter of the accumulation does not advance — and a normal one is kept."""
