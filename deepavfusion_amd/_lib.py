@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, 'libdavfusion_hip.so')
 
 _p, _i, _l, _f, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 
-ABI_VERSION = 2      # DAV_ABI_VERSION of include/dav_kernels.h this package was written against (struct layouts, signatures)
+ABI_VERSION = 3      # DAV_ABI_VERSION of include/dav_kernels.h this package was written against (struct layouts, signatures)
 
 # name -> argtypes (must match include/dav_kernels.h)
 SIGNATURES = {
@@ -33,6 +33,7 @@ SIGNATURES = {
     'dav_attn_fwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _i, _l, _i, _l, _i, _l, _i, _f, _p],
     'dav_attn_bwd': [_p] * 10 + [_i] * 6 + [_l, _i] * 8 + [_f, _p],
     'dav_attn_bwd_part': [_p] * 10 + [_i] * 6 + [_l, _i] * 8 + [_f, _i, _p],
+    'dav_attn_bwd_ctx': [_p] * 10 + [_i] * 6 + [_l, _i] * 8 + [_f, _i, _i, _p],
     'dav_attn_bias_fwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _i, _l, _i, _l, _i, _l, _i, _f, _p, _i, _i, _p],
     'dav_attn_bias_bwd': [_p] * 10 + [_i] * 6 + [_l, _i] * 8 + [_f, _p, _i, _i, _p, _i, _p],
     'dav_window_unfold': [_p, _i, _p, _i, _i, _i, _i, _i, _i, _f, _p, _i, _p],

@@ -50,6 +50,10 @@ struct AttnParams {
   // logits [B][H][Nq][bias_ld] in natural units, what the relative-position table's gradient is reduced from
   const float* bias; int bias_nb, bias_ld;
   float* dS;
+  // backward: the dQ buffer holds this many rows BEFORE the first query row of every batch element that belong to keys / values
+  // only (the fusion-token context rows of a fused qkv gradient, models/deepavfusion.py:104-105): the dQ kernel zero-fills this
+  // head's columns of them, which the qkv weight-gradient / input-gradient GEMMs read (dav_attn_bwd_ctx)
+  int dq_ctx;
 };
 
 // 16-byte-slot XOR swizzle of a row-major LDS tile, chosen so that BOTH access patterns are conflict-free:
@@ -377,6 +381,13 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, const int bh,
 // QT query tiles per wave: each K / V fragment (and each transposed K fragment for dQ) read from LDS feeds QT MFMAs.
 template <int DQK, int DV, bool CHUNKED, int QT = 1>
 __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int bh, const int ychunk) {
+  if (p.dq_ctx > 0 && (CHUNKED ? ychunk == 0 : true)) {      // this head's dQ slots of the context-only rows (see AttnParams::dq_ctx)
+    const int b_ = bh / p.H, h_ = bh % p.H, cpr = DQK / 8;
+    for (int c = threadIdx.x; c < p.dq_ctx * cpr; c += blockDim.x) {
+      const int r = c / cpr, cc = c % cpr;
+      *reinterpret_cast<uint4*>(p.dQ + b_ * p.dq_bs + (long)(r - p.dq_ctx) * p.dq_rs + h_ * DQK + cc * 8) = uint4{0, 0, 0, 0};
+    }
+  }
   constexpr int DQKP = DQK < 32 ? 32 : DQK, KRB = DQKP * 2, KS = DQKP / 32, DVP = DV < 32 ? 32 : DV, VRB = DVP * 2, VS = DVP / 32, QC = DQK / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int Nkp = (p.Nk + 31) & ~31;
@@ -965,15 +976,16 @@ extern "C" int dav_attn_bwd(const void* Q, const void* K, const void* V, const v
                            o_bs, o_rs, do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, scale, 3, stream);
 }
 
-extern "C" int dav_attn_bias_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
-                                 float* Delta, void* dQ, void* dK, void* dV, int B, int H, int Nq, int Nk, int dqk, int dv,
-                                 long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs,
-                                 long do_bs, int do_rs, long dq_bs, int dq_rs, long dk_bs, int dk_rs, long dv_bs, int dv_rs,
-                                 float scale, const float* bias, int bias_nb, int bias_ld, float* dS, int part,
-                                 hipStream_t stream) {
-  if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0 || part < 1 || part > 3) return DAV_ERR_SHAPE;
+static int attn_bwd_any(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
+                        float* Delta, void* dQ, void* dK, void* dV, int B, int H, int Nq, int Nk, int dqk, int dv,
+                        long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs,
+                        long do_bs, int do_rs, long dq_bs, int dq_rs, long dk_bs, int dk_rs, long dv_bs, int dv_rs,
+                        float scale, const float* bias, int bias_nb, int bias_ld, float* dS, int dq_ctx_rows, int part,
+                        hipStream_t stream) {
+  if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0 || part < 1 || part > 3 || dq_ctx_rows < 0) return DAV_ERR_SHAPE;
   if (!bias_ok(bias, bias_nb, bias_ld, dS, B, Nk)) return DAV_ERR_SHAPE;
   AttnParams p = {};
+  p.dq_ctx = dq_ctx_rows;
   p.debug = attn_debug();
   { static const int pr = [] { const char* e = getenv("DAV_ATTN_PAIR"); return e ? atoi(e) : 1; }(); p.pair = pr; }
   p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.Of = (const bf16_t*)O; p.O = nullptr;
@@ -990,6 +1002,25 @@ extern "C" int dav_attn_bias_bwd(const void* Q, const void* K, const void* V, co
   if (dqk == 16 && dv == 64) return launch_bwd<16, 64>(p, stream, part);
   if (dqk == 16 && dv == 16) return launch_bwd<16, 16>(p, stream, part);
   return DAV_ERR_SHAPE;
+}
+
+extern "C" int dav_attn_bias_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
+                                 float* Delta, void* dQ, void* dK, void* dV, int B, int H, int Nq, int Nk, int dqk, int dv,
+                                 long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs,
+                                 long do_bs, int do_rs, long dq_bs, int dq_rs, long dk_bs, int dk_rs, long dv_bs, int dv_rs,
+                                 float scale, const float* bias, int bias_nb, int bias_ld, float* dS, int part,
+                                 hipStream_t stream) {
+  return attn_bwd_any(Q, K, V, O, dO, LSE, Delta, dQ, dK, dV, B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs,
+                      do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, scale, bias, bias_nb, bias_ld, dS, 0, part, stream);
+}
+
+extern "C" int dav_attn_bwd_ctx(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
+                                float* Delta, void* dQ, void* dK, void* dV, int B, int H, int Nq, int Nk, int dqk, int dv,
+                                long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs,
+                                long do_bs, int do_rs, long dq_bs, int dq_rs, long dk_bs, int dk_rs, long dv_bs, int dv_rs,
+                                float scale, int dq_ctx_rows, int part, hipStream_t stream) {
+  return attn_bwd_any(Q, K, V, O, dO, LSE, Delta, dQ, dK, dV, B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs,
+                      do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, scale, nullptr, 0, 0, nullptr, dq_ctx_rows, part, stream);
 }
 
 extern "C" int dav_attn_bwd_part(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,

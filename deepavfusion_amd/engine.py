@@ -498,8 +498,11 @@ def attention_fwd(q, k, v, B, H, Nq, Nk, dqk, dv, scale, q_bs, q_rs, k_bs, k_rs,
     return O, LSE
 
 
+_ATTN_CTX = os.environ.get('DAV_ATTN_CTX', '1') != '0'      # 0: a torch fill pass zeroes the context rows' dq slots (rounds 1-2)
+
+
 def attention_bwd(q, k, v, O, dO, LSE, dq, dk, dvv, B, H, Nq, Nk, dqk, dv, scale, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs,
-                  dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, part=3, Delta=None):
+                  dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, part=3, Delta=None, dq_ctx_rows=0):
     """``part`` 1 / 2: only the dQ (+ Delta) / only the dK-dV kernel, with the same ``Delta`` buffer passed to both calls
     (lets a caller put the two kernels of several attentions into two regions of a launch batch)."""
     if Delta is None:
@@ -507,7 +510,8 @@ def attention_bwd(q, k, v, O, dO, LSE, dq, dk, dvv, B, H, Nq, Nk, dqk, dv, scale
     ops.hold(q[0], k[0], v[0], dq[0], dk[0], dvv[0])
     p = lambda t: t[0].data_ptr() + t[0].element_size() * t[1]
     ops.attn_bwd(p(q), p(k), p(v), O, dO, LSE, Delta, p(dq), p(dk), p(dvv), B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs,
-                 v_bs, v_rs, Nq * H * dv, H * dv, Nq * H * dv, H * dv, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, scale, part=part)
+                 v_bs, v_rs, Nq * H * dv, H * dv, Nq * H * dv, H * dv, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, scale, part=part,
+                 dq_ctx_rows=dq_ctx_rows)
 
 
 def to_bf16(x):
@@ -589,13 +593,16 @@ def block_bwd_head(blk, t, g2, g2b, idle_before_attn=0):
     do = lin_bwd(blk.attn.proj, g1b, t['o'], Mq)
     lane_skip(idle_before_attn)         # batched beside a fusion block: line the attention backward up with its cross-attentions
     dqkv = _e((M, 3 * D), BF16, dev)
-    if nF > 0:      # attention writes dq for the modality rows and dk / dv for all rows: only the (dropped) queries of the
-        dqkv.view(B, R, 3 * D)[:, :nF, :D].zero_()      # fusion context rows are never written and must read as zero
+    # attention writes dq for the modality rows and dk / dv for all rows: only the (dropped) queries of the fusion context rows
+    # are never written and must read as zero — the dQ kernel fills them (dav_attn_bwd_ctx; the fp32 kernels have no such entry)
+    ctx_in_kernel = PRECISION != 'fp32' and _ATTN_CTX
+    if nF > 0 and not ctx_in_kernel:
+        dqkv.view(B, R, 3 * D)[:, :nF, :D].zero_()
     qkv = t['qkv']
     attention_bwd((qkv, nF * 3 * D), (qkv, D), (qkv, 2 * D), t['o'], do, t['lse'],
                   (dqkv, nF * 3 * D), (dqkv, D), (dqkv, 2 * D), B, heads, n, R, hd, hd, hd ** -0.5,
                   R * 3 * D, 3 * D, R * 3 * D, 3 * D, R * 3 * D, 3 * D,
-                  R * 3 * D, 3 * D, R * 3 * D, 3 * D, R * 3 * D, 3 * D)
+                  R * 3 * D, 3 * D, R * 3 * D, 3 * D, R * 3 * D, 3 * D, dq_ctx_rows=nF if ctx_in_kernel else 0)
     dh1 = lin_bwd(blk.attn.qkv, dqkv, t['h1'], M)
     return dict(dh1=dh1, g1=g1)
 

@@ -230,13 +230,21 @@ def relpos_bias_bwd(dS, index32, Bw, H, A, N, ld, T, dtable):
 
 
 def attn_bwd(q_ptr, k_ptr, v_ptr, O, dO, LSE, Delta, dq_ptr, dk_ptr, dv_ptr, B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs,
-             v_bs, v_rs, o_bs, o_rs, do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, scale, part=3):
-    """part 1: dQ (+ Delta) kernel only, 2: dK/dV kernel only (after part 1), 3: both."""
+             v_bs, v_rs, o_bs, o_rs, do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, scale, part=3, dq_ctx_rows=0):
+    """part 1: dQ (+ Delta) kernel only, 2: dK/dV kernel only (after part 1), 3: both.  dq_ctx_rows (bf16 path): rows in front of
+    the first query row of every batch element of the dQ buffer whose dqk columns the dQ kernel zero-fills (dav_attn_bwd_ctx)."""
     lib = _lib.load()
     if O.dtype == F32:
+        if dq_ctx_rows:
+            raise RuntimeError('dq_ctx_rows: bf16 path only')
         _lib.check(lib.dav_attn_bwd_f32(q_ptr, k_ptr, v_ptr, _ptr(O), _ptr(dO), _ptr(LSE), _ptr(Delta), dq_ptr, dk_ptr, dv_ptr,
                                         B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, do_bs, do_rs,
                                         dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, float(scale), part, _stream()), 'dav_attn_bwd_f32')
+        return
+    if dq_ctx_rows:
+        _lib.check(lib.dav_attn_bwd_ctx(q_ptr, k_ptr, v_ptr, _ptr(O), _ptr(dO), _ptr(LSE), _ptr(Delta), dq_ptr, dk_ptr, dv_ptr,
+                                        B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, do_bs, do_rs,
+                                        dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, float(scale), int(dq_ctx_rows), part, _stream()), 'dav_attn_bwd_ctx')
         return
     _lib.check(lib.dav_attn_bwd_part(q_ptr, k_ptr, v_ptr, _ptr(O), _ptr(dO), _ptr(LSE), _ptr(Delta), dq_ptr, dk_ptr, dv_ptr,
                                      B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, do_bs, do_rs,

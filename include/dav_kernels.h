@@ -37,7 +37,7 @@ typedef struct ihipStream_t* hipStream_t;
 extern "C" {
 #endif
 
-#define DAV_ABI_VERSION 2   /* 2: DavTnProblem.flags, dav_adamw_flat keep_grad + gscale_dev, dav_step_guard */
+#define DAV_ABI_VERSION 3   /* 2: DavTnProblem.flags, dav_adamw_flat keep_grad + gscale_dev, dav_step_guard; 3: dav_attn_bwd_ctx */
 int dav_abi_version(void);
 int dav_build_flags(void);   /* bit 0: experimental build (make EXPERIMENTAL=1): the rejected GEMM tile configurations exist */
 /* text of the last HIP error latched by a kernel launch of the calling thread (diagnostics) */
@@ -118,6 +118,15 @@ int dav_attn_bwd_part(const void* Q, const void* K, const void* V, const void* O
                  void* dQ, void* dK, void* dV, int B, int H, int Nq, int Nk, int dqk, int dv, long q_bs, int q_rs, long k_bs,
                  int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, long do_bs, int do_rs, long dq_bs, int dq_rs, long dk_bs,
                  int dk_rs, long dv_bs, int dv_rs, float scale, int part, hipStream_t stream);
+
+/* dav_attn_bwd_part for a query buffer that is the tail of a longer key / value buffer (the tower blocks' fused qkv: the fusion
+ * tokens are context rows — keys and values only, models/deepavfusion.py:104-105): dQ has dq_ctx_rows rows BEFORE its first query
+ * row in every batch element (dQ - dq_ctx_rows * dq_rs must be valid memory); the dQ kernel (part & 1) zero-fills the dqk columns
+ * of every head in them, so that the fused gradient buffer can go into the qkv GEMMs without a fill pass of its own. */
+int dav_attn_bwd_ctx(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, float* Delta,
+                 void* dQ, void* dK, void* dV, int B, int H, int Nq, int Nk, int dqk, int dv, long q_bs, int q_rs, long k_bs,
+                 int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, long do_bs, int do_rs, long dq_bs, int dq_rs, long dk_bs,
+                 int dk_rs, long dv_bs, int dv_rs, float scale, int dq_ctx_rows, int part, hipStream_t stream);
 
 /* Window attention of the Swin decoder blocks (models/swin.py:55-87; decoder_arch == 'swin', models/avmae.py:37-51): the same
  * kernels with an additive logit bias.  bias [bias_nb][H][Nq][bias_ld] fp32 in LOG2 units (natural value x log2 e), zero

@@ -333,6 +333,15 @@ def attention():
         report(tag + ' dq', rel(gq, q.grad), 2e-2)
         report(tag + ' dk', rel(gk, k.grad), 2e-2)
         report(tag + ' dv', rel(gv, v.grad), 2e-2)
+        if fused and qo > 0:
+            # dav_attn_bwd_ctx: the dQ kernel zero-fills the q slots of the qo context-only rows in front of the queries — into a
+            # buffer full of NaNs the whole fused gradient must come out equal to the one written into zeros above
+            dbuf2 = torch.full_like(buf, float('nan'))
+            ops.attn_bwd(p(qt), p(kt), p(vt), O, dO, LSE, Delta, dbuf2.data_ptr() + 2 * qt[1], dbuf2.data_ptr() + 2 * kt[1],
+                         dbuf2.data_ptr() + 2 * vt[1], B, H, Nq, Nk, dqk, dv, *strides, Nq * H * dv, H * dv, Nq * H * dv, H * dv,
+                         *strides, scale, dq_ctx_rows=qo)
+            same = torch.equal(dbuf2, dbuf) and float(dbuf2[:, :qo, 0].abs().max()) == 0.0
+            report(tag + f' ctx rows {qo}', 0.0 if same else 1.0, 1e-9)
 
 
 @check
