@@ -47,16 +47,17 @@ struct NTParams {
   int force_cfg;                 // host side only: tile configuration asked for explicitly (0 = chosen per group at issue time)
 };
 
-struct TNParams {
+struct TNParams {                     // (pointers first: 96 bytes, 40 of them fit the grouped kernels' by-value table)
   const bf16_t* A; const bf16_t* B;   // A[Mc, N] (lda), B[Mc, K] (ldb)
-  int Mc, N, K, lda, ldb;
+  float* C;                           // fp32 [N, K] (ldc)
+  float* bias_grad;                   // optional: column sums of A accumulated into [N]
+  int Mc, N, K, lda, ldb, ldc;
   RowMap amap, bmap;
-  float* C; int ldc;                  // fp32 [N, K]
   int beta;                           // 0: overwrite (only legal with splits == 1), 1: accumulate
   int splits;                         // split of the contraction over blockIdx.y (atomic accumulate)
-  float* bias_grad;                   // optional: column sums of A accumulated into [N]
   int debug_plain_store;              // timing experiments only: 1 (variant bit 8) plain stores instead of atomics; DAV_TN_DEBUG: 2 no epilogue, 4 no reads / MFMAs
 };
+static_assert(sizeof(TNParams) == 96, "TNParams layout");
 
 // ------------------------------------------------------------------------------------------------
 // NT kernel
@@ -1721,13 +1722,14 @@ __global__ __launch_bounds__(WM_* WN_ * 64, WM_ * WN_ <= 4 ? 2 : 1) void gemm_tn
 
 // grouped launch: up to TN_GROUP_MAX independent weight-gradient problems in ONE grid (the deferred wgrads of a
 // whole layer), each workgroup looks its (problem, tile, split) up from the by-value table
-constexpr int TN_GROUP_MAX = 32;
+constexpr int TN_GROUP_MAX = 40;      // (the table travels by value in the kernel arguments: 40 x 96 bytes + bookkeeping stays below the 4 KB they may take)
 struct TNGroup {
   TNParams prob[TN_GROUP_MAX];
   int first_block[TN_GROUP_MAX + 1];
   int count;
   int xcd_runs;                       // 1: every XCD owns one contiguous run of each problem's (split, tile) units
 };
+static_assert(sizeof(TNGroup) <= 4096, "kernel argument block");
 
 template <int T, int WM_, int WN_, int RS = 64, int NST = 2, int MINW = 1>
 __global__ __launch_bounds__(WM_* WN_ * 64, MINW) void gemm_tn_grouped_kernel(const TNGroup g) {
@@ -1980,7 +1982,7 @@ extern "C" int dav_gemm_tn_grouped_bf16(const DavTnProblem* probs, int count, hi
   // and the fp32 atomics of the split tiles (one dword per lane and instruction) cost 440-900 us per launch.
   static const bool tn256 = [] { const char* e = getenv("DAV_TN256"); return e && e[0] == '1'; }();
   static const long tn256_min = getenv("DAV_TN256_MIN") ? atol(getenv("DAV_TN256_MIN")) : 512;      // K-tile pairs below which the old kernel runs
-  if (tn256) {
+  if (tn256 && count <= TN256_MAX) {
     TN256Group g2;
     long units = 0;
     for (int i = 0; i < count; ++i) {

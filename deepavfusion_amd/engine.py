@@ -314,6 +314,20 @@ def wgrad_overwrite_end():
     return list(st['params'].values()) if st else []
 
 
+def deferred_operands_to(stream):
+    """The queued weight-gradient problems will be launched on ``stream`` although their operands were allocated while another
+    stream was current: tell the caching allocator, so that a block is not handed out again on its home stream while the
+    weight-gradient kernel may still be reading it."""
+    for pr in (_DEFERRED or []):
+        for k in ('A', 'B'):
+            t = pr.get(k)
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(stream)
+    for item in (_DEFERRED_LN or []):          # (workspace of partial rows, dgamma, dbeta, rows, D)
+        if torch.is_tensor(item[0]) and item[0].is_cuda:
+            item[0].record_stream(stream)
+
+
 def flush_wgrads():
     """Launch the queued weight-gradient problems on the current stream (their operands must be complete on it)."""
     if _DEFERRED_LN:

@@ -154,6 +154,9 @@ def gemm_tn(A, B, Mc, N, K, C_out, *, lda=None, ldb=None, ldc=None, a_rowmap=Non
                                     _ptr(bias_grad), variant, _stream()), 'dav_gemm_tn_bf16')
 
 
+TN_GROUP_MAX = 40          # dav_gemm_tn_grouped_bf16: problems per launch
+
+
 def gemm_tn_grouped(problems):
     """problems: list of dicts(A, B, Mc, N, K, C, lda, ldb, ldc, a_rowmap, b_rowmap, bias_grad[, overwrite]); see
     dav_gemm_tn_grouped_bf16 (overwrite: C is written instead of accumulated, DavTnProblem.flags bit 0)."""
@@ -164,8 +167,12 @@ def gemm_tn_grouped(problems):
                     a_rowmap=d.get('a_rowmap'), b_rowmap=d.get('b_rowmap'), beta=0 if d.get('overwrite') else 1,
                     bias_grad=d.get('bias_grad'))
         return
-    for i in range(0, len(problems), 32):
-        chunk = problems[i:i + 32]
+    # more than one launch (40 problems each at most): deal the list out in turns, so that every launch gets its share of the long
+    # and of the short contractions — cut consecutively, 68 problems became 32 long + 32 medium + 4 small ones whose ~100 tiles
+    # had the 512 workgroup slots to themselves for a whole contraction
+    n_launch = (len(problems) + TN_GROUP_MAX - 1) // TN_GROUP_MAX
+    for i in range(n_launch):
+        chunk = problems[i::n_launch]
         arr = (_lib.DavTnProblem * len(chunk))()
         for q, d in zip(arr, chunk):
             q.A, q.B, q.C, q.bias_grad = _ptr(d['A']), _ptr(d['B']), _ptr(d['C']), _ptr(d.get('bias_grad'))

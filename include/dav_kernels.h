@@ -86,7 +86,7 @@ int dav_gemm_tn_bf16(const void* A, const void* B, int Mc, int N, int K, int lda
 
 /* Several weight-gradient problems (C_i[N_i,K_i] += A_i^T . B_i, optional bias_grad_i) in ONE launch — the deferred
  * wgrads of a whole layer — so that every 128x128 output tile is owned by one workgroup over (most of) its
- * contraction: no or very few split-K atomics.  count <= 32; every Mc_i % 64 == 0.  Row maps as above
+ * contraction: no or very few split-K atomics.  count <= 40; every Mc_i % 64 == 0.  Row maps as above
  * ({0,0,0} = identity).  The table is read on the host during the call only. */
 typedef struct DavTnProblem {
   const void* A; const void* B;       /* bf16 [Mc, N] (lda), bf16 [Mc, K] (ldb) */

@@ -27,7 +27,8 @@ for li in which:
             d['overwrite'] = True
         probs.append(d)
     fl = sum(2.0 * Mc * N * K for (Mc, N, K) in shapes)
-    chunks = [probs[i:i + 32] for i in range(0, len(probs), 32)]
+    n_l = (len(probs) + 39) // 40
+    chunks = [probs[i::n_l] for i in range(n_l)]
 
     def run():
         for c in chunks:
