@@ -33,6 +33,7 @@ SIGNATURES = {
     'dav_attn_fwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _i, _l, _i, _l, _i, _l, _i, _f, _p],
     'dav_attn_bwd': [_p] * 10 + [_i] * 6 + [_l, _i] * 8 + [_f, _p],
     'dav_attn_bwd_part': [_p] * 10 + [_i] * 6 + [_l, _i] * 8 + [_f, _i, _p],
+    'dav_add_cast': [_p, _p, _p, _p, _l, _p],
     'dav_attn_bwd_ctx': [_p] * 10 + [_i] * 6 + [_l, _i] * 8 + [_f, _i, _i, _p],
     'dav_attn_bias_fwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _i, _l, _i, _l, _i, _l, _i, _f, _p, _i, _i, _p],
     'dav_attn_bias_bwd': [_p] * 10 + [_i] * 6 + [_l, _i] * 8 + [_f, _p, _i, _i, _p, _i, _p],

@@ -229,7 +229,12 @@ def _encoder_bwd(enc, t, dxi_b, dxa_b, dxf_b, dxi32, dxa32, dxf32, layer_cb=None
                                           before_ln1=lambda: main.wait_stream(sf))
             main.wait_stream(sa)
             main.wait_stream(sf)
-            g_f, g_fb = (dx_f + dxf_a) if sa is not main else dx_f.add_(dxf_a), None
+            if sa is main:
+                g_f, g_fb = dx_f.add_(dxf_a), None
+            elif _ADD_CAST and E.PRECISION != 'fp32' and dx_f.is_contiguous() and dxf_a.is_contiguous() and dx_f.numel() % 4 == 0:
+                g_f, g_fb = ops.add_cast(dx_f, dxf_a)          # the sum and the next block's bf16 operand in one pass
+            else:
+                g_f, g_fb = dx_f + dxf_a, None
         del hold
         E.flush_wgrads()          # every wgrad of this layer (both towers + fusion block) as one grouped GEMM
         if layer_cb is not None and l > 0:
@@ -420,6 +425,7 @@ def avmae_fwd(model, image, audio, noise_i, noise_a):
 
 
 _DEC_WGRAD_JOINT = os.environ.get('DAV_DEC_WGRAD_JOINT', '1') != '0'
+_ADD_CAST = os.environ.get('DAV_ADD_CAST', '1') != '0'
 
 
 def avmae_bwd(model, t, g_li, g_la, g_pi=None, g_pa=None, layer_cb=None):

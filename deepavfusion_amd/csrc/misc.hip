@@ -300,6 +300,17 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* x, bf16_t* 
     reinterpret_cast<uint2*>(y)[i] = w;
   }
 }
+// out = a + b (fp32) together with its bf16 copy: the sum of the fusion tokens' two gradient streams at a layer boundary and the
+// GEMM operand of the next block's backward in one pass (was: a torch add, then dav_cast_bf16)
+__global__ __launch_bounds__(256) void add_cast_kernel(const float* a, const float* b, float* out, bf16_t* out_bf16, long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+    const float4 r = float4{x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w};
+    reinterpret_cast<float4*>(out)[i] = r;
+    uint2 w; w.x = pack2bf(r.x, r.y); w.y = pack2bf(r.z, r.w);
+    reinterpret_cast<uint2*>(out_bf16)[i] = w;
+  }
+}
 __global__ __launch_bounds__(256) void cast_bf16_tail_kernel(const float* x, bf16_t* y, long start, long n) {
   const long i = start + blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) y[i] = f2bf(x[i]);
@@ -579,6 +590,15 @@ extern "C" int dav_cast_bf16(const float* x, void* y_bf16, long n, hipStream_t s
     DAV_LAUNCH(cast_bf16_kernel, dim3((int)g), dim3(256), 0, stream, x, (bf16_t*)y_bf16, n4);
   }
   if (n & 3) DAV_LAUNCH(cast_bf16_tail_kernel, dim3(1), dim3(64), 0, stream, x, (bf16_t*)y_bf16, n4 << 2, n);
+  return dav_launch_status();
+}
+
+extern "C" int dav_add_cast(const float* a, const float* b, float* out, void* out_bf16, long n, hipStream_t stream) {
+  if (n <= 0 || (n & 3)) return DAV_ERR_SHAPE;
+  if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15 || ((uintptr_t)out_bf16 & 7)) return DAV_ERR_ALIGN;
+  const long n4 = n >> 2;
+  long g = (n4 + 255) / 256; g = g > 8192 ? 8192 : g;
+  DAV_LAUNCH(add_cast_kernel, dim3((int)g), dim3(256), 0, stream, a, b, out, (bf16_t*)out_bf16, n4);
   return dav_launch_status();
 }
 

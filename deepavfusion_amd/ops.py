@@ -431,6 +431,15 @@ def adamw_flat(p, g, m, v, p_bf16, seg_end, hyper, nseg, beta1, beta2, eps, bias
                                   int(zero_grad), _ptr(keep_grad), _ptr(gscale_dev), _stream()), 'dav_adamw_flat')
 
 
+def add_cast(a, b):
+    """(a + b as fp32, the same as bf16) in one pass (dav_add_cast); a, b: contiguous fp32 of the same shape, numel % 4 == 0."""
+    lib = _lib.load()
+    out = torch.empty_like(a)
+    out_b = torch.empty(a.shape, dtype=BF16, device=a.device)
+    _lib.check(lib.dav_add_cast(_ptr(a), _ptr(b), _ptr(out), _ptr(out_b), a.numel(), _stream()), 'dav_add_cast')
+    return out, out_b
+
+
 def step_guard(loss_a, loss_b, gnorm, clip, grad_scale, out_scale, bad_count):
     """Device-side replacement of train.py:166-167 / util/misc.py:118-120 for a captured step (dav_step_guard)."""
     lib = _lib.load()

@@ -37,7 +37,7 @@ typedef struct ihipStream_t* hipStream_t;
 extern "C" {
 #endif
 
-#define DAV_ABI_VERSION 3   /* 2: DavTnProblem.flags, dav_adamw_flat keep_grad + gscale_dev, dav_step_guard; 3: dav_attn_bwd_ctx */
+#define DAV_ABI_VERSION 3   /* 2: DavTnProblem.flags, dav_adamw_flat keep_grad + gscale_dev, dav_step_guard; 3: dav_attn_bwd_ctx, dav_add_cast */
 int dav_abi_version(void);
 int dav_build_flags(void);   /* bit 0: experimental build (make EXPERIMENTAL=1): the rejected GEMM tile configurations exist */
 /* text of the last HIP error latched by a kernel launch of the calling thread (diagnostics) */
@@ -225,6 +225,10 @@ int dav_pair_reduce(const void* d_bf16, int B, int nv, int na, int Wd, void* dPv
 
 /* ---- casts, grad norm, optimizer ----------------------------------------------------------- */
 int dav_cast_bf16(const float* x, void* y_bf16, long n, hipStream_t stream);
+/* out = a + b (fp32, n % 4 == 0) and out_bf16 = bf16(out) in one pass: the gradient w.r.t. the fusion tokens is the sum of what the
+ * image tower and the audio tower return (models/deepavfusion.py:104-105 feeds the same tokens to both), and the next block's
+ * backward wants it in both precisions.  (ABI 3) */
+int dav_add_cast(const float* a, const float* b, float* out, void* out_bf16, long n, hipStream_t stream);
 int dav_cast_transpose_bf16(const float* x, void* y_bf16, int R, int C, hipStream_t stream);   /* y[c,r] = x[r,c] */
 /* get_grad_norm_ (util/misc.py:151-163) over one flat fp32 buffer: out = scale * ||x||_2 */
 size_t dav_l2norm_workspace_bytes(long n);

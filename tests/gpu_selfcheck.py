@@ -562,6 +562,10 @@ def misc_kernels():
     y = torch.empty(1000, 77, device=dev, dtype=BF16)
     ops.cast_bf16(x, y)
     report('cast_bf16 exact', float((y != x.to(BF16)).sum()), 0.0)
+    for shape in [(64, 16, 768), (3, 5, 128), (1, 4)]:
+        a, b = rnd(*shape, seed=91), rnd(*shape, seed=92)
+        o32, ob = ops.add_cast(a, b)
+        report(f'add_cast {shape}', float((o32 != a + b).sum()) + float((ob != (a + b).to(BF16)).sum()), 0.0)
     yt = torch.empty(77, 1000, device=dev, dtype=BF16)
     ops.cast_transpose_bf16(x, yt)
     report('cast_transpose exact', float((yt != x.t().to(BF16)).sum()), 0.0)
