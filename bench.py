@@ -71,9 +71,26 @@ def _spawn_ranks(n):
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out = procs[0].communicate()[0].decode()
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out)
+    # rank 0's stdout is read by a thread while ALL children are polled: a rank that dies before the rendezvous would leave the
+    # others (and a blocking communicate() on rank 0) waiting forever — kill the rest as soon as any rank exits non-zero
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rcs = [None] * n
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+        if any(rc not in (None, 0) for rc in rcs):
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    p.kill()
+                    rcs[i] = p.wait()
+            break
+        time.sleep(0.2)
+    reader.join(timeout=10)
+    sys.stdout.write(b''.join(c for c in chunks if c).decode())
     sys.stdout.flush()
     return max(abs(rc) for rc in rcs)
 

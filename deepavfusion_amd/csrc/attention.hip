@@ -309,10 +309,14 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, const int bh,
         bf16x8 pf[QT];
 #pragma unroll
         for (int u = 0; u < QT; ++u) {
-          float mx = max3_raw(st[u][0][0], st[u][0][1], st[u][0][2]);
-          mx = max3_raw(mx, st[u][0][3], st[u][1][0]);
-          mx = max3_raw(mx, st[u][1][1], st[u][1][2]);
-          mx = max_raw(mx, st[u][1][3]);
+          // The FIRST maximum is a compiler-visible op reading one register of EACH of the two score MFMAs: hipcc pads nothing
+          // inside an asm statement, so an asm v_max3 as the first reader of an MFMA result would rely on whatever happens to
+          // sit between the two (advisor finding, round 3); after this op both results are architecturally complete and the asm
+          // chain below (which depends on it) may read the rest.  Under -fno-honor-nans it is ONE v_max_f32 (no quieting pair).
+          float mx = __builtin_fmaxf(st[u][0][0], st[u][1][0]);
+          mx = max3_raw(mx, st[u][0][1], st[u][0][2]);
+          mx = max3_raw(mx, st[u][0][3], st[u][1][1]);
+          mx = max3_raw(mx, st[u][1][2], st[u][1][3]);
           mx = rows_max(mx) * mul;       // log2 domain (scale * log2(e) > 0 commutes with max)
           // deferred rescale: keep the reference max while no row's tile max exceeds it by more than 2^8 — the
           // probabilities then stay <= 256 (bf16 keeps its relative precision), O and the row sum need no multiply

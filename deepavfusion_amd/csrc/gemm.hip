@@ -1850,7 +1850,9 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
   }
   if (vec_ok && !(variant & 15)) {
     if (cfg == 0) cfg = nt_auto_config(M, N, K);
+#ifdef DAV_EXPERIMENTAL
     if (cfg == 3 && nt_ld_on()) cfg = 51;
+#endif
     if (cfg == 60 && !nt256_ok(p)) return DAV_ERR_SHAPE;
     switch (cfg) {
       case 60: launch_nt256<false>(p, stream); return dav_launch_status();

@@ -30,14 +30,17 @@ class Compose(torch.nn.Module):
 
 class RandomVol(torch.nn.Module):
     """util/audio_transforms.py:8-17: a random gain in dB, then clamp to [-1, 1].  The reference applies this transform per
-    SAMPLE inside the dataset (one draw per call on a [channels, samples] waveform); on a batch [B, samples] (the GPU front-end
-    of this package) every sample therefore gets its own draw."""
-    def __init__(self, gain=(-6, 6)):
+    SAMPLE inside the dataset: ONE draw per call, whatever the waveform's shape ([samples] or [channels, samples] — a stereo
+    clip gets one gain for both channels).  ``per_sample=True`` (set by the GPU front-end of this package, which transforms a
+    whole batch [B, samples] at once) draws one gain per row of the first dimension instead — what B per-sample calls would
+    have drawn.  The mode is explicit: [channels, samples] and [B, samples] cannot be told apart by shape."""
+    def __init__(self, gain=(-6, 6), per_sample=False):
         super().__init__()
         self.gain = gain
+        self.per_sample = per_sample
 
     def forward(self, waveform):
-        if waveform.dim() >= 2 and waveform.shape[0] > 1:        # a batch: one gain per sample, as per-sample calls would draw
+        if self.per_sample and waveform.dim() >= 2:
             g = torch.tensor([random.uniform(self.gain[0], self.gain[1]) for _ in range(waveform.shape[0])],
                              dtype=waveform.dtype, device=waveform.device).view(-1, *([1] * (waveform.dim() - 1)))
             return torch.clamp(waveform * torch.pow(10.0, g / 20.0), -1, 1)

@@ -97,6 +97,12 @@ class Trainer:
         if skip_grad is not None:
             if self.flat is None:
                 raise NotImplementedError('skip_grad needs the flat gradient buffer (FlatAdamW)')
+            if self.distributed and self.accum_iter > 1:
+                # the set-aside gradients of earlier no_sync micro-steps were never reduced and the per-rank "norm > skip_grad"
+                # decision can differ between ranks (different accums -> collectives out of step): the reference has the same
+                # flaw (util/misc.py:81-104 under DDP); refuse instead of training ranks on different gradients
+                raise NotImplementedError('skip_grad with data-parallel gradient accumulation (accum_iter > 1) is not supported: '
+                                          'ranks would step with different gradients')
             if self.flat.stale and self.accums == 0:         # kept gradients of a replayed captured step: nothing of value in the buffer
                 self.flat.zero_grad()
             backup = self.flat.flat_g.clone()
@@ -166,7 +172,12 @@ class GraphedStep:
     ``segments`` consecutive graphs that share one memory pool — [forward + decoders' backward], then equal groups of
     encoder layers, last to first — and after each replayed segment the gradient buckets that segment
     completed (known from capture time) are all-reduced on the comm stream, i.e. overlapped with the next segment;
-    grad norm + AdamW form a last graph behind the final reduction.  Collectives themselves are never captured."""
+    grad norm + AdamW form a last graph behind the final reduction.  Collectives themselves are never captured.
+
+    Non-finite guard: a replay whose loss (or clipped norm) is not finite leaves parameters / moments untouched ON THE DEVICE, but
+    the host-side counters still advance for it (``n_steps``, Adam's step count and bias corrections in ``prepare_step``): a run
+    is NOT meant to continue past such a step — ``check()`` raises (train.py calls it every print_freq steps, at the end of every
+    epoch and before every checkpoint), exactly where the reference raises on the step itself (train.py:166-167)."""
 
     def __init__(self, trainer: Trainer, image_shape, audio_shape, warmup: int = 2, segments: int = 0, clip_grad=None):
         """``clip_grad``: max global gradient norm (``opt.clip_grad``; util/misc.py:118-120) — the norm is then taken in a

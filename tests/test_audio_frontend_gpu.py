@@ -63,12 +63,17 @@ def test_pad_randomvol_and_other_geometries():
     assert float(inside.max() - inside.min()) < 1e-5 and 0.5 <= float(inside.mean()) <= 2.0      # one gain in [-6, 6] dB
     # a batch gets one gain PER SAMPLE (the reference applies the transform per sample inside its dataset)
     wb = (0.05 * torch.randn(6, 4000)).clamp(-1, 1)
-    vb = aT.RandomVol()(wb.cuda()).cpu()
+    vb = aT.RandomVol(per_sample=True)(wb.cuda()).cpu()
     gains = [float((vb[i] / wb[i])[wb[i].abs() > 1e-3].median()) for i in range(6)]
     for i in range(6):
         r = (vb[i] / wb[i])[wb[i].abs() > 1e-3]
         assert float(r.max() - r.min()) < 1e-4 and 0.5 <= gains[i] <= 2.0
     assert max(gains) - min(gains) > 1e-3
+    # default mode: ONE draw per call whatever the shape (a stereo [2, samples] clip gets one gain, as in the reference)
+    st = (0.05 * torch.randn(2, 4000)).clamp(-1, 1)
+    vs = aT.RandomVol()(st.cuda()).cpu()
+    gs = [float((vs[i] / st[i])[st[i].abs() > 1e-3].median()) for i in range(2)]
+    assert abs(gs[0] - gs[1]) < 1e-5
     # another rate / mel count (8 kHz, 64 mels): n_fft 400, hop 125
     w8 = (0.3 * torch.randn(3, 12000)).clamp(-1, 1)
     _check(aT.LogMelSpectrogram(sample_rate=8000, n_mels=64).cuda()(w8.cuda()), A.log_mel(w8, 8000, 64))

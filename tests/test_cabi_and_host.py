@@ -356,3 +356,93 @@ def test_bench_starts_its_own_ranks_when_launched_plainly():
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     assert d['dry'] and d['world'] == 4 and d['rank'] == 0 and d['master'] == '127.0.0.1' and d['port'] > 0 and d['argv_gpus'] == 4
+
+
+def _asm_first_readers(asm_text):
+    """-> (checked, offenders): inline-asm VALU instructions that read a register of the most recent (program order) MFMA result
+    with NO compiler-visible VALU reader of that same result earlier IN THE SAME BASIC BLOCK.  The compiler pads ITS OWN first
+    reader (s_nop) and looks through branches when it does; an asm statement gets nothing (CDNA4 guide section 5.7 item 2)."""
+    def regs(tok):
+        tok = tok.strip().rstrip(',')
+        m = re.fullmatch(r'v\[(\d+):(\d+)\]', tok)
+        if m:
+            return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.fullmatch(r'v(\d+)', tok)
+        return {int(m.group(1))} if m else set()
+    checked, offenders = 0, []
+    writers = []            # [registers of an MFMA result, seen-a-compiler-reader flag], program order within a kernel
+    in_asm = False
+    for line in asm_text.splitlines():
+        t = line.strip()
+        if t.startswith('.amdhsa_kernel'):
+            writers = []
+        if t.startswith(';;#ASMSTART'):
+            in_asm = True
+            continue
+        if t.startswith(';;#ASMEND'):
+            in_asm = False
+            continue
+        if t.endswith(':') or t.startswith('s_cbranch') or t.startswith('s_branch'):
+            for w in writers:          # a new basic block: a reader on another path protects nothing here
+                w[1] = False
+            continue
+        if not t or t[0] in '.;':
+            continue
+        op, _, rest = t.partition(' ')
+        toks = rest.split(';')[0].split(',')
+        if op.startswith('v_mfma'):
+            d = regs(toks[0])
+            writers = [w for w in writers if not (w[0] & d)] + [[d, False]]
+            writers = writers[-64:]
+            continue
+        if not op.startswith('v_'):
+            continue
+        src = set().union(*[regs(x) for x in toks[1:]]) if len(toks) > 1 else set()
+        dst = regs(toks[0])
+        for w in writers:
+            if w[0] & src:
+                if in_asm:
+                    checked += 1
+                    if not w[1]:
+                        offenders.append(t)
+                else:
+                    w[1] = True
+        writers = [w for w in writers if not (w[0] & dst and not (w[0] & src))] if dst else writers
+    return checked, offenders
+
+
+def test_isa_audit_no_inline_asm_is_the_first_reader_of_an_mfma_result():
+    """Compile csrc/attention.hip to gfx950 assembly and require that no inline-asm VALU instruction is the first reader of an
+    MFMA result (advisor finding, round 3: the raw v_max3 chain of the softmax used to be; its head is now a plain
+    __builtin_fmaxf over one register of each score MFMA, which hipcc pads).  The checker is validated on two synthetic
+    snippets: the hazardous form must be flagged, the protected form must pass."""
+    bad = """
+	.amdhsa_kernel k
+	v_mfma_f32_16x16x32_bf16 v[2:5], v[2:5], v[6:9], 0
+	s_cbranch_scc1 .L1
+	;;#ASMSTART
+	v_max3_f32 v1, v2, v3, v4
+	;;#ASMEND
+"""
+    good = """
+	.amdhsa_kernel k
+	v_mfma_f32_16x16x32_bf16 v[2:5], v[2:5], v[6:9], 0
+	s_nop 7
+	v_max_f32_e32 v1, v2, v6
+	;;#ASMSTART
+	v_max3_f32 v1, v1, v3, v4
+	;;#ASMEND
+"""
+    assert _asm_first_readers(bad) == (1, ['v_max3_f32 v1, v2, v3, v4'])
+    assert _asm_first_readers(good) == (1, [])
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc')
+    csrc = os.path.join(ROOT, 'deepavfusion_amd', 'csrc')
+    asm = subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fno-honor-nans', f'-I{ROOT}/include', f'-I{csrc}', '-S',
+                          '--cuda-device-only', '-o', '-', os.path.join(csrc, 'attention.hip')], capture_output=True, text=True, timeout=300)
+    assert asm.returncode == 0, asm.stderr[-2000:]
+    checked, offenders = _asm_first_readers(asm.stdout)
+    assert checked > 0 and not offenders, offenders[:6]

@@ -111,6 +111,7 @@ def test_full_size_step_is_schedule_independent_and_repeatable():
     and every GEMM / LayerNorm / attention gradient bit for bit (no stream race, at the size where every tile configuration of
     the bench is live)."""
     from deepavfusion_amd import engine as E
+    from deepavfusion_amd import ops
     model, sd, cfg, O = _build('base')
     image, audio, ni, na = O.synthetic_batch(cfg, 64, seed=77)
     image, audio, ni, na = image.cuda(), audio.cuda(), torch.from_numpy(ni).cuda(), torch.from_numpy(na).cuda()
@@ -120,9 +121,16 @@ def test_full_size_step_is_schedule_independent_and_repeatable():
             E.set_batch_policy(policy)
             for p in model.parameters():
                 p.grad = None
+            if policy == 'on':
+                ops.nt_issue_log(True)
             out = model(image, audio, ni, na)
             (out[0] + out[1]).backward()
             torch.cuda.synchronize()
+            if policy == 'on':      # the shipped table was tuned on the merged tower groups of this workload: entries must fire there
+                hits = _tuned_hits(ops.nt_issue_log(with_flags=True))
+                ops.nt_issue_log(False)
+                if os.environ.get('DAV_NT_TUNE', '1') != '0' and E.FUSION_ON_STREAM:
+                    assert hits >= 12, hits
             runs.append((float(out[0]), float(out[1]), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
     finally:
         E.set_batch_policy({'1': 'on', '0': 'off'}.get(os.environ.get('DAV_BATCH', ''), 'auto'))
@@ -349,6 +357,26 @@ def test_baseline_config_video_base_vs_oracle():
     video, audio = O.synthetic_video_batch(cfg, 1, seed=44)
     outs = model(video.cuda(), audio.cuda())
     w, loss = _probe(outs, 45)
+    loss.backward()
+    sdo = {k: v.clone().requires_grad_(k not in O.FROZEN and not O.is_buffer(k)) for k, v in sd.items()}
+    ov = O.video_earlyfusion_forward(sdo, cfg, video, audio)
+    ref = sum((t * wi).sum() for t, wi in zip(ov, w))
+    ref.backward()
+    for got, r in zip(outs, ov):
+        assert rel(got, r) < ACT_TOL
+    assert abs(float(loss) - float(ref)) <= 1e-2 * abs(float(ref)) + 1e-2 * float(sum(float((t * t).sum()) for t in ov) ** 0.5)
+    _check_video_grads(model, sdo)
+
+
+@pytest.mark.timeout(900)
+def test_baseline_config_video_base_at_bench_batch_vs_oracle():
+    """BASELINE.json configs[4] at the batch its throughput is published at (profiles/*bench_video.json: B = 16 clips): the
+    launch mix of the timed step (grid sizes of the chunked 816-row attention, the tile configurations of the 13056-row GEMMs,
+    the grouped weight-gradient launches) against the oracle — outputs, probe loss and every gradient."""
+    model, sd, cfg, O = _build_video('video_base')
+    video, audio = O.synthetic_video_batch(cfg, 16, seed=46)
+    outs = model(video.cuda(), audio.cuda())
+    w, loss = _probe(outs, 47)
     loss.backward()
     sdo = {k: v.clone().requires_grad_(k not in O.FROZEN and not O.is_buffer(k)) for k, v in sd.items()}
     ov = O.video_earlyfusion_forward(sdo, cfg, video, audio)
@@ -1077,13 +1105,37 @@ def test_random_path_configurations_vs_oracle():
     assert ran >= 6 and not bad, bad[:8]
 
 
-@pytest.mark.parametrize('name,batch', [('base', 4), ('base', 64), ('base_as', 2), ('large', 2), ('base_swin', 2)])
+def _tuned_hits(issued):
+    """issued: ops.nt_issue_log(with_flags=True).  Launches whose signature (b_kn + sorted (M, N, K, epilogue flags)) is an entry of
+    the shipped tuned table (deepavfusion_amd/tuning/nt_gfx950.json) must have gone out with that entry's tile configuration;
+    returns how many did (csrc/gemm.hip nt_tuned_lookup)."""
+    import json
+    from deepavfusion_amd import _lib
+    table = {}
+    for e in json.load(open(_lib.NT_TUNING_PATH))['entries']:
+        table[(int(e['b_kn']),) + tuple(sorted(tuple(int(x) for x in q) for q in e['problems']))] = int(e['cfg'])
+    hits = 0
+    for cfg_id, bt, probs, flags in issued:
+        key = (int(bt),) + tuple(sorted((M, N, K, f) for (M, N, K), f in zip(probs, flags)))
+        if key in table:
+            assert cfg_id == table[key] or (table[key] == 60 and cfg_id == 3), (key, cfg_id, table[key])
+            hits += 1
+    return hits
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('name,batch', [('base', 4), ('base', 64), ('base_m75', 4), ('base_as', 2), ('base_as', 64), ('large', 2), ('large', 32),
+                                        ('base_swin', 2)])
 def test_baseline_config_shapes_vs_oracle(name, batch):
     """BASELINE.json configs[1] (ViT-B, attn_ratio 0.25 / mlp_ratio 1.0: the bench workload's model), configs[2] (ViT-B,
     AudioSet-style fusion widths: attn_ratio 1.0, mlp_ratio 4.0) and configs[3] (ViT-L) at their real widths and depths, at
     small batches (the oracle needs seconds of host time): masking indices, losses and every gradient.  ``base-64`` is the
     bench workload itself (B = 64 per GPU: the tile configurations, the tuned table and the grouped weight-gradient launches
-    of the timed step are live; the oracle takes about a minute of host time)."""
+    of the timed step are live; the oracle takes about a minute of host time).  ``base_m75-4`` is the bench's ``secondary``
+    workload (audio mask 0.75: 80 kept audio tokens — the metric string's "mask 0.75").  ``base_as-64`` and ``large-32`` are the
+    sizes profiles/*bench_base_as.json / *bench_large.json are timed at (round-3 review: the tuned table was tuned on exactly
+    those, other tile configurations and the 40-problem grouped weight-gradient launches are live there): for ``large-32`` the
+    issue log must show that entries of the shipped tuned table really fired."""
     from deepavfusion_amd import ops
     model, sd, cfg, O = _build(name)
     image, audio, ni, na = O.synthetic_batch(cfg, batch, seed=25)
@@ -1091,7 +1143,10 @@ def test_baseline_config_shapes_vs_oracle(name, batch):
     out = model(image.cuda(), audio.cuda(), torch.from_numpy(ni).cuda(), torch.from_numpy(na).cuda())
     (out[0] + out[1]).backward()
     issued = ops.nt_issue_log()
+    hits = _tuned_hits(ops.nt_issue_log(with_flags=True))
     ops.nt_issue_log(False)
+    if (name, batch) == ('large', 32) and os.environ.get('DAV_NT_TUNE', '1') != '0' and not os.environ.get('DAV_BATCH'):
+        assert hits >= 8, hits          # the decoders' single-problem entries ([11264, 1536, 512] ...) in the default stream schedule
     if os.environ.get('DAV_TEST_EXPECT_NT256'):       # (the 256 x 256 variant below: the opt-in body must really have run)
         n60 = sum(1 for e in issued if e[0] == 60)
         assert n60 >= int(os.environ['DAV_TEST_EXPECT_NT256']), (n60, sorted({e[0] for e in issued}))

@@ -156,6 +156,8 @@ def main_worker(local_rank, args):
         if num_tasks > 1:
             loader.sampler.set_epoch(epoch)
         train_one_epoch(loader, trainer, epoch, device, args, graphed, frontend)
+        if graphed is not None:
+            graphed.check()          # never write a checkpoint behind a skipped (non-finite) captured step: raise like train.py:166-167
         ckpt.checkpoint(epoch + 1, {'epoch': epoch + 1})
 
 
