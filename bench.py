@@ -231,6 +231,28 @@ def main():
     loss = float(out[0]) + float(out[1])
     ms = dt / a.steps * 1e3
     pairs_per_s = B * world * a.steps / dt
+    # ---- data-parallel runs: what the collectives cost the step.  The same captured step is replayed with the reducer's whole
+    # schedule intact but NO collective issued (GradReducer.skip_collectives): comm_ms_exposed = step time - that.  After the
+    # timed region; ranks train on un-averaged gradients meanwhile, which nothing reads any more. -------------------------------
+    comm = None
+    if (world > 1 or force_dist) and not (a.no_graph or a.roofline_only):
+        red = trainer.model.reducer
+        red.skip_collectives = True
+        for _ in range(2):
+            step()
+        sync()
+        n_nc = max(5, a.steps // 2)
+        t1 = time.perf_counter()
+        for _ in range(n_nc):
+            step()
+        sync()
+        t_nc = torch.tensor([(time.perf_counter() - t1) / n_nc * 1e3], device=dev, dtype=torch.float64)
+        if world > 1:
+            torch.distributed.all_reduce(t_nc, op=torch.distributed.ReduceOp.MAX)
+        red.skip_collectives = False
+        comm = {'ms_per_step_no_collectives': round(float(t_nc), 3), 'comm_ms_exposed': round(ms - float(t_nc), 3),
+                'algo': red.algo, 'bf16_wire': red.bf16_wire, 'buckets': len(red.buckets), 'segments': getattr(gs, 'n_seg', None),
+                'grad_bytes': int(red.flat.flat_g.numel() * 4)}
     if rank != 0:
         return 0
 
@@ -250,6 +272,8 @@ def main():
         'step_mfma_frac': round(flops_pair * pairs_per_s / world / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
     }
 
+    if comm is not None:
+        result['dp'] = comm
     if a.roofline_only:
         result['note'] = 'roofline-only run: value/ms_per_step are ONE eager step, not the metric; see roofline'
 
@@ -312,6 +336,59 @@ def main():
         total_ms = time_replay(replay_nt, reps)
         fl = sum(2.0 * M * N * K for _c, _b, probs in big for (M, N, K) in probs)
         ach = fl / (total_ms * 1e-3) / 1e12
+        # per launch class: the K <= 512 launches (decoder qkv / fc1 / proj and their input gradients) sit at the MFMA / HBM ridge
+        # (2K flop per output byte; fc1: 23 MB in, 2 x 92 MB out for 47 GFLOP), so their rate is reported against BOTH roofs
+        classes = []
+        for cname, pick in (('K <= 512 (decoders)', lambda probs: max(K for (_M, _N, K) in probs) <= 512),
+                            ('K >= 768 (towers, fusion, wide-K decoder fc2)', lambda probs: max(K for (_M, _N, K) in probs) > 512)):
+            sub = [(c, bt, probs) for (c, bt, probs) in big if pick(probs)]
+            if not sub:
+                continue
+
+            def replay_sub(sub=sub):
+                for c, bt, probs in sub:
+                    with E.batch(auto_lanes=True):
+                        for (M, N, K) in probs:
+                            A, Bm, C = bufs[(M, N, K, bt)]
+                            ops.gemm_nt(A, Bm, M, N, K, ldb=N if bt else K, C_out=C, c_bf16=True, variant=(c << 4) | (bt << 12))
+            ms_c = time_replay(replay_sub, reps)
+            fl_c = sum(2.0 * M * N * K for _c, _b, probs in sub for (M, N, K) in probs)
+            by_c = sum(2.0 * (M * K + N * K + M * N) for _c, _b, probs in sub for (M, N, K) in probs)
+            tf_c, gbs_c = fl_c / (ms_c * 1e-3) / 1e12, by_c / (ms_c * 1e-3) / 1e9
+            classes.append({'class': cname, 'launches': len(sub), 'tflops': round(tf_c, 1), 'mfma_frac': round(tf_c / MFMA_BF16_PEAK_TFLOPS, 4),
+                            'algorithmic_GBps': round(gbs_c, 0), 'hbm_frac': round(gbs_c / HBM_PEAK_GBS, 4),
+                            'bound': 'mfma/hbm ridge' if gbs_c / HBM_PEAK_GBS > 0.5 * tf_c / MFMA_BF16_PEAK_TFLOPS else 'mfma',
+                            'avg_launch_us': round(ms_c * 1e3 / len(sub), 2)})
+        # ---- the same set IN THE STEP: one eager step (default stream schedule) with a HIP event pair around every big NT launch, on
+        # the stream it is launched on — begin -> end of the kernel while the other streams' kernels run beside it (what a
+        # rocprofv3 kernel trace of the step shows per kernel: profiles/r04_instep_kernel_stats.csv is the offline twin) ----------
+        in_step = None
+        if not a.roofline_only:
+            orig_nt = ops.gemm_nt
+            pairs = []
+
+            def timed_nt(A_, B_m, M, N, K, **kw):
+                if A_.dtype != torch.bfloat16 or ((M + 127) // 128) * ((N + 127) // 128) < BIG_LAUNCH_TILES or E.batch.current() is not None:
+                    return orig_nt(A_, B_m, M, N, K, **kw)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                orig_nt(A_, B_m, M, N, K, **kw)
+                e1.record()
+                pairs.append((e0, e1, 2.0 * M * N * K))
+            eager_step()
+            torch.cuda.synchronize()
+            ops.gemm_nt = timed_nt
+            try:
+                eager_step()
+                torch.cuda.synchronize()
+            finally:
+                ops.gemm_nt = orig_nt
+            if pairs:
+                us = sum(e0.elapsed_time(e1) for e0, e1, _f in pairs) * 1e3
+                fl_s = sum(f for _e0, _e1, f in pairs)
+                in_step = {'what': 'the same launches timed inside one eager step of the default stream schedule (HIP event pair per launch on its own stream; other streams\' kernels run beside it)',
+                           'launches': len(pairs), 'avg_launch_us': round(us / len(pairs), 2), 'achieved': round(fl_s / (us * 1e-6) / 1e12, 1),
+                           'frac': round(fl_s / (us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), 'ms_per_step': round(us * 1e-3, 3)}
         traffic = None          # HBM bytes per launch: offline rocprofv3 PMC passes over THIS replay (profiles/), only for the profiled workload
         tf = os.path.join(ROOT, 'profiles', 'dominant_kernel_traffic.json')
         if os.path.exists(tf):
@@ -325,7 +402,14 @@ def main():
                               'algorithmic_bytes_per_launch': int(sum(2.0 * (M * K + N * K + M * N) for _c, _b, probs in big for (M, N, K) in probs) / len(big)),
                               'launches_per_step': len(big), 'problems_per_step': sum(len(pr) for _c, _b, pr in big),
                               'avg_launch_us': round(total_ms * 1e3 / len(big), 2),
-                              'avg_gflop_per_launch': round(fl / len(big) / 1e9, 3)}
+                              'avg_gflop_per_launch': round(fl / len(big) / 1e9, 3),
+                              'classes': classes, 'in_step': in_step}
+        st = os.path.join(ROOT, 'profiles', 'step_traffic.json')        # offline rocprofv3 FETCH_SIZE / WRITE_SIZE passes over the whole step
+        if os.path.exists(st):
+            rec = json.load(open(st)).get(f'{a.config}_b{B}')
+            if rec:
+                result['step_fabric'] = {'GB_per_step': rec['GB_per_step'], 'GBps': round(rec['GB_per_step'] / (ms * 1e-3), 0),
+                                         'hbm_frac_of_8TBps': round(rec['GB_per_step'] / (ms * 1e-3) / HBM_PEAK_GBS, 3), 'source': rec.get('source')}
         # the same kernel in the LANES schedule (engine.BATCH_POLICY 'on', three lanes on one queue: the towers' and the fusion
         # block's equal-rank GEMMs merged into one grid): what the kernel reaches with 1400-2400 tiles per launch — reported
         # beside the as-issued figure because the default stream schedule (faster end to end) launches per tower.

@@ -133,14 +133,37 @@ def concat_all_gather(tensor):
 
 
 class GradReducer:
-    """Bucketed, overlapped all-reduce(avg) of FlatParams.flat_g over the data-parallel group."""
+    """Bucketed, overlapped reduction (average) of FlatParams.flat_g over the data-parallel group.
 
-    def __init__(self, flat, bucket_mb: float = 64.0, first_bucket_mb: float = 8.0, process_group=None):
+    Switches for the first multi-GPU runs (all read at construction; README "Data-parallel switches"):
+      DAV_DP_ALGO=allreduce|rs_ag   one all-reduce per bucket (default, what DistributedDataParallel issues: util/misc.py:32-34)
+                                    or reduce-scatter + all-gather per bucket (the two halves of a ring all-reduce as separate
+                                    collectives: same bytes on the wire, lets RCCL pick a different protocol per half)
+      DAV_DP_BUCKET_MB / DAV_DP_FIRST_BUCKET_MB   bucket sizes in MB of fp32 gradients (64 / 8) when the caller passes none
+      DAV_DP_BF16=1                 NOT the reference's arithmetic (opt-in): a bucket is cast to bf16, summed in bf16 on the wire
+                                    (half the bytes: the N = 2 point is bound by ONE xGMI link) and cast back into the fp32
+                                    gradient buffer
+      DAV_DP_SEGMENTS (util.misc.GraphedStep)   graphs per captured step between which the buckets are reduced (default 5)
+    ``skip_collectives`` (attribute; bench.py): run the whole schedule but issue no collective — the step time without
+    communication, from which bench.py derives ``comm_ms_exposed``."""
+
+    def __init__(self, flat, bucket_mb: Optional[float] = None, first_bucket_mb: Optional[float] = None, process_group=None):
+        if bucket_mb is None:
+            bucket_mb = float(os.environ.get('DAV_DP_BUCKET_MB', '64'))
+        if first_bucket_mb is None:
+            first_bucket_mb = float(os.environ.get('DAV_DP_FIRST_BUCKET_MB', '8'))
         self.flat = flat
         self.group = process_group
         self.world = dist.get_world_size(process_group) if is_dist_avail_and_initialized() else 1
+        self.rank = dist.get_rank(process_group) if is_dist_avail_and_initialized() else 0
         # test hook: run the collective code path even on a 1-rank group (exercises RCCL + streams on a single GPU)
         self.force = os.environ.get('DAV_FORCE_DIST', '0') == '1' and is_dist_avail_and_initialized()
+        self.algo = os.environ.get('DAV_DP_ALGO', 'allreduce')
+        if self.algo not in ('allreduce', 'rs_ag'):
+            raise ValueError(f'DAV_DP_ALGO={self.algo!r}: allreduce or rs_ag')
+        self.bf16_wire = os.environ.get('DAV_DP_BF16', '0') == '1'
+        self.skip_collectives = False
+        self._stage = None                 # bf16 staging buffer of the largest bucket (DAV_DP_BF16=1)
         self.buckets = self._make_buckets(flat, int(first_bucket_mb * 2 ** 20 // 4), int(bucket_mb * 2 ** 20 // 4))
         self._bucket_of = {}
         for bi, (lo, hi, plist) in enumerate(self.buckets):
@@ -199,10 +222,52 @@ class GradReducer:
         if self._pending[bi] == 0 and not self._launched[bi]:
             self._launch(bi)
 
+    def _reduce_avg(self, view):
+        """Average ``view`` (a 1-D slice of a gradient buffer, fp32 or the bf16 staging copy) over the group, in place, on the
+        current stream, with the configured algorithm."""
+        on_gpu = view.is_cuda
+        op = dist.ReduceOp.AVG if (self.use_avg and on_gpu) else dist.ReduceOp.SUM
+        n, w = view.numel(), self.world
+        chunk = n // w if self.algo == 'rs_ag' else 0
+        if chunk > 0:
+            # reduce-scatter + all-gather over the first chunk * world elements (rank r owns [r * chunk, (r + 1) * chunk): both
+            # collectives in place, NCCL's documented in-place layouts), a plain all-reduce for the < world leftover elements
+            main = view[:chunk * w]
+            mine = main[self.rank * chunk:(self.rank + 1) * chunk]
+            if on_gpu:
+                dist.reduce_scatter_tensor(mine, main, op=op, group=self.group)
+                dist.all_gather_into_tensor(main, mine, group=self.group)
+            else:      # gloo (CPU tests) has no reduce-scatter: one rooted reduce per shard is the same arithmetic
+                for r in range(w):
+                    dist.reduce(main[r * chunk:(r + 1) * chunk], dst=dist.get_global_rank(self.group, r) if self.group is not None else r,
+                                op=dist.ReduceOp.SUM, group=self.group)
+                parts = [torch.empty_like(mine) for _ in range(w)]
+                dist.all_gather(parts, mine.clone(), group=self.group)
+                for r in range(w):
+                    main[r * chunk:(r + 1) * chunk].copy_(parts[r])
+            if n > chunk * w:
+                dist.all_reduce(view[chunk * w:], op=op, group=self.group)
+        else:
+            dist.all_reduce(view, op=op, group=self.group)
+        if op == dist.ReduceOp.SUM and w > 1:
+            view.mul_(1.0 / w)
+
+    def _reduce_bucket(self, view):
+        if not self.bf16_wire:
+            self._reduce_avg(view)
+            return
+        # opt-in, NOT the reference's arithmetic: bf16 on the wire (fp32 -> bf16, reduce, bf16 -> fp32 back into the buffer)
+        if self._stage is None or self._stage.numel() < view.numel() or self._stage.device != view.device:
+            self._stage = torch.empty(max(hi - lo for lo, hi, _ in self.buckets), dtype=torch.bfloat16, device=view.device)
+        st = self._stage[:view.numel()]
+        st.copy_(view)
+        self._reduce_avg(st)
+        view.copy_(st)
+
     def _launch(self, bi):
         self._launched[bi] = True
         self.launch_order.append(bi)
-        if self.world == 1 and not self.force:
+        if (self.world == 1 and not self.force) or self.skip_collectives:
             return
         lo, hi, _ = self.buckets[bi]
         view = self.flat.flat_g[lo:hi]
@@ -214,14 +279,9 @@ class GradReducer:
             if sw is not None:
                 self.comm_stream.wait_stream(sw)
             with torch.cuda.stream(self.comm_stream):
-                if self.use_avg:
-                    dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group)
-                else:
-                    dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
-                    view.mul_(1.0 / self.world)
+                self._reduce_bucket(view)
         else:                                     # gloo (CPU tests): no AVG op
-            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
-            view.div_(self.world)
+            self._reduce_bucket(view)
 
     def launch_buckets(self, bucket_ids):
         """All-reduce the given buckets now (their gradients are complete on the current stream): used by the
@@ -250,7 +310,8 @@ class DataParallel(torch.nn.Module):
     """Stand-in for ``DistributedDataParallel(model)`` (util/misc.py:34): same forward, ``no_sync()`` for gradient
     accumulation (util/misc.py:144-148), parameters broadcast from rank 0 at construction."""
 
-    def __init__(self, module: torch.nn.Module, flat, bucket_mb: float = 64.0, first_bucket_mb: float = 8.0, process_group=None):
+    def __init__(self, module: torch.nn.Module, flat, bucket_mb: Optional[float] = None, first_bucket_mb: Optional[float] = None,
+                 process_group=None):
         super().__init__()
         self.module = module
         self.reducer = GradReducer(flat, bucket_mb=bucket_mb, first_bucket_mb=first_bucket_mb, process_group=process_group)

@@ -36,8 +36,8 @@ def get_grad_norm_(parameters, norm_type: float = 2.0) -> torch.Tensor:
 
 
 class Trainer:
-    def __init__(self, model, criterion=None, optimizer=None, accum_iter=1, use_amp=True, distributed=False, bucket_mb=64.0,
-                 first_bucket_mb=8.0):
+    def __init__(self, model, criterion=None, optimizer=None, accum_iter=1, use_amp=True, distributed=False, bucket_mb=None,
+                 first_bucket_mb=None):
         self.distributed = distributed
         self.model_without_ddp = model
         self.n_steps = torch.tensor([0])
@@ -198,7 +198,7 @@ class GraphedStep:
         self.reducer = trainer.model.reducer if trainer.distributed else None
         self.dist_active = self.world > 1 or (self.reducer is not None and self.reducer.force)
         if segments <= 0:
-            segments = int(os.environ.get('DAV_SEGMENTS', '0')) or (5 if self.dist_active else 1)
+            segments = (int(os.environ.get('DAV_DP_SEGMENTS', '0')) if self.dist_active else 0) or int(os.environ.get('DAV_SEGMENTS', '0')) or (5 if self.dist_active else 1)
         enc = self.model.encoder
         vis = enc.visual if hasattr(enc, 'visual') else (enc.video if hasattr(enc, 'video') else enc.image)      # image or video tower
         depth = len(vis.blocks)

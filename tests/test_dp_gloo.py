@@ -203,3 +203,72 @@ def test_segment_schedule_world4_gloo():
     res = [q.get(timeout=5) for _ in range(world)]
     assert all(r[1] == res[0][1] and r[2] == res[0][2] for r in res)      # same collective order and schedule on every rank
     assert res[0][1] == [b for s in res[0][2] for b in s]                 # buckets go out segment by segment
+
+
+def _switch_worker(rank, world, port, q, algo, bf16):
+    """DAV_DP_ALGO / DAV_DP_BF16 / DAV_DP_BUCKET_MB (README "Data-parallel switches"): every combination must produce the
+    group average in every gradient element — bucket lengths that are not multiples of the world size included (rs_ag reduces
+    the leftover elements with a plain all-reduce)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), DAV_DP_ALGO=algo, DAV_DP_BF16='1' if bf16 else '0',
+                      DAV_DP_BUCKET_MB='0.011', DAV_DP_FIRST_BUCKET_MB='0.003')
+    dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    from deepavfusion_amd.util.distributed import DataParallel
+    from deepavfusion_amd.util.flat import FlatParams
+    torch.manual_seed(3)
+    model = torch.nn.Sequential(torch.nn.Linear(41, 53), torch.nn.LayerNorm(53), torch.nn.Linear(53, 61), torch.nn.Linear(61, 47), torch.nn.Linear(47, 59),
+                                torch.nn.Linear(59, 43), torch.nn.Linear(43, 5))
+    flat = FlatParams(reversed(list(model.parameters())))
+    dp = DataParallel(model, flat)                    # sizes from the environment
+    dp.reducer.comm_stream = None
+    red = dp.reducer
+    assert red.algo == algo and red.bf16_wire == bool(bf16) and len(red.buckets) >= 3
+    if world == 3:      # (flat segments are padded to even lengths: only an odd world size meets a ragged bucket)
+        assert any((hi - lo) % world for lo, hi, _ in red.buckets)
+    red.begin_backward()
+    for i, p in enumerate(flat.params):                # small integers: exact in bf16 as well
+        p.grad.add_(torch.full_like(p, float((rank + 1) * (i % 7 + 1))))
+        red.grad_ready(p)
+    red.finish()
+    mean_rank = sum(r + 1 for r in range(world)) / world
+    for i, p in enumerate(flat.params):
+        assert torch.allclose(p.grad, torch.full_like(p, mean_rank * (i % 7 + 1)), rtol=1e-6 if not bf16 else 4e-3), (algo, bf16, i)
+    # skip_collectives (bench.py's no-communication replay): the schedule runs, the gradients stay local
+    flat.zero_grad()
+    red.skip_collectives = True
+    red.begin_backward()
+    for i, p in enumerate(flat.params):
+        p.grad.add_(torch.full_like(p, float(rank + 1)))
+        red.grad_ready(p)
+    red.finish()
+    assert all(torch.equal(p.grad, torch.full_like(p, float(rank + 1))) for p in flat.params)
+    assert sorted(red.launch_order) == list(range(len(red.buckets)))
+    q.put((rank, list(red.launch_order)))
+    dist.destroy_process_group()
+
+
+def _run_switch(world, algo, bf16):
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_switch_worker, args=(r, world, port, q, algo, bf16)) for r in range(world)]
+    for p in procs:
+        p.daemon = True
+        p.start()
+    try:
+        for p in procs:
+            p.join(timeout=180)
+            assert p.exitcode == 0, (world, algo, bf16)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+                p.join(5)
+                if p.is_alive():
+                    p.kill()
+    res = [q.get(timeout=5) for _ in range(world)]
+    assert all(r[1] == res[0][1] for r in res)
+
+
+def test_dp_switches_world2_and_world4_gloo():
+    for world, algo, bf16 in ((2, 'rs_ag', False), (2, 'allreduce', True), (4, 'rs_ag', True), (3, 'rs_ag', False)):
+        _run_switch(world, algo, bf16)

@@ -35,9 +35,9 @@ def _free_port():
     return p
 
 
-def _run_workers(mode, outdir, world, limit_s):
+def _run_workers(mode, outdir, world, limit_s, extra_env=None):
     port = str(_free_port())
-    env = dict(os.environ, DAV_WORKER_DUMP_S=str(int(limit_s - 20)), PYTHONUNBUFFERED='1')
+    env = dict(os.environ, DAV_WORKER_DUMP_S=str(int(limit_s - 20)), PYTHONUNBUFFERED='1', **(extra_env or {}))
     procs = []
     try:
         for r in range(world):
@@ -90,6 +90,24 @@ def test_dp_step_over_one_rank_rccl(tmp_path):
         assert abs(a[0] - b[0]) < 2e-3 * abs(a[0]) and abs(a[1] - b[1]) < 2e-3 * abs(a[1]) and abs(a[2] - b[2]) < 2e-2 * abs(a[2]), (a, b)
     assert r['graph_param_rel'] < 1e-3, r
     assert r['graph_runs'][1][-1][0] + r['graph_runs'][1][-1][1] < r['graph_runs'][1][0][0] + r['graph_runs'][1][0][1]    # it trains
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('algo,bf16', [('rs_ag', '0'), ('allreduce', '1')])
+def test_dp_switches_over_one_rank_rccl(tmp_path, algo, bf16):
+    """The round-4 data-parallel switches on real RCCL collectives (1-rank group): DAV_DP_ALGO=rs_ag issues
+    ncclReduceScatter + ncclAllGather per bucket, DAV_DP_BF16=1 reduces a bf16 staging copy; DAV_DP_SEGMENTS=3 moves the graph
+    cuts.  Same checks as the default form; the bf16 wire rounds every gradient to bf16 once, so its parameters are compared at
+    2e-3 instead of 1e-6."""
+    outdir = str(tmp_path)
+    codes = _run_workers('rccl1', outdir, 1, limit_s=240, extra_env=dict(DAV_DP_ALGO=algo, DAV_DP_BF16=bf16, DAV_DP_SEGMENTS='3'))
+    assert codes == [0], f'worker exit codes {codes}\n' + _diagnostics(outdir)
+    r = json.load(open(os.path.join(outdir, 'result0.json')))
+    assert r['n_buckets'] >= 3 and sorted(r['launch_order']) == list(range(r['n_buckets'])), r
+    assert r['eager_param_rel'] < (1e-6 if bf16 == '0' else 2e-3), r
+    assert r['accum_launches'][0] == 0 and r['accum_launches'][1] >= 3 and r['accum_n_steps'] == 1, r
+    assert r['graph_segments'] == 3 and r['graph_sched_complete'], r
+    assert r['graph_param_rel'] < (1e-3 if bf16 == '0' else 5e-3), r
 
 
 @pytest.mark.timeout(420)

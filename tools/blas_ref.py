@@ -5,7 +5,7 @@ to be achievable on this chip for these shapes."""
 import torch
 
 dev = 'cuda'
-for (M, N, K) in [(11264, 2304, 768), (7168, 3072, 768), (7168, 768, 3072), (7168, 768, 768), (22528, 2048, 512), (37120, 1536, 512), (4096, 4096, 4096)]:
+for (M, N, K) in [(5184, 2304, 768), (6080, 2304, 768), (4032, 3072, 768), (5184, 768, 2304), (14592, 1536, 512), (11264, 2304, 768), (7168, 3072, 768), (7168, 768, 3072), (7168, 768, 768), (22528, 2048, 512), (37120, 1536, 512), (4096, 4096, 4096)]:
     sets = [(torch.randn(M, K, device=dev).bfloat16(), (torch.randn(N, K, device=dev) * 0.05).bfloat16()) for _ in range(4)]
     outs = [torch.empty(M, N, device=dev, dtype=torch.bfloat16) for _ in range(4)]
     it = [0]
