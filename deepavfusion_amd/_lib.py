@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, 'libdavfusion_hip.so')
 
 _p, _i, _l, _f, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 
-ABI_VERSION = 3      # DAV_ABI_VERSION of include/dav_kernels.h this package was written against (struct layouts, signatures)
+ABI_VERSION = 4      # DAV_ABI_VERSION of include/dav_kernels.h this package was written against (struct layouts, signatures)
 
 # name -> argtypes (must match include/dav_kernels.h)
 SIGNATURES = {
@@ -88,10 +88,26 @@ SIGNATURES = {
     'dav_batch_stats': [_p, _p],
     'dav_adamw_flat': [_p, _p, _p, _p, _p, _l, _p, _p, _i, _f, _f, _f, _p, _f, _p, _i, _p, _p, _p],
     'dav_step_guard': [_p, _p, _p, _f, _f, _p, _p, _p],
+    'dav_fusion_tail_supported': [_i, _i, _i, _i, _i, _i, _i],
+    'dav_fusion_tail1_fwd': [_p, _p],
+    'dav_fusion_tail2_fwd': [_p, _p],
+    'dav_fusion_tail2_bwd': [_p, _p],
+    'dav_fusion_tail1_bwd': [_p, _p],
 }
 
 class DavLnReduce(C.Structure):
     _fields_ = [('workspace', C.c_void_p), ('dgamma', C.c_void_p), ('dbeta', C.c_void_p), ('rows', C.c_int), ('D', C.c_int)]
+
+
+class DavFusionTail(C.Structure):
+    """include/dav_kernels.h DavFusionTail (field order = the C struct's)."""
+    _fields_ = ([(n, C.c_int) for n in ('B', 'D', 'Da', 'Hd', 'nmm', 'nv', 'na')] + [('eps2', C.c_float)] +
+                [(n, C.c_void_p) for n in (
+                    'Wpv', 'Wpa', 'Wk', 'Wv', 'Wp', 'W1', 'W2', 'WpvT', 'WpaT', 'WkT', 'WvT', 'WpT', 'W1T', 'W2T',
+                    'bpv', 'bpa', 'bk', 'bv', 'bp', 'b1', 'b2', 'g2', 'be2', 'xmm32', 'o_v', 'o_a', 'xvo_b', 'xao_b',
+                    'kv_p', 'ka_p', 'vv_p', 'va_p', 'Kp', 'Vp', 'xmm1', 'o2', 'h2', 'z', 'u', 'mean2', 'rstd2', 'out',
+                    'g', 'gb', 'dz', 'dh2', 'g1', 'g1b', 'do2', 'ln2_partial', 'dKp', 'dVp', 'dkv_p', 'dka_p', 'dvv_p', 'dva_p',
+                    'dxvo_b', 'dxao_b', 'dov', 'doa')])
 
 
 class DavTnProblem(C.Structure):

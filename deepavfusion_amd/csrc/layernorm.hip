@@ -398,9 +398,9 @@ extern "C" int dav_layernorm_bwd_reduce_grouped(const DavLnReduce* items, int co
   static thread_local LNReduceGroup g;   // host staging, one per calling thread (the library is re-entrant across threads)
   int first = 0;
   for (int i = 0; i < count; ++i) {
-    if (items[i].D <= 0 || items[i].rows <= 0) return DAV_ERR_SHAPE;
+    if (items[i].D <= 0 || items[i].rows == 0) return DAV_ERR_SHAPE;
     g.partial[i] = (const float*)items[i].workspace; g.dgamma[i] = items[i].dgamma; g.dbeta[i] = items[i].dbeta;
-    g.nrows[i] = ln_bwd_grid(items[i].rows); g.D[i] = items[i].D;
+    g.nrows[i] = items[i].rows < 0 ? -items[i].rows : ln_bwd_grid(items[i].rows); g.D[i] = items[i].D;     // rows < 0: explicit partial-row count
     g.first_block[i] = first;
     first += (2 * items[i].D + 63) / 64;
   }

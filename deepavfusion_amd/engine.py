@@ -675,6 +675,8 @@ def _factorized_fwd(fb, x_f, x_i, x_a, heads, tkns, dp=None):
                                    na * D, D, nA * 2 * D, 2 * D, nA * 2 * D, 2 * D, dev)
     cv, ca = dict(q=q_v, kv=kv_v, o=o_v, lse=lse_v), dict(q=q_a, kv=kv_a, o=o_a, lse=lse_a)
     xmm1 = _e((B, nF, D), F32, dev)
+    if _fusion_tail_ok(fb, B, D, Da, tkns):
+        return _factorized_fwd_tails(fb, x_f, x_i, x_a, heads, tkns, xmm_b, xmm32, st_mm, xv_b, st_v, xa_b, st_a, cv, ca, q2, xmm1)
     # proj of the two aggregations: fp32 result lands in its rows of xmm1 (+ normed-xmm residual),
     # bf16 twin of the pre-residual value feeds the pair projections
     xvo_b, xao_b = _e((B * nv, D), BF16, dev), _e((B * na, D), BF16, dev)
@@ -707,6 +709,109 @@ def _factorized_fwd(fb, x_f, x_i, x_a, heads, tkns, dp=None):
     return out, tape
 
 
+# ---- fused tails (csrc/fusion_tail.hip): one workgroup per two samples walks a whole chain of the block's small stages --------
+# forward : LN x 3 | q / kv projections | 2 cross-attentions | TAIL-1 (proj_v, proj_a, k / v pair projections, pair expansion) |
+#           pair attention | TAIL-2 (proj, norm2, fc1 + GELU, fc2)                                   6 launches (11 before)
+# backward: TAIL-2 (fc2 / fc1 dgrads, norm2 backward, proj dgrad) | pair attention dQ, dK/dV | q dgrad | TAIL-1 (pair reduction, k / v
+#           dgrads, proj_v / proj_a dgrads) | cross-attention dQ, dK/dV | q / kv dgrads | LN x 3     9 launches (15 before)
+# DAV_FUSION_TAIL=0 restores the per-stage launches.
+FUSION_TAIL = os.environ.get('DAV_FUSION_TAIL', '1') != '0'
+
+
+def _fusion_tail_ok(fb, B, D, Da, tkns):
+    at = fb.attn
+    if not (FUSION_TAIL and PRECISION == 'bf16'):
+        return False
+    if any(l.bias is None for l in (at.k, at.v, at.proj, at.attn_v.proj, at.attn_a.proj, fb.mlp.fc1, fb.mlp.fc2)):
+        return False
+    return ops.fusion_tail_supported(D, Da, fb.mlp.fc1.weight.shape[0], tkns, B)
+
+
+def _tail_dims(fb, B, D, Da, tkns):
+    return dict(B=B, D=D, Da=Da, Hd=fb.mlp.fc1.weight.shape[0], nmm=tkns[0], nv=tkns[1], na=tkns[2], eps2=fb.norm2.eps)
+
+
+def _factorized_fwd_tails(fb, x_f, x_i, x_a, heads, tkns, xmm_b, xmm32, st_mm, xv_b, st_v, xa_b, st_a, cv, ca, q2, xmm1):
+    B, nF, D = x_f.shape
+    nmm, nv, na = tkns
+    dev, at = x_f.device, fb.attn
+    Da, hd, P = at.q.weight.shape[0], D // heads, nv * na
+    dims = _tail_dims(fb, B, D, Da, tkns)
+    xvo_b, xao_b = _e((B * nv, D), BF16, dev), _e((B * na, D), BF16, dev)
+    kv_p, ka_p = _e((B * nv, Da), F32, dev), _e((B * na, Da), F32, dev)
+    vv_p, va_p = _e((B * nv, D), F32, dev), _e((B * na, D), F32, dev)
+    Kp, Vp = _e((B * P, Da), BF16, dev), _e((B * P, D), BF16, dev)
+    ops.fusion_tail('tail1_fwd', dims, Wpv=wcache(at.attn_v.proj.weight), Wpa=wcache(at.attn_a.proj.weight), Wk=wcache(at.k.weight),
+                    Wv=wcache(at.v.weight), bpv=at.attn_v.proj.bias, bpa=at.attn_a.proj.bias, bk=at.k.bias, bv=at.v.bias, xmm32=xmm32,
+                    o_v=cv['o'], o_a=ca['o'], xvo_b=xvo_b, xao_b=xao_b, kv_p=kv_p, ka_p=ka_p, vv_p=vv_p, va_p=va_p, Kp=Kp, Vp=Vp, xmm1=xmm1)
+    scale = hd ** -0.5                                                                       # NOT (Da/heads)^-0.5 (:220-222)
+    o2, lse2 = attention_fwd((q2, 0), (Kp, 0), (Vp, 0), B, heads, nmm, P, Da // heads, hd, scale,
+                             nmm * Da, Da, P * Da, Da, P * D, D, dev)
+    Hd = dims['Hd']
+    h2, z, u = _e((B * nF, D), BF16, dev), _e((B * nF, Hd), BF16, dev), _e((B * nF, Hd), BF16, dev)
+    mean2, rstd2 = _e((B * nF,), F32, dev), _e((B * nF,), F32, dev)
+    out = _e((B, nF, D), F32, dev)
+    ops.fusion_tail('tail2_fwd', dims, o2=o2, Wp=wcache(at.proj.weight), W1=wcache(fb.mlp.fc1.weight), W2=wcache(fb.mlp.fc2.weight),
+                    bp=at.proj.bias, b1=fb.mlp.fc1.bias, b2=fb.mlp.fc2.bias, g2=fb.norm2.weight, be2=fb.norm2.bias, xmm32=xmm32, xmm1=xmm1,
+                    h2=h2, z=z, u=u, mean2=mean2, rstd2=rstd2, out=out)
+    tape = dict(dp=None, tails=True, x_f=x_f, x_i=x_i, x_a=x_a, xmm_b=xmm_b, st_mm=st_mm, xv_b=xv_b, st_v=st_v, xa_b=xa_b, st_a=st_a, cv=cv,
+                ca=ca, xvo_b=xvo_b, xao_b=xao_b, Kp=Kp, Vp=Vp, q2=q2, o2=o2, lse2=lse2, xmm1=xmm1, h2=h2, st2=(mean2, rstd2), z=z, u=u,
+                heads=heads, tkns=tkns)
+    return out, tape
+
+
+def _factorized_bwd_tails_head(fb, t, g):
+    """TAIL-2 backward + the weight-gradient problems of its stages.  -> (g1 fp32 [B,nF,D], do2 bf16 [B*nmm, D])"""
+    x_f = t['x_f']
+    B, nF, D = x_f.shape
+    nmm, nv, na = t['tkns']
+    dev, at = x_f.device, fb.attn
+    Da = at.q.weight.shape[0]
+    dims = _tail_dims(fb, B, D, Da, t['tkns'])
+    Hd = dims['Hd']
+    gb, dz, dh2 = _e((B * nF, D), BF16, dev), _e((B * nF, Hd), BF16, dev), _e((B * nF, D), BF16, dev)
+    g1, g1b, do2 = _e((B, nF, D), F32, dev), _e((B * nF, D), BF16, dev), _e((B * nmm, D), BF16, dev)
+    part = _e((B // 2, 2 * D), F32, dev)
+    ops.fusion_tail('tail2_bwd', dims, g=g, gb=gb, z=t['z'], dz=dz, dh2=dh2, W2T=wcache_t(fb.mlp.fc2.weight), W1T=wcache_t(fb.mlp.fc1.weight),
+                    WpT=wcache_t(at.proj.weight), xmm1=t['xmm1'], mean2=t['st2'][0], rstd2=t['st2'][1], g2=fb.norm2.weight, g1=g1, g1b=g1b,
+                    do2=do2, ln2_partial=part)
+    lin_bwd(fb.mlp.fc2, gb, t['u'], B * nF, need_dx=False)
+    lin_bwd(fb.mlp.fc1, dz, t['h2'], B * nF, need_dx=False)
+    lin_bwd(at.proj, g1b, t['o2'], B * nmm, dy_rowmap=(nmm, nF, 0), need_dx=False)
+    item = (part, gbuf(fb.norm2.weight), gbuf(fb.norm2.bias), -(B // 2), D)          # rows < 0: the workspace holds B / 2 partial rows
+    if _DEFERRED_LN is not None:
+        _DEFERRED_LN.append(item)
+        _DEFERRED_LN_READY.append((fb.norm2.weight, fb.norm2.bias))
+    else:
+        ops.layernorm_bwd_reduce_grouped([item])
+        _ready(fb.norm2.weight, fb.norm2.bias)
+    return g1, g1b, do2
+
+
+def _factorized_bwd_tails_mid(fb, t, g1, dKp, dVp):
+    """TAIL-1 backward + its weight-gradient problems.  -> (dov, doa): gradients of the two cross-attention outputs"""
+    x_f = t['x_f']
+    B, nF, D = x_f.shape
+    nmm, nv, na = t['tkns']
+    dev, at = x_f.device, fb.attn
+    Da = at.q.weight.shape[0]
+    dims = _tail_dims(fb, B, D, Da, t['tkns'])
+    dkv_p, dka_p = _e((B * nv, Da), BF16, dev), _e((B * na, Da), BF16, dev)
+    dvv_p, dva_p = _e((B * nv, D), BF16, dev), _e((B * na, D), BF16, dev)
+    dxvo_b, dxao_b = _e((B * nv, D), BF16, dev), _e((B * na, D), BF16, dev)
+    dov, doa = _e((B * nv, D), BF16, dev), _e((B * na, D), BF16, dev)
+    ops.fusion_tail('tail1_bwd', dims, dKp=dKp, dVp=dVp, dkv_p=dkv_p, dka_p=dka_p, dvv_p=dvv_p, dva_p=dva_p, WkT=wcache_t(at.k.weight),
+                    WvT=wcache_t(at.v.weight), WpvT=wcache_t(at.attn_v.proj.weight), WpaT=wcache_t(at.attn_a.proj.weight), g1=g1,
+                    dxvo_b=dxvo_b, dxao_b=dxao_b, dov=dov, doa=doa)
+    lin_bwd(at.k, dkv_p, t['xvo_b'], B * nv, k=D, need_dx=False, final=False)
+    lin_bwd(at.k, dka_p, t['xao_b'], B * na, k=D, w_col_off=D, use_bias=False, need_dx=False)
+    lin_bwd(at.v, dvv_p, t['xvo_b'], B * nv, k=D, need_dx=False, final=False)
+    lin_bwd(at.v, dva_p, t['xao_b'], B * na, k=D, w_col_off=D, use_bias=False, need_dx=False)
+    lin_bwd(at.attn_v.proj, dxvo_b, t['cv']['o'], B * nv, need_dx=False)
+    lin_bwd(at.attn_a.proj, dxao_b, t['ca']['o'], B * na, need_dx=False)
+    return dov, doa
+
+
 def _factorized_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
     """g fp32 [B,nF,D] grad of the block output.  Returns (dx_f fp32, dx_i, dx_a);
     dx_i / dx_a are freshly STORED (fp32 [B,n,D]) unless buffers are passed.  Same step / region structure as the forward;
@@ -722,21 +827,30 @@ def _factorized_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
     P = nv * na
     rm2, rmv, rma = (nmm, nF, 0), (nv, nF, nmm), (na, nF, nmm + nv)
     cv, ca = t['cv'], t['ca']
-    if gb is None:
-        gb = to_bf16(g)
-    dz = lin_bwd(fb.mlp.fc2, gb, t['u'], B * nF, gelu_aux=t['z'])
-    dh2 = lin_bwd(fb.mlp.fc1, dz, t['h2'], B * nF)
-    g1 = _e((B, nF, D), F32, dev)                 # gradient at xmm1 = residual-path gradient of the normed xmm
-    g1b = _e((B * nF, D), BF16, dev)
-    ln_bwd(fb.norm2, None, t['xmm1'], B, t['st2'], dy_bf16=dh2, dx1=g1, res1=g, dx1_bf16=g1b)
+    tails = bool(t.get('tails'))
+    if tails:
+        g1, g1b, do2 = _factorized_bwd_tails_head(fb, t, g)
+    else:
+        if gb is None:
+            gb = to_bf16(g)
+        dz = lin_bwd(fb.mlp.fc2, gb, t['u'], B * nF, gelu_aux=t['z'])
+        dh2 = lin_bwd(fb.mlp.fc1, dz, t['h2'], B * nF)
+        g1 = _e((B, nF, D), F32, dev)                 # gradient at xmm1 = residual-path gradient of the normed xmm
+        g1b = _e((B * nF, D), BF16, dev)
+        ln_bwd(fb.norm2, None, t['xmm1'], B, t['st2'], dy_bf16=dh2, dx1=g1, res1=g, dx1_bf16=g1b)
     # d(normed xmm) from the three projections of its row groups lands in one bf16 buffer
     dxmm_b = _e((B * nF, D), BF16, dev)
     # --- pair attention branch (rows [0, nmm)) ---
-    do2 = lin_bwd(at.proj, g1b, t['o2'], B * nmm, dy_rowmap=rm2)                              # [B*nmm, D]
+    if not tails:
+        do2 = lin_bwd(at.proj, g1b, t['o2'], B * nmm, dy_rowmap=rm2)                              # [B*nmm, D]
     dq2, dKp, dVp = _e((B * nmm, Da), BF16, dev), _e((B * P, Da), BF16, dev), _e((B * P, D), BF16, dev)
     attention_bwd((t['q2'], 0), (t['Kp'], 0), (t['Vp'], 0), t['o2'], do2, t['lse2'], (dq2, 0), (dKp, 0), (dVp, 0),
                   B, heads, nmm, P, Da // heads, hd, hd ** -0.5, nmm * Da, Da, P * Da, Da, P * D, D,
                   nmm * Da, Da, P * Da, Da, P * D, D)
+    if tails:
+        lin_bwd(at.q, dq2, t['xmm_b'], B * nmm, a_rowmap=rm2, dx=dxmm_b, dx_rowmap=rm2)
+        dov, doa = _factorized_bwd_tails_mid(fb, t, g1, dKp, dVp)
+        return _factorized_bwd_cross(fb, t, g1, dov, doa, dxmm_b, dx_i, dx_a)
     dkv_p, dka_p = _e((B * nv, Da), BF16, dev), _e((B * na, Da), BF16, dev)
     dvv_p, dva_p = _e((B * nv, D), BF16, dev), _e((B * na, D), BF16, dev)
     with region():
@@ -758,6 +872,20 @@ def _factorized_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
     with region():
         dov = lin_bwd(at.attn_v.proj, dxvo_b, cv['o'], B * nv)
         doa = lin_bwd(at.attn_a.proj, dxao_b, ca['o'], B * na)
+    return _factorized_bwd_cross(fb, t, g1, dov, doa, dxmm_b, dx_i, dx_a)
+
+
+def _factorized_bwd_cross(fb, t, g1, dov, doa, dxmm_b, dx_i, dx_a):
+    """The backward of the two aggregation cross-attentions, their q / kv projections and the three input LayerNorms (shared by the
+    per-stage and the fused-tail forms)."""
+    x_f, x_i, x_a, heads = t['x_f'], t['x_i'], t['x_a'], t['heads']
+    B, nF, D = x_f.shape
+    nI, nA = x_i.shape[1], x_a.shape[1]
+    nmm, nv, na = t['tkns']
+    dev, at = x_f.device, fb.attn
+    hd = D // heads
+    rmv, rma = (nv, nF, nmm), (na, nF, nmm + nv)
+    cv, ca = t['cv'], t['ca']
     dq_v, dkv_v = _e((B * nv, D), BF16, dev), _e((B * nI, 2 * D), BF16, dev)
     dq_a, dkv_a = _e((B * na, D), BF16, dev), _e((B * nA, 2 * D), BF16, dev)
     del_v, del_a = torch.empty_like(cv['lse']), torch.empty_like(ca['lse'])

@@ -457,3 +457,22 @@ def rows_scale_cast(g, scale, B, rows, D, out_bf16):
     """out_bf16[b, r] = bf16(scale[b] * g[b, r])  (DropPath backward, branch side)."""
     lib = _lib.load()
     _lib.check(lib.dav_rows_scale_cast(_ptr(g), _ptr(scale), B, rows, D, _ptr(out_bf16), _stream()), 'dav_rows_scale_cast')
+
+
+def fusion_tail_supported(D, Da, Hd, tkns, B):
+    return bool(_lib.load().dav_fusion_tail_supported(int(D), int(Da), int(Hd), int(tkns[0]), int(tkns[1]), int(tkns[2]), int(B)))
+
+
+def fusion_tail(stage, dims, **tensors):
+    """One fused chain of the factorised fusion block (dav_fusion_tail{1,2}_{fwd,bwd}; csrc/fusion_tail.hip).  ``stage``:
+    'tail1_fwd' | 'tail2_fwd' | 'tail2_bwd' | 'tail1_bwd'; ``dims``: dict(B, D, Da, Hd, nmm, nv, na, eps2); ``tensors``: the
+    DavFusionTail pointer fields by name (torch tensors; the ones a stage does not use may be omitted)."""
+    lib = _lib.load()
+    q = _lib.DavFusionTail()
+    for k in ('B', 'D', 'Da', 'Hd', 'nmm', 'nv', 'na'):
+        setattr(q, k, int(dims[k]))
+    q.eps2 = float(dims.get('eps2', 0.0))
+    for k, t in tensors.items():
+        setattr(q, k, _ptr(t))
+    fn = getattr(lib, 'dav_fusion_' + stage)
+    _lib.check(fn(C.byref(q), _stream()), 'dav_fusion_' + stage)

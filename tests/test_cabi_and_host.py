@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in include/dav_kernels.h but not exported'
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.dav_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.dav_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_no_cpu_fallback():
@@ -245,7 +245,7 @@ def test_every_entry_point_rejects_empty_input_with_the_documented_code():
     lib = _lib.load()
     host_only = {'dav_abi_version', 'dav_build_flags', 'dav_last_error_string', 'dav_tune', 'dav_nt_issue_log', 'dav_nt_tune_set', 'dav_batch_begin',
                  'dav_batch_lane', 'dav_batch_region', 'dav_batch_skip', 'dav_batch_suspend', 'dav_batch_end', 'dav_batch_abort',
-                 'dav_batch_stats', 'dav_layernorm_bwd_workspace_bytes', 'dav_l2norm_workspace_bytes'}
+                 'dav_batch_stats', 'dav_layernorm_bwd_workspace_bytes', 'dav_l2norm_workspace_bytes', 'dav_fusion_tail_supported'}
     kernels = sorted(set(_lib.SIGNATURES) - host_only)
     assert len(kernels) >= 40
     for name in kernels:

@@ -497,6 +497,64 @@ def test_fusion_block_module(golden):
             assert rel(p.grad, g[k]) < GRAD_TOL, k
 
 
+@pytest.mark.parametrize('Da_ratio,nI,nA,B', [(0.25, 49, 63, 4), (0.25, 49, 80, 2), (1.0, 49, 63, 2)])
+def test_fusion_tails_equal_the_per_stage_launches_and_the_oracle(Da_ratio, nI, nA, B):
+    """csrc/fusion_tail.hip: the fused tail chains of the factorised fusion block (ViT-B widths: D = 768, 12 heads, tokens
+    (16, 8, 8), MLP ratio 1) against (1) the per-stage launches they replace (DAV_FUSION_TAIL=0 form: same rounding points, so
+    outputs, input gradients and every weight gradient agree to a few bf16 roundings) and (2) the fp32 oracle of
+    models/fusion_blocks.py:235-289 at the usual bf16 tolerances."""
+    from deepavfusion_amd import engine as E
+    from deepavfusion_amd.models.fusion_blocks import FusionBlock_FactorizedAVInteractions as FB
+    from oracle import avmae_oracle as O
+    torch.manual_seed(3)
+    fb = FB(768, 12, attn_ratio=Da_ratio, mlp_ratio=1.0, qkv_bias=True, fusion_tkns=(16, 8, 8),
+            norm_layer=lambda d: torch.nn.LayerNorm(d, eps=1e-5)).cuda()
+    with torch.no_grad():
+        for n, q in fb.named_parameters():
+            if n.endswith('bias') or 'norm' in n:
+                q.add_(0.1 * torch.randn_like(q))
+    xf0, xi0, xa0 = torch.randn(B, 32, 768), torch.randn(B, nI, 768), torch.randn(B, nA, 768)
+    gy = torch.randn(B, 32, 768)
+    runs = {}
+    prev = E.FUSION_TAIL
+    try:
+        for tails in (True, False):
+            E.FUSION_TAIL = tails
+            for q in fb.parameters():
+                q.grad = None
+            xs = [x.clone().cuda().requires_grad_(True) for x in (xf0, xi0, xa0)]
+            y = fb(*xs)
+            y.backward(gy.cuda())
+            torch.cuda.synchronize()
+            runs[tails] = (y.detach().clone(), [x.grad.clone() for x in xs], {n: q.grad.clone() for n, q in fb.named_parameters()})
+    finally:
+        E.FUSION_TAIL = prev
+    assert E.ops.fusion_tail_supported(768, int(768 * Da_ratio), 768, (16, 8, 8), B)
+    a, b = runs[True], runs[False]
+    assert rel(a[0], b[0]) < 2e-3
+    for ga, gb_ in zip(a[1], b[1]):
+        assert rel(ga, gb_) < 5e-3
+    for n in a[2]:
+        if n.endswith(ZERO_GRADS):
+            continue
+        assert rel(a[2][n], b[2][n]) < 5e-3, n
+    # the oracle (fp32, CPU)
+    sd = {'blk.' + n: q.detach().cpu().clone().requires_grad_(True) for n, q in fb.named_parameters()}
+    xs = [x.clone().requires_grad_(True) for x in (xf0, xi0, xa0)]
+    yo = O.fusion_block_factorized(xs[0], xs[1], xs[2], sd, 'blk', 12, (16, 8, 8), 1e-5)
+    yo.backward(gy)
+    assert rel(a[0], yo) < ACT_TOL
+    for ga, xo in zip(a[1], xs):
+        assert rel(ga, xo.grad) < ACT_TOL
+    g_all = sum(float(v.grad.double().norm()) ** 2 for v in sd.values()) ** 0.5
+    for n in a[2]:
+        if n.endswith(ZERO_GRADS):
+            continue
+        ref = sd['blk.' + n].grad.double()
+        d = float((a[2][n].double().cpu() - ref).norm())
+        assert d <= GRAD_TOL * float(ref.norm()) + 1e-4 * g_all, (n, d, float(ref.norm()))
+
+
 def test_cross_attention_module_forward_backward(golden):
     """``CrossAttention.forward(x1, x2)`` called standalone (models/fusion_blocks.py:46-59) against the reference's own
     outputs and gradients (fixture cross_attention.* of tests/golden/gen_golden.py); the attention matrix is a softmax."""
