@@ -88,6 +88,7 @@ SIGNATURES = {
     'dav_batch_stats': [_p, _p],
     'dav_adamw_flat': [_p, _p, _p, _p, _p, _l, _p, _p, _i, _f, _f, _f, _p, _f, _p, _i, _p, _p, _p],
     'dav_step_guard': [_p, _p, _p, _f, _f, _p, _p, _p],
+    'dav_cast_transpose_grouped': [_p, _i, _p],
     'dav_fusion_tail_supported': [_i, _i, _i, _i, _i, _i, _i],
     'dav_fusion_tail1_fwd': [_p, _p],
     'dav_fusion_tail2_fwd': [_p, _p],
@@ -97,6 +98,10 @@ SIGNATURES = {
 
 class DavLnReduce(C.Structure):
     _fields_ = [('workspace', C.c_void_p), ('dgamma', C.c_void_p), ('dbeta', C.c_void_p), ('rows', C.c_int), ('D', C.c_int)]
+
+
+class DavTranspose(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('y_bf16', C.c_void_p), ('R', C.c_int), ('C', C.c_int)]
 
 
 class DavFusionTail(C.Structure):

@@ -29,7 +29,8 @@ def _streams(dev):
         return main, main, main
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        prio = int(os.environ.get('DAV_FUSION_PRIO', '0'))        # < 0: the fusion block's stream gets a higher dispatch priority
+        _SIDE_STREAMS[key] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev, priority=prio))
     sa, sf = _SIDE_STREAMS[key]
     return main, sa, sf
 
@@ -169,6 +170,14 @@ def _encoder_bwd(enc, t, dxi_b, dxa_b, dxf_b, dxi32, dxa32, dxf32, layer_cb=None
     blocks = list(zip(vis.blocks, enc.audio.blocks, enc.fusion_blocks))
     main, sa, sf = _streams(dev)
     batched = t['lanes']                  # the schedule the forward of this step chose
+    # the fused fusion-block tails read TRANSPOSED bf16 weights in the backward: all of them in one launch, up front
+    tw = []
+    for fb, (_ti, _ta, tf) in zip(enc.fusion_blocks, t['layers']):
+        if fb is not None and tf is not None and tf.get('tails'):
+            at = fb.attn
+            tw += [fb.mlp.fc2.weight, fb.mlp.fc1.weight, at.proj.weight, at.k.weight, at.v.weight, at.attn_v.proj.weight, at.attn_a.proj.weight]
+    if tw:
+        E.refresh_transposes(tw)
     for l, ((bi, ba, fb), (ti, ta, tf)) in reversed(list(enumerate(zip(blocks, t['layers'])))):
         # Memory lifetime across streams: the gradients entering this layer were allocated on one stream (main for the
         # final norms, the fusion / audio stream further down) and are READ by kernels of another.  Dropping the last

@@ -26,6 +26,8 @@
 // Grid = B / 2 workgroups of 8 waves: few, long-lived workgroups on their own stream beside the towers (whose layer takes
 // 350 / 870 us forward / backward) instead of ~2500 short-lived ones.  Bound: each workgroup streams the chain's weights
 // (2.4 .. 4.7 MB) through one CU's vector-memory path.
+#include <type_traits>
+
 #include "common.h"
 #include "dav_kernels.h"
 
@@ -52,10 +54,31 @@ __device__ __forceinline__ bf16x8 glb_b128(const bf16_t* p) {
 // acc[mt][j] += sum_k A[arow[mt] + fr][k] * W[16 (t + j) + fr][k]   over K (a multiple of 64), A rows in LDS, W rows in global.
 // Lane (fr = lane & 15, g = lane >> 4) ends up with rows arow[mt] + fr and columns 16 (t + j) + 4 g .. + 3.
 // ------------------------------------------------------------------------------------------------
-template <int MT, int NT, int K>
+// Weight fragments (64 contraction columns x NT tiles per step = 2 NT x 16 bytes per lane) travel through a ring of ST register
+// stages: the loads of step i + ST - 1 are issued before the MFMAs of step i, so ST - 1 steps of fragments (up to 24 KB per wave,
+// ~200 KB per CU) are in flight against the 1-3 us the weights take to arrive from L2 / MALL.  Written with plain loads, hipcc's
+// scheduler SINKS the requests to just above their use (two attempts, with and without sched_barrier: every step still waited
+// vmcnt(0) for fragments requested one step earlier, 28 GB/s per CU).  So the requests are inline-asm global_load_dwordx4 and
+// the waits are counted by hand (CDNA4 guide section 5.7 form (ii): "=v" loads, then a wait statement naming every destination
+// "+v" in front of the first consumer).  Rules that keep the count exact: no compiler-visible vector-memory instruction between
+// the sched_barriers that fence this function (A fragments come from LDS); vmcnt(0) on entry; the last step waits vmcnt(0).
+__device__ __forceinline__ void ft_gld(bf16x8& dst, const bf16_t* p, int byte_off) {
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "n"(byte_off));
+}
+template <int N> __device__ __forceinline__ void ft_wait(bf16x8 (&f)[3][2]) {
+  asm volatile("s_waitcnt vmcnt(%6)" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]), "+v"(f[2][0]), "+v"(f[2][1]) : "n"(N));
+}
+template <int N> __device__ __forceinline__ void ft_wait(bf16x8 (&f)[6][2]) {
+  asm volatile("s_waitcnt vmcnt(%12)" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]), "+v"(f[2][0]), "+v"(f[2][1]),
+               "+v"(f[3][0]), "+v"(f[3][1]), "+v"(f[4][0]), "+v"(f[4][1]), "+v"(f[5][0]), "+v"(f[5][1]) : "n"(N));
+}
+
+template <int MT, int NT, int K, int ST>
 __device__ __forceinline__ void ft_mac(f32x4 (&acc)[MT][NT], const char* act, const int (&arow)[MT], const bf16_t* W, int ldw, int t, int cnt,
                                        int lane) {
-  static_assert(K % 64 == 0, "contraction in steps of 64");
+  constexpr int KS = K / 64;
+  static_assert(K % 64 == 0 && KS % ST == 0 && ST >= 2 && (NT == 3 || NT == 6), "contraction in steps of 64, a whole number of ring turns");
+  static_assert(128 * (2 * ST - 1) + 64 < 4096, "immediate offsets");
   const int fr = lane & 15, g = lane >> 4;
   const bf16_t* wp[NT];
 #pragma unroll
@@ -63,10 +86,27 @@ __device__ __forceinline__ void ft_mac(f32x4 (&acc)[MT][NT], const char* act, co
   uint32_t ap[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) ap[mt] = lds_u32(act) + (uint32_t)((arow[mt] + fr) * FT_RS + 16 * g);
-  // weight fragments of 64 contraction columns per step, requested one step ahead of the MFMAs that use them.  The loop over
-  // 128-column double steps is a REAL loop (two named buffer sets, no copies): fully unrolled, hipcc hoists every global load of
-  // the 768-deep contraction to the top and spills 300 registers.
-  auto step = [&](const bf16x8 (&wa)[NT], const bf16x8 (&wb)[NT], int k0) {
+  bf16x8 wb[ST][NT][2];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = 0; s < ST - 1; ++s)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { ft_gld(wb[s][j][0], wp[j], 128 * s); ft_gld(wb[s][j][1], wp[j], 128 * s + 64); }
+  // one ring turn = ST steps; LAST: the turn that ends the contraction (its later steps have nothing left to request)
+  auto step = [&](auto last_c, auto s_c, int kb) {
+    constexpr bool LAST = decltype(last_c)::value;
+    constexpr int s = decltype(s_c)::value;
+    if constexpr (!LAST || s == 0) {               // step kb + s + ST - 1 exists: request it
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        ft_gld(wb[(s + ST - 1) % ST][j][0], wp[j], 128 * (s + ST - 1));
+        ft_gld(wb[(s + ST - 1) % ST][j][1], wp[j], 128 * (s + ST - 1) + 64);
+      }
+    }
+    // requests younger than this step's fragments: ST - 1 steps in the steady state, ST - 1 - s at the end of the contraction
+    ft_wait<(LAST ? ST - 1 - s : ST - 1) * 2 * NT>(wb[s]);
+    const int k0 = 64 * (kb + s);
     bf16x8 a0[MT], a1[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) { a0[mt] = lds_b128(ap[mt] + 2 * k0); a1[mt] = lds_b128(ap[mt] + 2 * k0 + 64); }
@@ -74,35 +114,23 @@ __device__ __forceinline__ void ft_mac(f32x4 (&acc)[MT][NT], const char* act, co
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j], a0[mt], acc[mt][j], 0, 0, 0);
-        acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], a1[mt], acc[mt][j], 0, 0, 0);
+        acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[s][j][0], a0[mt], acc[mt][j], 0, 0, 0);
+        acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[s][j][1], a1[mt], acc[mt][j], 0, 0, 0);
       }
   };
-  bf16x8 c0[NT], c1[NT], n0[NT], n1[NT];
+  auto turn = [&](auto last_c, int kb) {
+    step(last_c, std::integral_constant<int, 0>{}, kb);
+    step(last_c, std::integral_constant<int, 1>{}, kb);
+    if constexpr (ST > 2) step(last_c, std::integral_constant<int, 2>{}, kb);
+    if constexpr (ST > 3) step(last_c, std::integral_constant<int, 3>{}, kb);
+    static_assert(ST <= 4, "ring depth");
 #pragma unroll
-  for (int j = 0; j < NT; ++j) { c0[j] = glb_b128(wp[j]); c1[j] = glb_b128(wp[j] + 32); }
-  if constexpr (K % 128 == 0) {
+    for (int j = 0; j < NT; ++j) wp[j] += 64 * ST;
+  };
 #pragma unroll 1
-    for (int k0 = 0; k0 < K; k0 += 128) {
-#pragma unroll
-      for (int j = 0; j < NT; ++j) { n0[j] = glb_b128(wp[j] + k0 + 64); n1[j] = glb_b128(wp[j] + k0 + 96); }
-      step(c0, c1, k0);
-      if (k0 + 128 < K) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) { c0[j] = glb_b128(wp[j] + k0 + 128); c1[j] = glb_b128(wp[j] + k0 + 160); }
-      }
-      step(n0, n1, k0 + 64);
-    }
-  } else {                             // short contractions (192): three steps, unrolled
-    static_assert(K == 192, "odd multiple of 64: only the 192-wide pair projection");
-#pragma unroll
-    for (int j = 0; j < NT; ++j) { n0[j] = glb_b128(wp[j] + 64); n1[j] = glb_b128(wp[j] + 96); }
-    step(c0, c1, 0);
-#pragma unroll
-    for (int j = 0; j < NT; ++j) { c0[j] = glb_b128(wp[j] + 128); c1[j] = glb_b128(wp[j] + 160); }
-    step(n0, n1, 64);
-    step(c0, c1, 128);
-  }
+  for (int kb = 0; kb < KS - ST; kb += ST) turn(std::false_type{}, kb);
+  turn(std::true_type{}, KS - ST);
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 template <int MT, int NT>
@@ -113,13 +141,21 @@ __device__ __forceinline__ void ft_zero(f32x4 (&acc)[MT][NT]) {
     for (int j = 0; j < NT; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-// rows [row0, row0 + nrows) x COLS bf16 of a global matrix (row stride ld elements) -> LDS rows lrow0 ..
-template <int COLS>
-__device__ __forceinline__ void ft_load_rows(char* act, int lrow0, const bf16_t* src, long ld, int nrows, int tid) {
-  constexpr int CPR = COLS / 8;
-  for (int c = tid; c < nrows * CPR; c += FT_THREADS) {
-    const int r = c / CPR, ch = c % CPR;
-    *reinterpret_cast<uint4*>(act + (lrow0 + r) * FT_RS + ch * 16) = *reinterpret_cast<const uint4*>(src + (long)r * ld + ch * 8);
+// rows [0, NROWS) x COLS bf16 of a global matrix (row stride ld elements) -> LDS rows lrow0 ..; every thread requests all of its
+// 16-byte pieces before it stores the first (one memory latency per call, not one per piece)
+template <int COLS, int NROWS>
+__device__ __forceinline__ void ft_load_rows(char* act, int lrow0, const bf16_t* src, long ld, int tid) {
+  constexpr int CPR = COLS / 8, TOTAL = NROWS * CPR, PER = (TOTAL + FT_THREADS - 1) / FT_THREADS;
+  uint4 v[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int c = tid + i * FT_THREADS;
+    if (c < TOTAL) v[i] = *reinterpret_cast<const uint4*>(src + (long)(c / CPR) * ld + (c % CPR) * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int c = tid + i * FT_THREADS;
+    if (c < TOTAL) *reinterpret_cast<uint4*>(act + (lrow0 + c / CPR) * FT_RS + (c % CPR) * 16) = v[i];
   }
 }
 
@@ -139,8 +175,8 @@ __global__ __launch_bounds__(FT_THREADS, 2) void ft_tail1_fwd_kernel(const P p) 
   const int w = blockIdx.x;                       // samples 2w, 2w + 1
   constexpr int D = FT_D;
   const int nF = p.nmm + p.nv + p.na;             // 32
-  ft_load_rows<D>(act, 0, (const bf16_t*)p.o_v + (long)16 * w * D, D, 16, tid);
-  ft_load_rows<D>(act, 16, (const bf16_t*)p.o_a + (long)16 * w * D, D, 16, tid);
+  ft_load_rows<D, 16>(act, 0, (const bf16_t*)p.o_v + (long)16 * w * D, D, tid);
+  ft_load_rows<D, 16>(act, 16, (const bf16_t*)p.o_a + (long)16 * w * D, D, tid);
   __syncthreads();
   // --- the two aggregation projections: 96 column tiles, waves 0-3 the image side, 4-7 the audio side -------------------
   {
@@ -151,27 +187,29 @@ __global__ __launch_bounds__(FT_THREADS, 2) void ft_tail1_fwd_kernel(const P p) 
     const int arow[1] = {aud ? 16 : 0};
     const int s = 2 * w + (fr >> 3), i = fr & 7;
     const long xrow = ((long)s * nF + p.nmm + (aud ? p.nv : 0) + i) * D;
-    for (int t = 12 * (wave & 3); t < 12 * (wave & 3) + 12; t += 3) {
-      f32x4 acc[1][3];
+    for (int t = 12 * (wave & 3); t < 12 * (wave & 3) + 12; t += 6) {
+      f32x4 acc[1][6];
       ft_zero(acc);
-      ft_mac<1, 3, D>(acc, act, arow, W, D, t, 3, lane);
+      ft_mac<1, 6, D, 3>(acc, act, arow, W, D, t, 6, lane);
+      f32x4 res[6], bs[6];                         // residual rows and bias: all twelve requests go out before the first use
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
+      for (int j = 0; j < 6; ++j) { const int n = 16 * (t + j) + 4 * g; res[j] = ld_f32x4(p.xmm32 + xrow + n); bs[j] = ld_f32x4(bias + n); }
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
         const int n = 16 * (t + j) + 4 * g;
-        f32x4 v = acc[0][j] + ld_f32x4(bias + n);
+        const f32x4 v = acc[0][j] + bs[j];
         st_bf16x4(xo + (long)(16 * w + fr) * D + n, v);                              // pre-residual value: tape + pair projections
         st_bf16x4((bf16_t*)(act + (32 + (aud ? 16 : 0) + fr) * FT_RS) + n, v);       // ... which read it from LDS rows 32-63
-        st_f32x4(p.xmm1 + xrow + n, v + ld_f32x4(p.xmm32 + xrow + n));
+        st_f32x4(p.xmm1 + xrow + n, v + res[j]);
       }
     }
   }
   __syncthreads();
   // --- pair projections: Linear(cat(xv_i, xa_j)) = W[:, :D] xv_i + W[:, D:] xa_j + b (models/fusion_blocks.py:245-252) -----
-  // column tiles: [0, ta) k from xv (+ bias) | [ta, 2 ta) k from xa | then v from xv (+ bias) | v from xa;  ta = Da / 16
+  // column tiles in groups of 6: [0, ta) k from xv (+ bias) | [ta, 2 ta) k from xa | then v from xv (+ bias) | v from xa;  ta = Da / 16
   {
     const int ta = p.Da / 16, tv = D / 16, total = 2 * ta + 2 * tv;
-    for (int t = 3 * wave; t < total; t += 24) {
-      const int cnt = total - t < 3 ? total - t : 3;
+    for (int t = 6 * wave; t < total; t += 48) {
       int tl, N;
       const bf16_t* W; const float* bias; float* out; int ar;
       if (t < ta) { tl = t; W = (const bf16_t*)p.Wk; bias = p.bk; out = p.kv_p; ar = 32; N = p.Da; }
@@ -179,32 +217,45 @@ __global__ __launch_bounds__(FT_THREADS, 2) void ft_tail1_fwd_kernel(const P p) 
       else if (t < 2 * ta + tv) { tl = t - 2 * ta; W = (const bf16_t*)p.Wv; bias = p.bv; out = p.vv_p; ar = 32; N = D; }
       else { tl = t - 2 * ta - tv; W = (const bf16_t*)p.Wv + D; bias = nullptr; out = p.va_p; ar = 48; N = D; }
       const int arow[1] = {ar};
-      f32x4 acc[1][3];
+      f32x4 acc[1][6];
       ft_zero(acc);
-      ft_mac<1, 3, D>(acc, act, arow, W, 2 * D, tl, cnt, lane);
+      ft_mac<1, 6, D, 3>(acc, act, arow, W, 2 * D, tl, 6, lane);
+      f32x4 bs[6];
 #pragma unroll
-      for (int j = 0; j < 3; ++j)
-        if (j < cnt) {
-          const int n = 16 * (tl + j) + 4 * g;
-          f32x4 v = acc[0][j];
-          if (bias) v += ld_f32x4(bias + n);
-          st_f32x4(out + (long)(16 * w + fr) * N + n, v);
-        }
+      for (int j = 0; j < 6; ++j) bs[j] = bias ? ld_f32x4(bias + 16 * (tl + j) + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 6; ++j) st_f32x4(out + (long)(16 * w + fr) * N + 16 * (tl + j) + 4 * g, acc[0][j] + bs[j]);
     }
   }
   __syncthreads();
-  // --- pair expansion: row p = i * na + j of a sample = bf16(P_v[i] + P_a[j]) (what dav_pair_expand wrote) ---------------
+  // --- pair expansion: row p = i * na + j of a sample = bf16(P_v[i] + P_a[j]) (what dav_pair_expand wrote); 8 outputs per thread
+  //     and trip, every load of a trip requested before its first store -----------------------------------------------------
   {
     const int P_ = p.nv * p.na;
     for (int half = 0; half < 2; ++half) {
-      const int Wd = half ? D : p.Da, c4 = Wd / 4;
+      const int Wd = half ? D : p.Da, c4 = Wd / 4, total = 2 * P_ * c4;
       const float* Pv = half ? p.vv_p : p.kv_p;
       const float* Pa = half ? p.va_p : p.ka_p;
       bf16_t* out = (bf16_t*)(half ? p.Vp : p.Kp);
-      for (int e = tid; e < 2 * P_ * c4; e += FT_THREADS) {
-        const int c = (e % c4) * 4, pr = e / c4, s = 2 * w + pr / P_, q = pr % P_;
-        const f32x4 v = ld_f32x4(Pv + ((long)s * p.nv + q / p.na) * Wd + c) + ld_f32x4(Pa + ((long)s * p.na + q % p.na) * Wd + c);
-        st_bf16x4(out + ((long)s * P_ + q) * Wd + c, v);
+      for (int e0 = tid; e0 < total; e0 += 8 * FT_THREADS) {
+        f32x4 a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * FT_THREADS;
+          if (e < total) {
+            const int c = (e % c4) * 4, pr = e / c4, s = 2 * w + pr / P_, q = pr % P_;
+            a[u] = ld_f32x4(Pv + ((long)s * p.nv + q / p.na) * Wd + c);
+            b[u] = ld_f32x4(Pa + ((long)s * p.na + q % p.na) * Wd + c);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * FT_THREADS;
+          if (e < total) {
+            const int c = (e % c4) * 4, pr = e / c4, s = 2 * w + pr / P_, q = pr % P_;
+            st_bf16x4(out + ((long)s * P_ + q) * Wd + c, a[u] + b[u]);
+          }
+        }
       }
     }
   }
@@ -218,6 +269,9 @@ __device__ __forceinline__ Row3 ld_row(const float* r, int lane) {
   for (int c = 0; c < 3; ++c) x.v[c] = ld_f32x4(r + 4 * (lane + 64 * c));
   return x;
 }
+__device__ __forceinline__ f32x4 bf4(const uint2 a) {
+  return f32x4{__uint_as_float(a.x << 16), __uint_as_float(a.x & 0xffff0000u), __uint_as_float(a.y << 16), __uint_as_float(a.y & 0xffff0000u)};
+}
 
 // ------------------------------------------------------------------------------------------------
 // tail-2 forward: o2 -> proj (+ residual) -> norm2 -> fc1 + GELU -> fc2 (+ residual)
@@ -228,64 +282,80 @@ __global__ __launch_bounds__(FT_THREADS, 2) void ft_tail2_fwd_kernel(const P p) 
   const int w = blockIdx.x;
   constexpr int D = FT_D;
   const int nF = p.nmm + p.nv + p.na;
-  ft_load_rows<D>(act, 0, (const bf16_t*)p.o2 + (long)2 * p.nmm * w * D, D, 2 * p.nmm, tid);       // 32 rows
+  ft_load_rows<D, 32>(act, 0, (const bf16_t*)p.o2 + (long)32 * w * D, D, tid);
   __syncthreads();
   {   // proj of the pair attention: rows [0, nmm) of both samples of xmm1 (+ the normed-xmm residual)
     const int arow[2] = {0, 16};
     for (int t = 6 * wave; t < 6 * wave + 6; t += 3) {
       f32x4 acc[2][3];
       ft_zero(acc);
-      ft_mac<2, 3, D>(acc, act, arow, (const bf16_t*)p.Wp, D, t, 3, lane);
+      ft_mac<2, 3, D, 4>(acc, act, arow, (const bf16_t*)p.Wp, D, t, 3, lane);
+      f32x4 res[2][3], bs[3];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        const long xrow = ((long)(2 * w + mt) * nF + fr) * D;
+      for (int j = 0; j < 3; ++j) {
+        const int n = 16 * (t + j) + 4 * g;
+        bs[j] = ld_f32x4(p.bp + n);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const int n = 16 * (t + j) + 4 * g;
-          st_f32x4(p.xmm1 + xrow + n, acc[mt][j] + ld_f32x4(p.bp + n) + ld_f32x4(p.xmm32 + xrow + n));
-        }
+        for (int mt = 0; mt < 2; ++mt) res[mt][j] = ld_f32x4(p.xmm32 + ((long)(2 * w + mt) * nF + fr) * D + n);
       }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          st_f32x4(p.xmm1 + ((long)(2 * w + mt) * nF + fr) * D + 16 * (t + j) + 4 * g, acc[mt][j] + bs[j] + res[mt][j]);
     }
   }
   __syncthreads();
-  {   // norm2 over the 64 rows of the two samples (8 per wave): h2 -> LDS rows 0-63 (fc1's operand) and the tape
-    for (int r = wave * 8; r < wave * 8 + 8; ++r) {
-      const long grow = (long)64 * w + r;
-      Row3 x = ld_row(p.xmm1 + grow * D, lane);
-      float s = 0.f;
+  {   // norm2 over the 64 rows of the two samples (8 per wave, 4 in flight at a time): h2 -> LDS rows 0-63 (fc1's operand) + tape
+    f32x4 gam[3], bet[3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) s += x.v[c][0] + x.v[c][1] + x.v[c][2] + x.v[c][3];
-      const float mean = wave_sum(s) * (1.f / D);
-      float q = 0.f;
+    for (int c = 0; c < 3; ++c) { gam[c] = ld_f32x4(p.g2 + 4 * (lane + 64 * c)); bet[c] = ld_f32x4(p.be2 + 4 * (lane + 64 * c)); }
+    for (int r0 = wave * 8; r0 < wave * 8 + 8; r0 += 4) {
+      Row3 x[4];
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
+      for (int u = 0; u < 4; ++u) x[u] = ld_row(p.xmm1 + ((long)64 * w + r0 + u) * D, lane);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const float d = x.v[c][e] - mean; q += d * d; }
-      const float rstd = rsqrtf(wave_sum(q) * (1.f / D) + p.eps2);
+      for (int u = 0; u < 4; ++u) {
+        const int r = r0 + u;
+        const long grow = (long)64 * w + r;
+        float s = 0.f;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const int col = 4 * (lane + 64 * c);
-        const f32x4 y = (x.v[c] - mean) * rstd * ld_f32x4(p.g2 + col) + ld_f32x4(p.be2 + col);
-        st_bf16x4((bf16_t*)p.h2 + grow * D + col, y);
-        st_bf16x4((bf16_t*)(act + r * FT_RS) + col, y);
+        for (int c = 0; c < 3; ++c) s += x[u].v[c][0] + x[u].v[c][1] + x[u].v[c][2] + x[u].v[c][3];
+        const float mean = wave_sum(s) * (1.f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float d = x[u].v[c][e] - mean; q += d * d; }
+        const float rstd = rsqrtf(wave_sum(q) * (1.f / D) + p.eps2);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int col = 4 * (lane + 64 * c);
+          const f32x4 y = (x[u].v[c] - mean) * rstd * gam[c] + bet[c];
+          st_bf16x4((bf16_t*)p.h2 + grow * D + col, y);
+          st_bf16x4((bf16_t*)(act + r * FT_RS) + col, y);
+        }
+        if (lane == 0) { p.mean2[grow] = mean; p.rstd2[grow] = rstd; }
       }
-      if (lane == 0) { p.mean2[grow] = mean; p.rstd2[grow] = rstd; }
     }
   }
   __syncthreads();
   const int arow4[4] = {0, 16, 32, 48};
   {   // fc1 + exact GELU; the bf16 twin is GELU'(pre-activation) (what the fc2 input gradient multiplies by)
     for (int t = 6 * wave; t < 6 * wave + 6; t += 3) {
+      f32x4 bs[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) bs[j] = ld_f32x4(p.b1 + 16 * (t + j) + 4 * g);
       f32x4 acc[4][3];
       ft_zero(acc);
-      ft_mac<4, 3, D>(acc, act, arow4, (const bf16_t*)p.W1, D, t, 3, lane);
+      ft_mac<4, 3, D, 3>(acc, act, arow4, (const bf16_t*)p.W1, D, t, 3, lane);
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         const long row = ((long)64 * w + 16 * mt + fr) * D;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
           const int n = 16 * (t + j) + 4 * g;
-          const f32x4 z = acc[mt][j] + ld_f32x4(p.b1 + n);
+          const f32x4 z = acc[mt][j] + bs[j];
           f32x4 u, d;
 #pragma unroll
           for (int e = 0; e < 4; ++e) { float uu, dd; gelu_pair_f(z[e], uu, dd); u[e] = uu; d[e] = dd; }
@@ -296,22 +366,26 @@ __global__ __launch_bounds__(FT_THREADS, 2) void ft_tail2_fwd_kernel(const P p) 
     }
   }
   __syncthreads();
-  ft_load_rows<D>(act, 0, (const bf16_t*)p.u + (long)64 * w * D, D, 64, tid);
+  ft_load_rows<D, 64>(act, 0, (const bf16_t*)p.u + (long)64 * w * D, D, tid);
   __syncthreads();
   {   // fc2 (+ residual xmm1)
     for (int t = 6 * wave; t < 6 * wave + 6; t += 3) {
       f32x4 acc[4][3];
       ft_zero(acc);
-      ft_mac<4, 3, D>(acc, act, arow4, (const bf16_t*)p.W2, D, t, 3, lane);
+      ft_mac<4, 3, D, 3>(acc, act, arow4, (const bf16_t*)p.W2, D, t, 3, lane);
+      f32x4 res[4][3], bs[3];
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        const long row = ((long)64 * w + 16 * mt + fr) * D;
+      for (int j = 0; j < 3; ++j) {
+        const int n = 16 * (t + j) + 4 * g;
+        bs[j] = ld_f32x4(p.b2 + n);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const int n = 16 * (t + j) + 4 * g;
-          st_f32x4(p.out + row + n, acc[mt][j] + ld_f32x4(p.b2 + n) + ld_f32x4(p.xmm1 + row + n));
-        }
+        for (int mt = 0; mt < 4; ++mt) res[mt][j] = ld_f32x4(p.xmm1 + ((long)64 * w + 16 * mt + fr) * D + n);
       }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          st_f32x4(p.out + ((long)64 * w + 16 * mt + fr) * D + 16 * (t + j) + 4 * g, acc[mt][j] + bs[j] + res[mt][j]);
     }
   }
 }
@@ -325,75 +399,89 @@ __global__ __launch_bounds__(FT_THREADS, 2) void ft_tail2_bwd_kernel(const P p) 
   const int w = blockIdx.x;
   constexpr int D = FT_D;
   const int arow4[4] = {0, 16, 32, 48};
-  // the block's output gradient: fp32 rows -> bf16 (fc2's weight-gradient operand + this stage's A rows)
-  for (int c = tid; c < 64 * (D / 4); c += FT_THREADS) {
-    const int r = c / (D / 4), col = (c % (D / 4)) * 4;
-    const f32x4 v = ld_f32x4(p.g + ((long)64 * w + r) * D + col);
-    st_bf16x4((bf16_t*)p.gb + ((long)64 * w + r) * D + col, v);
-    st_bf16x4((bf16_t*)(act + r * FT_RS) + col, v);
+  // the block's output gradient: fp32 rows -> bf16 (fc2's weight-gradient operand + this stage's A rows); 8 pieces per thread in flight
+  for (int c0 = tid; c0 < 64 * (D / 4); c0 += 8 * FT_THREADS) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int c = c0 + u * FT_THREADS; v[u] = ld_f32x4(p.g + ((long)64 * w + c / (D / 4)) * D + (c % (D / 4)) * 4); }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = c0 + u * FT_THREADS, r = c / (D / 4), col = (c % (D / 4)) * 4;
+      st_bf16x4((bf16_t*)p.gb + ((long)64 * w + r) * D + col, v[u]);
+      st_bf16x4((bf16_t*)(act + r * FT_RS) + col, v[u]);
+    }
   }
   __syncthreads();
   for (int t = 6 * wave; t < 6 * wave + 6; t += 3) {      // dz[m][k] = sum_n g[m][n] W2[n][k], times GELU'
     f32x4 acc[4][3];
     ft_zero(acc);
-    ft_mac<4, 3, D>(acc, act, arow4, (const bf16_t*)p.W2T, D, t, 3, lane);
+    ft_mac<4, 3, D, 3>(acc, act, arow4, (const bf16_t*)p.W2T, D, t, 3, lane);
+    uint2 zz[4][3];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const long row = ((long)64 * w + 16 * mt + fr) * D;
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int n = 16 * (t + j) + 4 * g;
-        const uint2 a = *reinterpret_cast<const uint2*>((const bf16_t*)p.z + row + n);
-        const f32x4 d = {__uint_as_float(a.x << 16), __uint_as_float(a.x & 0xffff0000u), __uint_as_float(a.y << 16), __uint_as_float(a.y & 0xffff0000u)};
-        st_bf16x4((bf16_t*)p.dz + row + n, acc[mt][j] * d);
-      }
-    }
+      for (int j = 0; j < 3; ++j) zz[mt][j] = *reinterpret_cast<const uint2*>((const bf16_t*)p.z + ((long)64 * w + 16 * mt + fr) * D + 16 * (t + j) + 4 * g);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        st_bf16x4((bf16_t*)p.dz + ((long)64 * w + 16 * mt + fr) * D + 16 * (t + j) + 4 * g, acc[mt][j] * bf4(zz[mt][j]));
   }
   __syncthreads();
-  ft_load_rows<D>(act, 0, (const bf16_t*)p.dz + (long)64 * w * D, D, 64, tid);
+  ft_load_rows<D, 64>(act, 0, (const bf16_t*)p.dz + (long)64 * w * D, D, tid);
   __syncthreads();
   for (int t = 6 * wave; t < 6 * wave + 6; t += 3) {      // dh2 = dz W1
     f32x4 acc[4][3];
     ft_zero(acc);
-    ft_mac<4, 3, D>(acc, act, arow4, (const bf16_t*)p.W1T, D, t, 3, lane);
+    ft_mac<4, 3, D, 3>(acc, act, arow4, (const bf16_t*)p.W1T, D, t, 3, lane);
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const long row = ((long)64 * w + 16 * mt + fr) * D;
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) st_bf16x4((bf16_t*)p.dh2 + row + 16 * (t + j) + 4 * g, acc[mt][j]);
-    }
+      for (int j = 0; j < 3; ++j) st_bf16x4((bf16_t*)p.dh2 + ((long)64 * w + 16 * mt + fr) * D + 16 * (t + j) + 4 * g, acc[mt][j]);
   }
   __syncthreads();
-  {   // norm2 backward, 8 rows per wave; g1 = dx + g (the residual path); dgamma / dbeta: per-lane column sums over the wave's rows
-    f32x4 dg[3], db[3];
+  {   // norm2 backward, 8 rows per wave (2 in flight); g1 = dx + g (the residual path); dgamma / dbeta: per-lane column sums
+    f32x4 dg[3], db[3], gam[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { dg[c] = f32x4{0.f, 0.f, 0.f, 0.f}; db[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    for (int r = wave * 8; r < wave * 8 + 8; ++r) {
-      const long grow = (long)64 * w + r;
-      const Row3 x = ld_row(p.xmm1 + grow * D, lane);
-      const float mean = p.mean2[grow], rstd = p.rstd2[grow];
-      f32x4 dy[3], xh[3], dyg[3];
-      float s1 = 0.f, s2 = 0.f;
+    for (int c = 0; c < 3; ++c) { dg[c] = f32x4{0.f, 0.f, 0.f, 0.f}; db[c] = f32x4{0.f, 0.f, 0.f, 0.f}; gam[c] = ld_f32x4(p.g2 + 4 * (lane + 64 * c)); }
+    for (int r0 = wave * 8; r0 < wave * 8 + 8; r0 += 2) {
+      Row3 x[2], gg[2];
+      uint2 dyr[2][3];
+      float mean[2], rstd[2];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const int col = 4 * (lane + 64 * c);
-        const uint2 a = *reinterpret_cast<const uint2*>((const bf16_t*)p.dh2 + grow * D + col);
-        dy[c] = f32x4{__uint_as_float(a.x << 16), __uint_as_float(a.x & 0xffff0000u), __uint_as_float(a.y << 16), __uint_as_float(a.y & 0xffff0000u)};
-        xh[c] = (x.v[c] - mean) * rstd;
-        dyg[c] = dy[c] * ld_f32x4(p.g2 + col);
+      for (int u = 0; u < 2; ++u) {
+        const long grow = (long)64 * w + r0 + u;
+        x[u] = ld_row(p.xmm1 + grow * D, lane);
+        gg[u] = ld_row(p.g + grow * D, lane);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { s1 += dyg[c][e]; s2 += dyg[c][e] * xh[c][e]; }
-        dg[c] += dy[c] * xh[c];
-        db[c] += dy[c];
+        for (int c = 0; c < 3; ++c) dyr[u][c] = *reinterpret_cast<const uint2*>((const bf16_t*)p.dh2 + grow * D + 4 * (lane + 64 * c));
+        mean[u] = p.mean2[grow]; rstd[u] = p.rstd2[grow];
       }
-      const float c1 = wave_sum(s1) * (1.f / D), c2 = wave_sum(s2) * (1.f / D);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const int col = 4 * (lane + 64 * c);
-        const f32x4 v = (dyg[c] - c1 - xh[c] * c2) * rstd + ld_f32x4(p.g + grow * D + col);
-        st_f32x4(p.g1 + grow * D + col, v);
-        st_bf16x4((bf16_t*)p.g1b + grow * D + col, v);
-        st_bf16x4((bf16_t*)(act + r * FT_RS) + col, v);
+      for (int u = 0; u < 2; ++u) {
+        const int r = r0 + u;
+        const long grow = (long)64 * w + r;
+        f32x4 dy[3], xh[3], dyg[3];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          dy[c] = bf4(dyr[u][c]);
+          xh[c] = (x[u].v[c] - mean[u]) * rstd[u];
+          dyg[c] = dy[c] * gam[c];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { s1 += dyg[c][e]; s2 += dyg[c][e] * xh[c][e]; }
+          dg[c] += dy[c] * xh[c];
+          db[c] += dy[c];
+        }
+        const float c1 = wave_sum(s1) * (1.f / D), c2 = wave_sum(s2) * (1.f / D);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int col = 4 * (lane + 64 * c);
+          const f32x4 v = (dyg[c] - c1 - xh[c] * c2) * rstd[u] + gg[u].v[c];
+          st_f32x4(p.g1 + grow * D + col, v);
+          st_bf16x4((bf16_t*)p.g1b + grow * D + col, v);
+          st_bf16x4((bf16_t*)(act + r * FT_RS) + col, v);
+        }
       }
     }
     // the waves' column sums -> one partial row [2 D] of this workgroup (LDS rows 64 .. hold 8 x 2 x D floats)
@@ -418,7 +506,7 @@ __global__ __launch_bounds__(FT_THREADS, 2) void ft_tail2_bwd_kernel(const P p) 
     for (int t = 6 * wave; t < 6 * wave + 6; t += 3) {
       f32x4 acc[2][3];
       ft_zero(acc);
-      ft_mac<2, 3, D>(acc, act, arow, (const bf16_t*)p.WpT, D, t, 3, lane);
+      ft_mac<2, 3, D, 4>(acc, act, arow, (const bf16_t*)p.WpT, D, t, 3, lane);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -437,23 +525,35 @@ __global__ __launch_bounds__(FT_THREADS, 2) void ft_tail1_bwd_kernel(const P p) 
   constexpr int D = FT_D;
   const int nF = p.nmm + p.nv + p.na, P_ = p.nv * p.na;
   // pair reduction (dav_pair_reduce): dP_v[i] = sum_j d[i na + j], dP_a[j] = sum_i d[i na + j]; fp32 sums, bf16 results.
-  // LDS rows: 0-15 dkv_p | 16-31 dka_p (Da columns) | 32-47 dvv_p | 48-63 dva_p (D columns)
+  // LDS rows: 0-15 dkv_p | 16-31 dka_p (Da columns) | 32-47 dvv_p | 48-63 dva_p (D columns); 2 outputs (16 loads) per thread in flight
   for (int half = 0; half < 2; ++half) {
-    const int Wd = half ? D : p.Da, c4 = Wd / 4;
+    const int Wd = half ? D : p.Da, c4 = Wd / 4, total = 2 * 2 * 8 * c4;       // (sample, side, index, column quad)
     const bf16_t* d = (const bf16_t*)(half ? p.dVp : p.dKp);
     bf16_t* ov = (bf16_t*)(half ? p.dvv_p : p.dkv_p);
     bf16_t* oa = (bf16_t*)(half ? p.dva_p : p.dka_p);
-    for (int e = tid; e < 2 * 2 * 8 * c4; e += FT_THREADS) {       // (sample, side, index, column quad)
-      const int c = (e % c4) * 4, r = e / c4, idx = r & 7, side = (r >> 3) & 1, sl = r >> 4, s = 2 * w + sl;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int e0 = tid; e0 < total; e0 += 2 * FT_THREADS) {
+      uint2 in[2][8];
 #pragma unroll
-      for (int o = 0; o < 8; ++o) {
-        const int pr = side ? o * p.na + idx : idx * p.na + o;
-        const uint2 a = *reinterpret_cast<const uint2*>(d + ((long)s * P_ + pr) * Wd + c);
-        acc += f32x4{__uint_as_float(a.x << 16), __uint_as_float(a.x & 0xffff0000u), __uint_as_float(a.y << 16), __uint_as_float(a.y & 0xffff0000u)};
+      for (int u = 0; u < 2; ++u) {
+        const int e = e0 + u * FT_THREADS;
+        if (e < total) {
+          const int c = (e % c4) * 4, r = e / c4, idx = r & 7, side = (r >> 3) & 1, s = 2 * w + (r >> 4);
+#pragma unroll
+          for (int o = 0; o < 8; ++o) in[u][o] = *reinterpret_cast<const uint2*>(d + ((long)s * P_ + (side ? o * p.na + idx : idx * p.na + o)) * Wd + c);
+        }
       }
-      st_bf16x4((side ? oa : ov) + ((long)s * 8 + idx) * Wd + c, acc);
-      st_bf16x4((bf16_t*)(act + (32 * half + 16 * side + 8 * sl + idx) * FT_RS) + c, acc);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = e0 + u * FT_THREADS;
+        if (e < total) {
+          const int c = (e % c4) * 4, r = e / c4, idx = r & 7, side = (r >> 3) & 1, sl = r >> 4, s = 2 * w + sl;
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int o = 0; o < 8; ++o) acc += bf4(in[u][o]);
+          st_bf16x4((side ? oa : ov) + ((long)s * 8 + idx) * Wd + c, acc);
+          st_bf16x4((bf16_t*)(act + (32 * half + 16 * side + 8 * sl + idx) * FT_RS) + c, acc);
+        }
+      }
     }
   }
   __syncthreads();
@@ -465,16 +565,19 @@ __global__ __launch_bounds__(FT_THREADS, 2) void ft_tail1_bwd_kernel(const P p) 
     const int ak[1] = {aud ? 16 : 0}, av[1] = {aud ? 48 : 32};
     const int s = 2 * w + (fr >> 3), i = fr & 7;
     const long grow = ((long)s * nF + p.nmm + (aud ? p.nv : 0) + i) * D;
-    for (int t = 12 * (wave & 3); t < 12 * (wave & 3) + 12; t += 3) {
-      f32x4 acc[1][3];
+    for (int t = 12 * (wave & 3); t < 12 * (wave & 3) + 12; t += 6) {
+      f32x4 acc[1][6];
       ft_zero(acc);
-      if (p.Da == 192) ft_mac<1, 3, 192>(acc, act, ak, WkT, p.Da, t, 3, lane);
-      else ft_mac<1, 3, 768>(acc, act, ak, WkT, p.Da, t, 3, lane);
-      ft_mac<1, 3, D>(acc, act, av, WvT, D, t, 3, lane);
+      if (p.Da == 192) ft_mac<1, 6, 192, 3>(acc, act, ak, WkT, p.Da, t, 6, lane);
+      else ft_mac<1, 6, 768, 3>(acc, act, ak, WkT, p.Da, t, 6, lane);
+      ft_mac<1, 6, D, 3>(acc, act, av, WvT, D, t, 6, lane);
+      f32x4 res[6];
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
+      for (int j = 0; j < 6; ++j) res[j] = ld_f32x4(p.g1 + grow + 16 * (t + j) + 4 * g);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
         const int n = 16 * (t + j) + 4 * g;
-        const f32x4 v = acc[0][j] + ld_f32x4(p.g1 + grow + n);
+        const f32x4 v = acc[0][j] + res[j];
         st_bf16x4(dxo + (long)(16 * w + fr) * D + n, v);
         st_bf16x4((bf16_t*)(act + (64 + (aud ? 16 : 0) + fr) * FT_RS) + n, v);
       }
@@ -486,12 +589,12 @@ __global__ __launch_bounds__(FT_THREADS, 2) void ft_tail1_bwd_kernel(const P p) 
     const bf16_t* WT = (const bf16_t*)(aud ? p.WpaT : p.WpvT);
     bf16_t* o = (bf16_t*)(aud ? p.doa : p.dov);
     const int arow[1] = {aud ? 80 : 64};
-    for (int t = 12 * (wave & 3); t < 12 * (wave & 3) + 12; t += 3) {
-      f32x4 acc[1][3];
+    for (int t = 12 * (wave & 3); t < 12 * (wave & 3) + 12; t += 6) {
+      f32x4 acc[1][6];
       ft_zero(acc);
-      ft_mac<1, 3, D>(acc, act, arow, WT, D, t, 3, lane);
+      ft_mac<1, 6, D, 3>(acc, act, arow, WT, D, t, 6, lane);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) st_bf16x4(o + (long)(16 * w + fr) * D + 16 * (t + j) + 4 * g, acc[0][j]);
+      for (int j = 0; j < 6; ++j) st_bf16x4(o + (long)(16 * w + fr) * D + 16 * (t + j) + 4 * g, acc[0][j]);
     }
   }
 }

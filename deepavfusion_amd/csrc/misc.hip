@@ -332,6 +332,36 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* x, bf1
   }
 }
 
+// grouped form: up to TR_GROUP_MAX transposes in ONE launch (the fused fusion-block tails read seven transposed weights per
+// layer in the backward: 84 launches of 15 us each per step otherwise); problem table by value in the kernel arguments
+constexpr int TR_GROUP_MAX = 96;
+struct TrGroup {
+  const float* x[TR_GROUP_MAX];
+  bf16_t* y[TR_GROUP_MAX];
+  int R[TR_GROUP_MAX], Cc[TR_GROUP_MAX];
+  int first_block[TR_GROUP_MAX + 1];
+  int count;
+};
+__global__ __launch_bounds__(256) void cast_transpose_grouped_kernel(const TrGroup g) {
+  __shared__ float tile[64][65];
+  int pi = 0;
+  while (pi + 1 < g.count && (int)blockIdx.x >= g.first_block[pi + 1]) ++pi;
+  const float* x = g.x[pi];
+  bf16_t* y = g.y[pi];
+  const int R = g.R[pi], Cc = g.Cc[pi], lb = (int)blockIdx.x - g.first_block[pi], nbx = (Cc + 63) / 64;
+  const int r0 = (lb / nbx) * 64, c0 = (lb % nbx) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < R && c < Cc) ? x[(long)r * Cc + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < Cc && r < R) y[(long)c * R + r] = f2bf(tile[tx][i]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // flat fp32 reductions / optimizer
 // ------------------------------------------------------------------------------------------------
@@ -605,6 +635,27 @@ extern "C" int dav_add_cast(const float* a, const float* b, float* out, void* ou
 extern "C" int dav_cast_transpose_bf16(const float* x, void* y_bf16, int R, int C, hipStream_t stream) {
   if (R <= 0 || C <= 0) return DAV_ERR_SHAPE;
   DAV_LAUNCH(cast_transpose_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, stream, x, (bf16_t*)y_bf16, R, C);
+  return dav_launch_status();
+}
+
+extern "C" int dav_cast_transpose_grouped(const DavTranspose* items, int count, hipStream_t stream) {
+  if (count <= 0 || !items) return DAV_ERR_SHAPE;
+  for (int i0 = 0; i0 < count; i0 += TR_GROUP_MAX) {
+    TrGroup g;
+    const int n = count - i0 < TR_GROUP_MAX ? count - i0 : TR_GROUP_MAX;
+    int first = 0;
+    for (int i = 0; i < n; ++i) {
+      const DavTranspose& it = items[i0 + i];
+      if (it.R <= 0 || it.C <= 0 || !it.x || !it.y_bf16) return DAV_ERR_SHAPE;
+      g.x[i] = it.x; g.y[i] = (bf16_t*)it.y_bf16; g.R[i] = it.R; g.Cc[i] = it.C;
+      g.first_block[i] = first;
+      first += ((it.C + 63) / 64) * ((it.R + 63) / 64);
+    }
+    g.first_block[n] = first;
+    g.count = n;
+    const TrGroup gl = g;
+    DAV_LAUNCH(cast_transpose_grouped_kernel, dim3(first), dim3(256), 0, stream, gl);
+  }
   return dav_launch_status();
 }
 

@@ -211,6 +211,27 @@ def wcache_t(p: torch.nn.Parameter) -> torch.Tensor:
     return c.wtb
 
 
+def refresh_transposes(params):
+    """Bring the transposed bf16 copies of ``params`` (the weights wcache_t will be asked for) up to date with ONE grouped
+    launch instead of one cast_transpose launch per weight at first use (bf16 path only)."""
+    if PRECISION == 'fp32':
+        return
+    todo = []
+    for p in params:
+        wcache(p)
+        c = p.__dict__['_dav_cache']
+        stamp = (c.ver, c.ptr) if not c.managed else ('managed', p.__dict__.get('_dav_epoch', 0))
+        if c.wtb is None or c.wt_ver != stamp:
+            w2 = p.detach().reshape(p.shape[0], -1)
+            if c.wtb is None:
+                c.wtb = torch.empty((w2.shape[1], w2.shape[0]), dtype=BF16, device=p.device)
+            todo.append((w2, c.wtb))
+            c.wt_ver = stamp
+    if todo:
+        with ops.unbatched():
+            ops.cast_transpose_grouped(todo)
+
+
 def invalidate_weight_cache(params):
     """The fp32 masters changed behind torch's version counters (optimizer kernel, flat-buffer cast): un-managed bf16 copies
     become stale; optimizer-managed mirrors were rewritten by the same kernel and are stamped in sync; transposed copies of
@@ -714,8 +735,14 @@ def _factorized_fwd(fb, x_f, x_i, x_a, heads, tkns, dp=None):
 #           pair attention | TAIL-2 (proj, norm2, fc1 + GELU, fc2)                                   6 launches (11 before)
 # backward: TAIL-2 (fc2 / fc1 dgrads, norm2 backward, proj dgrad) | pair attention dQ, dK/dV | q dgrad | TAIL-1 (pair reduction, k / v
 #           dgrads, proj_v / proj_a dgrads) | cross-attention dQ, dK/dV | q / kv dgrads | LN x 3     9 launches (15 before)
-# DAV_FUSION_TAIL=0 restores the per-stage launches.
-FUSION_TAIL = os.environ.get('DAV_FUSION_TAIL', '1') != '0'
+# OFF by default (DAV_FUSION_TAIL=1 switches it on): bit-for-rounding equal to the per-stage form and 15 launches -> 9, but the
+# step gets SLOWER (same-box alternation, ViT-B B = 64: 29.7-29.8 vs 26.6-26.9 ms).  Alone on the GPU the four tails take
+# 181 / 134 / 128 / 161 us — exactly the same with the weight requests one step or three steps ahead of their use (inline-asm
+# loads + counted waits, profiles/r04_fusion_tails.txt): a workgroup streams its 3.5-5.3 MB of weights at ~30 GB/s whatever the
+# pipeline depth, i.e. one CU keeps ~45 KB in flight against the ~1.5 us its L2 misses take, and with B / 2 = 32 workgroups the
+# tails put 4 x 150 us of such streaming on the fusion block's chain per layer, which then outlasts the towers' 350 us forward chain.
+# The batched per-stage GEMMs amortise every weight byte over 512-2048 rows instead.
+FUSION_TAIL = os.environ.get('DAV_FUSION_TAIL', '0') == '1'
 
 
 def _fusion_tail_ok(fb, B, D, Da, tkns):

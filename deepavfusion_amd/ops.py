@@ -476,3 +476,13 @@ def fusion_tail(stage, dims, **tensors):
         setattr(q, k, _ptr(t))
     fn = getattr(lib, 'dav_fusion_' + stage)
     _lib.check(fn(C.byref(q), _stream()), 'dav_fusion_' + stage)
+
+
+def cast_transpose_grouped(pairs):
+    """pairs: [(x fp32 [R, C], y bf16 [C, R]), ...] -> every y = bf16(x^T) in one launch (dav_cast_transpose_grouped)."""
+    if not pairs:
+        return
+    arr = (_lib.DavTranspose * len(pairs))()
+    for q, (x, y) in zip(arr, pairs):
+        q.x, q.y_bf16, q.R, q.C = _ptr(x), _ptr(y), int(x.shape[0]), int(x.shape[1])
+    _lib.check(_lib.load().dav_cast_transpose_grouped(arr, len(pairs), _stream()), 'dav_cast_transpose_grouped')

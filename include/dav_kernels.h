@@ -284,6 +284,9 @@ int dav_cast_bf16(const float* x, void* y_bf16, long n, hipStream_t stream);
  * backward wants it in both precisions.  (ABI 3) */
 int dav_add_cast(const float* a, const float* b, float* out, void* out_bf16, long n, hipStream_t stream);
 int dav_cast_transpose_bf16(const float* x, void* y_bf16, int R, int C, hipStream_t stream);   /* y[c,r] = x[r,c] */
+/* the same for several matrices in ONE launch (ABI 4): y_bf16 [C, R] = bf16(x [R, C] fp32) per item */
+typedef struct DavTranspose { const float* x; void* y_bf16; int R; int C; } DavTranspose;
+int dav_cast_transpose_grouped(const DavTranspose* items, int count, hipStream_t stream);
 /* get_grad_norm_ (util/misc.py:151-163) over one flat fp32 buffer: out = scale * ||x||_2 */
 size_t dav_l2norm_workspace_bytes(long n);
 int dav_l2norm(const float* x, long n, float scale, float* out, void* workspace, size_t workspace_bytes, hipStream_t stream);

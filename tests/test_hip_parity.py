@@ -1243,6 +1243,19 @@ def test_bench_workload_with_the_opt_in_256_tile_kernels_vs_oracle():
     assert r.returncode == 0 and '1 passed' in r.stdout, (r.stdout[-3000:], r.stderr[-1500:])
 
 
+@pytest.mark.timeout(300)
+def test_whole_step_with_the_opt_in_fused_fusion_tails_vs_oracle():
+    """DAV_FUSION_TAIL=1 (csrc/fusion_tail.hip, off by default: slower inside the step): the whole pre-training step at
+    ViT-B widths with the fused tails carrying every fusion block, as a fresh process, against the oracle (base-4)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DAV_FUSION_TAIL='1')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider',
+                        '-k', 'test_baseline_config_shapes_vs_oracle and base-4'], cwd=root, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and '1 passed' in r.stdout, (r.stdout[-3000:], r.stderr[-1500:])
+
+
 def test_load_state_dict_after_optimizer_refreshes_the_bf16_mirror():
     """With FlatAdamW the GEMMs read a bf16 mirror of the weights that the optimizer kernel maintains; weights written from
     the torch side afterwards (load_state_dict without any explicit sync) must still be the ones the next forward uses."""
