@@ -3,7 +3,7 @@
 // Everything in the fusion block is per SAMPLE, and behind the first-level projections every GEMM has 8 .. 32 rows per
 // sample: as batched GEMMs those were ~11 dependent launches per layer forward and ~14 backward, each a few dozen to a few
 // hundred workgroups that live for one launch latency + a 12-step k-loop of dependent L2 round trips (8-15 us alone, ~24 us
-// beside the towers' GEMMs) — 2.3 ms of the 26.9 ms step by knockout (profiles/r04_instep_knockout.txt).  Here ONE workgroup
+// beside the towers' GEMMs) — the whole block costs 2.3 ms of the 26.9 ms step by knockout (profiles/r04_instep_knockout.txt).  Here ONE workgroup
 // owns TWO samples and walks a whole chain of those stages itself:
 //
 //   tail-1 forward   proj_v | proj_a (+ residual rows of xmm1)  ->  k / v pair projections  ->  pair expansion (Kp, Vp)
@@ -23,9 +23,16 @@
 // Backward stages contract over the OUTPUT features of a Linear, so they read transposed bf16 weight copies ([in][out]
 // row-major, engine.wcache_t) through the very same code path.
 //
-// Grid = B / 2 workgroups of 8 waves: few, long-lived workgroups on their own stream beside the towers (whose layer takes
-// 350 / 870 us forward / backward) instead of ~2500 short-lived ones.  Bound: each workgroup streams the chain's weights
-// (2.4 .. 4.7 MB) through one CU's vector-memory path.
+// Grid = B / 2 workgroups of 8 waves: few, long-lived workgroups on their own stream beside the towers instead of ~2500 short-lived
+// ones per layer.
+//
+// OUTCOME (round 4, profiles/r04_fusion_tails.txt): results equal the per-stage launches to a few bf16 roundings and the oracle at the
+// usual tolerances (tests/test_hip_parity.py), 15 launches per layer become 9 — and the step gets SLOWER (29.7 vs 26.7 ms), so the
+// engine uses these kernels only with DAV_FUSION_TAIL=1.  Each workgroup streams its chain's weights (3.5-5.3 MB) through ONE CU at
+// ~30 GB/s whatever the prefetch depth (one step ahead with plain loads and three steps ahead through the inline-asm ring below give
+// the same 128-181 us per tail): a CU holds ~45 KB of requests in flight against ~1.5 us of L2-miss latency, and 32 workgroups re-read
+// every weight byte 32 times where the batched per-stage GEMMs amortise it over 512-2048 rows.  Four such tails per layer outlast
+// the towers' 350 us forward chain.
 #include <type_traits>
 
 #include "common.h"

@@ -553,7 +553,9 @@ __device__ __forceinline__ void nt_epilogue_s(const NTParams& p, f32x4 (&acc)[FM
 }
 
 #include "gemm_nt256.h"
-#include "gemm_tn256.h"
+#ifdef DAV_EXPERIMENTAL
+#include "gemm_tn256.h"      // 256 x 256 stream-K weight gradients: measured slower (round 3), kept for measurements only
+#endif
 
 // PIPE == 2: two extra LOADER waves per workgroup issue every global -> LDS piece of the ring; the WM_ x WN_ compute waves only wait
 // at the per-step barrier, read fragments and issue MFMAs.  A wave that issues LDS-DMA pieces is blocked by the vector-memory path's
@@ -1977,11 +1979,12 @@ extern "C" int dav_gemm_tn_grouped_bf16(const DavTnProblem* probs, int count, hi
     if (((uintptr_t)q.A | (uintptr_t)q.B | (uintptr_t)q.C) & 15 || (q.ldc & 3)) return DAV_ERR_ALIGN;      // 16-byte gradient accesses
     total_tiles += (long)((q.N + 127) / 128) * ((q.K + 127) / 128);
   }
-  // 256 x 256 persistent form (csrc/gemm_tn256.h): one slice of the K-tile-pair sequence per workgroup.  OFF by default
-  // (DAV_TN256=1 switches it on): bit-correct, but measured slower than the 128 x 128 tiles on the step's launches
+  // 256 x 256 persistent form (csrc/gemm_tn256.h; make EXPERIMENTAL=1 builds only since round 4): one slice of the K-tile-pair sequence per
+  // workgroup.  OFF by default (DAV_TN256=1 switches it on): bit-correct, but measured slower than the 128 x 128 tiles on the step's launches
   // (profiles/r03_tn256_group_bench.txt): its k-loop alone reaches 673-733 TF against 580-635 for the old kernel INCLUDING its
   // epilogue — the weight gradients are bound by re-streaming their operands from MALL / HBM, which a wider tile only halves —
   // and the fp32 atomics of the split tiles (one dword per lane and instruction) cost 440-900 us per launch.
+#ifdef DAV_EXPERIMENTAL
   static const bool tn256 = [] { const char* e = getenv("DAV_TN256"); return e && e[0] == '1'; }();
   static const long tn256_min = getenv("DAV_TN256_MIN") ? atol(getenv("DAV_TN256_MIN")) : 512;      // K-tile pairs below which the old kernel runs
   if (tn256 && count <= TN256_MAX) {
@@ -2009,6 +2012,7 @@ extern "C" int dav_gemm_tn_grouped_bf16(const DavTnProblem* probs, int count, hi
       return dav_launch_status();
     }
   }
+#endif
   // aim at ~4 workgroups of 8 waves per CU-slot pair (1024 blocks) but keep >= 8 k-steps of 64 rows per split
   int first = 0;
   for (int i = 0; i < count; ++i) {

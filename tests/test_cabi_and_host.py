@@ -446,3 +446,12 @@ def test_isa_audit_no_inline_asm_is_the_first_reader_of_an_mfma_result():
     assert asm.returncode == 0, asm.stderr[-2000:]
     checked, offenders = _asm_first_readers(asm.stdout)
     assert checked > 0 and not offenders, offenders[:6]
+
+
+def test_switch_table_is_complete_and_current():
+    """SWITCHES.md (tools/gen_switch_table.py): every DAV_* environment switch the sources read has a documented default, meaning
+    and covering test, and the committed table is the generated one."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'gen_switch_table.py'), '--check'], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]

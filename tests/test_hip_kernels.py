@@ -232,6 +232,9 @@ def test_tn256_weight_gradient_kernel_matches_reference():
     tiles (never split), row maps, bias gradients."""
     import subprocess
     import sys
+    from deepavfusion_amd import _lib
+    if not (_lib.load().dav_build_flags() & 1):
+        pytest.skip('the 256 x 256 weight-gradient body lives in EXPERIMENTAL builds only since round 4 (make EXPERIMENTAL=1)')
     code = ("import sys; sys.path.insert(0, 'tests'); import gpu_selfcheck as sc; sc.gemm_tn(); "
             "bad = [r for r in sc.RESULTS if not r[3]]; print(len(sc.RESULTS), 'checks', len(bad), 'bad', bad[:5]); sys.exit(1 if bad or not sc.RESULTS else 0)")
     r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, DAV_TN256='1', DAV_TN256_MIN='64'), cwd=ROOT, capture_output=True, timeout=600)

@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Generates SWITCHES.md: every DAV_* environment switch of the package / bench.py / train.py with its default, what it selects and
+the test that covers it.  The descriptions live HERE; the list of switches is grepped from the sources, and the script fails when a
+switch in the code has no entry (tests/test_cabi_and_host.py runs it in check mode, so the table cannot go stale).
+
+    python tools/gen_switch_table.py            # rewrite SWITCHES.md
+    python tools/gen_switch_table.py --check    # exit 1 if SWITCHES.md is out of date or a switch is undocumented
+"""
+import glob
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NOT_SWITCHES = {'DAV_ABI_VERSION', 'DAV_OK', 'DAV_LAUNCH', 'DAV_LAUNCH_NOW', 'DAV_EXPERIMENTAL'} | {f'DAV_ERR_{x}' for x in ('ALIGN', 'DTYPE', 'HIP', 'SHAPE', 'WORKSPACE')}
+
+# name: (default, class, what it selects, covered by)
+#   class: schedule | kernel | dp | optimizer | debug (timing ablations: results are WRONG by construction) | harness
+S = {
+    'DAV_BATCH': ('auto', 'schedule', "launch batching policy (engine.BATCH_POLICY): unset = one HIP stream per independent chain with batched regions; 1 = the towers / decoders as lanes of one launch batch; 0 = no batching at all", 'test_lane_batched_and_stream_schedules_agree, test_full_size_step_is_schedule_independent_and_repeatable'),
+    'DAV_LANE_MIN_ROWS': ('2^30', 'schedule', "with DAV_BATCH unset: lanes from this many rows (B x tokens per tower block) upwards", 'test_lane_batched_and_stream_schedules_agree (policy values)'),
+    'DAV_FUSION_STREAM': ('1', 'schedule', "lanes schedule only: the fusion block on its own stream (1) or as a third lane of the batch (0)", 'bench.py roofline.lanes_schedule (runs it), test_full_size_step...'),
+    'DAV_BATCH_FUSION_LANE': ('1', 'schedule', "0: the fusion block never joins a launch batch as a lane", '- (diagnostic)'),
+    'DAV_STREAMS': ('1', 'schedule', "0: everything on the current stream (serial schedule; tools/instep_gemm_bound.py uses it)", 'tools/instep_gemm_bound.py (profiles/r04_gemm_instep_bound.txt)'),
+    'DAV_DEC_STREAMS': ('0', 'schedule', "lanes schedule only: 1 = the two decoders on two streams all the same", '- (A/B in DESIGN_HISTORY section 4)'),
+    'DAV_DEC_WGRAD_JOINT': ('1', 'schedule', "both decoders' weight-gradient problems in one grouped launch after both backward passes", 'test_baseline_config_shapes_vs_oracle (default path)'),
+    'DAV_WGRAD_STREAM': ('0', 'schedule', "1: weight-gradient GEMMs on their own stream (measured slower)", '- (A/B in DESIGN_HISTORY)'),
+    'DAV_GROUPED_WGRAD': ('1', 'kernel', "0: one weight-gradient launch per Linear instead of one grouped launch per layer", 'test_batch64_grouped_wgrad_path_vs_oracle (default), gpu_selfcheck gemm_tn family'),
+    'DAV_WGRAD_OVERWRITE': ('1', 'kernel', "captured step: the first weight-gradient contribution to a Linear weight WRITES its tile (AdamW skips that zero-fill); 0 = accumulate / zero-fill", 'test_written_first_gradients_equal_accumulated_ones'),
+    'DAV_ADD_CAST': ('1', 'kernel', "sum of the fusion tokens' two gradient streams + its bf16 copy in one pass (dav_add_cast); 0 = torch add", 'test_end_to_end_vs_oracle_and_golden (default path)'),
+    'DAV_ATTN_CTX': ('1', 'kernel', "the dQ kernel zero-fills the q slots of the fusion-token context rows (dav_attn_bwd_ctx); 0 = a torch fill pass", 'gpu_selfcheck attention family, e2e tests'),
+    'DAV_ATTN_PAIR': ('1', 'kernel', "d = 32 attention: adjacent heads on the same XCD (pair_heads); 0 = linear (batch, head) order", 'gpu_selfcheck attention family (both orders)'),
+    'DAV_FUSION_TAIL': ('0', 'kernel', "1: the fused tail chains of the factorised fusion block (csrc/fusion_tail.hip: 15 -> 9 launches per layer; slower inside the step, profiles/r04_fusion_tails.txt)", 'test_fusion_tails_equal_the_per_stage_launches_and_the_oracle, test_whole_step_with_the_opt_in_fused_fusion_tails_vs_oracle'),
+    'DAV_FUSION_PRIO': ('0', 'schedule', "dispatch priority of the fusion block's stream (-1 = high, 1 = low; profiles/r04_fusion_tails.txt, r04_stream_priority_ab.txt)", '- (A/B only)'),
+    'DAV_NT_TUNE': ('1', 'kernel', "0: ignore the tuned tile-configuration table (deepavfusion_amd/tuning/nt_gfx950.json), rules only", 'test_nt_tuning_table_loads_and_rejects_malformed_blobs, test_baseline_config_shapes_vs_oracle[large-32] (entries must fire)'),
+    'DAV_NT_TUNE_FILE': ('tuning/nt_gfx950.json', 'kernel', "another tuned table", 'test_nt_tuning_table_loads_and_rejects_malformed_blobs'),
+    'DAV_NT_WIDE': ('1', 'kernel', "0: no 128 x 256 tiles for the K <= 512 wide-output GEMMs (rule of nt2_issue_auto)", 'gpu_selfcheck gemm_nt family (explicit configurations)'),
+    'DAV_NT_SMALL': ('5', 'kernel', "tile configuration of launches below DAV_NT_T5 tiles: 5 = 64 x 64 two-stage ring, 7 = four-stage ring", 'gpu_selfcheck gemm_nt family'),
+    'DAV_NT_T5': ('100', 'kernel', "tile-count threshold between the 64 x 64 and the 128 x 64 configurations", '- (tuning knob)'),
+    'DAV_NT_T8': ('400', 'kernel', "tile-count threshold between the 128 x 64 and the 128 x 128 configurations", '- (tuning knob)'),
+    'DAV_NT256': ('0', 'kernel', "1: the 256 x 256 NT body (configuration 60) by rule (faster alone, slower in the step: profiles/r03_nt256_instep_ab.txt)", 'test_bench_workload_with_the_opt_in_256_tile_kernels_vs_oracle'),
+    'DAV_NT256_N': ('1024', 'kernel', "minimum output width for the DAV_NT256 rule", 'test_bench_workload_with_the_opt_in_256_tile_kernels_vs_oracle'),
+    'DAV_NT256_TILES': ('150', 'kernel', "minimum 256 x 256 tile count for the DAV_NT256 rule", 'test_bench_workload_with_the_opt_in_256_tile_kernels_vs_oracle'),
+    'DAV_NT_LD': ('0', 'kernel', "EXPERIMENTAL builds only: loader-wave variant (configuration 51) in place of configuration 3", '- (make EXPERIMENTAL=1)'),
+    'DAV_TN256': ('0', 'kernel', "EXPERIMENTAL builds only (round 4): 1 = the persistent 256 x 256 stream-K weight-gradient kernel (slower: atomics)", 'test_tn256_weight_gradient_kernel_matches_reference (EXPERIMENTAL builds)'),
+    'DAV_TN256_MIN': ('512', 'kernel', "EXPERIMENTAL builds only: K-tile pairs below which DAV_TN256 falls back to the 128 x 128 kernel", 'test_tn256_weight_gradient_kernel_matches_reference (EXPERIMENTAL builds)'),
+    'DAV_TN_XCD': ('1', 'kernel', "weight-gradient tiles: one contiguous run of each problem's tiles per XCD; 0 = every 8th tile", 'gpu_selfcheck gemm_tn family'),
+    'DAV_EARLY_ADAMW': ('0', 'optimizer', "1: AdamW on ranges of the flat buffer as their gradients become final, on a side stream (slower)", 'test_early_adamw_ranges_equal_the_single_pass'),
+    'DAV_EARLY_ADAMW_CUTS': ('depth,9,6,3,1', 'optimizer', "layers after which DAV_EARLY_ADAMW launches a range", 'test_early_adamw_ranges_equal_the_single_pass'),
+    'DAV_SEGMENTS': ('0 (1 graph; 5 when data-parallel)', 'dp', "graphs per captured step (any run)", 'test_segmented_graph_step_matches_single_graph_and_schedules_every_bucket'),
+    'DAV_DP_SEGMENTS': ('5', 'dp', "graphs per captured data-parallel step, between which finished gradient buckets are reduced", 'test_dp_switches_over_one_rank_rccl'),
+    'DAV_DP_ALGO': ('allreduce', 'dp', "allreduce | rs_ag (reduce-scatter + all-gather per bucket)", 'test_dp_switches_world2_and_world4_gloo, test_dp_switches_over_one_rank_rccl'),
+    'DAV_DP_BUCKET_MB': ('64', 'dp', "gradient bucket size (MB of fp32) when the caller passes none", 'test_dp_switches_world2_and_world4_gloo'),
+    'DAV_DP_FIRST_BUCKET_MB': ('8', 'dp', "size of the first bucket (the decoders' last gradients start moving early)", 'test_dp_switches_world2_and_world4_gloo'),
+    'DAV_DP_BF16': ('0', 'dp', "1 (NOT the reference's arithmetic): gradient buckets reduced as bf16 on the wire", 'test_dp_switches_world2_and_world4_gloo, test_dp_switches_over_one_rank_rccl'),
+    'DAV_FORCE_DIST': ('0', 'harness', "1: build the data-parallel machinery on a 1-rank process group (tests / tools on one GPU)", 'test_dp_step_over_one_rank_rccl'),
+    'DAV_DIST_TIMEOUT_S': ('1800', 'dp', "process-group timeout in seconds", '- (init_distributed_mode)'),
+    'DAV_TUNE': ('', 'harness', "bench.py: comma list knob:value for dav_tune (launch-geometry experiments)", '- (bench only)'),
+    'DAV_DUMP_MIX': ('', 'harness', "bench.py: file that receives the recorded launch mix of one step (tools/mix_sweep.py input)", '- (bench only)'),
+    'DAV_BENCH_SPAWN_DRY': ('0', 'harness', "bench.py: CPU test hook of the rank spawner (no GPU call)", 'test_bench_starts_its_own_ranks_when_launched_plainly'),
+    'DAV_NT_DEBUG': ('0', 'debug', "NT GEMM dead-code ablations (no stores / no epilogue / no MFMAs): timing only, results wrong", '- (DESIGN_HISTORY section 3)'),
+    'DAV_TN_DEBUG': ('0', 'debug', "weight-gradient GEMM ablations: timing only", '- (DESIGN_HISTORY section 3)'),
+    'DAV_TN256_DEBUG': ('0', 'debug', "256 x 256 weight-gradient kernel ablations: timing only", '- (DESIGN_HISTORY section 3)'),
+    'DAV_ATTN_DEBUG': ('0', 'debug', "attention ablations (no tile loop / no staging): timing only", '- (DESIGN_HISTORY section 3)'),
+}
+
+
+def found():
+    names = set()
+    files = [os.path.join(ROOT, f) for f in ('bench.py', 'train.py')]
+    for pat in ('deepavfusion_amd/*.py', 'deepavfusion_amd/util/*.py', 'deepavfusion_amd/models/*.py', 'deepavfusion_amd/csrc/*.hip', 'deepavfusion_amd/csrc/*.h'):
+        files += glob.glob(os.path.join(ROOT, pat))
+    for f in files:
+        names |= set(re.findall(r'\bDAV_[A-Z0-9_]+\b', open(f, errors='replace').read()))
+    return names - NOT_SWITCHES
+
+
+def render():
+    names = found()
+    missing = sorted(names - set(S))
+    if missing:
+        raise SystemExit(f'switches in the sources without an entry in tools/gen_switch_table.py: {missing}')
+    out = ['# Environment switches', '',
+           'Generated by `tools/gen_switch_table.py` (a CPU test fails when this file is stale or a switch is undocumented).  Defaults are the',
+           'product path; everything else exists for same-box A/B measurements, tests or the first multi-GPU runs.  "debug" switches are',
+           'timing ablations whose results are wrong by construction.  Combinations other than the ones the named tests run are untested.', '']
+    for cls, title in (('schedule', 'Step schedule'), ('kernel', 'Kernel selection'), ('optimizer', 'Optimizer'), ('dp', 'Data parallel'),
+                       ('harness', 'Harness / tools'), ('debug', 'Timing ablations')):
+        rows = sorted(n for n in names if S[n][1] == cls)
+        if not rows:
+            continue
+        out += [f'## {title}', '', '| switch | default | selects | covered by |', '|---|---|---|---|']
+        out += [f'| `{n}` | {S[n][0]} | {S[n][2]} | {S[n][3]} |' for n in rows]
+        out.append('')
+    stale = sorted(set(S) - names)
+    if stale:
+        out += ['(entries kept for switches that no longer appear in the sources: ' + ', '.join(stale) + ')', '']
+    return '\n'.join(out)
+
+
+if __name__ == '__main__':
+    text = render()
+    path = os.path.join(ROOT, 'SWITCHES.md')
+    if '--check' in sys.argv:
+        if not os.path.exists(path) or open(path).read() != text:
+            raise SystemExit('SWITCHES.md is out of date: run python tools/gen_switch_table.py')
+    else:
+        open(path, 'w').write(text)
+        print(f'{path}: {len(found())} switches')

@@ -44,3 +44,12 @@ print(f'{steps} steps; per step: {T / 1e6:.2f} ms of kernel time (serialised), {
 print(f'{"kernel family":66s} {"n/step":>7s} {"ms/step":>8s} {"us each":>8s} {"fetch MB":>9s} {"write MB":>9s} {"GB/s":>6s}')
 for t, k, n, f, w in rows[:45]:
     print(f'{k:66s} {n:7.1f} {t / 1e6:8.3f} {t / 1e3 / max(n, 1e-9):8.1f} {f / 1e6:9.1f} {w / 1e6:9.1f} {(f + w) / max(t, 1):6.0f}')
+
+if len(sys.argv) > 4:                                # step_traffic.py fetch.csv write.csv <out.json> <key>: totals for bench.py's step_fabric field
+    import json
+    import os
+    path, key = sys.argv[3], sys.argv[4]
+    j = json.load(open(path)) if os.path.exists(path) else {'_comment': 'memory-side traffic of one whole training step (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes over bench.py --no-graph; Infinity-Cache hits included); tools/step_traffic.sh; key = <config>_b<batch>'}
+    j[key] = {'GB_per_step': round((FF + WW) / 1e9, 2), 'fetched_GB': round(FF / 1e9, 2), 'written_GB': round(WW / 1e9, 2),
+              'serialised_kernel_ms': round(T / 1e6, 2), 'source': 'profiles/r04_step_traffic.txt (tools/step_traffic.sh)'}
+    json.dump(j, open(path, 'w'), indent=1)
