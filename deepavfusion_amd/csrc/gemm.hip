@@ -1545,24 +1545,26 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TNParams p) {
 // tr-read fragments, bias gradient as one extra MFMA against a fragment of ones, split-K with fp32
 // atomics into the live gradient.
 // ------------------------------------------------------------------------------------------------
-template <int T, int WM_, int WN_, int RS = 64, int NST = 2>
+// T x TK output tiles (T rows of the gradient = columns of A, TK columns = columns of B; TK = T unless given: round 4 adds 256 x 128)
+template <int T, int WM_, int WN_, int RS = 64, int NST = 2, int TK = T>
 __device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, const int split_idx) {
   // RS contraction rows per ring stage, NST stages (NST - 1 stages of loads in flight while one is consumed)
-  constexpr int NT = WM_ * WN_ * 64, RB = T * 2, CPRW = T / 8;      // 16-byte chunks per tile row
-  constexpr int TILE_BYTES = RS * RB, STAGE_BYTES = 2 * TILE_BYTES;
-  constexpr int CH = RS * CPRW / NT;                                // chunks per thread per operand
-  constexpr int WTN = T / WM_, WTK = T / WN_, FM = WTN / 16, FN = WTK / 16;
-  static_assert(RS * CPRW % NT == 0 && (RS == 32 || RS == 64) && NST >= 2, "tile/threads mismatch");
+  constexpr int NT = WM_ * WN_ * 64, RB = T * 2, CPRW = T / 8;      // 16-byte chunks per tile row (A side)
+  constexpr int RBK = TK * 2, CPRWK = TK / 8;                       // ... (B side)
+  constexpr int TILE_BYTES = RS * RB, TILE_BYTES_B = RS * RBK, STAGE_BYTES = TILE_BYTES + TILE_BYTES_B;
+  constexpr int CH = RS * CPRW / NT, CHB = RS * CPRWK / NT;         // chunks per thread per operand
+  constexpr int WTN = T / WM_, WTK = TK / WN_, FM = WTN / 16, FN = WTK / 16;
+  static_assert(RS * CPRW % NT == 0 && RS * CPRWK % NT == 0 && (RS == 32 || RS == 64) && NST >= 2, "tile/threads mismatch");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int dbg = p.debug_plain_store;                              // (a register: read through p inside the loop it was a scalar load + wait per stage)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN_, wn = wave % WN_;
-  const int tiles_k = (p.K + T - 1) / T, tiles_n = (p.N + T - 1) / T;
+  const int tiles_k = (p.K + TK - 1) / TK, tiles_n = (p.N + T - 1) / T;
   // consecutive tile ids walk the SHORTER side of the tile grid first: a run of ids (what one XCD owns, see the grouped kernel)
   // then covers a few whole rows / columns of it and touches few distinct operand panels
   const bool k_minor = tiles_k <= tiles_n;
   const int bn = k_minor ? tile_idx / tiles_k : tile_idx % tiles_n, bk = k_minor ? tile_idx % tiles_k : tile_idx / tiles_n;
-  const int n0 = bn * T, k0 = bk * T;
+  const int n0 = bn * T, k0 = bk * TK;
   const int steps_total = p.Mc >> 6;                                // the split of the contraction is in 64-row units
   const int steps_per = (steps_total + p.splits - 1) / p.splits;
   int s_begin = split_idx * steps_per;
@@ -1573,18 +1575,24 @@ __device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, 
   // Source pointers of this thread's chunks, carried from stage to stage (the stages are issued in contraction order): one 64-bit
   // add per chunk and stage.  Re-deriving them per stage (row map division, two 32-bit multiplies and a 64-bit multiply-add per
   // chunk, all quarter rate) was ~100 VALU cycles per chunk against the 256 MFMA cycles of a wave's whole stage.
-  const bf16_t* ap[CH]; const bf16_t* bp[CH];
-  int ar[CH], br[CH];                                      // row index inside the row map's period
+  const bf16_t* ap[CH]; const bf16_t* bp[CHB];
+  int ar[CH], br[CHB];                                     // row index inside the row map's period
 #pragma unroll
   for (int i = 0; i < CH; ++i) {
     const int c = tid + NT * i, row = c / CPRW, pc = c % CPRW;
     const int lc = (((pc >> 1) ^ tn2_swz<RB>(row)) << 1) | (pc & 1);
     int ac = n0 + lc * 8; ac = ac < p.N ? ac : p.N - 8;     // out-of-range output columns: any valid data (discarded)
-    int bc = k0 + lc * 8; bc = bc < p.K ? bc : p.K - 8;
     const int m = s_begin * RS + row;
     ap[i] = p.A + map_row(m, p.amap) * p.lda + ac;
-    bp[i] = p.B + map_row(m, p.bmap) * p.ldb + bc;
     ar[i] = p.amap.rpb > 0 ? m % p.amap.rpb : 0;
+  }
+#pragma unroll
+  for (int i = 0; i < CHB; ++i) {
+    const int c = tid + NT * i, row = c / CPRWK, pc = c % CPRWK;
+    const int lc = (((pc >> 1) ^ tn2_swz<RBK>(row)) << 1) | (pc & 1);
+    int bc = k0 + lc * 8; bc = bc < p.K ? bc : p.K - 8;
+    const int m = s_begin * RS + row;
+    bp[i] = p.B + map_row(m, p.bmap) * p.ldb + bc;
     br[i] = p.bmap.rpb > 0 ? m % p.bmap.rpb : 0;
   }
   const long a_step = (long)RS * p.lda, b_step = (long)RS * p.ldb;
@@ -1594,8 +1602,12 @@ __device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, 
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       __builtin_amdgcn_global_load_lds(GLB_PTR(void, ap[i]), LDS_PTR(void, st + (wave * 64 + NT * i) * 16), 16, 0, 0);
+      ap[i] += a_step;
+    }
+#pragma unroll
+    for (int i = 0; i < CHB; ++i) {
       __builtin_amdgcn_global_load_lds(GLB_PTR(void, bp[i]), LDS_PTR(void, st + TILE_BYTES + (wave * 64 + NT * i) * 16), 16, 0, 0);
-      ap[i] += a_step; bp[i] += b_step;
+      bp[i] += b_step;
     }
     if (p.amap.rpb > 0) {                                  // (uniform) a mapped operand: period boundaries crossed by this advance
 #pragma unroll
@@ -1606,7 +1618,7 @@ __device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, 
     }
     if (p.bmap.rpb > 0) {
 #pragma unroll
-      for (int i = 0; i < CH; ++i) {
+      for (int i = 0; i < CHB; ++i) {
         br[i] += RS;
         while (br[i] >= p.bmap.rpb) { br[i] -= p.bmap.rpb; bp[i] += b_wrap; }
       }
@@ -1631,7 +1643,7 @@ __device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, 
   for (int s = s_begin; s < s_end; ++s) {
     // the loads of step s must have landed; those of the NST - 2 steps after it may still be in flight (each step is 2 CH loads
     // per wave) — once the tail stops issuing, drain everything
-    if (NST > 2 && s + NST - 2 < s_end) wait_vmcnt<(NST - 2) * 2 * CH>(); else wait_vmcnt<0>();
+    if (NST > 2 && s + NST - 2 < s_end) wait_vmcnt<(NST - 2) * (CH + CHB)>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (s + NST - 1 < s_end) dma_tile(stage == 0 ? NST - 1 : stage - 1);      // the stage step s - 1 has just released
     const char* Ab = smem + stage * STAGE_BYTES;
@@ -1644,7 +1656,7 @@ __device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, 
 #pragma unroll
       for (int i = 0; i < FM; ++i) af[i] = tn2_frag<RB>(Ab, kk * 32, wm * WTN + i * 16, lane);
 #pragma unroll
-      for (int j = 0; j < FN; ++j) bfr[j] = tn2_frag<RB>(Bb, kk * 32, wn * WTK + j * 16, lane);
+      for (int j = 0; j < FN; ++j) bfr[j] = tn2_frag<RBK>(Bb, kk * 32, wn * WTK + j * 16, lane);
       // operands swapped (B fragment first): the 16 x 16 block comes out TRANSPOSED — lane (fr, fg) holds C[n = fr][k = 4 fg .. + 3],
       // four consecutive columns of one row — so the read-modify-write of the gradient tile is one 16-byte access per lane and
       // fragment instead of four scalar ones (as the NT kernels' epilogue)
@@ -1733,13 +1745,13 @@ struct TNGroup {
 };
 static_assert(sizeof(TNGroup) <= 4096, "kernel argument block");
 
-template <int T, int WM_, int WN_, int RS = 64, int NST = 2, int MINW = 1>
+template <int T, int WM_, int WN_, int RS = 64, int NST = 2, int MINW = 1, int TK = T>
 __global__ __launch_bounds__(WM_* WN_ * 64, MINW) void gemm_tn_grouped_kernel(const TNGroup g) {
   int pi = 0;
   while (pi + 1 < g.count && (int)blockIdx.x >= g.first_block[pi + 1]) ++pi;
   const TNParams& p = g.prob[pi];
   const int local = blockIdx.x - g.first_block[pi];
-  const int tiles = ((p.N + T - 1) / T) * ((p.K + T - 1) / T);
+  const int tiles = ((p.N + T - 1) / T) * ((p.K + TK - 1) / TK);
   int unit = local;
   if (g.xcd_runs) {
     // workgroup ids go round the 8 XCDs (private L2s): the ids with the same residue form one XCD's share of this problem.  Give
@@ -1750,7 +1762,7 @@ __global__ __launch_bounds__(WM_* WN_ * 64, MINW) void gemm_tn_grouped_kernel(co
     const int r = local & 7, j = local >> 3, q = total >> 3, rem = total & 7;
     unit = r * q + (r < rem ? r : rem) + j;
   }
-  tn2_body<T, WM_, WN_, RS, NST>(p, unit % tiles, unit / tiles);
+  tn2_body<T, WM_, WN_, RS, NST, TK>(p, unit % tiles, unit / tiles);
 }
 
 template <int T, int WM_, int WN_>
@@ -2013,6 +2025,16 @@ extern "C" int dav_gemm_tn_grouped_bf16(const DavTnProblem* probs, int count, hi
     }
   }
 #endif
+  // Round 4: 256 x 128 tiles, one owner per tile as before (no atomics) — 3/4 of the operand bytes per flop on the global -> LDS stream
+  // that bounds this kernel.  Measured SLOWER in both ring forms (profiles/r04_tn256x128.txt): 64-row stages x 2 at one workgroup per
+  // CU 567 / 520 TF against 693 / 624 for 128 x 128 (decoders' / a layer's launch) and +1.6 ms per step; 32-row stages x 3 at two
+  // workgroups per CU (128 registers) 652 / 532 TF and +2.7 ms.  EXPERIMENTAL builds only: DAV_TN_TILE=256 / 257.
+#ifdef DAV_EXPERIMENTAL
+  static const int tn_tile = getenv("DAV_TN_TILE") ? atoi(getenv("DAV_TN_TILE")) : 128;
+  if (tn_tile != 128 && tn_tile != 256 && tn_tile != 257) return DAV_ERR_SHAPE;      // 257: 256 x 128 on 32-row stages x 3, two workgroups per CU
+#else
+  constexpr int tn_tile = 128;
+#endif
   // aim at ~4 workgroups of 8 waves per CU-slot pair (1024 blocks) but keep >= 8 k-steps of 64 rows per split
   int first = 0;
   for (int i = 0; i < count; ++i) {
@@ -2023,7 +2045,7 @@ extern "C" int dav_gemm_tn_grouped_bf16(const DavTnProblem* probs, int count, hi
     p.bmap = RowMap{q.b_rowmap[0], q.b_rowmap[1], q.b_rowmap[2]};
     static const int tn_debug = getenv("DAV_TN_DEBUG") ? atoi(getenv("DAV_TN_DEBUG")) & 6 : 0;
     p.C = q.C; p.ldc = q.ldc; p.beta = (q.flags & 1) ? 0 : 1; p.bias_grad = q.bias_grad; p.debug_plain_store = tn_debug;
-    const int tiles = ((q.N + 127) / 128) * ((q.K + 127) / 128), steps = q.Mc >> 6;
+    const int tiles = ((q.N + (tn_tile & ~1) - 1) / (tn_tile & ~1)) * ((q.K + 127) / 128), steps = q.Mc >> 6;
     int splits = (int)((1024 + total_tiles - 1) / total_tiles);
     const int max_splits = steps / 8 > 0 ? steps / 8 : 1;
     if (splits > max_splits) splits = max_splits;
@@ -2044,6 +2066,20 @@ extern "C" int dav_gemm_tn_grouped_bf16(const DavTnProblem* probs, int count, hi
   // (by-value copy in an AUTOMATIC: a launch recorded inside dav_batch_begin .. dav_batch_end captures its arguments with [=],
   // which does not copy objects of static storage — two recorded grouped calls would both run with the last table)
   const TNGroup gl = g;
+#ifdef DAV_EXPERIMENTAL
+  if (tn_tile == 257) {
+    static bool big = false;
+    if (!big) { (void)hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel<256, 4, 2, 32, 3, 4, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); big = true; }
+    DAV_LAUNCH((gemm_tn_grouped_kernel<256, 4, 2, 32, 3, 4, 128>), dim3(first), dim3(512), (size_t)3 * 32 * (256 + 128) * 2, stream, gl);
+    return dav_launch_status();
+  }
+  if (tn_tile == 256) {
+    static bool big = false;
+    if (!big) { (void)hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel<256, 4, 2, 64, 2, 1, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); big = true; }
+    DAV_LAUNCH((gemm_tn_grouped_kernel<256, 4, 2, 64, 2, 1, 128>), dim3(first), dim3(512), (size_t)2 * 64 * (256 + 128) * 2, stream, gl);
+    return dav_launch_status();
+  }
+#endif
   DAV_LAUNCH((gemm_tn_grouped_kernel<128, 4, 2>), dim3(first), dim3(512), (size_t)2 * 2 * 64 * 128 * 2, stream, gl);
   return dav_launch_status();
 }
