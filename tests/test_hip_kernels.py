@@ -239,3 +239,14 @@ def test_tn256_weight_gradient_kernel_matches_reference():
             "bad = [r for r in sc.RESULTS if not r[3]]; print(len(sc.RESULTS), 'checks', len(bad), 'bad', bad[:5]); sys.exit(1 if bad or not sc.RESULTS else 0)")
     r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, DAV_TN256='1', DAV_TN256_MIN='64'), cwd=ROOT, capture_output=True, timeout=600)
     assert r.returncode == 0, (r.stdout.decode()[-3000:], r.stderr.decode()[-2000:])
+
+
+def test_opt_in_fused_attention_backward_matches_reference():
+    """csrc/attention.hip attn_bwd_fused_body (round 4, DAV_ATTN_FUSED_BWD=1, off by default): the d = 32 attention backward as one
+    kernel from one recomputation of the probabilities — the whole attention family of checks (dQ / dK / dV vs fp32 torch, incl. the
+    decoders' 228 x 228 and 352 x 352 problems the fused kernel takes) in a fresh process with the switch on."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, 'tests'); import gpu_selfcheck as sc; sc.attention(); "
+            "bad = [r for r in sc.RESULTS if not r[3]]; print(len(sc.RESULTS), 'checks', len(bad), 'bad', bad[:5]); sys.exit(1 if bad or not sc.RESULTS else 0)")
+    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, DAV_ATTN_FUSED_BWD='1'), cwd=ROOT, capture_output=True, timeout=600)
+    assert r.returncode == 0, (r.stdout.decode()[-3000:], r.stderr.decode()[-2000:])

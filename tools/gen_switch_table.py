@@ -30,6 +30,7 @@ S = {
     'DAV_ADD_CAST': ('1', 'kernel', "sum of the fusion tokens' two gradient streams + its bf16 copy in one pass (dav_add_cast); 0 = torch add", 'test_end_to_end_vs_oracle_and_golden (default path)'),
     'DAV_ATTN_CTX': ('1', 'kernel', "the dQ kernel zero-fills the q slots of the fusion-token context rows (dav_attn_bwd_ctx); 0 = a torch fill pass", 'gpu_selfcheck attention family, e2e tests'),
     'DAV_ATTN_PAIR': ('1', 'kernel', "d = 32 attention: adjacent heads on the same XCD (pair_heads); 0 = linear (batch, head) order", 'gpu_selfcheck attention family (both orders)'),
+    'DAV_ATTN_FUSED_BWD': ('0', 'kernel', "1: d = 32 attention backward as ONE kernel from one recomputation of the probabilities (attn_bwd_fused_body; no faster: profiles/r04_attn_fused_bwd.txt)", 'test_opt_in_fused_attention_backward_matches_reference'),
     'DAV_FUSION_TAIL': ('0', 'kernel', "1: the fused tail chains of the factorised fusion block (csrc/fusion_tail.hip: 15 -> 9 launches per layer; slower inside the step, profiles/r04_fusion_tails.txt)", 'test_fusion_tails_equal_the_per_stage_launches_and_the_oracle, test_whole_step_with_the_opt_in_fused_fusion_tails_vs_oracle'),
     'DAV_FUSION_PRIO': ('0', 'schedule', "dispatch priority of the fusion block's stream (-1 = high, 1 = low; profiles/r04_fusion_tails.txt, r04_stream_priority_ab.txt)", '- (A/B only)'),
     'DAV_NT_TUNE': ('1', 'kernel', "0: ignore the tuned tile-configuration table (deepavfusion_amd/tuning/nt_gfx950.json), rules only", 'test_nt_tuning_table_loads_and_rejects_malformed_blobs, test_baseline_config_shapes_vs_oracle[large-32] (entries must fire)'),
