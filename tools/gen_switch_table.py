@@ -45,6 +45,7 @@ S = {
     'DAV_NT_LD': ('0', 'kernel', "EXPERIMENTAL builds only: loader-wave variant (configuration 51) in place of configuration 3", '- (make EXPERIMENTAL=1)'),
     'DAV_TN256': ('0', 'kernel', "EXPERIMENTAL builds only (round 4): 1 = the persistent 256 x 256 stream-K weight-gradient kernel (slower: atomics)", 'test_tn256_weight_gradient_kernel_matches_reference (EXPERIMENTAL builds)'),
     'DAV_TN256_MIN': ('512', 'kernel', "EXPERIMENTAL builds only: K-tile pairs below which DAV_TN256 falls back to the 128 x 128 kernel", 'test_tn256_weight_gradient_kernel_matches_reference (EXPERIMENTAL builds)'),
+    'DAV_TN_TILE': ('128', 'kernel', "EXPERIMENTAL builds only: 256 / 257 = 256 x 128 owner-per-tile weight-gradient tiles on 64-row x 2 / 32-row x 3 rings (slower: profiles/r04_tn256x128.txt)", '- (gpu_selfcheck gemm_tn family run with it, profiles/r04_tn256x128.txt)'),
     'DAV_TN_XCD': ('1', 'kernel', "weight-gradient tiles: one contiguous run of each problem's tiles per XCD; 0 = every 8th tile", 'gpu_selfcheck gemm_tn family'),
     'DAV_EARLY_ADAMW': ('0', 'optimizer', "1: AdamW on ranges of the flat buffer as their gradients become final, on a side stream (slower)", 'test_early_adamw_ranges_equal_the_single_pass'),
     'DAV_EARLY_ADAMW_CUTS': ('depth,9,6,3,1', 'optimizer', "layers after which DAV_EARLY_ADAMW launches a range", 'test_early_adamw_ranges_equal_the_single_pass'),
