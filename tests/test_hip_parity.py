@@ -1173,6 +1173,8 @@ def _tuned_hits(issued):
     for e in json.load(open(_lib.NT_TUNING_PATH))['entries']:
         table[(int(e['b_kn']),) + tuple(sorted(tuple(int(x) for x in q) for q in e['problems']))] = int(e['cfg'])
     hits = 0
+    if os.environ.get('DAV_NT_TUNE', '1') == '0' or os.environ.get('DAV_NT256') == '1':
+        return 0                     # the table is switched off / overridden by the opt-in 256 x 256 rule in this process
     for cfg_id, bt, probs, flags in issued:
         key = (int(bt),) + tuple(sorted((M, N, K, f) for (M, N, K), f in zip(probs, flags)))
         if key in table:

@@ -57,6 +57,7 @@ S = {
     'DAV_DP_BF16': ('0', 'dp', "1 (NOT the reference's arithmetic): gradient buckets reduced as bf16 on the wire", 'test_dp_switches_world2_and_world4_gloo, test_dp_switches_over_one_rank_rccl'),
     'DAV_FORCE_DIST': ('0', 'harness', "1: build the data-parallel machinery on a 1-rank process group (tests / tools on one GPU)", 'test_dp_step_over_one_rank_rccl'),
     'DAV_DIST_TIMEOUT_S': ('1800', 'dp', "process-group timeout in seconds", '- (init_distributed_mode)'),
+    'DAV_BENCH_SHIFT_MB': ('', 'harness', "bench.py: hold this many MB (comma list = several blocks) in front of every allocation of the process (buffer-placement experiment, profiles/r04_placement_sweep.txt)", '- (bench only)'),
     'DAV_TUNE': ('', 'harness', "bench.py: comma list knob:value for dav_tune (launch-geometry experiments)", '- (bench only)'),
     'DAV_DUMP_MIX': ('', 'harness', "bench.py: file that receives the recorded launch mix of one step (tools/mix_sweep.py input)", '- (bench only)'),
     'DAV_BENCH_SPAWN_DRY': ('0', 'harness', "bench.py: CPU test hook of the rank spawner (no GPU call)", 'test_bench_starts_its_own_ranks_when_launched_plainly'),
