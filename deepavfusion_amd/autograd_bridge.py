@@ -78,9 +78,14 @@ def _vis(enc):
 # ------------------------------------------------------------------------------------------------
 # encoder (models/deepavfusion.py:88-118)
 # ------------------------------------------------------------------------------------------------
-def encoder_fwd(enc, image, audio, ik32, ak32, want_f32=False, collect_embs=False):
+def encoder_fwd(enc, image, audio, ik32, ak32, want_f32=False, collect_embs=False, fwd_gate=None):
+    """``fwd_gate(stage)`` (optional) is called on the main stream right before the first launch that reads the parameters of a
+    stage: -1 = patch embeddings / fusion tokens, l = encoder layer l (both towers + its fusion block), depth = the final norms
+    (util.misc.GraphedStep's deferred AdamW makes the stream wait there for the update of exactly those parameters)."""
     B = image.shape[0]
     vis = _vis(enc)
+    if fwd_gate is not None:
+        fwd_gate(-1)
     x_i, t_pi = E.patch_embed_fwd(vis, image, ik32)
     x_a, t_pa = E.patch_embed_fwd(enc.audio, audio, ak32)
     x_f = enc.fusion_tokens.detach().expand(B, -1, -1).clone(memory_format=torch.contiguous_format)   # never an alias of the parameter (B == 1)
@@ -94,6 +99,8 @@ def encoder_fwd(enc, image, audio, ik32, ak32, want_f32=False, collect_embs=Fals
         dpf = drop_path_scales(enc, fb, B, image.device, f'fusion.{l}') if fb is not None else None
         xf_ctx = x_f if fb is not None else None
         tf = None
+        if fwd_gate is not None:
+            fwd_gate(l)
         if batched:
             # ONE launch batch per layer, three lanes — image block, audio block, fusion block (all read the layer inputs
             # only, models/deepavfusion.py:104-107): LayerNorms / GEMMs / attentions of equal rank go out as grouped grids
@@ -138,6 +145,8 @@ def encoder_fwd(enc, image, audio, ik32, ak32, want_f32=False, collect_embs=Fals
         layers.append((ti, ta, tf))
         if collect_embs:
             embs.append((x_i, x_a, x_f))
+    if fwd_gate is not None:
+        fwd_gate(len(vis.blocks))
     xi_b, xi32, st_i = E.ln_fwd(vis.norm, None, x_i, B, want_f32=want_f32)
     xa_b, xa32, st_a = E.ln_fwd(enc.audio.norm, None, x_a, B, want_f32=want_f32)
     xf_b, xf32, st_f = E.ln_fwd(enc.fusion_norm, None, x_f, B, want_f32=want_f32)
@@ -399,14 +408,17 @@ def fusion_block(fb, xmm, xv, xa):
 # ------------------------------------------------------------------------------------------------
 # the whole AVMAE step (models/avmae.py:216-236)
 # ------------------------------------------------------------------------------------------------
-def avmae_fwd(model, image, audio, noise_i, noise_a):
+def avmae_fwd(model, image, audio, noise_i, noise_a, fwd_gate=None):
+    """``fwd_gate``: see encoder_fwd; stage depth + 1 = the two decoders."""
     enc = model.encoder
     B = image.shape[0]
     Li, La = model.image_gs[0] * model.image_gs[1], model.audio_gs[0] * model.audio_gs[1]
     nki, nka = int(Li * (1 - model.image_mask_ratio)), int(La * (1 - model.audio_mask_ratio))     # models/avmae.py:132
     ik, im, ir, ik32, ir32 = ops.mask_build(noise_i, nki)
     ak, am, ar, ak32, ar32 = ops.mask_build(noise_a, nka)
-    (xi_b, xa_b, xf_b), _, _, t_enc = encoder_fwd(enc, image, audio, ik32, ak32)
+    (xi_b, xa_b, xf_b), _, _, t_enc = encoder_fwd(enc, image, audio, ik32, ak32, fwd_gate=fwd_gate)
+    if fwd_gate is not None:
+        fwd_gate(len(enc.fusion_blocks) + 1)
     nF = enc.fusion_tokens.shape[1]
     dec_i, dec_a = model.decoder('image'), model.decoder('audio')
     main, sa, _ = _streams(image.device)

@@ -110,14 +110,21 @@ class FlatAdamW(torch.optim.Optimizer):
         ops.cast_bf16(self.flat.flat_p, self.flat_bf16)
         engine.invalidate_weight_cache(self.flat.params)
 
-    def prepare_step(self):
+    def group_hyper(self):
+        """[(lr, weight_decay)] per parameter group as they stand now (what ``prepare_step`` would upload)."""
+        return [(g['lr'], g['weight_decay']) for g in self.param_groups]
+
+    def prepare_step(self, group_hyper=None):
         """Host side of a step (kept outside hipGraph capture): bump t, upload per-tensor {lr, wd} and bias corrections.
+        ``group_hyper``: a ``group_hyper()`` snapshot to upload instead of the groups' current values (a deferred update uses the
+        learning rate of the step its gradients belong to, not the one the scheduler has set since).
         The staging tensors are FRESH pinned allocations every step: the host may be many replayed steps ahead of the GPU,
         and a reused staging buffer would be overwritten with a later step's values before this step's asynchronous copy
         has run (torch's pinned-memory allocator recycles a block only after the copy that read it has completed)."""
         self.step_count += 1
-        lrs = torch.tensor([g['lr'] for g in self.param_groups], dtype=torch.float32)
-        wds = torch.tensor([g['weight_decay'] for g in self.param_groups], dtype=torch.float32)
+        gh = group_hyper if group_hyper is not None else self.group_hyper()
+        lrs = torch.tensor([h[0] for h in gh], dtype=torch.float32)
+        wds = torch.tensor([h[1] for h in gh], dtype=torch.float32)
         pin = self._hyper.is_cuda
         hyper = torch.empty(self._hyper.shape, dtype=torch.float32, pin_memory=pin)
         hyper[:, 0] = lrs[self._gidx]

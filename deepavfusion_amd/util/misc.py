@@ -179,7 +179,7 @@ class GraphedStep:
     is NOT meant to continue past such a step — ``check()`` raises (train.py calls it every print_freq steps, at the end of every
     epoch and before every checkpoint), exactly where the reference raises on the step itself (train.py:166-167)."""
 
-    def __init__(self, trainer: Trainer, image_shape, audio_shape, warmup: int = 2, segments: int = 0, clip_grad=None):
+    def __init__(self, trainer: Trainer, image_shape, audio_shape, warmup: int = 2, segments: int = 0, clip_grad=None, defer=None):
         """``clip_grad``: max global gradient norm (``opt.clip_grad``; util/misc.py:118-120) — the norm is then taken in a
         pass of its own in front of AdamW and the factor min(1, clip / (norm + 1e-6)) reaches the update as a device scalar.
         Always on: the non-finite guard of train.py:166-167 — a step whose loss (or, with clipping, gradient norm) is not
@@ -218,10 +218,21 @@ class GraphedStep:
         # default: DAV_EARLY_ADAMW_CUTS) get their AdamW pass THERE, on a side stream, under the rest of the backward — instead
         # of one 1.8 ms memory-bound kernel running alone at the end of the step.  Which parameters are final where is learnt
         # from one of the warm-up passes (the engine reports every parameter once its gradient is complete).
-        self.early = (not self.dist_active and self.n_seg == 1 and self.clip_grad is None and os.environ.get('DAV_EARLY_ADAMW', '0') == '1')
+        single = not self.dist_active and self.n_seg == 1 and self.clip_grad is None
+        # Deferred AdamW (same conditions): the update with step i's gradients is the FIRST thing of replay i + 1, issued layer by
+        # layer on a side stream while the forward of replay i + 1 is already running — each forward stage waits only for the update
+        # of its own parameters (autograd_bridge ``fwd_gate``).  The loss sequence is that of the plain schedule (forward i + 1 sees
+        # parameters updated i times either way); what lags is the state BETWEEN calls: after call i the parameters carry i - 1
+        # updates and the gradients of step i, until the next call or ``flush()`` (before anything reads the parameters:
+        # checkpoint, evaluation, end of training).  The returned grad norm is the previous step's.
+        self.defer = single and (defer if defer is not None else os.environ.get('DAV_DEFER_ADAMW', '0') == '1')
+        self.early = single and not self.defer and os.environ.get('DAV_EARLY_ADAMW', '0') == '1'
         cuts_env = os.environ.get('DAV_EARLY_ADAMW_CUTS', '')
         self.early_cuts = ({int(c) for c in cuts_env.split(',') if c.strip()} if cuts_env
                            else {depth} | {l for l in (9, 6, 3, 1) if l < depth}) if self.early else set()
+        if self.defer:
+            self.early_cuts = set(range(1, depth + 1))
+        learn = self.early or self.defer
         index_of = {id(p): i for i, p in enumerate(self.opt.flat.params)}
         learnt, fresh = {}, []                 # cut -> parameter indices whose gradients became final since the previous cut
 
@@ -237,8 +248,8 @@ class GraphedStep:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for it in range(max(warmup, 1 if self.early else 0)):
-                if self.early and it == 0:
+            for it in range(max(warmup, 1 if learn else 0)):
+                if learn and it == 0:
                     engine.set_grad_ready_hook(learn_ready)
                     self._fwd_bwd(learn_cb)
                     engine.set_grad_ready_hook(None)
@@ -262,8 +273,29 @@ class GraphedStep:
             idx = [i for i in learnt[l] if i not in taken]
             taken.update(idx)
             self.early_ranges[l] = as_ranges(idx)
-        self.late_ranges = as_ranges([i for i in range(len(self.opt.flat.params)) if i not in taken]) if self.early else []
-        self.opt_stream = torch.cuda.Stream() if self.early else None
+        self.late_ranges = as_ranges([i for i in range(len(self.opt.flat.params)) if i not in taken]) if learn else []
+        self.opt_stream = torch.cuda.Stream() if learn else None
+        if self.defer:
+            # update order = the order the forward needs the parameters: [embeddings + layer 0] (what the backward finishes last),
+            # layers 1 .. depth-1 (the final norms ride with the last layer), the decoders
+            self.chunks = [self.late_ranges] + [self.early_ranges.get(l, []) for l in range(1, depth + 1)]
+            chunk_of = {}
+            for k, rs in enumerate(self.chunks):
+                for r in rs:
+                    for i in range(r['first'], r['first'] + r['n']):
+                        chunk_of[i] = k
+            blocks = [vis.blocks, enc.audio.blocks, enc.fusion_blocks]
+            norms = [m for m in (vis.norm, enc.audio.norm, getattr(enc, 'fusion_norm', None)) if m is not None]
+            in_layers = {id(p) for bl in blocks for b in bl if b is not None for p in b.parameters()} | {id(p) for m in norms for p in m.parameters()}
+            enc_ids = {id(p) for p in enc.parameters()}
+            stage_params = {-1: [p for p in enc.parameters() if id(p) not in in_layers],
+                            depth: [p for m in norms for p in m.parameters()],
+                            depth + 1: [p for p in self.model.parameters() if id(p) not in enc_ids]}
+            for l in range(depth):
+                stage_params[l] = [p for bl in blocks if bl[l] is not None for p in bl[l].parameters()]
+            # (a stage waits for the LAST chunk any of its parameters is in; chunks run in order on one stream)
+            self.stage_chunk = {st: max([chunk_of[index_of[id(p)]] for p in ps if id(p) in index_of], default=-1)
+                                for st, ps in stage_params.items()}
 
         # ---- capture ------------------------------------------------------------------------------------------
         self.graphs = [torch.cuda.CUDAGraph() for _ in range(self.n_seg)]
@@ -318,6 +350,32 @@ class GraphedStep:
         self.bad_steps = torch.zeros(1, dtype=torch.int32, device=dev)
         self._presq = torch.zeros(1, dtype=torch.float32, device=dev)
         self._presq_ws = torch.zeros(1024, dtype=torch.float32, device=dev)
+        self.prev_loss = torch.zeros(2, dtype=torch.float32, device=dev)      # deferred AdamW: the losses its guard judges
+        self.pending = False                                                  # deferred AdamW: gradients waiting for their update
+        if self.defer:
+            self.grad_norm = torch.zeros((), dtype=torch.float32, device=dev)
+
+        def deferred_update():                # AdamW of the PREVIOUS replay's gradients, chunk by chunk on the side stream
+            self.opt_stream.wait_stream(torch.cuda.current_stream())
+            self.chunk_events = []
+            with torch.cuda.stream(self.opt_stream):
+                ops.step_guard(self.prev_loss[0:1], self.prev_loss[1:2], None, None, 1.0, self.step_scale, self.bad_steps)
+                for rs in self.chunks:
+                    for r in rs:
+                        self.opt.launch_range(r, keep_grad=self.keep_grad, gscale_dev=self.step_scale)
+                    ev = torch.cuda.Event()
+                    ev.record(self.opt_stream)
+                    self.chunk_events.append(ev)
+                # (a buffer of its own: this pass is captured twice — in the step and in the flush graph — over one memory pool)
+                torch.sqrt(torch.cat([r['sumsq'] for rs in self.chunks for r in rs]).sum(), out=self.grad_norm)
+            engine.invalidate_weight_cache(self.opt.flat.params)
+        waited = [-1]
+
+        def fwd_gate(stage):
+            k = self.stage_chunk.get(stage, -1)
+            if k > waited[0]:
+                torch.cuda.current_stream().wait_event(self.chunk_events[k])
+                waited[0] = k
 
         def optimizer_pass():
             if self.early:                       # what the backward did not take along: the first layers, the embeddings
@@ -346,15 +404,28 @@ class GraphedStep:
                 # copies left over from the warm-up passes would otherwise be read, stale, by every replay
                 engine.invalidate_weight_cache(self.model.parameters())
                 engine.refresh_weight_cache(self.model)
-                self.loss_image, self.loss_audio = self._fwd_bwd(layer_cb)
+                if self.defer:
+                    deferred_update()
+                self.loss_image, self.loss_audio = self._fwd_bwd(layer_cb, fwd_gate if self.defer else None)
+                if self.defer:
+                    torch.cuda.current_stream().wait_stream(self.opt_stream)
+                    self.prev_loss[0:1].copy_(self.loss_image.reshape(1))
+                    self.prev_loss[1:2].copy_(self.loss_audio.reshape(1))
             finally:
                 # (also on an exception: a write-first mode left on would make later EAGER backwards overwrite instead of
                 # accumulate the first contribution to every Linear weight's gradient)
                 kept = {id(p) for p in engine.wgrad_overwrite_end()}
-            if not self.dist_active:
+            if not self.dist_active and not self.defer:
                 optimizer_pass()
             self.graphs[seg[0]].capture_end()
             self.opt_graph = None
+            self.flush_graph = None
+            if self.defer:                       # the update alone: what ``flush()`` replays
+                self.flush_graph = torch.cuda.CUDAGraph()
+                self.flush_graph.capture_begin(pool=self.graphs[0].pool(), capture_error_mode=CAPTURE_MODE)
+                deferred_update()
+                torch.cuda.current_stream().wait_stream(self.opt_stream)
+                self.flush_graph.capture_end()
             if self.dist_active:
                 self.opt_graph = torch.cuda.CUDAGraph()
                 self.opt_graph.capture_begin(pool=self.graphs[0].pool(), capture_error_mode=CAPTURE_MODE)
@@ -379,12 +450,20 @@ class GraphedStep:
             raise RuntimeError(f'Loss is {float(self.loss_image + self.loss_audio)}, stopping training '
                                f'({n} captured step(s) had a non-finite loss or gradient norm; their updates were skipped)')
 
-    def _fwd_bwd(self, layer_cb):
+    def flush(self):
+        """Deferred AdamW only: apply the update the last call left pending (a no-op otherwise).  Call before anything reads the
+        parameters or the optimizer state — checkpoint, evaluation, the end of training."""
+        if self.defer and self.pending:
+            self.opt.prepare_step(self.pending_hyper)
+            self.flush_graph.replay()
+            self.pending = False
+
+    def _fwd_bwd(self, layer_cb, fwd_gate=None):
         """Forward + hand-written backward straight on the engine (no autograd), unit upstream gradients."""
         B, dev = self.image.shape[0], self.image.device
         Li, La = self.model.image_gs[0] * self.model.image_gs[1], self.model.audio_gs[0] * self.model.audio_gs[1]
         noise_i, noise_a = torch.rand(B, Li, device=dev), torch.rand(B, La, device=dev)
-        outs, tape, aux = self.bridge.avmae_fwd(self.model, self.image, self.audio, noise_i, noise_a)
+        outs, tape, aux = self.bridge.avmae_fwd(self.model, self.image, self.audio, noise_i, noise_a, fwd_gate=fwd_gate)
         self.loss_image_dev, self.loss_audio_dev = outs[0], outs[1]      # (the early AdamW passes' guard reads them inside the backward)
         one = torch.ones((), device=dev)
         self.bridge.avmae_bwd(self.model, tape, one, one, layer_cb=layer_cb)
@@ -393,6 +472,20 @@ class GraphedStep:
     def __call__(self, image, audio):
         self.image.copy_(image, non_blocking=True)
         self.audio.copy_(audio, non_blocking=True)
+        if self.defer:
+            if self.pending:
+                self.opt.prepare_step(self.pending_hyper)
+                self.graphs[0].replay()
+            else:
+                # nothing to apply yet (first call, or right after flush()): a non-finite "previous loss" makes the guard skip the
+                # update on the device — the one replay the skip counter must not see
+                self.prev_loss.fill_(float('nan'))
+                self.graphs[0].replay()
+                self.bad_steps.sub_(1)
+            self.pending, self.pending_hyper = True, self.opt.group_hyper()      # (the learning rate of THIS step's gradients)
+            self.opt.flat.stale = self.kept_params > 0
+            self.tr.n_steps += 1
+            return self.loss_image, self.loss_audio, self.grad_norm
         self.opt.prepare_step()
         if self.reducer is not None:
             self.reducer.begin_backward()

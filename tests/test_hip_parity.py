@@ -811,6 +811,58 @@ def test_early_adamw_ranges_equal_the_single_pass(monkeypatch):
     assert rel(finals[1], finals[0]) < 2e-4 and rel(moments[1], moments[0]) < 2e-3      # (fp32 atomics in the bias gradients: not bit-equal)
 
 
+def test_deferred_adamw_equals_the_plain_schedule(monkeypatch):
+    """DAV_DEFER_ADAMW=1 / GraphedStep(defer=True): the update with step i's gradients is issued at the top of replay i + 1, layer by
+    layer on a side stream under that replay's forward (each forward stage gated on its own parameters' chunk).  The update is
+    element-wise and every forward sees the same parameters as in the plain schedule: the same seeds — with a learning rate that
+    changes every step, and a ``flush()`` in the middle of the run — must give the same losses, and after the final ``flush()`` the
+    same parameters and moments; the reported gradient norm is the previous step's; no replay counts as skipped."""
+    from deepavfusion_amd.util import lr_sched
+    from deepavfusion_amd.util.flat import FlatAdamW
+    from deepavfusion_amd.util.misc import GraphedStep, Trainer
+    finals, moments, losses, norms, mirrors = [], [], [], [], []
+    for defer in (False, True):
+        model, sd, cfg, O = _build('micro')
+        nd = [n for n, p in model.named_parameters() if 'bias' in n or 'norm' in n]
+        groups = lr_sched.param_groups_pretrained(model, 0.05, no_weight_decay_list=nd, image_pt='', audio_pt='')
+        opt = FlatAdamW(groups, lr=1e-3, betas=(0.9, 0.95), model=model)
+        tr = Trainer(model, optimizer=opt, accum_iter=1)
+        image, audio, _, _ = O.structured_batch(cfg, 64, seed=3)
+        image, audio = image.cuda(), audio.cuda()
+        torch.manual_seed(77)
+        gs = GraphedStep(tr, image.shape, audio.shape, defer=defer)
+        assert gs.defer == defer
+        if defer:
+            covered = sorted(i for rs in gs.chunks for r in rs for i in range(r['first'], r['first'] + r['n']))
+            assert covered == list(range(len(opt.flat.params)))                       # every parameter in exactly one chunk
+            assert len([rs for rs in gs.chunks if rs]) >= 3                           # embeddings + layer 0 | layer 1 | decoders
+            ks = [gs.stage_chunk[st] for st in sorted(gs.stage_chunk)]
+            assert ks == sorted(ks) and ks[0] >= 0, gs.stage_chunk                    # the forward meets the chunks in update order
+        run, gns = [], []
+        for s in range(6):
+            torch.manual_seed(500 + s)
+            for g in opt.param_groups:
+                g['lr'] = 1e-3 * (1.0 + 0.5 * s)                                       # (a schedule: the update must use ITS step's value)
+            li, la, gn = gs(image, audio)
+            run.append(float(li) + float(la)); gns.append(float(gn))
+            if s == 2:
+                gs.flush()                                                            # e.g. a checkpoint in the middle of an epoch
+                gs.flush()                                                            # (idempotent)
+        gs.flush()
+        torch.cuda.synchronize()
+        gs.check()
+        assert int(opt.step_count) == 6
+        finals.append(opt.flat.flat_p.clone()); moments.append(opt.exp_avg_sq.clone()); losses.append(run); norms.append(gns)
+        mirrors.append(opt.flat_bf16.clone())
+    assert all(np.isfinite(losses[1])) and losses[1][-1] < losses[1][0]
+    for a, b in zip(*losses):
+        assert abs(a - b) <= 1e-5 * abs(b), losses
+    for s in (1, 2, 4, 5):                                                            # (call 3 follows a flush: nothing pending, norm of zeros)
+        assert abs(norms[1][s] - norms[0][s - 1]) <= 1e-4 * norms[0][s - 1], norms
+    assert rel(finals[1], finals[0]) < 2e-4 and rel(moments[1], moments[0]) < 2e-3      # (fp32 atomics in the bias gradients: not bit-equal)
+    assert rel(mirrors[1].float(), mirrors[0].float()) < 2e-3
+
+
 def test_trainer_skip_grad_drops_an_outlier_micro_step():
     """util/misc.py:81-104: with ``skip_grad`` a micro-step whose own gradient norm exceeds the limit is dropped — the gradients
     accumulated before it survive, the step counter of the accumulation does not advance — and a normal one is kept."""

@@ -1,8 +1,7 @@
-mkdir -p gpurun_out/r04
-rm -f gpurun_out/r04/placement_sweep.txt
-for rep in 1 2; do
-for sh in "" 1 3 17 64.5 257 1025.25 4099; do
-  DAV_BENCH_SHIFT_MB=$sh python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('shift_MB=[$sh]', d['ms_per_step'], d['median_ms_per_step_device_events'], 'm75', d['secondary']['ms_per_step'])" >> gpurun_out/r04/placement_sweep.txt
-done
-done
-cat gpurun_out/r04/placement_sweep.txt
+#!/bin/bash
+# deferred AdamW: parity test, then the A/B
+mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "deferred_adamw or early_adamw or graphed_step_equals or guards_non_finite" > gpurun_out/r04_defer_test.log 2>&1
+tail -5 gpurun_out/r04_defer_test.log
+timeout 900 python tools/defer_adamw_ab.py > gpurun_out/r04_defer_ab.txt 2>&1
+tail -8 gpurun_out/r04_defer_ab.txt
