@@ -349,8 +349,32 @@ def deferred_operands_to(stream):
             item[0].record_stream(stream)
 
 
+# DAV_WGRAD_SIDE=1: the grouped weight-gradient launch of a layer goes out on a side stream (a parallel branch of the captured graph)
+# instead of between two layers of the input-gradient chain, where it runs ALONE for its whole duration (profiles/r04_timeline.txt:
+# 5.3 of the step's 18 ms with a single kernel on the GPU).  DAV_WGRAD_SIDE_PRIO: dispatch priority of that stream.
+def wgrad_side():
+    return os.environ.get('DAV_WGRAD_SIDE', '0') == '1'
+
+
 def flush_wgrads():
-    """Launch the queued weight-gradient problems on the current stream (their operands must be complete on it)."""
+    """Launch the queued weight-gradient problems on the current stream (their operands must be complete on it) — or, with
+    DAV_WGRAD_SIDE=1, on the weight-gradient stream behind everything enqueued on the current stream so far
+    (``join_wgrad_stream`` before anything reads the gradients)."""
+    if wgrad_side() and (_DEFERRED or _DEFERRED_LN) and torch.cuda.is_current_stream_capturing():      # (eager passes: gradient-ready hooks assume stream order)
+        cur = torch.cuda.current_stream()
+        key = cur.device.index if cur.device.index is not None else torch.cuda.current_device()
+        if key not in _WGRAD_STREAMS:
+            _WGRAD_STREAMS[key] = torch.cuda.Stream(cur.device, priority=int(os.environ.get('DAV_WGRAD_SIDE_PRIO', '0')))
+        sw = _WGRAD_STREAMS[key]
+        sw.wait_stream(cur)
+        deferred_operands_to(sw)
+        with torch.cuda.stream(sw):
+            _flush_wgrads_now()
+        return
+    _flush_wgrads_now()
+
+
+def _flush_wgrads_now():
     if _DEFERRED_LN:
         items = list(_DEFERRED_LN)
         del _DEFERRED_LN[:]

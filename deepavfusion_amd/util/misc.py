@@ -324,6 +324,8 @@ class GraphedStep:
                 guard_done[0] = True
 
         def layer_cb(l):
+            if l in self.cuts or (self.early and self.early_ranges.get(l)):
+                engine.join_wgrad_stream(dev)      # (DAV_WGRAD_SIDE: the weight gradients launched so far are part of what ends here)
             if l in self.cuts:
                 self.graphs[seg[0]].capture_end()
                 seg[0] += 1

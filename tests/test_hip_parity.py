@@ -863,6 +863,42 @@ def test_deferred_adamw_equals_the_plain_schedule(monkeypatch):
     assert rel(mirrors[1].float(), mirrors[0].float()) < 2e-3
 
 
+def test_wgrad_side_stream_equals_the_serial_placement(monkeypatch):
+    """DAV_WGRAD_SIDE=1: inside a captured step a layer's grouped weight-gradient launch is a parallel branch of the graph (side
+    stream, joined before the optimizer and at every graph cut) instead of a node between two layers of the input-gradient chain.
+    Same arithmetic, other placement: same seeds must give the same losses, gradient norm, parameters and moments — also with the
+    step cut into segments (where the join has to come before the cut)."""
+    from deepavfusion_amd.util import lr_sched
+    from deepavfusion_amd.util.flat import FlatAdamW
+    from deepavfusion_amd.util.misc import GraphedStep, Trainer
+    finals, moments, losses, norms = [], [], [], []
+    for mode, segments in (('0', 1), ('1', 1), ('1', 3)):
+        monkeypatch.setenv('DAV_WGRAD_SIDE', mode)
+        model, sd, cfg, O = _build('micro')
+        nd = [n for n, p in model.named_parameters() if 'bias' in n or 'norm' in n]
+        groups = lr_sched.param_groups_pretrained(model, 0.05, no_weight_decay_list=nd, image_pt='', audio_pt='')
+        opt = FlatAdamW(groups, lr=1e-3, betas=(0.9, 0.95), model=model)
+        tr = Trainer(model, optimizer=opt, accum_iter=1)
+        image, audio, _, _ = O.structured_batch(cfg, 64, seed=3)
+        image, audio = image.cuda(), audio.cuda()
+        torch.manual_seed(77)
+        gs = GraphedStep(tr, image.shape, audio.shape, segments=segments)
+        run = []
+        for s in range(5):
+            torch.manual_seed(500 + s)
+            li, la, gn = gs(image, audio)
+            run.append(float(li) + float(la))
+        torch.cuda.synchronize()
+        gs.check()
+        finals.append(opt.flat.flat_p.clone()); moments.append(opt.exp_avg_sq.clone()); losses.append(run); norms.append(float(gn))
+    assert all(np.isfinite(losses[1])) and losses[1][-1] < losses[1][0]
+    for k in (1, 2):
+        for a, b in zip(losses[0], losses[k]):
+            assert abs(a - b) <= 1e-5 * abs(a), losses
+        assert abs(norms[0] - norms[k]) <= 1e-4 * norms[0], norms
+        assert rel(finals[k], finals[0]) < 2e-4 and rel(moments[k], moments[0]) < 2e-3      # (fp32 atomics in the bias gradients: not bit-equal)
+
+
 def test_trainer_skip_grad_drops_an_outlier_micro_step():
     """util/misc.py:81-104: with ``skip_grad`` a micro-step whose own gradient norm exceeds the limit is dropped — the gradients
     accumulated before it survive, the step counter of the accumulation does not advance — and a normal one is kept."""

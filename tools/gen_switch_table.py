@@ -24,6 +24,8 @@ S = {
     'DAV_STREAMS': ('1', 'schedule', "0: everything on the current stream (serial schedule; tools/instep_gemm_bound.py uses it)", 'tools/instep_gemm_bound.py (profiles/r04_gemm_instep_bound.txt)'),
     'DAV_DEC_STREAMS': ('0', 'schedule', "lanes schedule only: 1 = the two decoders on two streams all the same", '- (A/B in DESIGN_HISTORY section 4)'),
     'DAV_DEC_WGRAD_JOINT': ('1', 'schedule', "both decoders' weight-gradient problems in one grouped launch after both backward passes", 'test_baseline_config_shapes_vs_oracle (default path)'),
+    'DAV_WGRAD_SIDE': ('0', 'schedule', "1: captured step: a layer's grouped weight-gradient launch goes out on a side stream (parallel graph branch) instead of between two layers of the input-gradient chain (profiles/r04_wgrad_side.txt)", 'test_wgrad_side_stream_equals_the_serial_placement'),
+    'DAV_WGRAD_SIDE_PRIO': ('0', 'schedule', "dispatch priority of that stream (-1 high)", '- (A/B in profiles/r04_wgrad_side.txt)'),
     'DAV_WGRAD_STREAM': ('0', 'schedule', "1: weight-gradient GEMMs on their own stream (measured slower)", '- (A/B in DESIGN_HISTORY)'),
     'DAV_GROUPED_WGRAD': ('1', 'kernel', "0: one weight-gradient launch per Linear instead of one grouped launch per layer", 'test_batch64_grouped_wgrad_path_vs_oracle (default), gpu_selfcheck gemm_tn family'),
     'DAV_WGRAD_OVERWRITE': ('1', 'kernel', "captured step: the first weight-gradient contribution to a Linear weight WRITES its tile (AdamW skips that zero-fill); 0 = accumulate / zero-fill", 'test_written_first_gradients_equal_accumulated_ones'),
