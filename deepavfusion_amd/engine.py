@@ -366,6 +366,7 @@ def flush_wgrads():
         if key not in _WGRAD_STREAMS:
             _WGRAD_STREAMS[key] = torch.cuda.Stream(cur.device, priority=int(os.environ.get('DAV_WGRAD_SIDE_PRIO', '0')))
         sw = _WGRAD_STREAMS[key]
+        _WGRAD_PENDING[key] = True
         sw.wait_stream(cur)
         deferred_operands_to(sw)
         with torch.cuda.stream(sw):
@@ -419,6 +420,7 @@ def _flush_wgrads_now():
 # so it is opt-in: DAV_WGRAD_STREAM=1.
 # ------------------------------------------------------------------------------------------------
 _WGRAD_STREAMS = {}
+_WGRAD_PENDING = {}      # device -> work enqueued on the weight-gradient stream since the last join
 
 
 def wgrad_stream(dev):
@@ -432,8 +434,11 @@ def wgrad_stream(dev):
 
 def join_wgrad_stream(dev):
     """Make the current stream wait for every weight-gradient kernel enqueued so far."""
-    sw = _WGRAD_STREAMS.get(dev.index if dev.index is not None else torch.cuda.current_device())
-    if sw is not None:
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    sw = _WGRAD_STREAMS.get(key)
+    # only when something was enqueued there since the last join: a wait on an idle stream left over from an earlier step (another
+    # test, another schedule) would put an event that belongs to no capture into the graph being captured
+    if sw is not None and _WGRAD_PENDING.pop(key, False):
         torch.cuda.current_stream(dev).wait_stream(sw)
 
 
@@ -536,6 +541,7 @@ def lin_bwd(lin, dy, a, M, *, dy_rowmap=None, a_rowmap=None, lda=None, need_dx=T
                     b_rowmap=a_rowmap, beta=1, bias_grad=gb)
     else:
         sw.wait_stream(torch.cuda.current_stream(dev))
+        _WGRAD_PENDING[dev.index if dev.index is not None else torch.cuda.current_device()] = True
         dy.record_stream(sw)          # keep the operands' memory from being recycled before the side stream read them
         a.record_stream(sw)
         with torch.cuda.stream(sw):

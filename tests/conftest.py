@@ -50,3 +50,17 @@ def golden():
             cache[name] = np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
         return cache[name]
     return load
+
+
+@pytest.fixture(autouse=True)
+def _collect_between_tests():
+    """Captured steps (hipGraphs + their private memory pools) of a finished test are destroyed HERE, at the test boundary — not by a
+    cyclic-GC pass that happens to run in the middle of a later test's graph capture or replay (DAV_TEST_GC: off = never collect,
+    debugging aid)."""
+    import gc
+    mode = os.environ.get('DAV_TEST_GC', 'collect')
+    if mode == 'off':
+        gc.disable()
+    yield
+    if mode == 'collect':
+        gc.collect()
