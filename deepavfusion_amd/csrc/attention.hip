@@ -958,13 +958,17 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
 // by the softmax recomputation on the VALU (8 v_exp_f32 + 30 plain slots per 32 x 16 scores in EACH of the two kernels), not by
 // the LDS pipe, and 11 tile pairs balance worse over the waves than 22 tiles.  Kept at one; the bodies take the tile count.
 template <int DQK, int DV> constexpr int bwd_tiles() { return 1; }
+#ifndef DKV32_MIN_BLOCKS
+#define DKV32_MIN_BLOCKS 4      // HIP's second __launch_bounds__ argument = WAVES PER SIMD: 4 -> 128 registers and two 8-wave workgroups per CU
+                                // (the d = 32 dK / dV body wants 130: 2 spilled, 12 bytes of scratch per lane); 3 -> no spill, ONE workgroup per CU
+#endif
 template <int DQK, int DV, bool CHUNKED>
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
   attn_bwd_dq_body<DQK, DV, CHUNKED, CHUNKED ? 1 : bwd_tiles<DQK, DV>()>(p, (DQK <= 32 && p.pair) ? pair_heads(blockIdx.x, gridDim.x) : (int)blockIdx.x, blockIdx.y);
 }
 // (narrow heads: 4 waves per SIMD = two 8-wave workgroups per CU — at 130 registers only ONE fitted, 2 waves per SIMD under a VALU-bound loop)
 template <int DQK, int DV, bool CHUNKED>
-__global__ __launch_bounds__(512, (DQK <= 32 && DV <= 32) ? 4 : 1) void attn_bwd_dkv_kernel(AttnParams p) {
+__global__ __launch_bounds__(512, (DQK <= 32 && DV <= 32) ? DKV32_MIN_BLOCKS : 1) void attn_bwd_dkv_kernel(AttnParams p) {
   attn_bwd_dkv_body<DQK, DV, CHUNKED, CHUNKED ? 1 : bwd_tiles<DQK, DV>()>(p, (DQK <= 32 && p.pair) ? pair_heads(blockIdx.x, gridDim.x) : (int)blockIdx.x, blockIdx.y);
 }
 
@@ -977,7 +981,7 @@ struct AttnGroup {
 // WHICH: 0 forward, 1 dQ, 2 dK/dV.  The workgroup size is the largest any problem of the group asks for: the
 // surplus waves of a smaller problem stage tiles and then find no tile of their own.
 template <int DQK, int DV, int WHICH>
-__global__ __launch_bounds__(512, (WHICH == 2 && DQK <= 32 && DV <= 32) ? 4 : 1) void attn_grouped_kernel(const AttnGroup g) {
+__global__ __launch_bounds__(512, (WHICH == 2 && DQK <= 32 && DV <= 32) ? DKV32_MIN_BLOCKS : 1) void attn_grouped_kernel(const AttnGroup g) {
   int pi = 0;
   while (pi + 1 < g.count && (int)blockIdx.x >= g.first_block[pi + 1]) ++pi;
   int bh = (int)blockIdx.x - g.first_block[pi];
