@@ -611,7 +611,7 @@ __device__ __forceinline__ void nt2_loader(const NTParams& p, int m0, int n0, in
 }
 
 template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK, bool PROF = false, int PIPE = 0>
-__device__ __forceinline__ void nt2_body(const NTParams& p, int bid) {
+__device__ __forceinline__ void nt2_body(const NTParams& p, int bid, int tid_in = -1) {
   // PROF (tile configuration 30, tools/gemm_phase_prof.py only): per-wave shader-cycle sums of the k-loop phases —
   // [wait for the DMA, barrier, DMA issue, fragment reads + MFMAs, prologue, epilogue] — written to the int64 buffer
   // passed in place of res_rows (s_memtime; the instrumentation itself costs ~10 %).
@@ -630,7 +630,9 @@ __device__ __forceinline__ void nt2_body(const NTParams& p, int bid) {
   static_assert(BK == 64 || BK == 32, "BK");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (tid_in: the persistent walk passes the lane id through an opaque asm per tile, so that nothing derived from it is hoisted out of
+  // the tile loop and kept in registers across the whole body: +35 registers, one workgroup per CU instead of two)
+  const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN_, wn = wave % WN_;
   const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
   {
@@ -1091,6 +1093,21 @@ __global__ __launch_bounds__((WM_* WN_ + (PIPE >= 2 ? PIPE : 0)) * 64, PIPE == 4
   nt2_body<BM, BN, WM_, WN_, STAGES, BT, BK, false, PIPE>(p, blockIdx.x);
 }
 
+// DAV_NT_PERSIST=<n> (opt-in): the same body, a grid capped at n workgroup slots, each workgroup walking the tiles blockIdx.x, + gridDim.x, ...
+// (n a multiple of 8: the tile -> XCD mapping of nt2_body stays that of the hardware's dispatch).  A kernel of its own: wrapped in the tile
+// loop the body costs 8 more registers even with the lane id laundered per tile (35 more without: everything derived from it is hoisted out of
+// the loop and kept), and the 128 x 256 tiles start to spill.
+template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK = 64>
+__global__ __launch_bounds__(WM_* WN_ * 64, (WM_ * WN_ == 8 && BM * BN > 128 * 128) ? 4 : (WM_ * WN_ <= 4 ? 2 : 1)) void gemm_nt2_persist_kernel(NTParams p) {
+  const int ntiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  for (int bid = blockIdx.x; bid < ntiles; bid += gridDim.x) {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    nt2_body<BM, BN, WM_, WN_, STAGES, BT, BK, false, 0>(p, bid, t);
+    if (bid + (int)gridDim.x < ntiles) __syncthreads();      // the epilogue's staging area is the next tile's first ring stage
+  }
+}
+
 // Grouped launch: up to NT_GROUP_MAX independent problems (any M / N / K / epilogue, one tile configuration) in ONE grid —
 // e.g. the qkv GEMMs of the image and the audio tower of a layer (738 + 864 tiles = 3.1 rounds of 512 workgroup slots
 // instead of 1.44 -> 2 and 1.69 -> 2).  Each problem's block range starts at a multiple of 8 so that blockIdx & 7 (the XCD
@@ -1233,7 +1250,19 @@ void nt2_issue(const void* const* params, int n, hipStream_t stream) {
     const int cnt = n - base < NT_GROUP_MAX ? n - base : NT_GROUP_MAX;
     if (cnt == 1) {
       const NTParams& p = *(const NTParams*)params[base];
-      const int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+      int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+      // DAV_NT_PERSIST=<n>: at most n 8-wave workgroups (2 n of the 4-wave tiles), each walking several tiles — see gemm_nt2_persist_kernel
+      static const int persist = getenv("DAV_NT_PERSIST") ? atoi(getenv("DAV_NT_PERSIST")) & ~7 : 0;
+      const int cap = persist * (8 / (WM_ * WN_) > 0 ? 8 / (WM_ * WN_) : 1);
+      if constexpr (PIPE == 0 && BM * BN <= 128 * 128) {      // (the 128 x 256 tiles spill inside the tile loop: not offered)
+        if (persist > 0 && grid > cap) {
+          auto pkern = gemm_nt2_persist_kernel<BM, BN, WM_, WN_, STAGES, BT, BK>;
+          static bool pbig = false;
+          if (lds > 64 * 1024 && !pbig) { (void)hipFuncSetAttribute((const void*)pkern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); pbig = true; }
+          DAV_LAUNCH_NOW(pkern, dim3(cap), dim3(NT), lds, stream, p);
+          continue;
+        }
+      }
       DAV_LAUNCH_NOW(kern, dim3(grid), dim3(NT), lds, stream, p);
       continue;
     }

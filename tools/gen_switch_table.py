@@ -38,6 +38,7 @@ S = {
     'DAV_NT_TUNE': ('1', 'kernel', "0: ignore the tuned tile-configuration table (deepavfusion_amd/tuning/nt_gfx950.json), rules only", 'test_nt_tuning_table_loads_and_rejects_malformed_blobs, test_baseline_config_shapes_vs_oracle[large-32] (entries must fire)'),
     'DAV_NT_TUNE_FILE': ('tuning/nt_gfx950.json', 'kernel', "another tuned table", 'test_nt_tuning_table_loads_and_rejects_malformed_blobs'),
     'DAV_NT_WIDE': ('1', 'kernel', "0: no 128 x 256 tiles for the K <= 512 wide-output GEMMs (rule of nt2_issue_auto)", 'gpu_selfcheck gemm_nt family (explicit configurations)'),
+    'DAV_NT_PERSIST': ('0', 'kernel', "n: single NT launches of the 128 x 128 / 128 x 64 / 64 x 64 tiles run on at most n 8-wave workgroup slots, each workgroup walking several tiles (gemm_nt2_persist_kernel); a wash in the step (profiles/r04_nt_persist.txt)", '- (same body; GPU parity subset run with it, profiles/r04_nt_persist.txt)'),
     'DAV_NT_SMALL': ('5', 'kernel', "tile configuration of launches below DAV_NT_T5 tiles: 5 = 64 x 64 two-stage ring, 7 = four-stage ring", 'gpu_selfcheck gemm_nt family'),
     'DAV_NT_T5': ('100', 'kernel', "tile-count threshold between the 64 x 64 and the 128 x 64 configurations", '- (tuning knob)'),
     'DAV_NT_T8': ('400', 'kernel', "tile-count threshold between the 128 x 64 and the 128 x 128 configurations", '- (tuning knob)'),
