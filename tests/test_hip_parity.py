@@ -1161,8 +1161,42 @@ def _tuned_hits(issued):
     return hits
 
 
+# The oracle's step for the two configurations that a later test runs AGAIN in a fresh process (another kernel body switched on by an
+# environment variable read once per process): computed once per session, handed to the child through a file (the oracle at B = 64 is a
+# minute of host time; the result is a function of (configuration, batch, seed) only — closed-form weights, seeded inputs).
+_ORACLE_SHARED = {('base', 64), ('base', 4)}
+
+
+def _oracle_cache_path(name, batch, seed):
+    import tempfile
+    return os.path.join(tempfile.gettempdir(), f'dav_oracle_step_{os.getuid()}_{name}_{batch}_{seed}.pt')
+
+
+def _oracle_step_cached(name, batch, seed, O, sd, cfg, image, audio, ni, na):
+    path = _oracle_cache_path(name, batch, seed)
+    shared = (name, batch) in _ORACLE_SHARED
+    hit = shared and bool(os.environ.get('DAV_TEST_ORACLE_FROM_CACHE')) and os.path.exists(path)
+    if os.environ.get('DAV_TEST_ORACLE_LOG'):
+        with open(os.environ['DAV_TEST_ORACLE_LOG'], 'a') as f:
+            f.write(f'{name}-{batch}: shared {shared}, from cache {hit}\n')
+    if hit:
+        d = torch.load(path, weights_only=False)      # (our own file: losses, predictions, numpy index arrays, gradients)
+        return d['li'], d['la'], d['pi'], d['pa'], d['aux'], d['grad']
+    sdo = {k: v.clone().requires_grad_(k not in O.FROZEN and not O.is_buffer(k)) for k, v in sd.items()}
+    li, la, pi, pa, aux = O.avmae_forward(sdo, cfg, image, audio, ni, na)
+    (li + la).backward()
+    grad = {k: v.grad.detach() for k, v in sdo.items() if v.grad is not None}
+    res = (li.detach(), la.detach(), pi.detach(), pa.detach(), aux, grad)
+    if shared and not os.environ.get('DAV_TEST_ORACLE_FROM_CACHE'):
+        try:
+            torch.save(dict(li=res[0], la=res[1], pi=res[2], pa=res[3], aux=aux, grad=grad), path)
+        except OSError:
+            pass
+    return res
+
+
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize('name,batch', [('base', 4), ('base', 64), ('base_m75', 4), ('base_as', 2), ('base_as', 64), ('large', 2), ('large', 32),
+@pytest.mark.parametrize('name,batch', [('base', 4), ('base', 64), ('base_m75', 4), ('base_as', 2), ('base_as', 64), ('large', 32),
                                         ('base_swin', 2)])
 def test_baseline_config_shapes_vs_oracle(name, batch):
     """BASELINE.json configs[1] (ViT-B, attn_ratio 0.25 / mlp_ratio 1.0: the bench workload's model), configs[2] (ViT-B,
@@ -1173,7 +1207,9 @@ def test_baseline_config_shapes_vs_oracle(name, batch):
     workload (audio mask 0.75: 80 kept audio tokens — the metric string's "mask 0.75").  ``base_as-64`` and ``large-32`` are the
     sizes profiles/*bench_base_as.json / *bench_large.json are timed at (round-3 review: the tuned table was tuned on exactly
     those, other tile configurations and the 40-problem grouped weight-gradient launches are live there): for ``large-32`` the
-    issue log must show that entries of the shipped tuned table really fired."""
+    issue log must show that entries of the shipped tuned table really fired.  (``large-2``, collected until round 4, went when
+    ``large-32`` came: same model, and the small-batch tile configurations are those of ``base-4`` / ``base_as-2``; the suite's time is
+    the oracle's host time, which varies 2 x between boxes.)"""
     from deepavfusion_amd import ops
     model, sd, cfg, O = _build(name)
     image, audio, ni, na = O.synthetic_batch(cfg, batch, seed=25)
@@ -1188,19 +1224,17 @@ def test_baseline_config_shapes_vs_oracle(name, batch):
     if os.environ.get('DAV_TEST_EXPECT_NT256'):       # (the 256 x 256 variant below: the opt-in body must really have run)
         n60 = sum(1 for e in issued if e[0] == 60)
         assert n60 >= int(os.environ['DAV_TEST_EXPECT_NT256']), (n60, sorted({e[0] for e in issued}))
-    sdo = {k: v.clone().requires_grad_(k not in O.FROZEN and not O.is_buffer(k)) for k, v in sd.items()}
-    li, la, pi, pa, aux = O.avmae_forward(sdo, cfg, image, audio, ni, na)
-    (li + la).backward()
+    li, la, pi, pa, aux, ograd = _oracle_step_cached(name, batch, 25, O, sd, cfg, image, audio, ni, na)
     for k in ('image_ids_keep', 'audio_ids_keep', 'image_ids_restore', 'audio_ids_restore'):
         assert np.array_equal(model._last_masks[k].cpu().numpy(), aux[k]), k
     assert abs(float(out[0]) - float(li)) <= LOSS_RTOL * float(li) and abs(float(out[1]) - float(la)) <= LOSS_RTOL * float(la)
     assert rel(out[2], pi) < ACT_TOL and rel(out[3], pa) < ACT_TOL
-    g_all = sum(float(v.grad.double().norm()) ** 2 for v in sdo.values() if v.grad is not None) ** 0.5
+    g_all = sum(float(v.double().norm()) ** 2 for v in ograd.values()) ** 0.5
     rels = []
     for n, p in model.named_parameters():
         if not p.requires_grad or n.endswith(ZERO_GRADS):
             continue
-        ref = sdo[n].grad.double()
+        ref = ograd[n].double()
         d = float((p.grad.detach().double().cpu() - ref).norm())
         rels.append(d / max(float(ref.norm()), 1e-30))
         assert d <= GRAD_TOL * float(ref.norm()) + 1e-4 * g_all, (n, d, float(ref.norm()))
@@ -1217,7 +1251,8 @@ def test_bench_workload_with_the_opt_in_256_tile_kernels_vs_oracle():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DAV_NT256='1', DAV_NT256_N='512', DAV_NT256_TILES='64', DAV_NT_TUNE='0', DAV_TEST_EXPECT_NT256='8')
+    env = dict(os.environ, DAV_NT256='1', DAV_NT256_N='512', DAV_NT256_TILES='64', DAV_NT_TUNE='0', DAV_TEST_EXPECT_NT256='8',
+               DAV_TEST_ORACLE_FROM_CACHE='1')      # (the oracle's step from this session's base-64 test, if it ran)
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider',
                         '-k', 'test_baseline_config_shapes_vs_oracle and base-64'], cwd=root, env=env, capture_output=True, text=True, timeout=580)
     assert r.returncode == 0 and '1 passed' in r.stdout, (r.stdout[-3000:], r.stderr[-1500:])
@@ -1230,7 +1265,7 @@ def test_whole_step_with_the_opt_in_fused_fusion_tails_vs_oracle():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DAV_FUSION_TAIL='1')
+    env = dict(os.environ, DAV_FUSION_TAIL='1', DAV_TEST_ORACLE_FROM_CACHE='1')
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider',
                         '-k', 'test_baseline_config_shapes_vs_oracle and base-4'], cwd=root, env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0 and '1 passed' in r.stdout, (r.stdout[-3000:], r.stderr[-1500:])
