@@ -766,10 +766,10 @@ def test_written_first_gradients_equal_accumulated_ones(monkeypatch):
     assert kept[0] > n_linear // 2 and kept[1] == 0, (kept, n_linear)
     assert all(np.isfinite(losses[0])) and losses[0][-1] < losses[0][0]
     for k, (a, b) in enumerate(zip(*losses)):
-        # bit-equal until the eager step (s == 3: its weight gradients split the contraction and add with fp32 atomics in both modes, in
+        # equal to all printed digits up to the eager step (s == 3: its weight gradients split the contraction and add with fp32 atomics in both modes, in
         # whatever order the hardware retires them); behind it the two runs are two samples of that noise, amplified by AdamW:
         # 1.4e-5 seen once in ~40 runs of the suite
-        assert abs(a - b) <= (1e-6 if k < 3 else 5e-5) * abs(b), losses
+        assert abs(a - b) <= (1e-5 if k <= 3 else 5e-5) * abs(b), losses
     # not bit-equal: a written tile is never split over the contraction, an accumulated one may be (fp32 atomics), and AdamW turns
     # rounding noise on exactly-zero gradients (key biases) into lr-sized steps; a LOST contribution would show at >= 4e-3
     assert rel(finals[0], finals[1]) < 2e-4
