@@ -45,7 +45,7 @@ def test_early_adamw_ranges_equal_the_single_pass(monkeypatch):
         finals.append(opt.flat.flat_p.clone()); moments.append(opt.exp_avg_sq.clone()); losses.append(run); norms.append(float(gn))
     assert all(np.isfinite(losses[1])) and losses[1][-1] < losses[1][0]
     for a, b in zip(*losses):
-        assert abs(a - b) <= 1e-5 * abs(b), losses
+        assert abs(a - b) <= 5e-5 * abs(b), losses          # (two samples of the bias gradients' atomic-add noise, amplified by AdamW)
     assert abs(norms[0] - norms[1]) <= 1e-4 * norms[0], norms
     assert rel(finals[1], finals[0]) < 2e-4 and rel(moments[1], moments[0]) < 2e-3      # (fp32 atomics in the bias gradients: not bit-equal)
 
@@ -95,7 +95,7 @@ def test_deferred_adamw_equals_the_plain_schedule(monkeypatch):
         mirrors.append(opt.flat_bf16.clone())
     assert all(np.isfinite(losses[1])) and losses[1][-1] < losses[1][0]
     for a, b in zip(*losses):
-        assert abs(a - b) <= 1e-5 * abs(b), losses
+        assert abs(a - b) <= 5e-5 * abs(b), losses          # (two samples of the bias gradients' atomic-add noise, amplified by AdamW)
     for s in (1, 2, 4, 5):                                                            # (call 3 follows a flush: nothing pending, norm of zeros)
         assert abs(norms[1][s] - norms[0][s - 1]) <= 1e-4 * norms[0][s - 1], norms
     assert rel(finals[1], finals[0]) < 2e-4 and rel(moments[1], moments[0]) < 2e-3      # (fp32 atomics in the bias gradients: not bit-equal)
@@ -133,7 +133,7 @@ def test_wgrad_side_stream_equals_the_serial_placement(monkeypatch):
     assert all(np.isfinite(losses[1])) and losses[1][-1] < losses[1][0]
     for k in (1, 2):
         for a, b in zip(losses[0], losses[k]):
-            assert abs(a - b) <= 1e-5 * abs(a), losses
+            assert abs(a - b) <= 5e-5 * abs(a), losses      # (two samples of the bias gradients' atomic-add noise, amplified by AdamW)
         assert abs(norms[0] - norms[k]) <= 1e-4 * norms[0], norms
         assert rel(finals[k], finals[0]) < 2e-4 and rel(moments[k], moments[0]) < 2e-3      # (fp32 atomics in the bias gradients: not bit-equal)
 
