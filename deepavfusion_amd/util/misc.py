@@ -65,7 +65,15 @@ class Trainer:
             d['optimizer'] = self.optimizer
         return d
 
+    def _flush_deferred(self):
+        """A captured step with a deferred optimizer pass (GraphedStep(defer=True)) may hold one update back: anything that is about to
+        touch the gradients from the eager side applies it first."""
+        g = getattr(self, 'deferred_step', None)
+        if g is not None:
+            g.flush()
+
     def zero_grad(self):
+        self._flush_deferred()
         if self.flat is not None:
             self.flat.zero_grad()
         elif self.optimizer is not None:
@@ -81,6 +89,7 @@ class Trainer:
         return get_grad_norm_(self.model_without_ddp.parameters()) / max(self.accums, 1)
 
     def backward(self, loss, create_graph=False):
+        self._flush_deferred()
         if self.flat is not None and self.flat.stale and self.accums == 0:      # eager step after replays of a captured one
             self.flat.zero_grad()
         loss.backward(create_graph=create_graph)
@@ -354,6 +363,12 @@ class GraphedStep:
         self._presq_ws = torch.zeros(1024, dtype=torch.float32, device=dev)
         self.prev_loss = torch.zeros(2, dtype=torch.float32, device=dev)      # deferred AdamW: the losses its guard judges
         self.pending = False                                                  # deferred AdamW: gradients waiting for their update
+        if self.defer:
+            # nothing on the eager side may see the lagging state: Trainer.backward / zero_grad flush before touching the gradients,
+            # an eager forward (training or evaluation) and state_dict() flush before reading the parameters
+            trainer.deferred_step = self
+            self.model.register_forward_pre_hook(lambda m, args: self.flush())
+            self.model.register_state_dict_pre_hook(lambda m, prefix, keep_vars: self.flush())
         if self.defer:
             self.grad_norm = torch.zeros((), dtype=torch.float32, device=dev)
 
