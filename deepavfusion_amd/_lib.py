@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, 'libdavfusion_hip.so')
 
 _p, _i, _l, _f, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 
-ABI_VERSION = 4      # DAV_ABI_VERSION of include/dav_kernels.h this package was written against (struct layouts, signatures)
+ABI_VERSION = 5      # DAV_ABI_VERSION of include/dav_kernels.h this package was written against (struct layouts, signatures)
 
 # name -> argtypes (must match include/dav_kernels.h)
 SIGNATURES = {
@@ -30,6 +30,7 @@ SIGNATURES = {
     'dav_nt_tune_set': [_p, _i],
     'dav_gemm_tn_bf16': [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _i, _p],
     'dav_gemm_tn_grouped_bf16': [_p, _i, _p],
+    'dav_gemm_tn_grouped_adamw_bf16': [_p, _i, _p, _p],
     'dav_attn_fwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _i, _l, _i, _l, _i, _l, _i, _f, _p],
     'dav_attn_bwd': [_p] * 10 + [_i] * 6 + [_l, _i] * 8 + [_f, _p],
     'dav_attn_bwd_part': [_p] * 10 + [_i] * 6 + [_l, _i] * 8 + [_f, _i, _p],
@@ -119,6 +120,13 @@ class DavTnProblem(C.Structure):
     _fields_ = [('A', C.c_void_p), ('B', C.c_void_p), ('C', C.c_void_p), ('bias_grad', C.c_void_p),
                 ('Mc', C.c_int), ('N', C.c_int), ('K', C.c_int), ('lda', C.c_int), ('ldb', C.c_int), ('ldc', C.c_int),
                 ('a_rowmap', C.c_int * 3), ('b_rowmap', C.c_int * 3), ('flags', C.c_int)]
+
+
+class DavTnAdamW(C.Structure):
+    """include/dav_kernels.h DavTnAdamW: the flat buffers and scalars of the optimizer pass fused into a grouped weight-gradient launch."""
+    _fields_ = [('g_base', C.c_void_p), ('p_base', C.c_void_p), ('m_base', C.c_void_p), ('v_base', C.c_void_p), ('bf16_base', C.c_void_p),
+                ('hyper', C.c_void_p), ('bias_corr', C.c_void_p), ('gscale_dev', C.c_void_p), ('sumsq', C.c_void_p),
+                ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float)]
 
 
 ERRORS = {-1: 'bad shape', -2: 'unsupported dtype', -3: 'insufficient workspace', -4: 'HIP error', -5: 'misaligned pointer/stride'}

@@ -58,6 +58,14 @@ struct TNParams {                     // (pointers first: 96 bytes, 40 of them f
   int debug_plain_store;              // timing experiments only: 1 (variant bit 8) plain stores instead of atomics; DAV_TN_DEBUG: 2 no epilogue, 4 no reads / MFMAs
 };
 static_assert(sizeof(TNParams) == 96, "TNParams layout");
+// Fused optimizer pass of a grouped weight-gradient launch (DavTnAdamW): the flat buffers' bases — a tile's element offset in all of them
+// is (its C pointer - g_base) — and the scalars of dav_adamw_flat.  A problem takes part when bits 8.. of debug_plain_store hold its
+// parameter's index + 1 into `hyper`.
+struct TNOpt {
+  const float* g_base; float* p_base; float* m_base; float* v_base; bf16_t* bf16_base;
+  const float* hyper; const float* bias_corr; const float* gscale; float* sumsq;
+  float beta1, beta2, eps;
+};
 
 // ------------------------------------------------------------------------------------------------
 // NT kernel
@@ -1576,7 +1584,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TNParams p) {
 // ------------------------------------------------------------------------------------------------
 // T x TK output tiles (T rows of the gradient = columns of A, TK columns = columns of B; TK = T unless given: round 4 adds 256 x 128)
 template <int T, int WM_, int WN_, int RS = 64, int NST = 2, int TK = T>
-__device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, const int split_idx) {
+__device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, const int split_idx, const TNOpt* opt = nullptr) {
   // RS contraction rows per ring stage, NST stages (NST - 1 stages of loads in flight while one is consumed)
   constexpr int NT = WM_ * WN_ * 64, RB = T * 2, CPRW = T / 8;      // 16-byte chunks per tile row (A side)
   constexpr int RBK = TK * 2, CPRWK = TK / 8;                       // ... (B side)
@@ -1585,7 +1593,8 @@ __device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, 
   constexpr int WTN = T / WM_, WTK = TK / WN_, FM = WTN / 16, FN = WTK / 16;
   static_assert(RS * CPRW % NT == 0 && RS * CPRWK % NT == 0 && (RS == 32 || RS == 64) && NST >= 2, "tile/threads mismatch");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int dbg = p.debug_plain_store;                              // (a register: read through p inside the loop it was a scalar load + wait per stage)
+  const int dbg = p.debug_plain_store & 255;                        // (a register: read through p inside the loop it was a scalar load + wait per stage)
+  const int opt_idx = p.debug_plain_store >> 8;                     // > 0: the owner of a WRITTEN tile applies AdamW to it instead of storing it (index + 1 of the parameter)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN_, wn = wave % WN_;
   const int tiles_k = (p.K + TK - 1) / TK, tiles_n = (p.N + T - 1) / T;
@@ -1703,6 +1712,60 @@ __device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, 
 
   if (dbg & 2) return;          // timing experiment: no epilogue
   const int fr = lane & 15, fg = lane >> 4;
+  if (opt != nullptr && opt_idx > 0 && p.splits == 1 && !p.beta) {
+    // Fused optimizer pass: this workgroup holds the FINAL gradient of its 128 x 128 weights in registers (a written tile, never split
+    // over the contraction): AdamW on them here — master, both moments, bf16 mirror — with the arithmetic of adamw_flat_kernel in its
+    // order; the gradient itself is never stored.  One row of fragments at a time (FN 16-byte loads of p, m and v each in flight).
+    const TNOpt& o = *opt;
+    const float lr = o.hyper[2 * (opt_idx - 1)], wd = o.hyper[2 * (opt_idx - 1) + 1];
+    const float bc1 = o.bias_corr[0], bc2_sqrt = o.bias_corr[1];
+    const float gsd = o.gscale ? o.gscale[0] : 1.f;
+    const bool skip = o.gscale != nullptr && !(gsd > 0.f);          // dav_step_guard: leave parameters and moments alone
+    const float gs = skip ? 0.f : gsd;
+    const float decay = 1.f - lr * wd, step = lr / bc1, ob1 = 1.f - o.beta1, ob2 = 1.f - o.beta2;
+    const long base = p.C - o.g_base;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int n = n0 + wm * WTN + i * 16 + fr;
+      float4 P[FN], M[FN], V[FN];
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int k = k0 + wn * WTK + j * 16 + fg * 4;
+        const bool in = n < p.N && k < p.K && !skip;
+        const long off = base + (long)n * p.ldc + k;
+        P[j] = in ? *reinterpret_cast<const float4*>(o.p_base + off) : float4{0.f, 0.f, 0.f, 0.f};
+        M[j] = in ? *reinterpret_cast<const float4*>(o.m_base + off) : float4{0.f, 0.f, 0.f, 0.f};
+        V[j] = in ? *reinterpret_cast<const float4*>(o.v_base + off) : float4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int k = k0 + wn * WTK + j * 16 + fg * 4;
+        if (n >= p.N || k >= p.K) continue;
+        const float g0 = acc[i][j][0], g1 = acc[i][j][1], g2 = acc[i][j][2], g3 = acc[i][j][3];
+        ss += g0 * g0 + g1 * g1 + g2 * g2 + g3 * g3;
+        if (skip) continue;
+        const long off = base + (long)n * p.ldc + k;
+        const float gx = g0 * gs, gy = g1 * gs, gz = g2 * gs, gw = g3 * gs;
+        float4 mi = M[j], vi = V[j], pi = P[j];
+        mi.x = o.beta1 * mi.x + ob1 * gx; mi.y = o.beta1 * mi.y + ob1 * gy; mi.z = o.beta1 * mi.z + ob1 * gz; mi.w = o.beta1 * mi.w + ob1 * gw;
+        vi.x = o.beta2 * vi.x + ob2 * gx * gx; vi.y = o.beta2 * vi.y + ob2 * gy * gy;
+        vi.z = o.beta2 * vi.z + ob2 * gz * gz; vi.w = o.beta2 * vi.w + ob2 * gw * gw;
+        pi.x = pi.x * decay - step * mi.x / (sqrtf(vi.x) / bc2_sqrt + o.eps);
+        pi.y = pi.y * decay - step * mi.y / (sqrtf(vi.y) / bc2_sqrt + o.eps);
+        pi.z = pi.z * decay - step * mi.z / (sqrtf(vi.z) / bc2_sqrt + o.eps);
+        pi.w = pi.w * decay - step * mi.w / (sqrtf(vi.w) / bc2_sqrt + o.eps);
+        *reinterpret_cast<float4*>(o.p_base + off) = pi;
+        *reinterpret_cast<float4*>(o.m_base + off) = mi;
+        *reinterpret_cast<float4*>(o.v_base + off) = vi;
+        uint2 w; w.x = pack2bf(pi.x, pi.y); w.y = pack2bf(pi.z, pi.w);
+        *reinterpret_cast<uint2*>(o.bf16_base + off) = w;
+      }
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) unsafeAtomicAdd(o.sumsq, ss);
+  } else {
+  // splits > 1: partial sums meet through fp32 atomics; splits == 1: this workgroup owns the tile (plain
   // splits > 1: partial sums meet through fp32 atomics; splits == 1: this workgroup owns the tile (plain
   // read-modify-write when accumulating)
   const bool atomic = p.splits > 1 && !(dbg & 1);
@@ -1747,6 +1810,7 @@ __device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, 
       }
     }
   }
+  }
   if (do_bias && fr == 0) {                               // the bias-gradient accumulators keep the untransposed layout; one
 #pragma unroll                                            // contribution per element and launch: a no-return atomic costs no latency
     for (int i = 0; i < FM; ++i)
@@ -1769,20 +1833,22 @@ constexpr int TN_GROUP_MAX = 40;      // (the table travels by value in the kern
 struct TNGroup {
   TNParams prob[TN_GROUP_MAX];
   int first_block[TN_GROUP_MAX + 1];
-  int count;
-  int xcd_runs;                       // 1: every XCD owns one contiguous run of each problem's (split, tile) units
+  int count;                          // bits 0..15: problems; bit 30 (TN_XCD_RUNS): every XCD owns one contiguous run of each problem's (split, tile) units
+  TNOpt opt;                          // the fused optimizer pass's buffers (FUSED instantiation only); with it the table is exactly 4096 bytes
 };
+constexpr int TN_XCD_RUNS = 1 << 30;
 static_assert(sizeof(TNGroup) <= 4096, "kernel argument block");
 
-template <int T, int WM_, int WN_, int RS = 64, int NST = 2, int MINW = 1, int TK = T>
+template <int T, int WM_, int WN_, int RS = 64, int NST = 2, int MINW = 1, int TK = T, bool FUSED = false>
 __global__ __launch_bounds__(WM_* WN_ * 64, MINW) void gemm_tn_grouped_kernel(const TNGroup g) {
   int pi = 0;
-  while (pi + 1 < g.count && (int)blockIdx.x >= g.first_block[pi + 1]) ++pi;
+  const int count = g.count & 0xffff;
+  while (pi + 1 < count && (int)blockIdx.x >= g.first_block[pi + 1]) ++pi;
   const TNParams& p = g.prob[pi];
   const int local = blockIdx.x - g.first_block[pi];
   const int tiles = ((p.N + T - 1) / T) * ((p.K + TK - 1) / TK);
   int unit = local;
-  if (g.xcd_runs) {
+  if (g.count & TN_XCD_RUNS) {
     // workgroup ids go round the 8 XCDs (private L2s): the ids with the same residue form one XCD's share of this problem.  Give
     // that share a contiguous run of units — a few whole rows / columns of the tile grid, streaming the contraction side by
     // side — so that the XCD pulls few distinct operand panels through the fabric instead of nearly all of them
@@ -1791,7 +1857,7 @@ __global__ __launch_bounds__(WM_* WN_ * 64, MINW) void gemm_tn_grouped_kernel(co
     const int r = local & 7, j = local >> 3, q = total >> 3, rem = total & 7;
     unit = r * q + (r < rem ? r : rem) + j;
   }
-  tn2_body<T, WM_, WN_, RS, NST, TK>(p, unit % tiles, unit / tiles);
+  tn2_body<T, WM_, WN_, RS, NST, TK>(p, unit % tiles, unit / tiles, FUSED ? &g.opt : nullptr);
 }
 
 template <int T, int WM_, int WN_>
@@ -2010,8 +2076,22 @@ extern "C" int dav_nt_issue_log(int enable, int* out, int capacity) {
   return 0;
 }
 
-extern "C" int dav_gemm_tn_grouped_bf16(const DavTnProblem* probs, int count, hipStream_t stream) {
+static int tn_grouped_impl(const DavTnProblem* probs, int count, const DavTnAdamW* opt, hipStream_t stream) {
   if (count <= 0 || count > TN_GROUP_MAX) return DAV_ERR_SHAPE;
+  bool any_fused = false;
+  if (opt) {
+    if (!opt->g_base || !opt->p_base || !opt->m_base || !opt->v_base || !opt->bf16_base || !opt->hyper || !opt->bias_corr || !opt->sumsq) return DAV_ERR_SHAPE;
+    if (((uintptr_t)opt->g_base | (uintptr_t)opt->p_base | (uintptr_t)opt->m_base | (uintptr_t)opt->v_base) & 15 || ((uintptr_t)opt->bf16_base & 7)) return DAV_ERR_ALIGN;
+    for (int i = 0; i < count; ++i)
+      if (probs[i].flags & 2) {
+        // a fused tile is a WRITTEN one (its owner sees the whole gradient) inside the flat gradient buffer, 16-byte offsets
+        if (!(probs[i].flags & 1) || probs[i].C < opt->g_base || ((probs[i].C - opt->g_base) & 3)) return DAV_ERR_SHAPE;
+        any_fused = true;
+      }
+  } else {
+    for (int i = 0; i < count; ++i)
+      if (probs[i].flags & 2) return DAV_ERR_SHAPE;      // asks for the optimizer pass without its buffers
+  }
   static thread_local TNGroup g;   // host staging (one per calling thread); copied by value into the kernel arguments at launch
   long total_tiles = 0;
   for (int i = 0; i < count; ++i) {
@@ -2074,6 +2154,7 @@ extern "C" int dav_gemm_tn_grouped_bf16(const DavTnProblem* probs, int count, hi
     p.bmap = RowMap{q.b_rowmap[0], q.b_rowmap[1], q.b_rowmap[2]};
     static const int tn_debug = getenv("DAV_TN_DEBUG") ? atoi(getenv("DAV_TN_DEBUG")) & 6 : 0;
     p.C = q.C; p.ldc = q.ldc; p.beta = (q.flags & 1) ? 0 : 1; p.bias_grad = q.bias_grad; p.debug_plain_store = tn_debug;
+    if (q.flags & 2) p.debug_plain_store |= (int)(((unsigned)q.flags >> 8) + 1u) << 8;      // parameter index + 1 (see tn2_body)
     const int tiles = ((q.N + (tn_tile & ~1) - 1) / (tn_tile & ~1)) * ((q.K + 127) / 128), steps = q.Mc >> 6;
     int splits = (int)((1024 + total_tiles - 1) / total_tiles);
     const int max_splits = steps / 8 > 0 ? steps / 8 : 1;
@@ -2084,12 +2165,18 @@ extern "C" int dav_gemm_tn_grouped_bf16(const DavTnProblem* probs, int count, hi
     first += tiles * splits;
   }
   g.first_block[count] = first;
-  g.count = count;
   // (round 3: -21 % memory-side fetch, -5 % kernel time, -0.2 ms per step on two boxes.  Cutting the WHOLE launch's unit sequence
   // into eight equal-work ranges, one per XCD, took the fetch down 3 x (33.5 -> 11.5 GB per step) and the kernel time UP 6 %: the
   // weight gradients are not bound by fabric traffic — profiles/r03_step_traffic.txt)
   static const int xcd_runs = getenv("DAV_TN_XCD") ? atoi(getenv("DAV_TN_XCD")) != 0 : 1;
-  g.xcd_runs = xcd_runs;
+  g.count = count | (xcd_runs ? TN_XCD_RUNS : 0);
+  if (any_fused) {
+    g.opt = TNOpt{opt->g_base, opt->p_base, opt->m_base, opt->v_base, (bf16_t*)opt->bf16_base, opt->hyper, opt->bias_corr, opt->gscale_dev, opt->sumsq,
+                  opt->beta1, opt->beta2, opt->eps};
+    const TNGroup gf = g;
+    DAV_LAUNCH((gemm_tn_grouped_kernel<128, 4, 2, 64, 2, 1, 128, true>), dim3(first), dim3(512), (size_t)2 * 2 * 64 * 128 * 2, stream, gf);
+    return dav_launch_status();
+  }
   // 4 x 2 waves (32 x 64 wave tiles): +1 % over 2 x 4 in the step; thinner or deeper rings (32-row stages x 3 / 4, 64-row x 3),
   // 4-wave workgroups and three workgroups per CU were all measured slower (profiles/r02_tn_ring_variants.txt)
   // (by-value copy in an AUTOMATIC: a launch recorded inside dav_batch_begin .. dav_batch_end captures its arguments with [=],
@@ -2111,6 +2198,14 @@ extern "C" int dav_gemm_tn_grouped_bf16(const DavTnProblem* probs, int count, hi
 #endif
   DAV_LAUNCH((gemm_tn_grouped_kernel<128, 4, 2>), dim3(first), dim3(512), (size_t)2 * 2 * 64 * 128 * 2, stream, gl);
   return dav_launch_status();
+}
+
+extern "C" int dav_gemm_tn_grouped_bf16(const DavTnProblem* probs, int count, hipStream_t stream) {
+  return tn_grouped_impl(probs, count, nullptr, stream);
+}
+extern "C" int dav_gemm_tn_grouped_adamw_bf16(const DavTnProblem* probs, int count, const DavTnAdamW* opt, hipStream_t stream) {
+  if (!opt) return DAV_ERR_SHAPE;
+  return tn_grouped_impl(probs, count, opt, stream);
 }
 
 extern "C" int dav_gemm_tn_bf16(const void* A, const void* B, int Mc, int N, int K, int lda, int ldb,

@@ -335,6 +335,37 @@ def wgrad_overwrite_end():
     return list(st['params'].values()) if st else []
 
 
+# Fused optimizer pass (dav_gemm_tn_grouped_adamw_bf16; util.misc.GraphedStep(fuse=True) / DAV_FUSED_ADAMW=1): a Linear weight whose ONE
+# weight-gradient problem of the step is a written tile set gets its AdamW update from the workgroups that own those tiles — the gradient
+# never goes to memory and the optimizer kernel behind the backward skips the weight.  ``wgrad_contrib_*`` counts the problems per weight in
+# a warm-up pass (decoder_embed sees two: patch tokens and fusion tokens); ``fused_adamw_*`` brackets the captured backward.
+_CONTRIB = None            # None: off; {address of the weight's gradient: number of weight-gradient problems this step}
+_FUSED = None              # None: off; dict(opt=<ops.gemm_tn_grouped opt>, index_of={id(weight): row in the hyper table}, allowed={id(weight)}, used={})
+
+
+def wgrad_contrib_begin():
+    global _CONTRIB
+    _CONTRIB = {}
+
+
+def wgrad_contrib_end():
+    global _CONTRIB
+    st, _CONTRIB = _CONTRIB, None
+    return st or {}
+
+
+def fused_adamw_begin(opt, index_of, allowed):
+    global _FUSED
+    _FUSED = dict(opt=opt, index_of=index_of, allowed=allowed, used={})
+
+
+def fused_adamw_end():
+    """-> the weights whose update the weight-gradient launches of the bracketed backward carried."""
+    global _FUSED
+    st, _FUSED = _FUSED, None
+    return list(st['used'].values()) if st else []
+
+
 def deferred_operands_to(stream):
     """The queued weight-gradient problems will be launched on ``stream`` although their operands were allocated while another
     stream was current: tell the caching allocator, so that a block is not handed out again on its home stream while the
@@ -398,6 +429,10 @@ def _flush_wgrads_now():
         # longest contractions first: tiles are dispatched in list order as workgroup slots free up, and a tile's run time is
         # proportional to its contraction length (49 .. 95 k-steps in one launch) — the short ones fill the tail
         now.sort(key=lambda pr: -pr['Mc'])
+        if _CONTRIB is not None:
+            for pr in now:
+                k = pr.get('gbase', pr['C'].data_ptr())
+                _CONTRIB[k] = _CONTRIB.get(k, 0) + (1 if pr.get('weight') is not None else 2)      # (a column block never qualifies)
         if _OVERWRITE is not None:
             for pr in now:
                 key = pr['C'].data_ptr()
@@ -407,7 +442,16 @@ def _flush_wgrads_now():
                     _OVERWRITE['touched'].add(pr.get('gbase', key))
                 if pr['overwrite']:
                     _OVERWRITE['params'][id(pr['weight'])] = pr['weight']
-        ops.gemm_tn_grouped(now)
+        if _FUSED is not None:
+            for pr in now:
+                w = pr.get('weight')
+                if pr.get('overwrite') and w is not None and id(w) in _FUSED['allowed']:
+                    pr['fused_idx'] = _FUSED['index_of'][id(w)]
+                    _FUSED['used'][id(w)] = w
+        if _FUSED is not None:
+            ops.gemm_tn_grouped(now, opt=_FUSED['opt'])
+        else:
+            ops.gemm_tn_grouped(now)
         for pr in now:
             _ready(*pr['ready'])
         probs = later
@@ -536,6 +580,8 @@ def lin_bwd(lin, dy, a, M, *, dy_rowmap=None, a_rowmap=None, lda=None, need_dx=T
         return dx
     if _OVERWRITE is not None:
         _OVERWRITE['touched'].add(gwv.data_ptr())
+    if _CONTRIB is not None:
+        _CONTRIB[gwv.data_ptr()] = _CONTRIB.get(gwv.data_ptr(), 0) + 2      # an immediate (un-deferred) contribution: never a fused weight
     if sw is None:
         ops.gemm_tn(dy, a, M, N, K, Cw, lda=N, ldb=lda if lda is not None else K, ldc=Kfull, a_rowmap=dy_rowmap,
                     b_rowmap=a_rowmap, beta=1, bias_grad=gb)

@@ -157,10 +157,19 @@ def gemm_tn(A, B, Mc, N, K, C_out, *, lda=None, ldb=None, ldc=None, a_rowmap=Non
 TN_GROUP_MAX = 40          # dav_gemm_tn_grouped_bf16: problems per launch
 
 
-def gemm_tn_grouped(problems):
-    """problems: list of dicts(A, B, Mc, N, K, C, lda, ldb, ldc, a_rowmap, b_rowmap, bias_grad[, overwrite]); see
-    dav_gemm_tn_grouped_bf16 (overwrite: C is written instead of accumulated, DavTnProblem.flags bit 0)."""
+def gemm_tn_grouped(problems, opt=None):
+    """problems: list of dicts(A, B, Mc, N, K, C, lda, ldb, ldc, a_rowmap, b_rowmap, bias_grad[, overwrite][, fused_idx]); see
+    dav_gemm_tn_grouped_bf16 (overwrite: C is written instead of accumulated, DavTnProblem.flags bit 0).  ``opt`` (a dict of the
+    DavTnAdamW fields: tensors g, p, m, v, bf16, hyper, bias_corr, gscale_dev, sumsq + beta1, beta2, eps): problems that carry
+    ``fused_idx`` (the parameter's row in ``hyper``; overwrite required) get their AdamW update from the workgroups that own their
+    gradient tiles and the gradient is not stored (dav_gemm_tn_grouped_adamw_bf16)."""
     lib = _lib.load()
+    fused = opt is not None and any(d.get('fused_idx') is not None for d in problems)
+    if fused:
+        o = _lib.DavTnAdamW()
+        o.g_base, o.p_base, o.m_base, o.v_base, o.bf16_base = _ptr(opt['g']), _ptr(opt['p']), _ptr(opt['m']), _ptr(opt['v']), _ptr(opt['bf16'])
+        o.hyper, o.bias_corr, o.gscale_dev, o.sumsq = _ptr(opt['hyper']), _ptr(opt['bias_corr']), _ptr(opt.get('gscale_dev')), _ptr(opt['sumsq'])
+        o.beta1, o.beta2, o.eps = float(opt['beta1']), float(opt['beta2']), float(opt['eps'])
     if problems and problems[0]['A'].dtype == F32:      # fp32 path: one launch per problem
         for d in problems:
             gemm_tn(d['A'], d['B'], d['Mc'], d['N'], d['K'], d['C'], lda=d['lda'], ldb=d['ldb'], ldc=d['ldc'],
@@ -180,7 +189,15 @@ def gemm_tn_grouped(problems):
             q.a_rowmap[:] = d.get('a_rowmap') or (0, 0, 0)
             q.b_rowmap[:] = d.get('b_rowmap') or (0, 0, 0)
             q.flags = 1 if d.get('overwrite') else 0
-        _lib.check(lib.dav_gemm_tn_grouped_bf16(arr, len(chunk), _stream()), 'dav_gemm_tn_grouped_bf16')
+            if fused and d.get('fused_idx') is not None:
+                if not d.get('overwrite'):
+                    raise RuntimeError('a fused optimizer tile must be a written (overwrite) one')
+                q.flags |= 2 | (int(d['fused_idx']) << 8)
+        if fused and any(q.flags & 2 for q in arr):
+            import ctypes
+            _lib.check(lib.dav_gemm_tn_grouped_adamw_bf16(arr, len(chunk), ctypes.byref(o), _stream()), 'dav_gemm_tn_grouped_adamw_bf16')
+        else:
+            _lib.check(lib.dav_gemm_tn_grouped_bf16(arr, len(chunk), _stream()), 'dav_gemm_tn_grouped_bf16')
 
 
 def attn_fwd(q_ptr, k_ptr, v_ptr, O, LSE, B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, scale):

@@ -188,7 +188,7 @@ class GraphedStep:
     is NOT meant to continue past such a step — ``check()`` raises (train.py calls it every print_freq steps, at the end of every
     epoch and before every checkpoint), exactly where the reference raises on the step itself (train.py:166-167)."""
 
-    def __init__(self, trainer: Trainer, image_shape, audio_shape, warmup: int = 2, segments: int = 0, clip_grad=None, defer=None):
+    def __init__(self, trainer: Trainer, image_shape, audio_shape, warmup: int = 2, segments: int = 0, clip_grad=None, defer=None, fuse=None):
         """``clip_grad``: max global gradient norm (``opt.clip_grad``; util/misc.py:118-120) — the norm is then taken in a
         pass of its own in front of AdamW and the factor min(1, clip / (norm + 1e-6)) reaches the update as a device scalar.
         Always on: the non-finite guard of train.py:166-167 — a step whose loss (or, with clipping, gradient norm) is not
@@ -236,6 +236,11 @@ class GraphedStep:
         # checkpoint, evaluation, end of training).  The returned grad norm is the previous step's.
         self.defer = single and (defer if defer is not None else os.environ.get('DAV_DEFER_ADAMW', '0') == '1')
         self.early = single and not self.defer and os.environ.get('DAV_EARLY_ADAMW', '0') == '1'
+        # Fused AdamW (same conditions, and the written-first weight gradients on): a Linear weight whose one weight-gradient problem of the
+        # step is a written tile set is updated by the workgroups that own those tiles (dav_gemm_tn_grouped_adamw_bf16) — its gradient is
+        # never stored, and the optimizer kernel behind the backward covers only what is left (biases, norms, embeddings, column blocks).
+        self.fuse = (single and not self.defer and not self.early and os.environ.get('DAV_WGRAD_OVERWRITE', '1') != '0'
+                     and (fuse if fuse is not None else os.environ.get('DAV_FUSED_ADAMW', '0') == '1'))
         cuts_env = os.environ.get('DAV_EARLY_ADAMW_CUTS', '')
         self.early_cuts = ({int(c) for c in cuts_env.split(',') if c.strip()} if cuts_env
                            else {depth} | {l for l in (9, 6, 3, 1) if l < depth}) if self.early else set()
@@ -257,8 +262,13 @@ class GraphedStep:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for it in range(max(warmup, 1 if learn else 0)):
-                if learn and it == 0:
+            contrib = {}
+            for it in range(max(warmup, 1 if (learn or self.fuse) else 0)):
+                if self.fuse and it == 0:
+                    engine.wgrad_contrib_begin()
+                    self._fwd_bwd(None)
+                    contrib = engine.wgrad_contrib_end()
+                elif learn and it == 0:
                     engine.set_grad_ready_hook(learn_ready)
                     self._fwd_bwd(learn_cb)
                     engine.set_grad_ready_hook(None)
@@ -394,7 +404,14 @@ class GraphedStep:
                 torch.cuda.current_stream().wait_event(self.chunk_events[k])
                 waited[0] = k
 
+        self.fused_sumsq = torch.zeros(1, dtype=torch.float32, device=dev)      # sum(g^2) of the tiles whose update the weight-gradient launches carry
+
         def optimizer_pass():
+            if self.fuse:
+                guard()                              # (already issued behind the forward: a no-op here)
+                self.opt.launch_step(fused_norm_and_zero=True, keep_grad=self.keep_grad, gscale_dev=self.step_scale)
+                self.grad_norm = (self.opt.sumsq + self.fused_sumsq).sqrt()
+                return
             if self.early:                       # what the backward did not take along: the first layers, the embeddings
                 torch.cuda.current_stream().wait_stream(self.opt_stream)
                 guard()
@@ -423,7 +440,16 @@ class GraphedStep:
                 engine.refresh_weight_cache(self.model)
                 if self.defer:
                     deferred_update()
-                self.loss_image, self.loss_audio = self._fwd_bwd(layer_cb, fwd_gate if self.defer else None)
+                if self.fuse:
+                    flat = self.opt.flat
+                    b1, b2 = self.opt.defaults['betas']
+                    grad_at = {int(flat.flat_g[o:o + 1].data_ptr()): id(p) for p, o in zip(flat.params, flat.offsets)}
+                    allowed = {grad_at[a] for a, n in contrib.items() if n == 1 and a in grad_at}
+                    self.fused_sumsq.zero_()
+                    engine.fused_adamw_begin(dict(g=flat.flat_g, p=flat.flat_p, m=self.opt.exp_avg, v=self.opt.exp_avg_sq, bf16=self.opt.flat_bf16,
+                                                  hyper=self.opt._hyper, bias_corr=self.opt._bc, gscale_dev=self.step_scale, sumsq=self.fused_sumsq,
+                                                  beta1=b1, beta2=b2, eps=self.opt.defaults['eps']), index_of, allowed)
+                self.loss_image, self.loss_audio = self._fwd_bwd(layer_cb, fwd_gate if self.defer else None, after_fwd=guard if self.fuse else None)
                 if self.defer:
                     torch.cuda.current_stream().wait_stream(self.opt_stream)
                     self.prev_loss[0:1].copy_(self.loss_image.reshape(1))
@@ -432,6 +458,7 @@ class GraphedStep:
                 # (also on an exception: a write-first mode left on would make later EAGER backwards overwrite instead of
                 # accumulate the first contribution to every Linear weight's gradient)
                 kept = {id(p) for p in engine.wgrad_overwrite_end()}
+                fused = {id(p) for p in engine.fused_adamw_end()}
             if not self.dist_active and not self.defer:
                 optimizer_pass()
             self.graphs[seg[0]].capture_end()
@@ -456,8 +483,10 @@ class GraphedStep:
         engine.set_grad_ready_hook(saved_hook)
         self.opt.flat.zero_grad()
         # the captured AdamW pass reads this table at replay time: gradients the captured backward WRITES are not zero-filled
-        self.keep_grad.copy_(torch.tensor([1 if id(p) in kept else 0 for p in self.opt.flat.params], dtype=torch.uint8))
+        # (byte bit 1: the optimizer kernel skips the parameter altogether — its update came with its gradient, dav_adamw_flat)
+        self.keep_grad.copy_(torch.tensor([(3 if id(p) in fused else 1) if id(p) in kept else 0 for p in self.opt.flat.params], dtype=torch.uint8))
         self.kept_params = len(kept)
+        self.fused_params = len(fused)
 
     def check(self):
         """Host side of the non-finite guard (one device read: call it where the loss is read anyway, e.g. every
@@ -475,13 +504,15 @@ class GraphedStep:
             self.flush_graph.replay()
             self.pending = False
 
-    def _fwd_bwd(self, layer_cb, fwd_gate=None):
+    def _fwd_bwd(self, layer_cb, fwd_gate=None, after_fwd=None):
         """Forward + hand-written backward straight on the engine (no autograd), unit upstream gradients."""
         B, dev = self.image.shape[0], self.image.device
         Li, La = self.model.image_gs[0] * self.model.image_gs[1], self.model.audio_gs[0] * self.model.audio_gs[1]
         noise_i, noise_a = torch.rand(B, Li, device=dev), torch.rand(B, La, device=dev)
         outs, tape, aux = self.bridge.avmae_fwd(self.model, self.image, self.audio, noise_i, noise_a, fwd_gate=fwd_gate)
         self.loss_image_dev, self.loss_audio_dev = outs[0], outs[1]      # (the early AdamW passes' guard reads them inside the backward)
+        if after_fwd is not None:
+            after_fwd()                                                  # (fused AdamW: the step guard's scalar before the first weight-gradient launch)
         one = torch.ones((), device=dev)
         self.bridge.avmae_bwd(self.model, tape, one, one, layer_cb=layer_cb)
         return outs[0], outs[1]

@@ -37,7 +37,7 @@ typedef struct ihipStream_t* hipStream_t;
 extern "C" {
 #endif
 
-#define DAV_ABI_VERSION 4   /* 2: DavTnProblem.flags, dav_adamw_flat keep_grad + gscale_dev, dav_step_guard; 3: dav_attn_bwd_ctx, dav_add_cast */
+#define DAV_ABI_VERSION 5   /* 2: DavTnProblem.flags, dav_adamw_flat keep_grad + gscale_dev, dav_step_guard; 3: dav_attn_bwd_ctx, dav_add_cast; 4: fused fusion tails, grouped cast-transpose; 5: dav_gemm_tn_grouped_adamw_bf16 */
 int dav_abi_version(void);
 int dav_build_flags(void);   /* bit 0: experimental build (make EXPERIMENTAL=1): the rejected GEMM tile configurations exist */
 /* text of the last HIP error latched by a kernel launch of the calling thread (diagnostics) */
@@ -93,11 +93,26 @@ typedef struct DavTnProblem {
   float* C; float* bias_grad;         /* fp32 [N, K] (ldc), fp32 [N] or NULL; both accumulated */
   int Mc, N, K, lda, ldb, ldc;
   int a_rowmap[3], b_rowmap[3];
-  int flags;                          /* bit 0: C is WRITTEN, its old contents ignored (the first contribution to a gradient
+  int flags;                          /* bit 1 + bits 8..: see dav_gemm_tn_grouped_adamw_bf16.  bit 0: C is WRITTEN, its old contents ignored (the first contribution to a gradient
                                          that the optimizer pass did not zero-fill, see dav_adamw_flat keep_grad); bias_grad
                                          is accumulated regardless.  Such a problem is never split over the contraction. */
 } DavTnProblem;
 int dav_gemm_tn_grouped_bf16(const DavTnProblem* problems, int count, hipStream_t stream);
+
+/* The same launch with the optimizer pass FUSED into it (ABI 5; the captured single-process step of util/misc.py GraphedStep): a problem
+ * with flags bit 1 set (legal only together with bit 0, C inside the flat gradient buffer) does not store its gradient tile — the workgroup
+ * that owns the tile holds the FINAL gradient of those weights and applies AdamW to them in place: fp32 master, both moments and the bf16
+ * mirror at element offset (C - g_base) of the flat buffers, hyper[2 * idx] = {lr, weight_decay} with idx = flags >> 8 (the parameter's
+ * row in dav_adamw_flat's table), the arithmetic of dav_adamw_flat in its order (Trainer.step, util/misc.py:96-136 -> torch.optim.AdamW);
+ * sum(g^2) of those tiles is ADDED to *sumsq (not zeroed here); gscale_dev as in dav_adamw_flat.  The caller skips these parameters in
+ * dav_adamw_flat (keep_grad byte bit 1) — 8 bytes per weight less traffic (the gradient's round trip) and no optimizer kernel running alone
+ * behind the backward for them.  Problems without bit 1 behave as in dav_gemm_tn_grouped_bf16. */
+typedef struct DavTnAdamW {
+  const float* g_base; float* p_base; float* m_base; float* v_base; void* bf16_base;
+  const float* hyper; const float* bias_corr; const float* gscale_dev; float* sumsq;
+  float beta1, beta2, eps;
+} DavTnAdamW;
+int dav_gemm_tn_grouped_adamw_bf16(const DavTnProblem* problems, int count, const DavTnAdamW* opt, hipStream_t stream);
 
 /* ---- attention ---------------------------------------------------------------------------- */
 /* softmax(scale * Q K^T) V per (batch, head); element (b, n, h, d) of X is X[b*x_bs + n*x_rs + h*dX + d].
@@ -296,7 +311,8 @@ int dav_l2norm(const float* x, long n, float scale, float* out, void* workspace,
  * util/misc.py:151-163 is its square root), (b) rewrite the bf16 weight mirror p_bf16, (c) zero the gradients
  * (Trainer.zero_grad) — one trip over the buffers instead of three.  keep_grad (NULL or one byte per segment): segments
  * with a non-zero byte are NOT zero-filled — their next gradient will be written, not accumulated (DavTnProblem.flags bit 0),
- * which saves the fill here and the read there.  All accesses are 16-byte ones: the buffers must be
+ * which saves the fill here and the read there; byte bit 1 (ABI 5): the segment is skipped altogether — the weight-gradient launch
+ * that computed its gradient has already updated it (dav_gemm_tn_grouped_adamw_bf16).  All accesses are 16-byte ones: the buffers must be
  * 16-byte aligned (p_bf16 8-byte), n and every seg_end a multiple of 4 (FlatParams aligns segments to 64 elements).
  * gscale_dev (optional): device scalar from dav_step_guard, see there. */
 int dav_adamw_flat(float* p, float* g, float* m, float* v, void* p_bf16, long n, const long* seg_end, const float* hyper,

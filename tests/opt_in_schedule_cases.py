@@ -143,3 +143,62 @@ def test_wgrad_side_stream_equals_the_serial_placement(monkeypatch):
         assert rel(finals[k], finals[0]) < 2e-4 and rel(moments[k], moments[0]) < 2e-3      # (fp32 atomics in the bias gradients: not bit-equal)
 
 
+
+
+def test_fused_adamw_equals_the_optimizer_kernel(monkeypatch):
+    """GraphedStep(fuse=True) / DAV_FUSED_ADAMW=1: a Linear weight whose one weight-gradient problem of the step is a written tile set gets
+    its AdamW update from the workgroups that own those tiles (dav_gemm_tn_grouped_adamw_bf16: the gradient is never stored, the optimizer
+    kernel skips the weight).  Same arithmetic in the same order: same seeds (with a learning rate that changes every step) must give the
+    same losses, gradient norm, parameters, moments and bf16 mirror as the optimizer kernel alone; most Linear weights must really have
+    taken the fused route, a weight with two contributions per step (decoder_embed) must not; a replay with a non-finite loss leaves
+    everything untouched here too, and ``check()`` raises."""
+    from deepavfusion_amd.util import lr_sched
+    from deepavfusion_amd.util.flat import FlatAdamW
+    from deepavfusion_amd.util.misc import GraphedStep, Trainer
+    finals, moments, losses, norms, mirrors = [], [], [], [], []
+    for fuse in (False, True):
+        model, sd, cfg, O = _build('micro')
+        nd = [n for n, p in model.named_parameters() if 'bias' in n or 'norm' in n]
+        groups = lr_sched.param_groups_pretrained(model, 0.05, no_weight_decay_list=nd, image_pt='', audio_pt='')
+        opt = FlatAdamW(groups, lr=1e-3, betas=(0.9, 0.95), model=model)
+        tr = Trainer(model, optimizer=opt, accum_iter=1)
+        image, audio, _, _ = O.structured_batch(cfg, 64, seed=3)
+        image, audio = image.cuda(), audio.cuda()
+        torch.manual_seed(77)
+        gs = GraphedStep(tr, image.shape, audio.shape, fuse=fuse)
+        assert gs.fuse == fuse
+        if fuse:
+            n_linear = sum(1 for n, p in model.named_parameters() if p.ndim == 2 and p.requires_grad and 'embed' not in n and 'token' not in n)
+            assert gs.fused_params > n_linear // 2, (gs.fused_params, n_linear)
+            names = {id(p): n for n, p in model.named_parameters()}
+            kg = gs.keep_grad.cpu().tolist()
+            fused_names = [names[id(p)] for p, k in zip(opt.flat.params, kg) if k & 2]
+            assert not any('decoder_embed' in n for n in fused_names), fused_names      # two contributions per step: stays with the kernel
+            assert all(k in (0, 1, 3) for k in kg)
+        run, gns = [], []
+        for s in range(6):
+            torch.manual_seed(500 + s)
+            for g in opt.param_groups:
+                g['lr'] = 1e-3 * (1.0 + 0.5 * s)
+            li, la, gn = gs(image, audio)
+            run.append(float(li) + float(la)); gns.append(float(gn))
+        torch.cuda.synchronize()
+        gs.check()
+        finals.append(opt.flat.flat_p.clone()); moments.append((opt.exp_avg.clone(), opt.exp_avg_sq.clone())); losses.append(run); norms.append(gns)
+        mirrors.append(opt.flat_bf16.clone())
+        if fuse:                                       # the guard: a NaN input -> nothing moves, the host check raises
+            before = (opt.flat.flat_p.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.flat_bf16.clone())
+            bad = image.clone(); bad[0, 0, 0, 0] = float('nan')
+            gs(bad, audio)
+            torch.cuda.synchronize()
+            after = (opt.flat.flat_p, opt.exp_avg, opt.exp_avg_sq, opt.flat_bf16)
+            assert all(torch.equal(a, b) for a, b in zip(before, after))
+            with pytest.raises(RuntimeError):
+                gs.check()
+    assert all(np.isfinite(losses[1])) and losses[1][-1] < losses[1][0]
+    for a, b in zip(*losses):
+        assert abs(a - b) <= 5e-5 * abs(b), losses
+    for a, b in zip(*norms):
+        assert abs(a - b) <= 1e-4 * abs(b), norms
+    assert rel(finals[1], finals[0]) < 2e-4 and rel(moments[1][0], moments[0][0]) < 2e-3 and rel(moments[1][1], moments[0][1]) < 2e-3
+    assert rel(mirrors[1].float(), mirrors[0].float()) < 2e-3

@@ -777,19 +777,19 @@ def test_written_first_gradients_equal_accumulated_ones(monkeypatch):
 
 @pytest.mark.timeout(600)
 def test_opt_in_schedules_in_a_process_of_their_own():
-    """The three opt-in placements of the optimizer / weight-gradient work inside the captured step (DAV_EARLY_ADAMW, deferred AdamW,
-    DAV_WGRAD_SIDE; tests/opt_in_schedule_cases.py) build graphs with one MORE parallel branch than the default step.  They run in a
+    """The opt-in placements of the optimizer / weight-gradient work inside the captured step (DAV_EARLY_ADAMW, deferred AdamW,
+    DAV_WGRAD_SIDE, fused AdamW; tests/opt_in_schedule_cases.py) build graphs with one MORE parallel branch than the default step.  They run in a
     fresh interpreter: with them in this process, the destruction of their captured steps left the HIP runtime's graph launch
     (hip::Graph::UpdateStreams inside hipGraphLaunch, ROCm 7.2) segfaulting at the replay of a LATER, unrelated captured step —
     reproducible with any three of those tests followed by another graph test, gone when no captured step is ever destroyed
     (gc disabled).  A training process builds its captured step once and never destroys it."""
     import subprocess
     env = dict(os.environ)
-    env.pop('DAV_EARLY_ADAMW', None); env.pop('DAV_DEFER_ADAMW', None); env.pop('DAV_WGRAD_SIDE', None)
+    env.pop('DAV_EARLY_ADAMW', None); env.pop('DAV_DEFER_ADAMW', None); env.pop('DAV_WGRAD_SIDE', None); env.pop('DAV_FUSED_ADAMW', None)
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'opt_in_schedule_cases.py'), '-x', '-q', '-m', 'gpu',
                         '-p', 'no:cacheprovider'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=580)
     tail = (r.stdout + r.stderr)[-3000:]
-    assert r.returncode == 0 and '3 passed' in r.stdout, tail
+    assert r.returncode == 0 and '4 passed' in r.stdout, tail
 
 
 def test_trainer_skip_grad_drops_an_outlier_micro_step():

@@ -51,6 +51,7 @@ S = {
     'DAV_TN_TILE': ('128', 'kernel', "EXPERIMENTAL builds only: 256 / 257 = 256 x 128 owner-per-tile weight-gradient tiles on 64-row x 2 / 32-row x 3 rings (slower: profiles/r04_tn256x128.txt)", '- (gpu_selfcheck gemm_tn family run with it, profiles/r04_tn256x128.txt)'),
     'DAV_TN_XCD': ('1', 'kernel', "weight-gradient tiles: one contiguous run of each problem's tiles per XCD; 0 = every 8th tile", 'gpu_selfcheck gemm_tn family'),
     'DAV_EARLY_ADAMW': ('0', 'optimizer', "1: AdamW on ranges of the flat buffer as their gradients become final, on a side stream (slower)", 'test_early_adamw_ranges_equal_the_single_pass'),
+    'DAV_FUSED_ADAMW': ('0', 'optimizer', "1: captured single-process step: a Linear weight whose one weight-gradient problem is a written tile set is updated by the workgroups that own those tiles (dav_gemm_tn_grouped_adamw_bf16); the optimizer kernel covers the rest (profiles/r04_fused_adamw.txt)", 'test_fused_adamw_equals_the_optimizer_kernel'),
     'DAV_DEFER_ADAMW': ('0', 'optimizer', "1: the update with step i's gradients runs at the top of replay i + 1, layer by layer on a side stream under that replay's forward; GraphedStep.flush() applies the last one (profiles/r04_defer_adamw.txt)", 'test_deferred_adamw_equals_the_plain_schedule'),
     'DAV_ADAMW_WGS': ('0 (whole grid)', 'optimizer', "cap on the AdamW kernel's workgroups (a narrow grid trickles beside other work instead of evicting it)", '- (element-wise grid-stride loop; profiles/r04_defer_adamw.txt)'),
     'DAV_EARLY_ADAMW_CUTS': ('depth,9,6,3,1', 'optimizer', "layers after which DAV_EARLY_ADAMW launches a range", 'test_early_adamw_ranges_equal_the_single_pass'),
