@@ -775,6 +775,7 @@ def test_written_first_gradients_equal_accumulated_ones(monkeypatch):
     assert rel(finals[0], finals[1]) < 2e-4
 
 
+@pytest.mark.fresh_process
 @pytest.mark.timeout(600)
 def test_opt_in_schedules_in_a_process_of_their_own():
     """The opt-in placements of the optimizer / weight-gradient work inside the captured step (DAV_EARLY_ADAMW, deferred AdamW,
@@ -1073,6 +1074,7 @@ def test_checkpoint_round_trip_and_reference_format(tmp_path):
     assert worst < 2e-6, worst
 
 
+@pytest.mark.fresh_process
 def test_captured_step_repeats_bit_for_bit_across_replays():
     """Race screen: in the captured step the three branches of a layer really run concurrently (eager launches barely
     overlap), so a missing stream dependency or a buffer recycled while another stream still reads it shows up as
@@ -1244,6 +1246,7 @@ def test_baseline_config_shapes_vs_oracle(name, batch):
     assert np.median(rels) < ACT_TOL
 
 
+@pytest.mark.fresh_process
 @pytest.mark.timeout(600)
 def test_bench_workload_with_the_opt_in_256_tile_kernels_vs_oracle():
     """The 256 x 256 NT body (configuration 60, DAV_NT256=1) is off by default (slower inside the step, DESIGN_HISTORY.md section 3)
@@ -1262,16 +1265,18 @@ def test_bench_workload_with_the_opt_in_256_tile_kernels_vs_oracle():
 
 
 @pytest.mark.timeout(300)
-def test_whole_step_with_the_opt_in_fused_fusion_tails_vs_oracle():
+def test_whole_step_with_the_opt_in_fused_fusion_tails_vs_oracle(monkeypatch):
     """DAV_FUSION_TAIL=1 (csrc/fusion_tail.hip, off by default: slower inside the step): the whole pre-training step at
-    ViT-B widths with the fused tails carrying every fusion block, as a fresh process, against the oracle (base-4)."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DAV_FUSION_TAIL='1', DAV_TEST_ORACLE_FROM_CACHE='1')
-    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider',
-                        '-k', 'test_baseline_config_shapes_vs_oracle and base-4'], cwd=root, env=env, capture_output=True, text=True, timeout=280)
-    assert r.returncode == 0 and '1 passed' in r.stdout, (r.stdout[-3000:], r.stderr[-1500:])
+    ViT-B widths with the fused tails carrying every fusion block, against the oracle (base-4; the switch is a module attribute of
+    the engine, the oracle's step comes from this session's base-4 test when that ran)."""
+    from deepavfusion_amd import engine as E
+    monkeypatch.setattr(E, 'FUSION_TAIL', True)
+    monkeypatch.setenv('DAV_TEST_ORACLE_FROM_CACHE', '1')
+    calls = []
+    real = E.ops.fusion_tail
+    monkeypatch.setattr(E.ops, 'fusion_tail', lambda *a, **k: (calls.append(a[0]), real(*a, **k))[1])
+    test_baseline_config_shapes_vs_oracle('base', 4)
+    assert len(calls) >= 4 * 12, len(calls)              # four tails per fusion block, twelve blocks: the fused kernels really carried the step
 
 
 def test_load_state_dict_after_optimizer_refreshes_the_bf16_mirror():
@@ -1307,6 +1312,7 @@ def test_load_state_dict_after_optimizer_refreshes_the_bf16_mirror():
     assert l3 == l4 and l3 != l1
 
 
+@pytest.mark.fresh_process
 @pytest.mark.timeout(300)
 def test_train_py_runs_and_resumes(tmp_path):
     """train.py (drop-in for the reference's pre-training worker, train.py:20-187) end to end as a fresh process: ViT-Tiny,
