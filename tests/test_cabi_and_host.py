@@ -340,6 +340,56 @@ def test_written_first_contribution_bookkeeping(monkeypatch):
     assert launches and not launches[0][0].get('overwrite')
 
 
+def test_fused_adamw_bookkeeping(monkeypatch):
+    """engine.flush_wgrads under fused_adamw_begin(): which weight-gradient problems carry their weight's AdamW update
+    (DavTnProblem.flags bit 1) — only WRITTEN full-weight problems of weights that see exactly ONE problem per step (counted in a warm-up
+    pass by wgrad_contrib_begin / _end).  Pure host logic, the grouped launch is intercepted."""
+    from deepavfusion_amd import engine as E, ops
+    launches = []
+    monkeypatch.setattr(ops, 'gemm_tn_grouped', lambda probs, opt=None: launches.append(([dict(p) for p in probs], opt)))
+    lin = [torch.nn.Linear(8, 8) for _ in range(4)]
+    g = [torch.zeros(8, 8) for _ in range(4)]
+
+    def prob(i, mc, full=True):
+        return dict(A=None, B=None, Mc=mc, N=8, K=8 if full else 4, C=g[i], lda=8, ldb=8, ldc=8, bias_grad=None, ready=(),
+                    gbase=g[i].data_ptr(), weight=lin[i].weight if full else None)
+
+    def one_step():
+        with E.deferred_wgrads():
+            E._DEFERRED.extend([prob(0, 128), prob(1, 64), prob(1, 192), prob(2, 64, full=False)])      # 1: two problems; 2: a column block
+            E.flush_wgrads()
+            E._DEFERRED.append(prob(3, 64))
+    # warm-up pass: count
+    E.wgrad_contrib_begin()
+    one_step()
+    contrib = E.wgrad_contrib_end()
+    assert E._CONTRIB is None
+    assert contrib[g[0].data_ptr()] == 1 and contrib[g[1].data_ptr()] == 2 and contrib[g[2].data_ptr()] >= 2 and contrib[g[3].data_ptr()] == 1
+    allowed = {id(lin[i].weight) for i in range(4) if contrib[g[i].data_ptr()] == 1}
+    assert allowed == {id(lin[0].weight), id(lin[3].weight)}
+    # captured pass: written-first + fused
+    launches.clear()
+    opt = dict(tag='the optimizer buffers')
+    E.wgrad_overwrite_begin()
+    E.fused_adamw_begin(opt, {id(lin[i].weight): 10 + i for i in range(4)}, allowed)
+    one_step()
+    used = E.fused_adamw_end()
+    E.wgrad_overwrite_end()
+    assert E._FUSED is None
+    assert all(o is opt for _, o in launches)
+    flat = {(p['C'].data_ptr(), p['Mc']): p for l, _ in launches for p in l}
+    assert flat[(g[0].data_ptr(), 128)].get('fused_idx') == 10 and flat[(g[3].data_ptr(), 64)].get('fused_idx') == 13
+    assert all(flat[k].get('fused_idx') is None for k in flat if k[0] in (g[1].data_ptr(), g[2].data_ptr()))
+    assert all(p.get('overwrite') for p in flat.values() if p.get('fused_idx') is not None)            # a fused tile is a written one
+    assert {id(p) for p in used} == allowed
+    # outside the bracket nothing is fused and the launch is called without the optimizer buffers
+    launches.clear()
+    monkeypatch.setattr(ops, 'gemm_tn_grouped', lambda probs: launches.append([dict(p) for p in probs]))
+    with E.deferred_wgrads():
+        E._DEFERRED.append(prob(0, 64))
+    assert launches and launches[0][0].get('fused_idx') is None
+
+
 def test_bench_starts_its_own_ranks_when_launched_plainly():
     """`python bench.py --gpus N` without torch.distributed.run around it (missing #1): the process starts N
     fresh children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, before any GPU call, and forwards rank 0's one line."""
