@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, 'libdavfusion_hip.so')
 
 _p, _i, _l, _f, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 
-ABI_VERSION = 5      # DAV_ABI_VERSION of include/dav_kernels.h this package was written against (struct layouts, signatures)
+ABI_VERSION = 6      # DAV_ABI_VERSION of include/dav_kernels.h this package was written against (struct layouts, signatures)
 
 # name -> argtypes (must match include/dav_kernels.h)
 SIGNATURES = {
@@ -31,6 +31,8 @@ SIGNATURES = {
     'dav_gemm_tn_bf16': [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _i, _p],
     'dav_gemm_tn_grouped_bf16': [_p, _i, _p],
     'dav_gemm_tn_grouped_adamw_bf16': [_p, _i, _p, _p],
+    'dav_gemm_tn_gang_workspace_bytes': [_p, _i],
+    'dav_gemm_tn_gang_bf16': [_p, _i, _p, _sz, _p],
     'dav_attn_fwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _i, _l, _i, _l, _i, _l, _i, _f, _p],
     'dav_attn_bwd': [_p] * 10 + [_i] * 6 + [_l, _i] * 8 + [_f, _p],
     'dav_attn_bwd_part': [_p] * 10 + [_i] * 6 + [_l, _i] * 8 + [_f, _i, _p],

@@ -257,8 +257,34 @@ __device__ __forceinline__ bf16x8 tn2_frag(const char* tile, int mk, int colbase
   return u.v;
 }
 
+// The same fragment through inline asm.  hipcc puts an s_waitcnt vmcnt(0) in front of every __builtin_amdgcn_ds_read_tr16_b64 that
+// is issued while an LDS-DMA is in flight (the builtin carries no memory operand that its wait-count pass could tell apart from the
+// DMA's LDS write): in the two-stage rings below that wait sat right behind the issue of the NEXT stage's DMA, so a workgroup never
+// computed under its own loads (tools/isa_events.py shows it: "D4 [v0] t8 ...").  An asm read is invisible to that pass — and to its
+// lgkmcnt bookkeeping: the callers wait with wait_lgkmcnt<N>() + sched_barrier before the first use ("memory" keeps the compiler's
+// own LDS loads on their side of the statement, so the counted waits see the issue order written in the source).
+//   tn2_frag_base: per-lane LDS byte offset of the fragment at contraction row 0 (the swizzle does not depend on mk % 32 == 0 / h)
+//   tn2_tr<OFF, RB>(addr): the two reads at addr + OFF and addr + OFF + 4 * RB
+template <int RB> __device__ __forceinline__ uint32_t tn2_frag_base(int colbase, int lane) {
+  const int g = lane >> 4, li = lane & 15;
+  const int row = 8 * g + (li >> 2);
+  const int colb = (colbase + 4 * (li & 3)) * 2;
+  return (uint32_t)(row * RB + ((((colb >> 5) ^ tn2_swz<RB>(row)) << 5) | (colb & 31)));
+}
+template <int OFF, int RB> __device__ __forceinline__ bf16x8 tn2_tr(uint32_t addr) {
+  static_assert(OFF >= 0 && OFF + 4 * RB < 65536, "ds offset field");
+  union { s16x4 h[2]; bf16x8 v; } u;
+  asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+               : "=&v"(u.h[0]), "=&v"(u.h[1]) : "v"(addr), "i"(OFF), "i"(OFF + 4 * RB) : "memory");
+  return u.v;
+}
+template <int V> struct IntC { static constexpr int value = V; };
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_lgkmcnt() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N < 15 ? N : 15) : "memory");
 }
 
 // Epilogue shared by the NT kernels: 16 tile rows of a wave at a time: registers -> (alpha, bias) -> the wave's small LDS
@@ -561,6 +587,7 @@ __device__ __forceinline__ void nt_epilogue_s(const NTParams& p, f32x4 (&acc)[FM
 }
 
 #include "gemm_nt256.h"
+#include "gemm_tn_gang.h"
 #ifdef DAV_EXPERIMENTAL
 #include "gemm_tn256.h"      // 256 x 256 stream-K weight gradients: measured slower (round 3), kept for measurements only
 #endif
@@ -723,6 +750,12 @@ __device__ __forceinline__ void nt2_body(const NTParams& p, int bid, int tid_in 
   }
 
   const int fr = lane & 15, fg = lane >> 4;
+  uint32_t bt_base[FN];
+  if constexpr (BT) {
+    const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) bt_base[j] = lds0 + tn2_frag_base<BRB>(wn * WTN + j * 16, lane);
+  }
   if (PROF) { const long long t = __builtin_readcyclecounter(); pt[4] = t - tk0; tk0 = t; }
   if constexpr (PIPE == 1) {
     // Software-pipelined k-loop (2-stage ring, BK = 64).  Measured on the plain loop below (tools/gemm_phase_prof.py): per
@@ -834,6 +867,45 @@ __device__ __forceinline__ void nt2_body(const NTParams& p, int bid, int tid_in 
     const char* Ab = smem + (kt % STAGES) * STAGE_BYTES;
     const char* Bb = Ab + A_BYTES;
     if (dbg4) continue;                    // timing experiment: the global -> LDS stream alone
+    if constexpr (BT) {
+      // b_kn operand: its fragments come from transposing reads, issued as asm (tn2_tr: a builtin read would make hipcc drain the
+      // DMA issued just above).  All reads of the stage go out first, each 32-deep half is multiplied when ITS reads are back.
+      constexpr int KK = BK / 32, RPK = FM + 2 * FN;          // ds_read instructions per half: FM b128 + 2 FN tr-b64
+      static_assert((KK - 1) * RPK <= 15 || KK == 1, "lgkmcnt field");
+      const uint32_t so = (uint32_t)((kt % STAGES) * STAGE_BYTES);
+      bf16x8 af[KK][FM], bfr[KK][FN];
+      auto rd = [&](auto kc) {
+        constexpr int kk = decltype(kc)::value;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          const int row = wm * WTM + i * 16 + fr;
+          af[kk][i] = *reinterpret_cast<const bf16x8*>(Ab + row * ARB + (((kk * 4 + fg) ^ rswz(row)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bfr[kk][j] = tn2_tr<A_BYTES + kk * 32 * BRB, BRB>(bt_base[j] + so);
+      };
+      auto mm = [&](auto kc) {
+        constexpr int kk = decltype(kc)::value;
+        wait_lgkmcnt<(KK - 1 - kk) * RPK>();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+      };
+      rd(IntC<0>{});
+      if constexpr (KK == 2) rd(IntC<1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      mm(IntC<0>{});
+      if constexpr (KK == 2) mm(IntC<1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      if (PROF) {
+        asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[FM - 1][FN - 1]));
+        const long long t = __builtin_readcyclecounter(); pt[3] += t - tk0; tk0 = t;
+      }
+      continue;
+    }
 #pragma unroll
     for (int kk = 0; kk < BK / 32; ++kk) {
       bf16x8 af[FM], bfr[FN];
@@ -1663,6 +1735,12 @@ __device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, 
     }
   };
 
+  const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
+  uint32_t abase[FM], bbase[FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) abase[i] = lds0 + tn2_frag_base<RB>(wm * WTN + i * 16, lane);
+#pragma unroll
+  for (int j = 0; j < FN; ++j) bbase[j] = lds0 + tn2_frag_base<RBK>(wn * WTK + j * 16, lane);
   f32x4 acc[FM][FN], accb[FM];
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
@@ -1684,17 +1762,24 @@ __device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, 
     if (NST > 2 && s + NST - 2 < s_end) wait_vmcnt<(NST - 2) * (CH + CHB)>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (s + NST - 1 < s_end) dma_tile(stage == 0 ? NST - 1 : stage - 1);      // the stage step s - 1 has just released
-    const char* Ab = smem + stage * STAGE_BYTES;
-    const char* Bb = Ab + TILE_BYTES;
+    const uint32_t so = (uint32_t)(stage * STAGE_BYTES);
     stage = stage + 1 == NST ? 0 : stage + 1;
     if (dbg & 4) continue;      // timing experiment (DAV_TN_DEBUG): the global -> LDS stream alone
+    // every fragment of the stage is requested up front (asm reads, see tn2_tr: the DMA issued above stays in flight), then each
+    // 32-row half is multiplied as soon as ITS reads are back (LDS returns in order: a counted lgkmcnt)
+    constexpr int KK = RS / 32, RPK = 2 * (FM + FN);          // ds_read instructions per 32-row half
+    bf16x8 af[KK][FM], bfr[KK][FN];
+    auto rd = [&](auto kc) {
+      constexpr int kk = decltype(kc)::value;
 #pragma unroll
-    for (int kk = 0; kk < RS / 32; ++kk) {
-      bf16x8 af[FM], bfr[FN];
+      for (int i = 0; i < FM; ++i) af[kk][i] = tn2_tr<kk * 32 * RB, RB>(abase[i] + so);
 #pragma unroll
-      for (int i = 0; i < FM; ++i) af[i] = tn2_frag<RB>(Ab, kk * 32, wm * WTN + i * 16, lane);
-#pragma unroll
-      for (int j = 0; j < FN; ++j) bfr[j] = tn2_frag<RBK>(Bb, kk * 32, wn * WTK + j * 16, lane);
+      for (int j = 0; j < FN; ++j) bfr[kk][j] = tn2_tr<TILE_BYTES + kk * 32 * RBK, RBK>(bbase[j] + so);
+    };
+    auto mm = [&](auto kc) {
+      constexpr int kk = decltype(kc)::value;
+      wait_lgkmcnt<(KK - 1 - kk) * RPK>();
+      __builtin_amdgcn_sched_barrier(0);
       // operands swapped (B fragment first): the 16 x 16 block comes out TRANSPOSED — lane (fr, fg) holds C[n = fr][k = 4 fg .. + 3],
       // four consecutive columns of one row — so the read-modify-write of the gradient tile is one 16-byte access per lane and
       // fragment instead of four scalar ones (as the NT kernels' epilogue)
@@ -1702,12 +1787,19 @@ __device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, 
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
       if (do_bias) {
 #pragma unroll
-        for (int i = 0; i < FM; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones.v, accb[i], 0, 0, 0);
+        for (int i = 0; i < FM; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][i], ones.v, accb[i], 0, 0, 0);
       }
-    }
+    };
+    static_assert((KK - 1) * RPK <= 15 || KK == 1, "lgkmcnt field");
+    rd(IntC<0>{});
+    if constexpr (KK == 2) rd(IntC<1>{});
+    __builtin_amdgcn_sched_barrier(0);
+    mm(IntC<0>{});
+    if constexpr (KK == 2) mm(IntC<1>{});
+    __builtin_amdgcn_sched_barrier(0);
   }
 
   if (dbg & 2) return;          // timing experiment: no epilogue
@@ -2206,6 +2298,119 @@ extern "C" int dav_gemm_tn_grouped_bf16(const DavTnProblem* probs, int count, hi
 extern "C" int dav_gemm_tn_grouped_adamw_bf16(const DavTnProblem* probs, int count, const DavTnAdamW* opt, hipStream_t stream) {
   if (!opt) return DAV_ERR_SHAPE;
   return tn_grouped_impl(probs, count, opt, stream);
+}
+
+// ---- gang-scheduled 256 x 256 weight gradients (csrc/gemm_tn_gang.h): host-side plan ------------------------------------------
+namespace {
+struct TGPlanItem { int prob, r0, c0, nr, nc; long weight; int queue, first; };
+// cuts every problem's grid of 256 x 256 tiles into gangs of <= 32 tiles (one XCD's CUs), longest contraction first onto the
+// least-loaded of the 8 queues; returns the total tile count
+long tn_gang_plan(const DavTnProblem* probs, int count, std::vector<TGPlanItem>& items, int q_start[9]) {
+  items.clear();
+  for (int i = 0; i < count; ++i) {
+    const DavTnProblem& q = probs[i];
+    const int tn = (q.N + 255) / 256, tk = (q.K + 255) / 256;
+    int nr = tn, nc = tk;
+    while (nr * nc > 32) { if (nr >= nc) nr = (nr + 1) / 2; else nc = (nc + 1) / 2; }
+    for (int r0 = 0; r0 < tn; r0 += nr)
+      for (int c0 = 0; c0 < tk; c0 += nc) {
+        const int r = std::min(nr, tn - r0), c = std::min(nc, tk - c0);
+        items.push_back(TGPlanItem{i, r0, c0, r, c, (long)r * c * ((q.Mc + 127) / 128), 0, 0});
+      }
+  }
+  std::vector<int> order(items.size());
+  for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return probs[items[a].prob].Mc > probs[items[b].prob].Mc; });
+  long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int tiles_q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int oi : order) {
+    int best = 0;
+    for (int q = 1; q < 8; ++q) if (load[q] < load[best]) best = q;
+    items[oi].queue = best; items[oi].first = tiles_q[best];
+    load[best] += items[oi].weight; tiles_q[best] += items[oi].nr * items[oi].nc;
+  }
+  q_start[0] = 0;
+  for (int q = 0; q < 8; ++q) q_start[q + 1] = q_start[q] + tiles_q[q];
+  return q_start[8];
+}
+int tn_gang_check(const DavTnProblem* probs, int count) {
+  if (count <= 0 || count > 4096) return DAV_ERR_SHAPE;
+  for (int i = 0; i < count; ++i) {
+    const DavTnProblem& q = probs[i];
+    if (q.Mc <= 0 || (q.Mc & 63) || q.N <= 0 || q.K <= 0 || (q.N & 7) || (q.K & 7) || (q.lda & 7) || (q.ldb & 7)) return DAV_ERR_SHAPE;
+    if (q.N > (32767 << 8) || q.K > (32767 << 8) || (q.flags & 2)) return DAV_ERR_SHAPE;
+    if (((uintptr_t)q.A | (uintptr_t)q.B | (uintptr_t)q.C) & 15 || (q.ldc & 3)) return DAV_ERR_ALIGN;
+  }
+  return DAV_OK;
+}
+}  // namespace
+
+extern "C" size_t dav_gemm_tn_gang_workspace_bytes(const DavTnProblem* probs, int count) {
+  if (!probs || tn_gang_check(probs, count) != DAV_OK) return 0;
+  long tiles = 0;
+  for (int i = 0; i < count; ++i) tiles += (long)((probs[i].N + 255) / 256) * ((probs[i].K + 255) / 256);
+  return sizeof(TGHeader) + (size_t)count * sizeof(TNParams) + (size_t)tiles * sizeof(TGDesc);
+}
+
+extern "C" int dav_gemm_tn_gang_bf16(const DavTnProblem* probs, int count, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (!probs || !workspace) return DAV_ERR_SHAPE;
+  const int chk = tn_gang_check(probs, count);
+  if (chk != DAV_OK) return chk;
+  if ((uintptr_t)workspace & 15) return DAV_ERR_ALIGN;
+  if (workspace_bytes < dav_gemm_tn_gang_workspace_bytes(probs, count)) return DAV_ERR_WORKSPACE;
+  std::vector<TGPlanItem> items;
+  int q_start[9];
+  tn_gang_plan(probs, count, items, q_start);
+  static const int dbg = getenv("DAV_TN_GANG_DEBUG") ? atoi(getenv("DAV_TN_GANG_DEBUG")) & 30 : 0;
+  // the tables go to the workspace through kernel arguments, <= TG_WCH problems / TG_WIT gangs per writer launch
+  size_t ii = 0;
+  bool header = true;
+  std::vector<std::vector<const TGPlanItem*>> by_prob(count);
+  for (const TGPlanItem& it : items) by_prob[it.prob].push_back(&it);
+  TGWrite w;
+  auto reset = [&](int first) {
+    w.ws = (char*)workspace; w.prob_first = first; w.prob_count = 0; w.item_count = 0; w.count_total = count; w.write_header = 0;
+    for (int q = 0; q < 9; ++q) w.q_start[q] = q_start[q];
+  };
+  auto flush = [&]() {
+    if (!w.prob_count && !w.item_count && !header) return;
+    w.write_header = header ? 1 : 0; header = false;
+    const TGWrite wl = w;
+    DAV_LAUNCH(gemm_tn_gang_write_kernel, dim3(wl.item_count + 1), dim3(64), 0, stream, wl);
+  };
+  (void)ii;
+  reset(0);
+  for (int i = 0; i < count; ++i) {
+    if ((int)by_prob[i].size() > TG_WIT) return DAV_ERR_SHAPE;
+    if (w.prob_count == TG_WCH || w.item_count + (int)by_prob[i].size() > TG_WIT) { flush(); reset(i); }
+    const DavTnProblem& q = probs[i];
+    TNParams& p = w.prob[w.prob_count++];
+    p.A = (const bf16_t*)q.A; p.B = (const bf16_t*)q.B; p.Mc = q.Mc; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = q.ldb;
+    p.amap = RowMap{q.a_rowmap[0], q.a_rowmap[1], q.a_rowmap[2]};
+    p.bmap = RowMap{q.b_rowmap[0], q.b_rowmap[1], q.b_rowmap[2]};
+    p.C = q.C; p.ldc = q.ldc; p.beta = (q.flags & 1) ? 0 : 1; p.bias_grad = q.bias_grad; p.debug_plain_store = 0; p.splits = 1;
+    for (const TGPlanItem* it : by_prob[i])
+      w.item[w.item_count++] = TGItem{i, q_start[it->queue] + it->first, (it->r0 << 16) | it->c0, (it->nr << 16) | it->nc};
+  }
+  flush();
+  static bool big = false;
+  if (!big) {
+    (void)hipFuncSetAttribute((const void*)gemm_tn_gang_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_gang_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    big = true;
+  }
+  static const int pfd = getenv("DAV_TN_GANG_PF") ? atoi(getenv("DAV_TN_GANG_PF")) : 5;      // L2 prefetch distance in K-tiles (0: no prefetch, all 8 waves own the DMA)
+  static const int n_wg = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (getenv("DAV_TN_GANG_WGS")) cus = atoi(getenv("DAV_TN_GANG_WGS"));
+    return cus > 0 ? cus : 256;
+  }();
+  const long tiles = q_start[8];
+  const int grid = (int)std::min<long>(n_wg, tiles);
+  if (pfd > 0) DAV_LAUNCH(gemm_tn_gang_kernel<true>, dim3(grid), dim3(512), TNG_LDS, stream, (char*)workspace, count, dbg, pfd);
+  else DAV_LAUNCH(gemm_tn_gang_kernel<false>, dim3(grid), dim3(512), TNG_LDS, stream, (char*)workspace, count, dbg, 0);
+  return dav_launch_status();
 }
 
 extern "C" int dav_gemm_tn_bf16(const void* A, const void* B, int Mc, int N, int K, int lda, int ldb,

@@ -200,6 +200,34 @@ def gemm_tn_grouped(problems, opt=None):
             _lib.check(lib.dav_gemm_tn_grouped_bf16(arr, len(chunk), _stream()), 'dav_gemm_tn_grouped_bf16')
 
 
+def _tn_problem_array(problems):
+    arr = (_lib.DavTnProblem * len(problems))()
+    for q, d in zip(arr, problems):
+        q.A, q.B, q.C, q.bias_grad = _ptr(d['A']), _ptr(d['B']), _ptr(d['C']), _ptr(d.get('bias_grad'))
+        q.Mc, q.N, q.K, q.lda, q.ldb, q.ldc = d['Mc'], d['N'], d['K'], d['lda'], d['ldb'], d['ldc']
+        q.a_rowmap[:] = d.get('a_rowmap') or (0, 0, 0)
+        q.b_rowmap[:] = d.get('b_rowmap') or (0, 0, 0)
+        q.flags = 1 if d.get('overwrite') else 0
+    return arr
+
+
+def gemm_tn_gang(problems):
+    """The queued weight-gradient problems of several layers (dicts as for gemm_tn_grouped, no two with the same C) as ONE
+    gang-scheduled launch of 256 x 256 tiles (dav_gemm_tn_gang_bf16).  The workspace is allocated here on the current stream."""
+    if not problems:
+        return
+    if problems[0]['A'].dtype == F32:
+        return gemm_tn_grouped(problems)
+    lib = _lib.load()
+    arr = _tn_problem_array(problems)
+    nbytes = int(lib.dav_gemm_tn_gang_workspace_bytes(arr, len(problems)))
+    if nbytes == 0:
+        raise RuntimeError('dav_gemm_tn_gang_workspace_bytes: invalid weight-gradient problem (shape / alignment)')
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=problems[0]['A'].device)
+    hold(ws)
+    _lib.check(lib.dav_gemm_tn_gang_bf16(arr, len(problems), _ptr(ws), nbytes, _stream()), 'dav_gemm_tn_gang_bf16')
+
+
 def attn_fwd(q_ptr, k_ptr, v_ptr, O, LSE, B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, scale):
     """q / k / v are raw addresses (views into fused projection buffers) of the dtype of ``O``."""
     lib = _lib.load()

@@ -37,7 +37,7 @@ typedef struct ihipStream_t* hipStream_t;
 extern "C" {
 #endif
 
-#define DAV_ABI_VERSION 5   /* 2: DavTnProblem.flags, dav_adamw_flat keep_grad + gscale_dev, dav_step_guard; 3: dav_attn_bwd_ctx, dav_add_cast; 4: fused fusion tails, grouped cast-transpose; 5: dav_gemm_tn_grouped_adamw_bf16 */
+#define DAV_ABI_VERSION 6   /* 2: DavTnProblem.flags, dav_adamw_flat keep_grad + gscale_dev, dav_step_guard; 3: dav_attn_bwd_ctx, dav_add_cast; 4: fused fusion tails, grouped cast-transpose; 5: dav_gemm_tn_grouped_adamw_bf16; 6: dav_gemm_tn_gang_bf16 */
 int dav_abi_version(void);
 int dav_build_flags(void);   /* bit 0: experimental build (make EXPERIMENTAL=1): the rejected GEMM tile configurations exist */
 /* text of the last HIP error latched by a kernel launch of the calling thread (diagnostics) */
@@ -98,6 +98,17 @@ typedef struct DavTnProblem {
                                          is accumulated regardless.  Such a problem is never split over the contraction. */
 } DavTnProblem;
 int dav_gemm_tn_grouped_bf16(const DavTnProblem* problems, int count, hipStream_t stream);
+
+/* The same problems (any number up to 4096: the queued weight gradients of SEVERAL layers, autograd of every nn.Linear on the path —
+ * models/fusion_blocks.py:41-44,227-232, timm Block of models/vits.py:32-34, models/avmae.py:53-60,83-88) as ONE persistent launch of
+ * 256 x 256 tiles, one workgroup per CU: every problem's tile grid is cut into gangs of <= 32 tiles that share operand panels, the
+ * gangs are dealt out to eight per-XCD ticket queues (longest contraction first) and the workgroups of an XCD draw the tiles of one gang
+ * together, so that a panel crosses the fabric once per XCD instead of once per tile.  One owner per tile over the whole contraction:
+ * no atomics on C, bit-repeatable.  flags bit 0 as above; bit 1 is not supported (DAV_ERR_SHAPE).  Two problems of one call must not
+ * address the same C.  workspace: caller-owned device memory of dav_gemm_tn_gang_workspace_bytes(problems, count) bytes (0 = invalid
+ * problems), 16-byte aligned, written and read on `stream` only (it must stay untouched until the launch has run). */
+size_t dav_gemm_tn_gang_workspace_bytes(const DavTnProblem* problems, int count);
+int dav_gemm_tn_gang_bf16(const DavTnProblem* problems, int count, void* workspace, size_t workspace_bytes, hipStream_t stream);
 
 /* The same launch with the optimizer pass FUSED into it (ABI 5; the captured single-process step of util/misc.py GraphedStep): a problem
  * with flags bit 1 set (legal only together with bit 0, C inside the flat gradient buffer) does not store its gradient tile — the workgroup
