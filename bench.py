@@ -170,11 +170,15 @@ def main():
     # from the library's own issue log), the grouped weight-gradient launches and the attention calls ------------------
     tn_log, attn_log = [], []
     if rank == 0:
-        orig_tn, orig_af, orig_ab = ops.gemm_tn_grouped, ops.attn_fwd, ops.attn_bwd
+        orig_tn, orig_tg, orig_af, orig_ab = ops.gemm_tn_grouped, ops.gemm_tn_gang, ops.attn_fwd, ops.attn_bwd
 
         def log_tn(problems):
-            tn_log.append([(d['Mc'], d['N'], d['K']) for d in problems])
+            tn_log.append(('grouped', [(d['Mc'], d['N'], d['K']) for d in problems]))
             return orig_tn(problems)
+
+        def log_tg(problems):
+            tn_log.append(('gang', [(d['Mc'], d['N'], d['K']) for d in problems]))
+            return orig_tg(problems)
 
         def log_af(q, k, v, O, LSE, B_, H, Nq, Nk, dqk, dv, *rest):
             attn_log.append(('fwd', B_, H, Nq, Nk, dqk, dv))
@@ -184,7 +188,7 @@ def main():
             if kw.get('part', 3) & 1:
                 attn_log.append(('bwd', B_, H, Nq, Nk, dqk, dv))
             return orig_ab(q, k, v, O, dO, LSE, Delta, dq, dk, dv_, B_, H, Nq, Nk, dqk, dv, *rest, **kw)
-        ops.gemm_tn_grouped, ops.attn_fwd, ops.attn_bwd = log_tn, log_af, log_ab
+        ops.gemm_tn_grouped, ops.gemm_tn_gang, ops.attn_fwd, ops.attn_bwd = log_tn, log_tg, log_af, log_ab
         ops.nt_issue_log(True)
 
     def eager_step():
@@ -196,7 +200,7 @@ def main():
     if rank == 0:
         nt_log = ops.nt_issue_log()
         ops.nt_issue_log(False)
-        ops.gemm_tn_grouped, ops.attn_fwd, ops.attn_bwd = orig_tn, orig_af, orig_ab
+        ops.gemm_tn_grouped, ops.gemm_tn_gang, ops.attn_fwd, ops.attn_bwd = orig_tn, orig_tg, orig_af, orig_ab
         if os.environ.get('DAV_DUMP_MIX'):            # the step's NT launches: [tile configuration, b_kn, [(M, N, K) ...], [epilogue flags ...]]
             with open(os.environ['DAV_DUMP_MIX'], 'w') as f:
                 json.dump({'nt': ops.nt_issue_log(with_flags=True), 'tn': tn_log, 'attn': attn_log}, f)
@@ -384,7 +388,7 @@ def main():
         # the stream it is launched on — begin -> end of the kernel while the other streams' kernels run beside it (what a
         # rocprofv3 kernel trace of the step shows per kernel: profiles/r04_instep_kernel_stats.csv is the offline twin) ----------
         in_step = None
-        if not a.roofline_only:
+        if not a.roofline_only and world == 1:      # (an eager step joins the gradient all-reduce: rank 0 alone would wait for the other ranks for ever)
             orig_nt = ops.gemm_nt
             pairs = []
 
@@ -466,28 +470,40 @@ def main():
                                                     'frac': round(fl2 / (ms2 * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
                                                     'launches_per_step': len(big2), 'avg_launch_us': round(ms2 * 1e3 / len(big2), 2)}
         del bufs
-    # ---- weight-gradient kernel (gemm_tn_grouped_kernel<128,4,2>): the step's grouped launches, one per layer / decoder pair
+    # ---- weight-gradient kernels: the step's launches as the engine issued them — the gang-scheduled 256 x 256 launch(es)
+    # (gemm_tn_gang_kernel: both decoders, then all encoder layers of a captured segment) and whatever small flushes stayed on the
+    # 128 x 128 grouped kernel.  Operands are shared per shape (read only), every problem has its own gradient buffer.
     if tn_log and not a.no_roofline:
-        tbufs = {}
-        for probs in tn_log:
+        tbufs, launches = {}, []
+        for kind, probs in tn_log:
+            plist = []
             for (Mc, N, K) in probs:
                 if (Mc, N, K) not in tbufs:
-                    tbufs[(Mc, N, K)] = (torch.randn(Mc, N, device=dev).bfloat16(), torch.randn(Mc, K, device=dev).bfloat16(),
-                                         torch.zeros(N, K, device=dev), torch.zeros(N, device=dev))
+                    tbufs[(Mc, N, K)] = (torch.randn(Mc, N, device=dev).bfloat16(), torch.randn(Mc, K, device=dev).bfloat16())
+                A_, B_ = tbufs[(Mc, N, K)]
+                plist.append(dict(A=A_, B=B_, Mc=Mc, N=N, K=K, C=torch.zeros(N, K, device=dev), lda=N, ldb=K, ldc=K,
+                                  bias_grad=torch.zeros(N, device=dev), overwrite=True))
+            launches.append((kind, plist))
 
         def replay_tn():
-            for probs in tn_log:
-                ops.gemm_tn_grouped([dict(A=tbufs[q][0], B=tbufs[q][1], Mc=q[0], N=q[1], K=q[2], C=tbufs[q][2], lda=q[1], ldb=q[2], ldc=q[2],
-                                          bias_grad=tbufs[q][3]) for q in dict.fromkeys(probs)])
-        uniq = [list(dict.fromkeys(probs)) for probs in tn_log]      # one buffer set per shape: equal shapes of a launch would race on C
+            for kind, plist in launches:
+                if kind == 'gang':
+                    ops.gemm_tn_gang(plist)
+                else:
+                    n_l = (len(plist) + ops.TN_GROUP_MAX - 1) // ops.TN_GROUP_MAX
+                    for i in range(n_l):
+                        ops.gemm_tn_grouped(plist[i::n_l])
         ms_tn = time_replay(replay_tn, reps)
-        fl_tn = sum(2.0 * Mc * N * K for probs in uniq for (Mc, N, K) in probs)
-        result['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'gemm_tn_grouped_kernel<128,4,2> (all weight gradients of a layer / of both decoders per launch)',
+        fl_tn = sum(2.0 * Mc * N * K for _k, probs in tn_log for (Mc, N, K) in probs)
+        n_gang = sum(1 for k, _p in tn_log if k == 'gang')
+        result['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'gemm_tn_gang_kernel (256 x 256 tiles, per-XCD ticket queues: both decoders / all encoder layers of a segment per launch)'
+                                    + ('' if n_gang == len(tn_log) else ' + gemm_tn_grouped_kernel<128,4,2> for the small flushes'),
                                     'achieved': round(fl_tn / (ms_tn * 1e-3) / 1e12, 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                     'frac': round(fl_tn / (ms_tn * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
-                                    'launches_per_step': len(tn_log), 'avg_launch_us': round(ms_tn * 1e3 / len(tn_log), 1),
-                                    'note': 'replay holds one problem per distinct shape of each launch (equal shapes would share the output buffer); it accumulates into the gradient tiles as the eager step does — the captured step WRITES the first contribution to a Linear weight (no tile read), so this figure is the conservative one'}
-        del tbufs
+                                    'launches_per_step': len(tn_log), 'gang_launches': n_gang, 'problems_per_step': sum(len(p) for _k, p in tn_log),
+                                    'ms_per_step': round(ms_tn, 3),
+                                    'note': 'isolated replay of the recorded launches on fresh operands, written (not accumulated) tiles as in the captured step'}
+        del tbufs, launches
     # ---- attention family (isolated replays of the step's shapes; in the step equal-rank calls of both towers are one grid)
     if attn_log and not a.no_roofline:
         classes = {}

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, 'libdavfusion_hip.so')
 
 _p, _i, _l, _f, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 
-ABI_VERSION = 6      # DAV_ABI_VERSION of include/dav_kernels.h this package was written against (struct layouts, signatures)
+ABI_VERSION = 7      # DAV_ABI_VERSION of include/dav_kernels.h this package was written against (struct layouts, signatures)
 
 # name -> argtypes (must match include/dav_kernels.h)
 SIGNATURES = {
@@ -30,7 +30,6 @@ SIGNATURES = {
     'dav_nt_tune_set': [_p, _i],
     'dav_gemm_tn_bf16': [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _i, _p],
     'dav_gemm_tn_grouped_bf16': [_p, _i, _p],
-    'dav_gemm_tn_grouped_adamw_bf16': [_p, _i, _p, _p],
     'dav_gemm_tn_gang_workspace_bytes': [_p, _i],
     'dav_gemm_tn_gang_bf16': [_p, _i, _p, _sz, _p],
     'dav_attn_fwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _i, _l, _i, _l, _i, _l, _i, _f, _p],
@@ -92,11 +91,6 @@ SIGNATURES = {
     'dav_adamw_flat': [_p, _p, _p, _p, _p, _l, _p, _p, _i, _f, _f, _f, _p, _f, _p, _i, _p, _p, _p],
     'dav_step_guard': [_p, _p, _p, _f, _f, _p, _p, _p],
     'dav_cast_transpose_grouped': [_p, _i, _p],
-    'dav_fusion_tail_supported': [_i, _i, _i, _i, _i, _i, _i],
-    'dav_fusion_tail1_fwd': [_p, _p],
-    'dav_fusion_tail2_fwd': [_p, _p],
-    'dav_fusion_tail2_bwd': [_p, _p],
-    'dav_fusion_tail1_bwd': [_p, _p],
 }
 
 class DavLnReduce(C.Structure):
@@ -107,28 +101,10 @@ class DavTranspose(C.Structure):
     _fields_ = [('x', C.c_void_p), ('y_bf16', C.c_void_p), ('R', C.c_int), ('C', C.c_int)]
 
 
-class DavFusionTail(C.Structure):
-    """include/dav_kernels.h DavFusionTail (field order = the C struct's)."""
-    _fields_ = ([(n, C.c_int) for n in ('B', 'D', 'Da', 'Hd', 'nmm', 'nv', 'na')] + [('eps2', C.c_float)] +
-                [(n, C.c_void_p) for n in (
-                    'Wpv', 'Wpa', 'Wk', 'Wv', 'Wp', 'W1', 'W2', 'WpvT', 'WpaT', 'WkT', 'WvT', 'WpT', 'W1T', 'W2T',
-                    'bpv', 'bpa', 'bk', 'bv', 'bp', 'b1', 'b2', 'g2', 'be2', 'xmm32', 'o_v', 'o_a', 'xvo_b', 'xao_b',
-                    'kv_p', 'ka_p', 'vv_p', 'va_p', 'Kp', 'Vp', 'xmm1', 'o2', 'h2', 'z', 'u', 'mean2', 'rstd2', 'out',
-                    'g', 'gb', 'dz', 'dh2', 'g1', 'g1b', 'do2', 'ln2_partial', 'dKp', 'dVp', 'dkv_p', 'dka_p', 'dvv_p', 'dva_p',
-                    'dxvo_b', 'dxao_b', 'dov', 'doa')])
-
-
 class DavTnProblem(C.Structure):
     _fields_ = [('A', C.c_void_p), ('B', C.c_void_p), ('C', C.c_void_p), ('bias_grad', C.c_void_p),
                 ('Mc', C.c_int), ('N', C.c_int), ('K', C.c_int), ('lda', C.c_int), ('ldb', C.c_int), ('ldc', C.c_int),
                 ('a_rowmap', C.c_int * 3), ('b_rowmap', C.c_int * 3), ('flags', C.c_int)]
-
-
-class DavTnAdamW(C.Structure):
-    """include/dav_kernels.h DavTnAdamW: the flat buffers and scalars of the optimizer pass fused into a grouped weight-gradient launch."""
-    _fields_ = [('g_base', C.c_void_p), ('p_base', C.c_void_p), ('m_base', C.c_void_p), ('v_base', C.c_void_p), ('bf16_base', C.c_void_p),
-                ('hyper', C.c_void_p), ('bias_corr', C.c_void_p), ('gscale_dev', C.c_void_p), ('sumsq', C.c_void_p),
-                ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float)]
 
 
 ERRORS = {-1: 'bad shape', -2: 'unsupported dtype', -3: 'insufficient workspace', -4: 'HIP error', -5: 'misaligned pointer/stride'}

@@ -78,14 +78,9 @@ def _vis(enc):
 # ------------------------------------------------------------------------------------------------
 # encoder (models/deepavfusion.py:88-118)
 # ------------------------------------------------------------------------------------------------
-def encoder_fwd(enc, image, audio, ik32, ak32, want_f32=False, collect_embs=False, fwd_gate=None):
-    """``fwd_gate(stage)`` (optional) is called on the main stream right before the first launch that reads the parameters of a
-    stage: -1 = patch embeddings / fusion tokens, l = encoder layer l (both towers + its fusion block), depth = the final norms
-    (util.misc.GraphedStep's deferred AdamW makes the stream wait there for the update of exactly those parameters)."""
+def encoder_fwd(enc, image, audio, ik32, ak32, want_f32=False, collect_embs=False):
     B = image.shape[0]
     vis = _vis(enc)
-    if fwd_gate is not None:
-        fwd_gate(-1)
     x_i, t_pi = E.patch_embed_fwd(vis, image, ik32)
     x_a, t_pa = E.patch_embed_fwd(enc.audio, audio, ak32)
     x_f = enc.fusion_tokens.detach().expand(B, -1, -1).clone(memory_format=torch.contiguous_format)   # never an alias of the parameter (B == 1)
@@ -99,8 +94,6 @@ def encoder_fwd(enc, image, audio, ik32, ak32, want_f32=False, collect_embs=Fals
         dpf = drop_path_scales(enc, fb, B, image.device, f'fusion.{l}') if fb is not None else None
         xf_ctx = x_f if fb is not None else None
         tf = None
-        if fwd_gate is not None:
-            fwd_gate(l)
         if batched:
             # ONE launch batch per layer, three lanes — image block, audio block, fusion block (all read the layer inputs
             # only, models/deepavfusion.py:104-107): LayerNorms / GEMMs / attentions of equal rank go out as grouped grids
@@ -145,8 +138,6 @@ def encoder_fwd(enc, image, audio, ik32, ak32, want_f32=False, collect_embs=Fals
         layers.append((ti, ta, tf))
         if collect_embs:
             embs.append((x_i, x_a, x_f))
-    if fwd_gate is not None:
-        fwd_gate(len(vis.blocks))
     xi_b, xi32, st_i = E.ln_fwd(vis.norm, None, x_i, B, want_f32=want_f32)
     xa_b, xa32, st_a = E.ln_fwd(enc.audio.norm, None, x_a, B, want_f32=want_f32)
     xf_b, xf32, st_f = E.ln_fwd(enc.fusion_norm, None, x_f, B, want_f32=want_f32)
@@ -179,14 +170,6 @@ def _encoder_bwd(enc, t, dxi_b, dxa_b, dxf_b, dxi32, dxa32, dxf32, layer_cb=None
     blocks = list(zip(vis.blocks, enc.audio.blocks, enc.fusion_blocks))
     main, sa, sf = _streams(dev)
     batched = t['lanes']                  # the schedule the forward of this step chose
-    # the fused fusion-block tails read TRANSPOSED bf16 weights in the backward: all of them in one launch, up front
-    tw = []
-    for fb, (_ti, _ta, tf) in zip(enc.fusion_blocks, t['layers']):
-        if fb is not None and tf is not None and tf.get('tails'):
-            at = fb.attn
-            tw += [fb.mlp.fc2.weight, fb.mlp.fc1.weight, at.proj.weight, at.k.weight, at.v.weight, at.attn_v.proj.weight, at.attn_a.proj.weight]
-    if tw:
-        E.refresh_transposes(tw)
     for l, ((bi, ba, fb), (ti, ta, tf)) in reversed(list(enumerate(zip(blocks, t['layers'])))):
         # Memory lifetime across streams: the gradients entering this layer were allocated on one stream (main for the
         # final norms, the fusion / audio stream further down) and are READ by kernels of another.  Dropping the last
@@ -254,14 +237,14 @@ def _encoder_bwd(enc, t, dxi_b, dxa_b, dxf_b, dxi32, dxa32, dxf32, layer_cb=None
             else:
                 g_f, g_fb = dx_f + dxf_a, None
         del hold
-        E.flush_wgrads()          # every wgrad of this layer (both towers + fusion block) as one grouped GEMM
+        if E.wgrad_flush_due(l, len(blocks)):
+            E.flush_wgrads()      # the queued weight gradients (this layer's and, merged, the layers' before it) as one launch
         if layer_cb is not None and l > 0:
             layer_cb(l)
     E.patch_embed_bwd(vis, t['t_pi'], g_i, g_ib)
     E.patch_embed_bwd(enc.audio, t['t_pa'], g_a, g_ab)
     E.gbuf(enc.fusion_tokens).add_(g_f.sum(dim=0, keepdim=True))          # backward of .expand(B, -1, -1)
     E._ready(enc.fusion_tokens)
-    E.join_wgrad_stream(dev)                                               # all parameter gradients final on this stream
 
 
 class _EncoderFn(torch.autograd.Function):
@@ -348,7 +331,6 @@ class _CrossAttentionFn(torch.autograd.Function):
             do = E.lin_bwd(ca.proj, E.to_bf16(g.contiguous().view(B * N1, D)), ctx.c['o'], B * N1)
             dx1 = torch.empty(B * N1, D, dtype=E.BF16, device=g.device)
             dx2 = E._cross_bwd_seq(ca, ctx.c, do, ctx.x1b, None, N1, ctx.x2b, N2, B, D, ca.num_heads, dx1, None)
-        E.join_wgrad_stream(g.device)
         return (None, dx1.float().view(B, N1, D), dx2.float().view(B, N2, D)) + (None,) * ctx.np
 
 
@@ -372,7 +354,6 @@ class _SwinBlockFn(torch.autograd.Function):
     def backward(ctx, g):
         with E.deferred_wgrads():
             dx, _ = E.swin_block_bwd(ctx.blk, ctx.tape, g.contiguous(), None)
-        E.join_wgrad_stream(g.device)
         return (None, dx, None) + (None,) * ctx.np
 
 
@@ -396,7 +377,6 @@ class _FusionBlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         dx_f, dx_i, dx_a = E.fusion_block_bwd(ctx.fb, ctx.tape, g.contiguous(), None)
-        E.join_wgrad_stream(g.device)
         return (None, dx_f, dx_i, dx_a) + (None,) * ctx.np
 
 
@@ -408,17 +388,14 @@ def fusion_block(fb, xmm, xv, xa):
 # ------------------------------------------------------------------------------------------------
 # the whole AVMAE step (models/avmae.py:216-236)
 # ------------------------------------------------------------------------------------------------
-def avmae_fwd(model, image, audio, noise_i, noise_a, fwd_gate=None):
-    """``fwd_gate``: see encoder_fwd; stage depth + 1 = the two decoders."""
+def avmae_fwd(model, image, audio, noise_i, noise_a):
     enc = model.encoder
     B = image.shape[0]
     Li, La = model.image_gs[0] * model.image_gs[1], model.audio_gs[0] * model.audio_gs[1]
     nki, nka = int(Li * (1 - model.image_mask_ratio)), int(La * (1 - model.audio_mask_ratio))     # models/avmae.py:132
     ik, im, ir, ik32, ir32 = ops.mask_build(noise_i, nki)
     ak, am, ar, ak32, ar32 = ops.mask_build(noise_a, nka)
-    (xi_b, xa_b, xf_b), _, _, t_enc = encoder_fwd(enc, image, audio, ik32, ak32, fwd_gate=fwd_gate)
-    if fwd_gate is not None:
-        fwd_gate(len(enc.fusion_blocks) + 1)
+    (xi_b, xa_b, xf_b), _, _, t_enc = encoder_fwd(enc, image, audio, ik32, ak32)
     nF = enc.fusion_tokens.shape[1]
     dec_i, dec_a = model.decoder('image'), model.decoder('audio')
     main, sa, _ = _streams(image.device)

@@ -740,213 +740,10 @@ __device__ __forceinline__ int pair_heads(int x, int n) {
   return (((x >> 4) << 3) + (x & 7)) * 2 + ((x >> 3) & 1);
 }
 
-// ------------------------------------------------------------------------------------------------
-// backward, fused (round 4): dQ, dK, dV from ONE recomputation of the probabilities, d = 32 resident problems (the decoders)
-// ------------------------------------------------------------------------------------------------
-// The two-kernel backward computes S, P, dP, dS twice — once with queries on the lane index (dQ kernel), once with keys on it (dK / dV
-// kernel) — because an MFMA operand wants the CONTRACTION index in the lane's 8-element vector: dV / dK contract over queries, dQ over
-// keys.  Here a wave owns up to FKT key tiles and walks over the query tiles ONCE (query-outer, own-keys-inner): every Q / dO fragment
-// read from LDS feeds all of the wave's key tiles (the dK/dV kernel was bound by exactly those reads), P and dS are computed once in
-// the dK/dV orientation, and for dQ the wave transposes its dS tile through a 2 KB LDS patch (one ds_write_b64 per 16 x 16 block,
-// read back with the transposing ds_read_b64_tr_b16) and multiplies it with K^T (tr-read from the staged K tile).  The wave's dQ
-// contributions of all its key tiles are summed in registers; per 32-query step the eight waves' partial tiles meet in a
-// double-buffered LDS staging area (plain 16-byte writes, ONE barrier per step), each wave sums four of the 32 rows over the eight
-// partials and stores them — final dQ rows — straight to global memory.  (First version: ds_add_f32 into an fp32 accumulator in
-// LDS — LDS float atomics retire about one lane per clock: 516 us instead of 115.)  One workgroup per CU.  exp + fma per score: once.
-constexpr int FKT = 3;             // own key tiles per wave: Nk <= 8 waves x 3 x 16 = 384
-constexpr int FQ_LD = 36;          // floats per row of a wave's partial dQ tile [32 queries][32 d] (16-byte aligned rows, banks spread)
-constexpr int FQ_PART = 32 * FQ_LD * 4;      // bytes per wave and buffer
-template <int D>
-__device__ __forceinline__ void attn_bwd_fused_body(const AttnParams& p, const int bh) {
-  static_assert(D == 32, "d = 32 heads");
-  constexpr int RB = 64;           // bytes per staged row (32 bf16)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int Nqp = (p.Nq + 31) & ~31, Nkp = (p.Nk + 31) & ~31;
-  char* Qs = smem;                                   // [Nqp][32]
-  char* dOs = Qs + Nqp * RB;                         // [Nqp][32]
-  char* Ks = dOs + Nqp * RB;                         // [Nkp + 16][32]: 16 zero rows behind the last tile (the K^T fragment of a tile spans 32 rows)
-  float* lse_s = reinterpret_cast<float*>(Ks + (Nkp + 16) * RB);
-  float* del_s = lse_s + Nqp;
-  char* stg = reinterpret_cast<char*>(del_s + Nqp);  // 2 buffers x 8 waves x [32][FQ_LD] fp32
-  char* patch0 = stg + 2 * 8 * FQ_PART;              // 8 waves x [32 key rows][32 queries] bf16 (rows 16-31 stay zero)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = bh / p.H, h = bh % p.H;
-  const int fr = lane & 15, g = lane >> 4;
-  const bf16_t* Qg = p.Q + b * p.q_bs + h * D;
-  const bf16_t* dOg = p.dO + b * p.do_bs + h * D;
-  const bf16_t* Og = p.Of + b * p.o_bs + h * D;
-  const bf16_t* Kg = p.K + b * p.k_bs + h * D;
-  char* patch = patch0 + wave * 2048;
-
-  stage_rows<D, D>(Qs, Qg, p.Nq, Nqp, p.q_rs, tid, blockDim.x);
-  stage_rows<D, D>(dOs, dOg, p.Nq, Nqp, p.do_rs, tid, blockDim.x);
-  stage_rows<D, D>(Ks, Kg, p.Nk, Nkp, p.k_rs, tid, blockDim.x);
-  for (int i = tid; i < Nqp; i += blockDim.x) {      // LSE (log2 domain) and delta = rowsum(dO * O) of every query row
-    const long sidx = ((long)b * p.H + h) * p.Nq + i;
-    float d = 0.f;
-    if (i < p.Nq) {
-      const bf16_t* orow = Og + (long)i * p.o_rs;
-      const bf16_t* dorow = dOg + (long)i * p.do_rs;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const bf16x8 o8 = gfrag(orow, 8 * c, true), d8 = gfrag(dorow, 8 * c, true);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) d += (float)d8[e] * (float)o8[e];
-      }
-      p.Delta[sidx] = d;
-    }
-    lse_s[i] = i < p.Nq ? p.LSE[sidx] * 1.44269504088896341f : 1e30f;      // 2^(s - 1e30) == 0 for padded query rows
-    del_s[i] = d;
-  }
-  for (int i = tid; i < 16 * RB / 16; i += blockDim.x) reinterpret_cast<uint4*>(Ks + Nkp * RB)[i] = uint4{0, 0, 0, 0};
-  for (int i = tid; i < 8 * 2048 / 16; i += blockDim.x) reinterpret_cast<uint4*>(patch0)[i] = uint4{0, 0, 0, 0};
-  stage_wait();
-  __syncthreads();
-
-  const float sl2 = p.scale * 1.44269504088896341f;
-  const int nkt = (p.Nk + 15) >> 4;
-  // own key tiles: wave, wave + 8, wave + 16 (a tile past the end works on clamped rows and stores nothing)
-  bool kok[FKT];
-  bf16x8 kf[FKT], vf[FKT], ktf[FKT][2];
-  f32x4 dk[FKT][2], dv[FKT][2];
-  int nown = 0;
-#pragma unroll
-  for (int u = 0; u < FKT; ++u) {
-    const int kt = wave + 8 * u;
-    if (kt < nkt) nown = u + 1;
-    const int key = kt * 16 + fr;
-    kok[u] = key < p.Nk;
-    const int kc = kok[u] ? key : p.Nk - 1;
-    kf[u] = gfrag(p.K + b * p.k_bs + (long)kc * p.k_rs + h * D, 8 * g, true);
-    vf[u] = gfrag(p.V + b * p.v_bs + (long)kc * p.v_rs + h * D, 8 * g, true);
-    // K^T fragments of the tile for dQ (rows beyond the tile read the next tile's keys or the zero padding: their dS^T rows are zero)
-    const int kr = kt < nkt ? kt * 16 : 0;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) ktf[u][c] = lds_frag_tr<RB>(lds_addr(Ks) + kr * RB + frag_tr_off<RB>(c * 16, lane));
-#pragma unroll
-    for (int c = 0; c < 2; ++c) { dk[u][c] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[u][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  }
-  // this lane's write position in the patch: row = key fr, columns q = 16 t + 4 g .. + 3 (8 bytes), 16-byte slots swizzled as the reads expect
-  uint32_t pw[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) pw[t] = lds_addr(patch) + (uint32_t)(fr * RB + ((((2 * t + (g >> 1)) ^ row_swz<RB>(fr)) << 4) | (8 * (g & 1))));
-  uint32_t pr[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) pr[t] = lds_addr(patch) + frag_tr_off<RB>(t * 16, lane);
-  uint32_t qa_ = lds_addr(Qs) + frag_off<RB>(fr, 0, g), oa = lds_addr(dOs) + frag_off<RB>(fr, 0, g);
-  uint32_t ota[2], qta[2];
-#pragma unroll
-  for (int c = 0; c < 2; ++c) { ota[c] = lds_addr(dOs) + frag_tr_off<RB>(c * 16, lane); qta[c] = lds_addr(Qs) + frag_tr_off<RB>(c * 16, lane); }
-  uint32_t la = lds_addr(lse_s) + 16 * g, da = lds_addr(del_s) + 16 * g;
-
-  for (int qa = 0; qa < Nqp; qa += 32) {
-    bf16x8 qf[2], dof[2], dot[2], qt[2];
-    f32x4 lse4[2], del4[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      qf[t] = lds_frag(qa_ + t * 16 * RB);
-      dof[t] = lds_frag(oa + t * 16 * RB);
-      lse4[t] = lds_f4(la + t * 64);
-      del4[t] = lds_f4(da + t * 64);
-    }
-#pragma unroll
-    for (int c = 0; c < 2; ++c) { dot[c] = lds_frag_tr<RB>(ota[c]); qt[c] = lds_frag_tr<RB>(qta[c]); }
-    f32x4 dqT[2][2];                 // [d tile][query tile]: lane holds d = 16 c + 4 g .. + 3 of query 16 t + fr
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int t = 0; t < 2; ++t) dqT[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < FKT; ++u) {
-      if (u < nown) {
-        f32x4 sS[2], dP[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          sS[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[t], kf[u], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-          dP[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof[t], vf[u], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float pr_ = __builtin_amdgcn_exp2f(__builtin_fmaf(sS[t][r], sl2, -lse4[t][r]));
-            sS[t][r] = pr_;                                   // P[q][key]
-            dP[t][r] = pr_ * (dP[t][r] - del4[t][r]);         // dS[q][key]
-          }
-        const bf16x8 pf = pack8(sS[0], sS[1]), dsf = pack8(dP[0], dP[1]);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          dv[u][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot[c], pf, dv[u][c], 0, 0, 0);
-          dk[u][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt[c], dsf, dk[u][c], 0, 0, 0);
-        }
-        // dS^T through the wave's patch: [key = fr][q = 16 t + 4 g + r] <- dS[q][key]
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-          u32x2_t w;
-          w.x = pack2bf(dP[t][0], dP[t][1]); w.y = pack2bf(dP[t][2], dP[t][3]);
-          *LDS_PTR(u32x2_t, (uintptr_t)pw[t]) = w;
-        }
-        bf16x8 dst[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) dst[t] = lds_frag_tr<RB>(pr[t]);      // lane: query 16 t + fr, keys {4 g .. + 3} and the zero rows 16 ..
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-          for (int t = 0; t < 2; ++t) dqT[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[u][c], dst[t], dqT[c][t], 0, 0, 0);
-      }
-    }
-    // the wave's partial dQ tile of rows qa .. qa + 31 -> staging buffer (qa / 32) & 1; after the barrier every wave sums four rows
-    // over the eight partials and stores them (the buffer is rewritten two steps later, behind the next step's barrier)
-    {
-      char* buf = stg + ((qa >> 5) & 1) * 8 * FQ_PART;
-      float* mine = reinterpret_cast<float*>(buf + wave * FQ_PART);
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) *reinterpret_cast<f32x4*>(mine + (16 * t + fr) * FQ_LD + 16 * c + 4 * g) = dqT[c][t];
-      __syncthreads();
-      const int row = 4 * wave + g, col = 2 * fr;
-      float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-      for (int wv = 0; wv < 8; ++wv) {
-        const f32x2 v = *reinterpret_cast<const f32x2*>(reinterpret_cast<const float*>(buf + wv * FQ_PART) + row * FQ_LD + col);
-        a0 += v[0]; a1 += v[1];
-      }
-      const int q = qa + row;
-      if (q < p.Nq) *reinterpret_cast<uint32_t*>(p.dQ + b * p.dq_bs + (long)q * p.dq_rs + h * D + col) = pack2bf(a0 * p.scale, a1 * p.scale);
-    }
-    qa_ += 32 * RB; oa += 32 * RB;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) { ota[c] += 32 * RB; qta[c] += 32 * RB; }
-    la += 128; da += 128;
-  }
-#pragma unroll
-  for (int u = 0; u < FKT; ++u) {
-    const int key = (wave + 8 * u) * 16 + fr;
-    if (u < nown && kok[u]) {
-      bf16_t* dkrow = p.dK + b * p.dk_bs + (long)key * p.dk_rs + h * D;
-      bf16_t* dvrow = p.dV + b * p.dv_bs + (long)key * p.dv_rs + h * D;
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        uint2 w;
-        w.x = pack2bf(dk[u][c][0] * p.scale, dk[u][c][1] * p.scale);
-        w.y = pack2bf(dk[u][c][2] * p.scale, dk[u][c][3] * p.scale);
-        *reinterpret_cast<uint2*>(dkrow + c * 16 + 4 * g) = w;
-        w.x = pack2bf(dv[u][c][0], dv[u][c][1]);
-        w.y = pack2bf(dv[u][c][2], dv[u][c][3]);
-        *reinterpret_cast<uint2*>(dvrow + c * 16 + 4 * g) = w;
-      }
-    }
-  }
-}
-__global__ __launch_bounds__(512, 2) void attn_bwd_fused32_kernel(AttnParams p) {
-  attn_bwd_fused_body<32>(p, p.pair ? pair_heads(blockIdx.x, gridDim.x) : (int)blockIdx.x);
-}
-inline size_t attn_fused_lds(const AttnParams& p) {
-  const size_t Nqp = (p.Nq + 31) & ~31, Nkp = (p.Nk + 31) & ~31;
-  return Nqp * (64 + 64 + 8) + (Nkp + 16) * 64 + 2 * 8 * FQ_PART + 8 * 2048;
-}
+// (round 4 tried the backward as ONE kernel from one recomputation of the probabilities — a wave owning three key tiles, walking the
+// query tiles once, dS transposed through an LDS patch, the waves' partial dQ tiles reduced per 32-query step: correct and no faster
+// (352 x 352: 113 vs 117 us, 228 x 228: 72 vs 60 us, profiles/r04_attn_fused_bwd.txt): halving the exp / fma work moves the bound to the
+// LDS pipe at one workgroup per CU.  Removed in round 5; DESIGN_HISTORY section 11.)
 
 // ---- kernels: one grid per problem, or (resident variants) several problems in one grid (batch.h) ------------------
 template <int DQK, int DV, bool CHUNKED, int QT>
@@ -1114,21 +911,6 @@ int launch_bwd(const AttnParams& p, hipStream_t stream, int part = 3) {
   const size_t row = attn_row_bytes<DQK, DV>();
   const size_t lds1 = attn_lds<DQK, DV, 1>(p), lds2 = attn_lds<DQK, DV, 2>(p);
   const int nw1 = waves_for(p.Nq), nw2 = waves_for(p.Nk);
-  if constexpr (DQK == 32 && DV == 32) {
-    // round 4: both passes in one kernel from one recomputation of P (attn_bwd_fused_body).  OFF by default (DAV_ATTN_FUSED_BWD=1):
-    // correct (tests/gpu_selfcheck.py attention family, e2e vs the oracle) and no faster — 352 x 352: 112-115 us against 116-118 for the
-    // dQ + dK/dV pair, 228 x 228: 72 against 60 us, step +0.15 ... +0.25 ms (profiles/r04_attn_fused_bwd.txt).  Halving the exp / fma
-    // work moves the bound to the LDS pipe (dS^T patch + staging of the partial dQ tiles on top of the fragment reads: ~46 LDS
-    // instructions per wave and 32-query step) at ONE workgroup per CU, where the pair runs three.
-    static const bool fused = [] { const char* e = getenv("DAV_ATTN_FUSED_BWD"); return e && e[0] == '1'; }();
-    if (fused && part == 3 && !davb::recording() && !p.bias && !p.dS && p.dq_ctx == 0 && p.Nk <= 8 * FKT * 16 && p.Nq >= 64 &&
-        attn_fused_lds(p) <= 160 * 1024 && !p.debug) {
-      const size_t lds = attn_fused_lds(p);
-      if (int rc = raise_lds_cap<attn_bwd_fused32_kernel>(lds)) return rc;
-      DAV_LAUNCH(attn_bwd_fused32_kernel, dim3(p.B * p.H), dim3(512), lds, stream, p);
-      return dav_launch_status();
-    }
-  }
   // dQ first: it also writes Delta, which the dK/dV kernel reads
   if (!(part & 1)) {
   } else if (lds1 <= ATTN_RESIDENT_MAX) {

@@ -58,14 +58,6 @@ struct TNParams {                     // (pointers first: 96 bytes, 40 of them f
   int debug_plain_store;              // timing experiments only: 1 (variant bit 8) plain stores instead of atomics; DAV_TN_DEBUG: 2 no epilogue, 4 no reads / MFMAs
 };
 static_assert(sizeof(TNParams) == 96, "TNParams layout");
-// Fused optimizer pass of a grouped weight-gradient launch (DavTnAdamW): the flat buffers' bases — a tile's element offset in all of them
-// is (its C pointer - g_base) — and the scalars of dav_adamw_flat.  A problem takes part when bits 8.. of debug_plain_store hold its
-// parameter's index + 1 into `hyper`.
-struct TNOpt {
-  const float* g_base; float* p_base; float* m_base; float* v_base; bf16_t* bf16_base;
-  const float* hyper; const float* bias_corr; const float* gscale; float* sumsq;
-  float beta1, beta2, eps;
-};
 
 // ------------------------------------------------------------------------------------------------
 // NT kernel
@@ -588,9 +580,6 @@ __device__ __forceinline__ void nt_epilogue_s(const NTParams& p, f32x4 (&acc)[FM
 
 #include "gemm_nt256.h"
 #include "gemm_tn_gang.h"
-#ifdef DAV_EXPERIMENTAL
-#include "gemm_tn256.h"      // 256 x 256 stream-K weight gradients: measured slower (round 3), kept for measurements only
-#endif
 
 // PIPE == 2: two extra LOADER waves per workgroup issue every global -> LDS piece of the ring; the WM_ x WN_ compute waves only wait
 // at the per-step barrier, read fragments and issue MFMAs.  A wave that issues LDS-DMA pieces is blocked by the vector-memory path's
@@ -1173,21 +1162,6 @@ __global__ __launch_bounds__((WM_* WN_ + (PIPE >= 2 ? PIPE : 0)) * 64, PIPE == 4
   nt2_body<BM, BN, WM_, WN_, STAGES, BT, BK, false, PIPE>(p, blockIdx.x);
 }
 
-// DAV_NT_PERSIST=<n> (opt-in): the same body, a grid capped at n workgroup slots, each workgroup walking the tiles blockIdx.x, + gridDim.x, ...
-// (n a multiple of 8: the tile -> XCD mapping of nt2_body stays that of the hardware's dispatch).  A kernel of its own: wrapped in the tile
-// loop the body costs 8 more registers even with the lane id laundered per tile (35 more without: everything derived from it is hoisted out of
-// the loop and kept), and the 128 x 256 tiles start to spill.
-template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK = 64>
-__global__ __launch_bounds__(WM_* WN_ * 64, (WM_ * WN_ == 8 && BM * BN > 128 * 128) ? 4 : (WM_ * WN_ <= 4 ? 2 : 1)) void gemm_nt2_persist_kernel(NTParams p) {
-  const int ntiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  for (int bid = blockIdx.x; bid < ntiles; bid += gridDim.x) {
-    int t = threadIdx.x;
-    asm volatile("" : "+v"(t));
-    nt2_body<BM, BN, WM_, WN_, STAGES, BT, BK, false, 0>(p, bid, t);
-    if (bid + (int)gridDim.x < ntiles) __syncthreads();      // the epilogue's staging area is the next tile's first ring stage
-  }
-}
-
 // Grouped launch: up to NT_GROUP_MAX independent problems (any M / N / K / epilogue, one tile configuration) in ONE grid —
 // e.g. the qkv GEMMs of the image and the audio tower of a layer (738 + 864 tiles = 3.1 rounds of 512 workgroup slots
 // instead of 1.44 -> 2 and 1.69 -> 2).  Each problem's block range starts at a multiple of 8 so that blockIdx & 7 (the XCD
@@ -1330,19 +1304,7 @@ void nt2_issue(const void* const* params, int n, hipStream_t stream) {
     const int cnt = n - base < NT_GROUP_MAX ? n - base : NT_GROUP_MAX;
     if (cnt == 1) {
       const NTParams& p = *(const NTParams*)params[base];
-      int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-      // DAV_NT_PERSIST=<n>: at most n 8-wave workgroups (2 n of the 4-wave tiles), each walking several tiles — see gemm_nt2_persist_kernel
-      static const int persist = getenv("DAV_NT_PERSIST") ? atoi(getenv("DAV_NT_PERSIST")) & ~7 : 0;
-      const int cap = persist * (8 / (WM_ * WN_) > 0 ? 8 / (WM_ * WN_) : 1);
-      if constexpr (PIPE == 0 && BM * BN <= 128 * 128) {      // (the 128 x 256 tiles spill inside the tile loop: not offered)
-        if (persist > 0 && grid > cap) {
-          auto pkern = gemm_nt2_persist_kernel<BM, BN, WM_, WN_, STAGES, BT, BK>;
-          static bool pbig = false;
-          if (lds > 64 * 1024 && !pbig) { (void)hipFuncSetAttribute((const void*)pkern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); pbig = true; }
-          DAV_LAUNCH_NOW(pkern, dim3(cap), dim3(NT), lds, stream, p);
-          continue;
-        }
-      }
+      const int grid = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
       DAV_LAUNCH_NOW(kern, dim3(grid), dim3(NT), lds, stream, p);
       continue;
     }
@@ -1415,13 +1377,9 @@ static int nt_tuned_lookup(bool bt, const void* const* params, int n) {
 
 // DAV_NT_WIDE=0 switches the 128 x 256 configuration off (A/B timing of the same box)
 [[maybe_unused]] static bool nt_ld_on() { static const bool on = [] { const char* e = getenv("DAV_NT_LD"); return e && e[0] == '1'; }(); return on; }
-// 256 x 256 tiles (configuration 60).  The rule is OFF by default (DAV_NT256=1 switches it on): alone on the GPU the configuration is
-// 7-25 % faster than 128 x 128 / 128 x 256 on every wide shape of the step, warm or cold operands, but the step gets 0.25 ms SLOWER with
-// it in every schedule (same-box alternation, profiles/r03_nt256_instep_ab.txt) — a workgroup that owns 128 KB of LDS keeps the
-// other streams' kernels off its CU.  When on: the group must hold DAV_NT256_TILES tiles (default 150) and every problem must be at least DAV_NT256_N columns wide (default 1024)
-static bool nt256_on() { static const bool on = [] { const char* e = getenv("DAV_NT256"); return e && e[0] == '1'; }(); return on; }
-static long nt256_min_tiles() { static const long v = getenv("DAV_NT256_TILES") ? atol(getenv("DAV_NT256_TILES")) : 150; return v; }
-static int nt256_min_n() { static const int v = getenv("DAV_NT256_N") ? atoi(getenv("DAV_NT256_N")) : 1024; return v; }
+// 256 x 256 tiles (configuration 60): an explicit / tunable configuration only.  Alone on the GPU it is 7-25 % faster than 128 x 128 /
+// 128 x 256 on every wide shape of the step, but as a rule it made the step 0.25 ms SLOWER in every schedule (round 3, same-box
+// alternation, profiles/r03_nt256_instep_ab.txt): a workgroup that owns 128 KB of LDS keeps the other streams' kernels off its CU.
 static bool nt_wide_on() { static const bool on = [] { const char* e = getenv("DAV_NT_WIDE"); return !(e && e[0] == '0'); }(); return on; }
 
 // Recorded with the tile configuration left open: chosen at issue time from the tile count of the WHOLE group.
@@ -1431,14 +1389,13 @@ void nt2_issue_auto(const void* const* params_in, int n, hipStream_t stream) {
   std::vector<const void*> sorted(params_in, params_in + n);
   std::stable_sort(sorted.begin(), sorted.end(), [](const void* a, const void* b) { return ((const NTParams*)a)->K > ((const NTParams*)b)->K; });
   const void* const* params = sorted.data();
-  long t128 = 0, t256 = 0, t256sq = 0;
+  long t128 = 0, t256 = 0;
   bool wide = true;
   bool narrow = true;
   bool all256 = true;                                     // every problem can go through the 256 x 256 body and is wide enough for it
   for (int i = 0; i < n; ++i) {
     const NTParams& p = *(const NTParams*)params[i];
-    t256sq += (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-    all256 = all256 && nt256_ok(p) && p.N >= nt256_min_n();
+    all256 = all256 && nt256_ok(p);
     t128 += (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     t256 += (long)((p.M + 127) / 128) * ((p.N + 255) / 256);
     narrow = narrow && p.N <= 64;
@@ -1457,23 +1414,6 @@ void nt2_issue_auto(const void* const* params_in, int n, hipStream_t stream) {
 #ifdef DAV_EXPERIMENTAL
   if (cfg == 3 && nt_ld_on()) cfg = 51;
 #endif
-  if (!forced && !tuned && nt256_on() && t256sq >= nt256_min_tiles() && all256) cfg = 60;
-  if (!forced && !tuned && nt256_on() && !all256 && n > 1) {
-    // mixed group (the towers' GEMMs with the fusion block's narrow projections riding along): the problems the 256 x 256 body
-    // can take go out as one launch of their own when they fill the chip, the rest by the rules
-    std::vector<const void*> wide_p, rest_p;
-    long tw = 0;
-    for (int i = 0; i < n; ++i) {
-      const NTParams& p = *(const NTParams*)params[i];
-      if (nt256_ok(p) && p.N >= nt256_min_n()) { wide_p.push_back(params[i]); tw += (long)((p.M + 255) / 256) * ((p.N + 255) / 256); }
-      else rest_p.push_back(params[i]);
-    }
-    if (tw >= nt256_min_tiles() && !rest_p.empty()) {
-      nt2_issue_auto<BT>(wide_p.data(), (int)wide_p.size(), stream);
-      nt2_issue_auto<BT>(rest_p.data(), (int)rest_p.size(), stream);
-      return;
-    }
-  }
   if (cfg == 60 && !all256) cfg = 3;                     // (an explicit or tuned 60 on a group the 256 x 256 body cannot take)
   nt_log_issue(cfg, BT, params, n);
   switch (cfg) {
@@ -1656,7 +1596,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TNParams p) {
 // ------------------------------------------------------------------------------------------------
 // T x TK output tiles (T rows of the gradient = columns of A, TK columns = columns of B; TK = T unless given: round 4 adds 256 x 128)
 template <int T, int WM_, int WN_, int RS = 64, int NST = 2, int TK = T>
-__device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, const int split_idx, const TNOpt* opt = nullptr) {
+__device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, const int split_idx) {
   // RS contraction rows per ring stage, NST stages (NST - 1 stages of loads in flight while one is consumed)
   constexpr int NT = WM_ * WN_ * 64, RB = T * 2, CPRW = T / 8;      // 16-byte chunks per tile row (A side)
   constexpr int RBK = TK * 2, CPRWK = TK / 8;                       // ... (B side)
@@ -1666,7 +1606,6 @@ __device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, 
   static_assert(RS * CPRW % NT == 0 && RS * CPRWK % NT == 0 && (RS == 32 || RS == 64) && NST >= 2, "tile/threads mismatch");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int dbg = p.debug_plain_store & 255;                        // (a register: read through p inside the loop it was a scalar load + wait per stage)
-  const int opt_idx = p.debug_plain_store >> 8;                     // > 0: the owner of a WRITTEN tile applies AdamW to it instead of storing it (index + 1 of the parameter)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN_, wn = wave % WN_;
   const int tiles_k = (p.K + TK - 1) / TK, tiles_n = (p.N + T - 1) / T;
@@ -1804,60 +1743,7 @@ __device__ __forceinline__ void tn2_body(const TNParams& p, const int tile_idx, 
 
   if (dbg & 2) return;          // timing experiment: no epilogue
   const int fr = lane & 15, fg = lane >> 4;
-  if (opt != nullptr && opt_idx > 0 && p.splits == 1 && !p.beta) {
-    // Fused optimizer pass: this workgroup holds the FINAL gradient of its 128 x 128 weights in registers (a written tile, never split
-    // over the contraction): AdamW on them here — master, both moments, bf16 mirror — with the arithmetic of adamw_flat_kernel in its
-    // order; the gradient itself is never stored.  One row of fragments at a time (FN 16-byte loads of p, m and v each in flight).
-    const TNOpt& o = *opt;
-    const float lr = o.hyper[2 * (opt_idx - 1)], wd = o.hyper[2 * (opt_idx - 1) + 1];
-    const float bc1 = o.bias_corr[0], bc2_sqrt = o.bias_corr[1];
-    const float gsd = o.gscale ? o.gscale[0] : 1.f;
-    const bool skip = o.gscale != nullptr && !(gsd > 0.f);          // dav_step_guard: leave parameters and moments alone
-    const float gs = skip ? 0.f : gsd;
-    const float decay = 1.f - lr * wd, step = lr / bc1, ob1 = 1.f - o.beta1, ob2 = 1.f - o.beta2;
-    const long base = p.C - o.g_base;
-    float ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const int n = n0 + wm * WTN + i * 16 + fr;
-      float4 P[FN], M[FN], V[FN];
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int k = k0 + wn * WTK + j * 16 + fg * 4;
-        const bool in = n < p.N && k < p.K && !skip;
-        const long off = base + (long)n * p.ldc + k;
-        P[j] = in ? *reinterpret_cast<const float4*>(o.p_base + off) : float4{0.f, 0.f, 0.f, 0.f};
-        M[j] = in ? *reinterpret_cast<const float4*>(o.m_base + off) : float4{0.f, 0.f, 0.f, 0.f};
-        V[j] = in ? *reinterpret_cast<const float4*>(o.v_base + off) : float4{0.f, 0.f, 0.f, 0.f};
-      }
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int k = k0 + wn * WTK + j * 16 + fg * 4;
-        if (n >= p.N || k >= p.K) continue;
-        const float g0 = acc[i][j][0], g1 = acc[i][j][1], g2 = acc[i][j][2], g3 = acc[i][j][3];
-        ss += g0 * g0 + g1 * g1 + g2 * g2 + g3 * g3;
-        if (skip) continue;
-        const long off = base + (long)n * p.ldc + k;
-        const float gx = g0 * gs, gy = g1 * gs, gz = g2 * gs, gw = g3 * gs;
-        float4 mi = M[j], vi = V[j], pi = P[j];
-        mi.x = o.beta1 * mi.x + ob1 * gx; mi.y = o.beta1 * mi.y + ob1 * gy; mi.z = o.beta1 * mi.z + ob1 * gz; mi.w = o.beta1 * mi.w + ob1 * gw;
-        vi.x = o.beta2 * vi.x + ob2 * gx * gx; vi.y = o.beta2 * vi.y + ob2 * gy * gy;
-        vi.z = o.beta2 * vi.z + ob2 * gz * gz; vi.w = o.beta2 * vi.w + ob2 * gw * gw;
-        pi.x = pi.x * decay - step * mi.x / (sqrtf(vi.x) / bc2_sqrt + o.eps);
-        pi.y = pi.y * decay - step * mi.y / (sqrtf(vi.y) / bc2_sqrt + o.eps);
-        pi.z = pi.z * decay - step * mi.z / (sqrtf(vi.z) / bc2_sqrt + o.eps);
-        pi.w = pi.w * decay - step * mi.w / (sqrtf(vi.w) / bc2_sqrt + o.eps);
-        *reinterpret_cast<float4*>(o.p_base + off) = pi;
-        *reinterpret_cast<float4*>(o.m_base + off) = mi;
-        *reinterpret_cast<float4*>(o.v_base + off) = vi;
-        uint2 w; w.x = pack2bf(pi.x, pi.y); w.y = pack2bf(pi.z, pi.w);
-        *reinterpret_cast<uint2*>(o.bf16_base + off) = w;
-      }
-    }
-    ss = wave_sum(ss);
-    if (lane == 0) unsafeAtomicAdd(o.sumsq, ss);
-  } else {
-  // splits > 1: partial sums meet through fp32 atomics; splits == 1: this workgroup owns the tile (plain
+  {
   // splits > 1: partial sums meet through fp32 atomics; splits == 1: this workgroup owns the tile (plain
   // read-modify-write when accumulating)
   const bool atomic = p.splits > 1 && !(dbg & 1);
@@ -1926,12 +1812,11 @@ struct TNGroup {
   TNParams prob[TN_GROUP_MAX];
   int first_block[TN_GROUP_MAX + 1];
   int count;                          // bits 0..15: problems; bit 30 (TN_XCD_RUNS): every XCD owns one contiguous run of each problem's (split, tile) units
-  TNOpt opt;                          // the fused optimizer pass's buffers (FUSED instantiation only); with it the table is exactly 4096 bytes
 };
 constexpr int TN_XCD_RUNS = 1 << 30;
 static_assert(sizeof(TNGroup) <= 4096, "kernel argument block");
 
-template <int T, int WM_, int WN_, int RS = 64, int NST = 2, int MINW = 1, int TK = T, bool FUSED = false>
+template <int T, int WM_, int WN_, int RS = 64, int NST = 2, int MINW = 1, int TK = T>
 __global__ __launch_bounds__(WM_* WN_ * 64, MINW) void gemm_tn_grouped_kernel(const TNGroup g) {
   int pi = 0;
   const int count = g.count & 0xffff;
@@ -1949,7 +1834,7 @@ __global__ __launch_bounds__(WM_* WN_ * 64, MINW) void gemm_tn_grouped_kernel(co
     const int r = local & 7, j = local >> 3, q = total >> 3, rem = total & 7;
     unit = r * q + (r < rem ? r : rem) + j;
   }
-  tn2_body<T, WM_, WN_, RS, NST, TK>(p, unit % tiles, unit / tiles, FUSED ? &g.opt : nullptr);
+  tn2_body<T, WM_, WN_, RS, NST, TK>(p, unit % tiles, unit / tiles);
 }
 
 template <int T, int WM_, int WN_>
@@ -2168,74 +2053,16 @@ extern "C" int dav_nt_issue_log(int enable, int* out, int capacity) {
   return 0;
 }
 
-static int tn_grouped_impl(const DavTnProblem* probs, int count, const DavTnAdamW* opt, hipStream_t stream) {
+static int tn_grouped_impl(const DavTnProblem* probs, int count, hipStream_t stream) {
   if (count <= 0 || count > TN_GROUP_MAX) return DAV_ERR_SHAPE;
-  bool any_fused = false;
-  if (opt) {
-    if (!opt->g_base || !opt->p_base || !opt->m_base || !opt->v_base || !opt->bf16_base || !opt->hyper || !opt->bias_corr || !opt->sumsq) return DAV_ERR_SHAPE;
-    if (((uintptr_t)opt->g_base | (uintptr_t)opt->p_base | (uintptr_t)opt->m_base | (uintptr_t)opt->v_base) & 15 || ((uintptr_t)opt->bf16_base & 7)) return DAV_ERR_ALIGN;
-    for (int i = 0; i < count; ++i)
-      if (probs[i].flags & 2) {
-        // a fused tile is a WRITTEN one (its owner sees the whole gradient) inside the flat gradient buffer, 16-byte offsets
-        if (!(probs[i].flags & 1) || probs[i].C < opt->g_base || ((probs[i].C - opt->g_base) & 3)) return DAV_ERR_SHAPE;
-        any_fused = true;
-      }
-  } else {
-    for (int i = 0; i < count; ++i)
-      if (probs[i].flags & 2) return DAV_ERR_SHAPE;      // asks for the optimizer pass without its buffers
-  }
   static thread_local TNGroup g;   // host staging (one per calling thread); copied by value into the kernel arguments at launch
   long total_tiles = 0;
   for (int i = 0; i < count; ++i) {
     const DavTnProblem& q = probs[i];
-    if (q.Mc <= 0 || (q.Mc & 63) || q.N <= 0 || q.K <= 0 || (q.N & 7) || (q.K & 7) || (q.lda & 7) || (q.ldb & 7)) return DAV_ERR_SHAPE;
+    if (q.Mc <= 0 || (q.Mc & 63) || q.N <= 0 || q.K <= 0 || (q.N & 7) || (q.K & 7) || (q.lda & 7) || (q.ldb & 7) || (q.flags & ~1)) return DAV_ERR_SHAPE;
     if (((uintptr_t)q.A | (uintptr_t)q.B | (uintptr_t)q.C) & 15 || (q.ldc & 3)) return DAV_ERR_ALIGN;      // 16-byte gradient accesses
     total_tiles += (long)((q.N + 127) / 128) * ((q.K + 127) / 128);
   }
-  // 256 x 256 persistent form (csrc/gemm_tn256.h; make EXPERIMENTAL=1 builds only since round 4): one slice of the K-tile-pair sequence per
-  // workgroup.  OFF by default (DAV_TN256=1 switches it on): bit-correct, but measured slower than the 128 x 128 tiles on the step's launches
-  // (profiles/r03_tn256_group_bench.txt): its k-loop alone reaches 673-733 TF against 580-635 for the old kernel INCLUDING its
-  // epilogue — the weight gradients are bound by re-streaming their operands from MALL / HBM, which a wider tile only halves —
-  // and the fp32 atomics of the split tiles (one dword per lane and instruction) cost 440-900 us per launch.
-#ifdef DAV_EXPERIMENTAL
-  static const bool tn256 = [] { const char* e = getenv("DAV_TN256"); return e && e[0] == '1'; }();
-  static const long tn256_min = getenv("DAV_TN256_MIN") ? atol(getenv("DAV_TN256_MIN")) : 512;      // K-tile pairs below which the old kernel runs
-  if (tn256 && count <= TN256_MAX) {
-    TN256Group g2;
-    long units = 0;
-    for (int i = 0; i < count; ++i) {
-      const DavTnProblem& q = probs[i];
-      TNParams& p = g2.prob[i];
-      p.A = (const bf16_t*)q.A; p.B = (const bf16_t*)q.B; p.Mc = q.Mc; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = q.ldb;
-      p.amap = RowMap{q.a_rowmap[0], q.a_rowmap[1], q.a_rowmap[2]};
-      p.bmap = RowMap{q.b_rowmap[0], q.b_rowmap[1], q.b_rowmap[2]};
-      static const int tn256_debug = getenv("DAV_TN256_DEBUG") ? atoi(getenv("DAV_TN256_DEBUG")) : 0;
-      p.C = q.C; p.ldc = q.ldc; p.beta = (q.flags & 1) ? 0 : 1; p.bias_grad = q.bias_grad; p.debug_plain_store = tn256_debug; p.splits = 1;
-      g2.first_unit[i] = (int)units;
-      units += (long)((q.N + 255) / 256) * ((q.K + 255) / 256) * (((q.Mc >> 6) + 1) >> 1);
-    }
-    if (units >= tn256_min && units < (1l << 30)) {
-      g2.first_unit[count] = (int)units;
-      g2.count = count;
-      long G = units / 4;                                  // at least four K-tile pairs per workgroup
-      G = G > 256 ? 256 : (G < 8 ? 8 : (G & ~7l));
-      static bool big = false;
-      if (!big) { (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); big = true; }
-      DAV_LAUNCH(gemm_tn256_kernel, dim3((int)G), dim3(512), NT256_LDS, stream, g2);
-      return dav_launch_status();
-    }
-  }
-#endif
-  // Round 4: 256 x 128 tiles, one owner per tile as before (no atomics) — 3/4 of the operand bytes per flop on the global -> LDS stream
-  // that bounds this kernel.  Measured SLOWER in both ring forms (profiles/r04_tn256x128.txt): 64-row stages x 2 at one workgroup per
-  // CU 567 / 520 TF against 693 / 624 for 128 x 128 (decoders' / a layer's launch) and +1.6 ms per step; 32-row stages x 3 at two
-  // workgroups per CU (128 registers) 652 / 532 TF and +2.7 ms.  EXPERIMENTAL builds only: DAV_TN_TILE=256 / 257.
-#ifdef DAV_EXPERIMENTAL
-  static const int tn_tile = getenv("DAV_TN_TILE") ? atoi(getenv("DAV_TN_TILE")) : 128;
-  if (tn_tile != 128 && tn_tile != 256 && tn_tile != 257) return DAV_ERR_SHAPE;      // 257: 256 x 128 on 32-row stages x 3, two workgroups per CU
-#else
-  constexpr int tn_tile = 128;
-#endif
   // aim at ~4 workgroups of 8 waves per CU-slot pair (1024 blocks) but keep >= 8 k-steps of 64 rows per split
   int first = 0;
   for (int i = 0; i < count; ++i) {
@@ -2246,8 +2073,7 @@ static int tn_grouped_impl(const DavTnProblem* probs, int count, const DavTnAdam
     p.bmap = RowMap{q.b_rowmap[0], q.b_rowmap[1], q.b_rowmap[2]};
     static const int tn_debug = getenv("DAV_TN_DEBUG") ? atoi(getenv("DAV_TN_DEBUG")) & 6 : 0;
     p.C = q.C; p.ldc = q.ldc; p.beta = (q.flags & 1) ? 0 : 1; p.bias_grad = q.bias_grad; p.debug_plain_store = tn_debug;
-    if (q.flags & 2) p.debug_plain_store |= (int)(((unsigned)q.flags >> 8) + 1u) << 8;      // parameter index + 1 (see tn2_body)
-    const int tiles = ((q.N + (tn_tile & ~1) - 1) / (tn_tile & ~1)) * ((q.K + 127) / 128), steps = q.Mc >> 6;
+    const int tiles = ((q.N + 127) / 128) * ((q.K + 127) / 128), steps = q.Mc >> 6;
     int splits = (int)((1024 + total_tiles - 1) / total_tiles);
     const int max_splits = steps / 8 > 0 ? steps / 8 : 1;
     if (splits > max_splits) splits = max_splits;
@@ -2258,46 +2084,23 @@ static int tn_grouped_impl(const DavTnProblem* probs, int count, const DavTnAdam
   }
   g.first_block[count] = first;
   // (round 3: -21 % memory-side fetch, -5 % kernel time, -0.2 ms per step on two boxes.  Cutting the WHOLE launch's unit sequence
-  // into eight equal-work ranges, one per XCD, took the fetch down 3 x (33.5 -> 11.5 GB per step) and the kernel time UP 6 %: the
-  // weight gradients are not bound by fabric traffic — profiles/r03_step_traffic.txt)
+  // into eight equal-work ranges, one per XCD, took the fetch down 3 x (33.5 -> 11.5 GB per step) and the kernel time UP 6 %:
+  // profiles/r03_step_traffic.txt — what bounded this kernel was not the fabric but a compiler-inserted drain of its own DMA, see tn2_tr)
   static const int xcd_runs = getenv("DAV_TN_XCD") ? atoi(getenv("DAV_TN_XCD")) != 0 : 1;
   g.count = count | (xcd_runs ? TN_XCD_RUNS : 0);
-  if (any_fused) {
-    g.opt = TNOpt{opt->g_base, opt->p_base, opt->m_base, opt->v_base, (bf16_t*)opt->bf16_base, opt->hyper, opt->bias_corr, opt->gscale_dev, opt->sumsq,
-                  opt->beta1, opt->beta2, opt->eps};
-    const TNGroup gf = g;
-    DAV_LAUNCH((gemm_tn_grouped_kernel<128, 4, 2, 64, 2, 1, 128, true>), dim3(first), dim3(512), (size_t)2 * 2 * 64 * 128 * 2, stream, gf);
-    return dav_launch_status();
-  }
   // 4 x 2 waves (32 x 64 wave tiles): +1 % over 2 x 4 in the step; thinner or deeper rings (32-row stages x 3 / 4, 64-row x 3),
-  // 4-wave workgroups and three workgroups per CU were all measured slower (profiles/r02_tn_ring_variants.txt)
+  // 4-wave workgroups, three workgroups per CU, 256 x 128 owner-per-tile tiles (round 4) and a 256 x 256 stream-K form with fp32
+  // atomics (round 3) were all measured slower (profiles/r02_tn_ring_variants.txt, r04_tn256x128.txt, r03_tn256_group_bench.txt)
   // (by-value copy in an AUTOMATIC: a launch recorded inside dav_batch_begin .. dav_batch_end captures its arguments with [=],
   // which does not copy objects of static storage — two recorded grouped calls would both run with the last table)
   const TNGroup gl = g;
-#ifdef DAV_EXPERIMENTAL
-  if (tn_tile == 257) {
-    static bool big = false;
-    if (!big) { (void)hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel<256, 4, 2, 32, 3, 4, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); big = true; }
-    DAV_LAUNCH((gemm_tn_grouped_kernel<256, 4, 2, 32, 3, 4, 128>), dim3(first), dim3(512), (size_t)3 * 32 * (256 + 128) * 2, stream, gl);
-    return dav_launch_status();
-  }
-  if (tn_tile == 256) {
-    static bool big = false;
-    if (!big) { (void)hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel<256, 4, 2, 64, 2, 1, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); big = true; }
-    DAV_LAUNCH((gemm_tn_grouped_kernel<256, 4, 2, 64, 2, 1, 128>), dim3(first), dim3(512), (size_t)2 * 64 * (256 + 128) * 2, stream, gl);
-    return dav_launch_status();
-  }
-#endif
   DAV_LAUNCH((gemm_tn_grouped_kernel<128, 4, 2>), dim3(first), dim3(512), (size_t)2 * 2 * 64 * 128 * 2, stream, gl);
   return dav_launch_status();
 }
 
 extern "C" int dav_gemm_tn_grouped_bf16(const DavTnProblem* probs, int count, hipStream_t stream) {
-  return tn_grouped_impl(probs, count, nullptr, stream);
-}
-extern "C" int dav_gemm_tn_grouped_adamw_bf16(const DavTnProblem* probs, int count, const DavTnAdamW* opt, hipStream_t stream) {
-  if (!opt) return DAV_ERR_SHAPE;
-  return tn_grouped_impl(probs, count, opt, stream);
+  if (!probs) return DAV_ERR_SHAPE;
+  return tn_grouped_impl(probs, count, stream);
 }
 
 // ---- gang-scheduled 256 x 256 weight gradients (csrc/gemm_tn_gang.h): host-side plan ------------------------------------------
@@ -2338,7 +2141,7 @@ int tn_gang_check(const DavTnProblem* probs, int count) {
   for (int i = 0; i < count; ++i) {
     const DavTnProblem& q = probs[i];
     if (q.Mc <= 0 || (q.Mc & 63) || q.N <= 0 || q.K <= 0 || (q.N & 7) || (q.K & 7) || (q.lda & 7) || (q.ldb & 7)) return DAV_ERR_SHAPE;
-    if (q.N > (32767 << 8) || q.K > (32767 << 8) || (q.flags & 2)) return DAV_ERR_SHAPE;
+    if (q.N > (32767 << 8) || q.K > (32767 << 8) || (q.flags & ~1)) return DAV_ERR_SHAPE;
     if (((uintptr_t)q.A | (uintptr_t)q.B | (uintptr_t)q.C) & 15 || (q.ldc & 3)) return DAV_ERR_ALIGN;
   }
   return DAV_OK;
@@ -2394,12 +2197,7 @@ extern "C" int dav_gemm_tn_gang_bf16(const DavTnProblem* probs, int count, void*
   }
   flush();
   static bool big = false;
-  if (!big) {
-    (void)hipFuncSetAttribute((const void*)gemm_tn_gang_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)gemm_tn_gang_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    big = true;
-  }
-  static const int pfd = getenv("DAV_TN_GANG_PF") ? atoi(getenv("DAV_TN_GANG_PF")) : 5;      // L2 prefetch distance in K-tiles (0: no prefetch, all 8 waves own the DMA)
+  if (!big) { (void)hipFuncSetAttribute((const void*)gemm_tn_gang_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); big = true; }
   static const int n_wg = [] {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -2408,8 +2206,7 @@ extern "C" int dav_gemm_tn_gang_bf16(const DavTnProblem* probs, int count, void*
   }();
   const long tiles = q_start[8];
   const int grid = (int)std::min<long>(n_wg, tiles);
-  if (pfd > 0) DAV_LAUNCH(gemm_tn_gang_kernel<true>, dim3(grid), dim3(512), TNG_LDS, stream, (char*)workspace, count, dbg, pfd);
-  else DAV_LAUNCH(gemm_tn_gang_kernel<false>, dim3(grid), dim3(512), TNG_LDS, stream, (char*)workspace, count, dbg, 0);
+  DAV_LAUNCH(gemm_tn_gang_kernel, dim3(grid), dim3(512), TNG_LDS, stream, (char*)workspace, count, dbg);
   return dav_launch_status();
 }
 

@@ -15,6 +15,9 @@
 //     the XCD it actually runs on (s_getreg XCC_ID; placement is a speed matter only).  The 32 workgroups of an XCD start
 //     together, draw consecutive tickets = the tiles of one gang, and walk the contraction in step: a panel is fetched once per
 //     XCD and k-phase.  An empty queue steals from the next XCD's.
+// Tried and dropped (profiles/r05_tn_gang_2_asm_reads_prefetch.txt): group 0 owning the whole LDS-DMA stream while group 1 prefetches
+// the panels into L2 a few K-tiles ahead (the gang's tiles wait out the fabric latency of a shared line together) — 2238 vs 1954 us
+// on the 12 encoder layers: four DMA pieces per wave and interval cost group 0 more than the warm L2 returns.
 // One owner per tile, whole contraction, fixed order: no atomics on the gradient, results independent of who drew which ticket.
 // The merged launch (a dozen layers' problems) is what makes whole tiles per workgroup balance: ~4000 tiles over 256 CUs.
 //
@@ -85,14 +88,7 @@ __device__ __forceinline__ bf16x8 tng_tr(uint32_t base) {
 }
 
 // one whole output tile (bn, bk) of problem p: contraction rows [0, Mc)
-// PF: the LDS-DMA stream belongs to group 0 alone (waves 0-3, four 1 KB pieces per half-tile each, vmcnt(12)); group 1 (waves 4-7)
-// issues no DMA and never waits on vmcnt — it prefetches the operand panels `pfd` K-tiles ahead INTO L2 with one dword load per
-// 128-byte line (2 per wave and K-tile, result discarded).  The gang's tiles walk the contraction in lock-step, so without this
-// every one of them waits out the fabric latency of the one request that fetches a shared line (3 half-tiles = 48 KB in flight per
-// CU at ~1.6 us = 30 GB/s per CU: profiles/r05_tn_gang.txt); a prefetch in the waves that own the DMA would sit in the same in-order
-// vmcnt queue and hold their counted waits back by the same latency.
-template <bool PF>
-__device__ __forceinline__ void tng_tile(const TNParams& p, const int bn, const int bk, const int dbg, const int pfd) {
+__device__ __forceinline__ void tng_tile(const TNParams& p, const int bn, const int bk, const int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -105,10 +101,9 @@ __device__ __forceinline__ void tng_tile(const TNParams& p, const int bn, const 
 
   // ---- LDS-DMA sources.  Piece e of this wave = token rows (2 wave + e) * 4 + (lane >> 4) of the K-tile, 16-byte chunk lane & 15
   // of the 256-byte image row; the image's 32-byte granule g holds source granule g ^ 2 (row & 3).
-  constexpr int NP = PF ? 4 : 2;                            // DMA pieces per issuing wave and half-tile
-  int a_col[2], b_col[2], krow[NP];
+  int a_col[2], b_col[2], krow[2];
 #pragma unroll
-  for (int ee = 0; ee < NP; ++ee) krow[ee] = ((PF ? (wave & 3) : wave) * NP + ee) * 4 + (lane >> 4);
+  for (int ee = 0; ee < 2; ++ee) krow[ee] = (wave * 2 + ee) * 4 + (lane >> 4);
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int c16 = lane & 15;
@@ -118,33 +113,19 @@ __device__ __forceinline__ void tng_tile(const TNParams& p, const int bn, const 
     a_col[h] = ac; b_col[h] = bc;
   }
   auto issue = [&](bool isA, int h, int d, int kt) {
-    if (PF && wr != 0) return;
-    char* slot = smem + (isA ? 0 : NT256_BREG) + d * 32768 + h * NT256_HT + (PF ? (wave & 3) * 4096 : wave * 2048);
+    char* slot = smem + (isA ? 0 : NT256_BREG) + d * 32768 + h * NT256_HT + wave * 2048;
     // zero A operand for the padding K-tile and for everything past the end (group 0 reads one K-tile ahead and sums what it
     // reads into the bias gradient; the trailing reloads are discarded anyway); B: any finite data
     const bool pad = kt >= nk;
     const int ktc = pad ? nk - 1 : kt;
 #pragma unroll
-    for (int ee = 0; ee < NP; ++ee) {
+    for (int ee = 0; ee < 2; ++ee) {
       const int m = ktc * 64 + krow[ee];
       const bf16_t* src;
       if (isA) src = pad ? reinterpret_cast<const bf16_t*>(g_tng_zeros) + (lane & 15) * 8 : p.A + tng_row(m, p.amap, amagic) * p.lda + a_col[h];
       else src = p.B + tng_row(m, p.bmap, bmagic) * p.ldb + b_col[h];
       __builtin_amdgcn_global_load_lds(GLB_PTR(void, src), LDS_PTR(void, slot + ee * 1024), 16, 0, 0);
     }
-  };
-
-  // ---- L2 prefetch (PF, group 1): lane id 0..255 of the group = (row of the K-tile, 128-byte line of the 512-byte panel row)
-  const int pf_id = (wave & 3) * 64 + lane, pf_row = pf_id >> 2;
-  int pf_ac = n0 + (pf_id & 3) * 64, pf_bc = k0 + (pf_id & 3) * 64;
-  pf_ac = pf_ac < p.N ? pf_ac : p.N - 8; pf_bc = pf_bc < p.K ? pf_bc : p.K - 8;
-  auto prefetch = [&](bool isA, int kt) {
-    if (!PF || wr == 0 || kt >= nk) return;
-    const int m = kt * 64 + pf_row;
-    const bf16_t* src = isA ? p.A + tng_row(m, p.amap, amagic) * p.lda + pf_ac : p.B + tng_row(m, p.bmap, bmagic) * p.ldb + pf_bc;
-    // a 4-byte LDS-DMA into a scratch patch behind the ring: no VGPR destination (an asm load's destination register could be
-    // reused by the compiler while the load is in flight), counted by nobody but the tile's closing vmcnt(0)
-    __builtin_amdgcn_global_load_lds(GLB_PTR(void, src), LDS_PTR(void, smem + NT256_LDS + 256 + (wave & 3) * 256), 4, 0, 0);
   };
 
   // ---- fragment read offsets (transposing reads): 16-lane group gq reads the [4 k][16 col] block at k = 8 (gq >> 1) (+ 4 h2),
@@ -217,12 +198,7 @@ __device__ __forceinline__ void tng_tile(const TNParams& p, const int bn, const 
   // prologue (buffers are free: the previous tile ended with vmcnt(0) + barrier)
   issue(true, 0, 0, 0); issue(false, 0, 0, 0); issue(false, 1, 0, 0); issue(true, 1, 0, 0);
   issue(true, 0, 1, 1); issue(false, 0, 1, 1); issue(false, 1, 1, 1);
-  if (PF) {
-    if (wr == 0) wait_vmcnt<12>();
-    else for (int kt = 2; kt < pfd; ++kt) { prefetch(true, kt); prefetch(false, kt); }
-  } else {
-    wait_vmcnt<6>();
-  }
+  wait_vmcnt<6>();
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 
@@ -243,8 +219,7 @@ __device__ __forceinline__ void tng_tile(const TNParams& p, const int bn, const 
       if ((I) == 3) { read_a(TGI<((D) ^ 1) * 32768>{}); read_b(b0, TGI<((D) ^ 1) * 32768>{}); }                  \
       TNG_SB;                                                                        \
       issue_for(I, D, T);                                                            \
-      if (PF) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");           \
-      else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");               \
+      asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");                    \
       TNG_SB;                                                                        \
       if ((I) == 1) bias_acc(1);                                                     \
       if ((I) == 3) bias_acc(0);                                                     \
@@ -265,8 +240,6 @@ __device__ __forceinline__ void tng_tile(const TNParams& p, const int bn, const 
       if ((I) == 2) read_a(TGI<(D) * 32768 + 16384>{});                                                  \
       TNG_SB;                                                                        \
       issue_for(I, D, T);                                                            \
-      if ((I) == 0) prefetch(true, (T) + pfd);                                       \
-      if ((I) == 2) prefetch(false, (T) + pfd);                                      \
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                             \
       TNG_SB;                                                                        \
       if ((I) == 0) bias_acc(0);                                                     \
@@ -275,7 +248,7 @@ __device__ __forceinline__ void tng_tile(const TNParams& p, const int bn, const 
       mfmas((I) >> 1, ((I) == 1 || (I) == 2) ? 1 : 0);                              \
       __builtin_amdgcn_s_setprio(0);                                                 \
       TNG_SB;                                                                        \
-      if (!PF) wait_vmcnt<6>();                                                      \
+      wait_vmcnt<6>();                                                               \
       TNG_SB;                                                                        \
       __builtin_amdgcn_s_barrier();                                                  \
       TNG_SB;                                                                        \
@@ -345,10 +318,9 @@ __device__ __forceinline__ void tng_tile(const TNParams& p, const int bn, const 
   }
 }
 
-constexpr size_t TNG_LDS = NT256_LDS + 256 + 1024;                 // + the ticket slot + the prefetch sink (the ONE shared array: a second __shared__ object de-pipelines the k-loop)
+constexpr size_t TNG_LDS = NT256_LDS + 16;                 // + the ticket slot (the ONE shared array: a second __shared__ object de-pipelines the k-loop)
 
-template <bool PF>
-__global__ __launch_bounds__(512) void gemm_tn_gang_kernel(char* __restrict__ ws, const int count, const int dbg, const int pfd) {
+__global__ __launch_bounds__(512) void gemm_tn_gang_kernel(char* __restrict__ ws, const int count, const int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   TGHeader* hd = reinterpret_cast<TGHeader*>(ws);
   const int* probs = reinterpret_cast<const int*>(ws + sizeof(TGHeader));
@@ -378,7 +350,7 @@ __global__ __launch_bounds__(512) void gemm_tn_gang_kernel(char* __restrict__ ws
       union { TNParams p; int w[sizeof(TNParams) / 4]; } u;
 #pragma unroll
       for (int i = 0; i < (int)(sizeof(TNParams) / 4); ++i) u.w[i] = __builtin_amdgcn_readfirstlane(probs[pi * (int)(sizeof(TNParams) / 4) + i]);
-      tng_tile<PF>(u.p, bnbk >> 16, bnbk & 0xffff, dbg, pfd);
+      tng_tile(u.p, bnbk >> 16, bnbk & 0xffff, dbg);
     }
   }
 }

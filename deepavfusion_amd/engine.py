@@ -291,6 +291,24 @@ class region:
 # `flush_wgrads()` launches everything recorded so far as one grouped GEMM (dav_gemm_tn_grouped_bf16)
 # and then reports the parameters ready.  DAV_GROUPED_WGRAD=0 restores one launch per weight.
 # ------------------------------------------------------------------------------------------------
+# DAV_WGRAD_GANG (default 1): a flush with at least DAV_WGRAD_GANG_MIN_TILES 256 x 256 tiles goes out as ONE gang-scheduled launch
+# (dav_gemm_tn_gang_bf16); 0 = the 128 x 128 grouped kernel, <= 40 problems per launch.  DAV_WGRAD_MERGE (default 0 = all): encoder
+# layers whose weight gradients share a launch — the flush after a layer's backward is skipped unless the layer closes a group (or a
+# captured segment: ``WGRAD_FLUSH_LAYERS``, set by util.misc.GraphedStep to its cuts).  A whole tile per workgroup only balances
+# when thousands of tiles share a launch (profiles/r05_tn_gang_*.txt: 12 launches 2.83 ms, one launch 1.95 ms).
+WGRAD_GANG = os.environ.get('DAV_WGRAD_GANG', '1') != '0'
+WGRAD_GANG_MIN_TILES = int(os.environ.get('DAV_WGRAD_GANG_MIN_TILES', '128'))
+WGRAD_MERGE = int(os.environ.get('DAV_WGRAD_MERGE', '0'))
+WGRAD_FLUSH_LAYERS = set()
+
+
+def wgrad_flush_due(layer: int, depth: int) -> bool:
+    """Whether the queued weight gradients go out after encoder layer ``layer``'s backward (layers run depth-1 .. 0)."""
+    if not WGRAD_GANG or layer == 0 or layer in WGRAD_FLUSH_LAYERS:
+        return True
+    return WGRAD_MERGE > 0 and (depth - layer) % WGRAD_MERGE == 0
+
+
 _DEFERRED = None
 _DEFERRED_LN = None          # deferred LayerNorm dgamma/dbeta reductions (partial-row workspaces)
 _DEFERRED_LN_READY = []
@@ -335,37 +353,6 @@ def wgrad_overwrite_end():
     return list(st['params'].values()) if st else []
 
 
-# Fused optimizer pass (dav_gemm_tn_grouped_adamw_bf16; util.misc.GraphedStep(fuse=True) / DAV_FUSED_ADAMW=1): a Linear weight whose ONE
-# weight-gradient problem of the step is a written tile set gets its AdamW update from the workgroups that own those tiles — the gradient
-# never goes to memory and the optimizer kernel behind the backward skips the weight.  ``wgrad_contrib_*`` counts the problems per weight in
-# a warm-up pass (decoder_embed sees two: patch tokens and fusion tokens); ``fused_adamw_*`` brackets the captured backward.
-_CONTRIB = None            # None: off; {address of the weight's gradient: number of weight-gradient problems this step}
-_FUSED = None              # None: off; dict(opt=<ops.gemm_tn_grouped opt>, index_of={id(weight): row in the hyper table}, allowed={id(weight)}, used={})
-
-
-def wgrad_contrib_begin():
-    global _CONTRIB
-    _CONTRIB = {}
-
-
-def wgrad_contrib_end():
-    global _CONTRIB
-    st, _CONTRIB = _CONTRIB, None
-    return st or {}
-
-
-def fused_adamw_begin(opt, index_of, allowed):
-    global _FUSED
-    _FUSED = dict(opt=opt, index_of=index_of, allowed=allowed, used={})
-
-
-def fused_adamw_end():
-    """-> the weights whose update the weight-gradient launches of the bracketed backward carried."""
-    global _FUSED
-    st, _FUSED = _FUSED, None
-    return list(st['used'].values()) if st else []
-
-
 def deferred_operands_to(stream):
     """The queued weight-gradient problems will be launched on ``stream`` although their operands were allocated while another
     stream was current: tell the caching allocator, so that a block is not handed out again on its home stream while the
@@ -380,29 +367,8 @@ def deferred_operands_to(stream):
             item[0].record_stream(stream)
 
 
-# DAV_WGRAD_SIDE=1: the grouped weight-gradient launch of a layer goes out on a side stream (a parallel branch of the captured graph)
-# instead of between two layers of the input-gradient chain, where it runs ALONE for its whole duration (profiles/r04_timeline.txt:
-# 5.3 of the step's 18 ms with a single kernel on the GPU).  DAV_WGRAD_SIDE_PRIO: dispatch priority of that stream.
-def wgrad_side():
-    return os.environ.get('DAV_WGRAD_SIDE', '0') == '1'
-
-
 def flush_wgrads():
-    """Launch the queued weight-gradient problems on the current stream (their operands must be complete on it) — or, with
-    DAV_WGRAD_SIDE=1, on the weight-gradient stream behind everything enqueued on the current stream so far
-    (``join_wgrad_stream`` before anything reads the gradients)."""
-    if wgrad_side() and (_DEFERRED or _DEFERRED_LN) and torch.cuda.is_current_stream_capturing():      # (eager passes: gradient-ready hooks assume stream order)
-        cur = torch.cuda.current_stream()
-        key = cur.device.index if cur.device.index is not None else torch.cuda.current_device()
-        if key not in _WGRAD_STREAMS:
-            _WGRAD_STREAMS[key] = torch.cuda.Stream(cur.device, priority=int(os.environ.get('DAV_WGRAD_SIDE_PRIO', '0')))
-        sw = _WGRAD_STREAMS[key]
-        _WGRAD_PENDING[key] = True
-        sw.wait_stream(cur)
-        deferred_operands_to(sw)
-        with torch.cuda.stream(sw):
-            _flush_wgrads_now()
-        return
+    """Launch the queued weight-gradient problems on the current stream (their operands must be complete on it)."""
     _flush_wgrads_now()
 
 
@@ -429,10 +395,6 @@ def _flush_wgrads_now():
         # longest contractions first: tiles are dispatched in list order as workgroup slots free up, and a tile's run time is
         # proportional to its contraction length (49 .. 95 k-steps in one launch) — the short ones fill the tail
         now.sort(key=lambda pr: -pr['Mc'])
-        if _CONTRIB is not None:
-            for pr in now:
-                k = pr.get('gbase', pr['C'].data_ptr())
-                _CONTRIB[k] = _CONTRIB.get(k, 0) + (1 if pr.get('weight') is not None else 2)      # (a column block never qualifies)
         if _OVERWRITE is not None:
             for pr in now:
                 key = pr['C'].data_ptr()
@@ -442,48 +404,13 @@ def _flush_wgrads_now():
                     _OVERWRITE['touched'].add(pr.get('gbase', key))
                 if pr['overwrite']:
                     _OVERWRITE['params'][id(pr['weight'])] = pr['weight']
-        if _FUSED is not None:
-            for pr in now:
-                w = pr.get('weight')
-                if pr.get('overwrite') and w is not None and id(w) in _FUSED['allowed']:
-                    pr['fused_idx'] = _FUSED['index_of'][id(w)]
-                    _FUSED['used'][id(w)] = w
-        if _FUSED is not None:
-            ops.gemm_tn_grouped(now, opt=_FUSED['opt'])
+        if WGRAD_GANG and PRECISION == 'bf16' and sum(-(-pr['N'] // 256) * -(-pr['K'] // 256) for pr in now) >= WGRAD_GANG_MIN_TILES:
+            ops.gemm_tn_gang(now)          # one persistent launch of 256 x 256 tiles, gangs of panel-sharing tiles per XCD
         else:
             ops.gemm_tn_grouped(now)
         for pr in now:
             _ready(*pr['ready'])
         probs = later
-
-
-# ------------------------------------------------------------------------------------------------
-# weight-gradient stream: wgrad GEMMs depend only on tensors that already exist and nothing in the
-# backward chain waits for them, so they are enqueued on their own stream (a parallel graph branch)
-# and could fill CUs the dgrad chain leaves idle.  Measured slower on MI355X (extra cross-stream edges, L2 thrash),
-# so it is opt-in: DAV_WGRAD_STREAM=1.
-# ------------------------------------------------------------------------------------------------
-_WGRAD_STREAMS = {}
-_WGRAD_PENDING = {}      # device -> work enqueued on the weight-gradient stream since the last join
-
-
-def wgrad_stream(dev):
-    if os.environ.get('DAV_WGRAD_STREAM', '0') != '1':      # measured: a loss on MI355X (46.6 vs 38.4 ms/step); off by default
-        return None
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
-    if key not in _WGRAD_STREAMS:
-        _WGRAD_STREAMS[key] = torch.cuda.Stream(dev)
-    return _WGRAD_STREAMS[key]
-
-
-def join_wgrad_stream(dev):
-    """Make the current stream wait for every weight-gradient kernel enqueued so far."""
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
-    sw = _WGRAD_STREAMS.get(key)
-    # only when something was enqueued there since the last join: a wait on an idle stream left over from an earlier step (another
-    # test, another schedule) would put an event that belongs to no capture into the graph being captured
-    if sw is not None and _WGRAD_PENDING.pop(key, False):
-        torch.cuda.current_stream(dev).wait_stream(sw)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -569,9 +496,8 @@ def lin_bwd(lin, dy, a, M, *, dy_rowmap=None, a_rowmap=None, lda=None, need_dx=T
     gwv = gw.view(N, -1)
     Cw = gwv if w_col_off == 0 else gwv.view(-1)[w_col_off:]
     gb = gbuf(lin.bias) if (use_bias and lin.bias is not None) else None
-    sw = wgrad_stream(dev)
     if _DEFERRED is not None and M % 64 == 0 and N % 8 == 0 and K % 8 == 0:
-        # weight gradients are off the dependency chain: queue them and launch ONE grouped GEMM per layer
+        # weight gradients are off the dependency chain: queue them and launch ONE grouped GEMM per flush
         _DEFERRED.append(dict(A=dy, B=a, Mc=M, N=N, K=K, C=Cw, lda=N, ldb=lda if lda is not None else K, ldc=Kfull,
                               a_rowmap=dy_rowmap, b_rowmap=a_rowmap, bias_grad=gb,
                               ready=(lin.weight, lin.bias) if final else (),
@@ -580,19 +506,8 @@ def lin_bwd(lin, dy, a, M, *, dy_rowmap=None, a_rowmap=None, lda=None, need_dx=T
         return dx
     if _OVERWRITE is not None:
         _OVERWRITE['touched'].add(gwv.data_ptr())
-    if _CONTRIB is not None:
-        _CONTRIB[gwv.data_ptr()] = _CONTRIB.get(gwv.data_ptr(), 0) + 2      # an immediate (un-deferred) contribution: never a fused weight
-    if sw is None:
-        ops.gemm_tn(dy, a, M, N, K, Cw, lda=N, ldb=lda if lda is not None else K, ldc=Kfull, a_rowmap=dy_rowmap,
-                    b_rowmap=a_rowmap, beta=1, bias_grad=gb)
-    else:
-        sw.wait_stream(torch.cuda.current_stream(dev))
-        _WGRAD_PENDING[dev.index if dev.index is not None else torch.cuda.current_device()] = True
-        dy.record_stream(sw)          # keep the operands' memory from being recycled before the side stream read them
-        a.record_stream(sw)
-        with torch.cuda.stream(sw):
-            ops.gemm_tn(dy, a, M, N, K, Cw, lda=N, ldb=lda if lda is not None else K, ldc=Kfull, a_rowmap=dy_rowmap,
-                        b_rowmap=a_rowmap, beta=1, bias_grad=gb)
+    ops.gemm_tn(dy, a, M, N, K, Cw, lda=N, ldb=lda if lda is not None else K, ldc=Kfull, a_rowmap=dy_rowmap,
+                b_rowmap=a_rowmap, beta=1, bias_grad=gb)
     if final:
         _ready(lin.weight, lin.bias)
     return dx
@@ -772,8 +687,6 @@ def _factorized_fwd(fb, x_f, x_i, x_a, heads, tkns, dp=None):
                                    na * D, D, nA * 2 * D, 2 * D, nA * 2 * D, 2 * D, dev)
     cv, ca = dict(q=q_v, kv=kv_v, o=o_v, lse=lse_v), dict(q=q_a, kv=kv_a, o=o_a, lse=lse_a)
     xmm1 = _e((B, nF, D), F32, dev)
-    if _fusion_tail_ok(fb, B, D, Da, tkns):
-        return _factorized_fwd_tails(fb, x_f, x_i, x_a, heads, tkns, xmm_b, xmm32, st_mm, xv_b, st_v, xa_b, st_a, cv, ca, q2, xmm1)
     # proj of the two aggregations: fp32 result lands in its rows of xmm1 (+ normed-xmm residual),
     # bf16 twin of the pre-residual value feeds the pair projections
     xvo_b, xao_b = _e((B * nv, D), BF16, dev), _e((B * na, D), BF16, dev)
@@ -806,115 +719,6 @@ def _factorized_fwd(fb, x_f, x_i, x_a, heads, tkns, dp=None):
     return out, tape
 
 
-# ---- fused tails (csrc/fusion_tail.hip): one workgroup per two samples walks a whole chain of the block's small stages --------
-# forward : LN x 3 | q / kv projections | 2 cross-attentions | TAIL-1 (proj_v, proj_a, k / v pair projections, pair expansion) |
-#           pair attention | TAIL-2 (proj, norm2, fc1 + GELU, fc2)                                   6 launches (11 before)
-# backward: TAIL-2 (fc2 / fc1 dgrads, norm2 backward, proj dgrad) | pair attention dQ, dK/dV | q dgrad | TAIL-1 (pair reduction, k / v
-#           dgrads, proj_v / proj_a dgrads) | cross-attention dQ, dK/dV | q / kv dgrads | LN x 3     9 launches (15 before)
-# OFF by default (DAV_FUSION_TAIL=1 switches it on): bit-for-rounding equal to the per-stage form and 15 launches -> 9, but the
-# step gets SLOWER (same-box alternation, ViT-B B = 64: 29.7-29.8 vs 26.6-26.9 ms).  Alone on the GPU the four tails take
-# 181 / 134 / 128 / 161 us — exactly the same with the weight requests one step or three steps ahead of their use (inline-asm
-# loads + counted waits, profiles/r04_fusion_tails.txt): a workgroup streams its 3.5-5.3 MB of weights at ~30 GB/s whatever the
-# pipeline depth, i.e. one CU keeps ~45 KB in flight against the ~1.5 us its L2 misses take, and with B / 2 = 32 workgroups the
-# tails put 4 x 150 us of such streaming on the fusion block's chain per layer, which then outlasts the towers' 350 us forward chain.
-# The batched per-stage GEMMs amortise every weight byte over 512-2048 rows instead.
-FUSION_TAIL = os.environ.get('DAV_FUSION_TAIL', '0') == '1'
-
-
-def _fusion_tail_ok(fb, B, D, Da, tkns):
-    at = fb.attn
-    if not (FUSION_TAIL and PRECISION == 'bf16'):
-        return False
-    if any(l.bias is None for l in (at.k, at.v, at.proj, at.attn_v.proj, at.attn_a.proj, fb.mlp.fc1, fb.mlp.fc2)):
-        return False
-    return ops.fusion_tail_supported(D, Da, fb.mlp.fc1.weight.shape[0], tkns, B)
-
-
-def _tail_dims(fb, B, D, Da, tkns):
-    return dict(B=B, D=D, Da=Da, Hd=fb.mlp.fc1.weight.shape[0], nmm=tkns[0], nv=tkns[1], na=tkns[2], eps2=fb.norm2.eps)
-
-
-def _factorized_fwd_tails(fb, x_f, x_i, x_a, heads, tkns, xmm_b, xmm32, st_mm, xv_b, st_v, xa_b, st_a, cv, ca, q2, xmm1):
-    B, nF, D = x_f.shape
-    nmm, nv, na = tkns
-    dev, at = x_f.device, fb.attn
-    Da, hd, P = at.q.weight.shape[0], D // heads, nv * na
-    dims = _tail_dims(fb, B, D, Da, tkns)
-    xvo_b, xao_b = _e((B * nv, D), BF16, dev), _e((B * na, D), BF16, dev)
-    kv_p, ka_p = _e((B * nv, Da), F32, dev), _e((B * na, Da), F32, dev)
-    vv_p, va_p = _e((B * nv, D), F32, dev), _e((B * na, D), F32, dev)
-    Kp, Vp = _e((B * P, Da), BF16, dev), _e((B * P, D), BF16, dev)
-    ops.fusion_tail('tail1_fwd', dims, Wpv=wcache(at.attn_v.proj.weight), Wpa=wcache(at.attn_a.proj.weight), Wk=wcache(at.k.weight),
-                    Wv=wcache(at.v.weight), bpv=at.attn_v.proj.bias, bpa=at.attn_a.proj.bias, bk=at.k.bias, bv=at.v.bias, xmm32=xmm32,
-                    o_v=cv['o'], o_a=ca['o'], xvo_b=xvo_b, xao_b=xao_b, kv_p=kv_p, ka_p=ka_p, vv_p=vv_p, va_p=va_p, Kp=Kp, Vp=Vp, xmm1=xmm1)
-    scale = hd ** -0.5                                                                       # NOT (Da/heads)^-0.5 (:220-222)
-    o2, lse2 = attention_fwd((q2, 0), (Kp, 0), (Vp, 0), B, heads, nmm, P, Da // heads, hd, scale,
-                             nmm * Da, Da, P * Da, Da, P * D, D, dev)
-    Hd = dims['Hd']
-    h2, z, u = _e((B * nF, D), BF16, dev), _e((B * nF, Hd), BF16, dev), _e((B * nF, Hd), BF16, dev)
-    mean2, rstd2 = _e((B * nF,), F32, dev), _e((B * nF,), F32, dev)
-    out = _e((B, nF, D), F32, dev)
-    ops.fusion_tail('tail2_fwd', dims, o2=o2, Wp=wcache(at.proj.weight), W1=wcache(fb.mlp.fc1.weight), W2=wcache(fb.mlp.fc2.weight),
-                    bp=at.proj.bias, b1=fb.mlp.fc1.bias, b2=fb.mlp.fc2.bias, g2=fb.norm2.weight, be2=fb.norm2.bias, xmm32=xmm32, xmm1=xmm1,
-                    h2=h2, z=z, u=u, mean2=mean2, rstd2=rstd2, out=out)
-    tape = dict(dp=None, tails=True, x_f=x_f, x_i=x_i, x_a=x_a, xmm_b=xmm_b, st_mm=st_mm, xv_b=xv_b, st_v=st_v, xa_b=xa_b, st_a=st_a, cv=cv,
-                ca=ca, xvo_b=xvo_b, xao_b=xao_b, Kp=Kp, Vp=Vp, q2=q2, o2=o2, lse2=lse2, xmm1=xmm1, h2=h2, st2=(mean2, rstd2), z=z, u=u,
-                heads=heads, tkns=tkns)
-    return out, tape
-
-
-def _factorized_bwd_tails_head(fb, t, g):
-    """TAIL-2 backward + the weight-gradient problems of its stages.  -> (g1 fp32 [B,nF,D], do2 bf16 [B*nmm, D])"""
-    x_f = t['x_f']
-    B, nF, D = x_f.shape
-    nmm, nv, na = t['tkns']
-    dev, at = x_f.device, fb.attn
-    Da = at.q.weight.shape[0]
-    dims = _tail_dims(fb, B, D, Da, t['tkns'])
-    Hd = dims['Hd']
-    gb, dz, dh2 = _e((B * nF, D), BF16, dev), _e((B * nF, Hd), BF16, dev), _e((B * nF, D), BF16, dev)
-    g1, g1b, do2 = _e((B, nF, D), F32, dev), _e((B * nF, D), BF16, dev), _e((B * nmm, D), BF16, dev)
-    part = _e((B // 2, 2 * D), F32, dev)
-    ops.fusion_tail('tail2_bwd', dims, g=g, gb=gb, z=t['z'], dz=dz, dh2=dh2, W2T=wcache_t(fb.mlp.fc2.weight), W1T=wcache_t(fb.mlp.fc1.weight),
-                    WpT=wcache_t(at.proj.weight), xmm1=t['xmm1'], mean2=t['st2'][0], rstd2=t['st2'][1], g2=fb.norm2.weight, g1=g1, g1b=g1b,
-                    do2=do2, ln2_partial=part)
-    lin_bwd(fb.mlp.fc2, gb, t['u'], B * nF, need_dx=False)
-    lin_bwd(fb.mlp.fc1, dz, t['h2'], B * nF, need_dx=False)
-    lin_bwd(at.proj, g1b, t['o2'], B * nmm, dy_rowmap=(nmm, nF, 0), need_dx=False)
-    item = (part, gbuf(fb.norm2.weight), gbuf(fb.norm2.bias), -(B // 2), D)          # rows < 0: the workspace holds B / 2 partial rows
-    if _DEFERRED_LN is not None:
-        _DEFERRED_LN.append(item)
-        _DEFERRED_LN_READY.append((fb.norm2.weight, fb.norm2.bias))
-    else:
-        ops.layernorm_bwd_reduce_grouped([item])
-        _ready(fb.norm2.weight, fb.norm2.bias)
-    return g1, g1b, do2
-
-
-def _factorized_bwd_tails_mid(fb, t, g1, dKp, dVp):
-    """TAIL-1 backward + its weight-gradient problems.  -> (dov, doa): gradients of the two cross-attention outputs"""
-    x_f = t['x_f']
-    B, nF, D = x_f.shape
-    nmm, nv, na = t['tkns']
-    dev, at = x_f.device, fb.attn
-    Da = at.q.weight.shape[0]
-    dims = _tail_dims(fb, B, D, Da, t['tkns'])
-    dkv_p, dka_p = _e((B * nv, Da), BF16, dev), _e((B * na, Da), BF16, dev)
-    dvv_p, dva_p = _e((B * nv, D), BF16, dev), _e((B * na, D), BF16, dev)
-    dxvo_b, dxao_b = _e((B * nv, D), BF16, dev), _e((B * na, D), BF16, dev)
-    dov, doa = _e((B * nv, D), BF16, dev), _e((B * na, D), BF16, dev)
-    ops.fusion_tail('tail1_bwd', dims, dKp=dKp, dVp=dVp, dkv_p=dkv_p, dka_p=dka_p, dvv_p=dvv_p, dva_p=dva_p, WkT=wcache_t(at.k.weight),
-                    WvT=wcache_t(at.v.weight), WpvT=wcache_t(at.attn_v.proj.weight), WpaT=wcache_t(at.attn_a.proj.weight), g1=g1,
-                    dxvo_b=dxvo_b, dxao_b=dxao_b, dov=dov, doa=doa)
-    lin_bwd(at.k, dkv_p, t['xvo_b'], B * nv, k=D, need_dx=False, final=False)
-    lin_bwd(at.k, dka_p, t['xao_b'], B * na, k=D, w_col_off=D, use_bias=False, need_dx=False)
-    lin_bwd(at.v, dvv_p, t['xvo_b'], B * nv, k=D, need_dx=False, final=False)
-    lin_bwd(at.v, dva_p, t['xao_b'], B * na, k=D, w_col_off=D, use_bias=False, need_dx=False)
-    lin_bwd(at.attn_v.proj, dxvo_b, t['cv']['o'], B * nv, need_dx=False)
-    lin_bwd(at.attn_a.proj, dxao_b, t['ca']['o'], B * na, need_dx=False)
-    return dov, doa
-
-
 def _factorized_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
     """g fp32 [B,nF,D] grad of the block output.  Returns (dx_f fp32, dx_i, dx_a);
     dx_i / dx_a are freshly STORED (fp32 [B,n,D]) unless buffers are passed.  Same step / region structure as the forward;
@@ -930,30 +734,21 @@ def _factorized_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
     P = nv * na
     rm2, rmv, rma = (nmm, nF, 0), (nv, nF, nmm), (na, nF, nmm + nv)
     cv, ca = t['cv'], t['ca']
-    tails = bool(t.get('tails'))
-    if tails:
-        g1, g1b, do2 = _factorized_bwd_tails_head(fb, t, g)
-    else:
-        if gb is None:
-            gb = to_bf16(g)
-        dz = lin_bwd(fb.mlp.fc2, gb, t['u'], B * nF, gelu_aux=t['z'])
-        dh2 = lin_bwd(fb.mlp.fc1, dz, t['h2'], B * nF)
-        g1 = _e((B, nF, D), F32, dev)                 # gradient at xmm1 = residual-path gradient of the normed xmm
-        g1b = _e((B * nF, D), BF16, dev)
-        ln_bwd(fb.norm2, None, t['xmm1'], B, t['st2'], dy_bf16=dh2, dx1=g1, res1=g, dx1_bf16=g1b)
+    if gb is None:
+        gb = to_bf16(g)
+    dz = lin_bwd(fb.mlp.fc2, gb, t['u'], B * nF, gelu_aux=t['z'])
+    dh2 = lin_bwd(fb.mlp.fc1, dz, t['h2'], B * nF)
+    g1 = _e((B, nF, D), F32, dev)                 # gradient at xmm1 = residual-path gradient of the normed xmm
+    g1b = _e((B * nF, D), BF16, dev)
+    ln_bwd(fb.norm2, None, t['xmm1'], B, t['st2'], dy_bf16=dh2, dx1=g1, res1=g, dx1_bf16=g1b)
     # d(normed xmm) from the three projections of its row groups lands in one bf16 buffer
     dxmm_b = _e((B * nF, D), BF16, dev)
     # --- pair attention branch (rows [0, nmm)) ---
-    if not tails:
-        do2 = lin_bwd(at.proj, g1b, t['o2'], B * nmm, dy_rowmap=rm2)                              # [B*nmm, D]
+    do2 = lin_bwd(at.proj, g1b, t['o2'], B * nmm, dy_rowmap=rm2)                                  # [B*nmm, D]
     dq2, dKp, dVp = _e((B * nmm, Da), BF16, dev), _e((B * P, Da), BF16, dev), _e((B * P, D), BF16, dev)
     attention_bwd((t['q2'], 0), (t['Kp'], 0), (t['Vp'], 0), t['o2'], do2, t['lse2'], (dq2, 0), (dKp, 0), (dVp, 0),
                   B, heads, nmm, P, Da // heads, hd, hd ** -0.5, nmm * Da, Da, P * Da, Da, P * D, D,
                   nmm * Da, Da, P * Da, Da, P * D, D)
-    if tails:
-        lin_bwd(at.q, dq2, t['xmm_b'], B * nmm, a_rowmap=rm2, dx=dxmm_b, dx_rowmap=rm2)
-        dov, doa = _factorized_bwd_tails_mid(fb, t, g1, dKp, dVp)
-        return _factorized_bwd_cross(fb, t, g1, dov, doa, dxmm_b, dx_i, dx_a)
     dkv_p, dka_p = _e((B * nv, Da), BF16, dev), _e((B * na, Da), BF16, dev)
     dvv_p, dva_p = _e((B * nv, D), BF16, dev), _e((B * na, D), BF16, dev)
     with region():
@@ -979,8 +774,7 @@ def _factorized_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
 
 
 def _factorized_bwd_cross(fb, t, g1, dov, doa, dxmm_b, dx_i, dx_a):
-    """The backward of the two aggregation cross-attentions, their q / kv projections and the three input LayerNorms (shared by the
-    per-stage and the fused-tail forms)."""
+    """The backward of the two aggregation cross-attentions, their q / kv projections and the three input LayerNorms ."""
     x_f, x_i, x_a, heads = t['x_f'], t['x_i'], t['x_a'], t['heads']
     B, nF, D = x_f.shape
     nI, nA = x_i.shape[1], x_a.shape[1]

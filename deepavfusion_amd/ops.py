@@ -157,19 +157,10 @@ def gemm_tn(A, B, Mc, N, K, C_out, *, lda=None, ldb=None, ldc=None, a_rowmap=Non
 TN_GROUP_MAX = 40          # dav_gemm_tn_grouped_bf16: problems per launch
 
 
-def gemm_tn_grouped(problems, opt=None):
-    """problems: list of dicts(A, B, Mc, N, K, C, lda, ldb, ldc, a_rowmap, b_rowmap, bias_grad[, overwrite][, fused_idx]); see
-    dav_gemm_tn_grouped_bf16 (overwrite: C is written instead of accumulated, DavTnProblem.flags bit 0).  ``opt`` (a dict of the
-    DavTnAdamW fields: tensors g, p, m, v, bf16, hyper, bias_corr, gscale_dev, sumsq + beta1, beta2, eps): problems that carry
-    ``fused_idx`` (the parameter's row in ``hyper``; overwrite required) get their AdamW update from the workgroups that own their
-    gradient tiles and the gradient is not stored (dav_gemm_tn_grouped_adamw_bf16)."""
+def gemm_tn_grouped(problems):
+    """problems: list of dicts(A, B, Mc, N, K, C, lda, ldb, ldc, a_rowmap, b_rowmap, bias_grad[, overwrite]); see
+    dav_gemm_tn_grouped_bf16 (overwrite: C is written instead of accumulated, DavTnProblem.flags bit 0)."""
     lib = _lib.load()
-    fused = opt is not None and any(d.get('fused_idx') is not None for d in problems)
-    if fused:
-        o = _lib.DavTnAdamW()
-        o.g_base, o.p_base, o.m_base, o.v_base, o.bf16_base = _ptr(opt['g']), _ptr(opt['p']), _ptr(opt['m']), _ptr(opt['v']), _ptr(opt['bf16'])
-        o.hyper, o.bias_corr, o.gscale_dev, o.sumsq = _ptr(opt['hyper']), _ptr(opt['bias_corr']), _ptr(opt.get('gscale_dev')), _ptr(opt['sumsq'])
-        o.beta1, o.beta2, o.eps = float(opt['beta1']), float(opt['beta2']), float(opt['eps'])
     if problems and problems[0]['A'].dtype == F32:      # fp32 path: one launch per problem
         for d in problems:
             gemm_tn(d['A'], d['B'], d['Mc'], d['N'], d['K'], d['C'], lda=d['lda'], ldb=d['ldb'], ldc=d['ldc'],
@@ -182,22 +173,7 @@ def gemm_tn_grouped(problems, opt=None):
     n_launch = (len(problems) + TN_GROUP_MAX - 1) // TN_GROUP_MAX
     for i in range(n_launch):
         chunk = problems[i::n_launch]
-        arr = (_lib.DavTnProblem * len(chunk))()
-        for q, d in zip(arr, chunk):
-            q.A, q.B, q.C, q.bias_grad = _ptr(d['A']), _ptr(d['B']), _ptr(d['C']), _ptr(d.get('bias_grad'))
-            q.Mc, q.N, q.K, q.lda, q.ldb, q.ldc = d['Mc'], d['N'], d['K'], d['lda'], d['ldb'], d['ldc']
-            q.a_rowmap[:] = d.get('a_rowmap') or (0, 0, 0)
-            q.b_rowmap[:] = d.get('b_rowmap') or (0, 0, 0)
-            q.flags = 1 if d.get('overwrite') else 0
-            if fused and d.get('fused_idx') is not None:
-                if not d.get('overwrite'):
-                    raise RuntimeError('a fused optimizer tile must be a written (overwrite) one')
-                q.flags |= 2 | (int(d['fused_idx']) << 8)
-        if fused and any(q.flags & 2 for q in arr):
-            import ctypes
-            _lib.check(lib.dav_gemm_tn_grouped_adamw_bf16(arr, len(chunk), ctypes.byref(o), _stream()), 'dav_gemm_tn_grouped_adamw_bf16')
-        else:
-            _lib.check(lib.dav_gemm_tn_grouped_bf16(arr, len(chunk), _stream()), 'dav_gemm_tn_grouped_bf16')
+        _lib.check(lib.dav_gemm_tn_grouped_bf16(_tn_problem_array(chunk), len(chunk), _stream()), 'dav_gemm_tn_grouped_bf16')
 
 
 def _tn_problem_array(problems):
@@ -502,25 +478,6 @@ def rows_scale_cast(g, scale, B, rows, D, out_bf16):
     """out_bf16[b, r] = bf16(scale[b] * g[b, r])  (DropPath backward, branch side)."""
     lib = _lib.load()
     _lib.check(lib.dav_rows_scale_cast(_ptr(g), _ptr(scale), B, rows, D, _ptr(out_bf16), _stream()), 'dav_rows_scale_cast')
-
-
-def fusion_tail_supported(D, Da, Hd, tkns, B):
-    return bool(_lib.load().dav_fusion_tail_supported(int(D), int(Da), int(Hd), int(tkns[0]), int(tkns[1]), int(tkns[2]), int(B)))
-
-
-def fusion_tail(stage, dims, **tensors):
-    """One fused chain of the factorised fusion block (dav_fusion_tail{1,2}_{fwd,bwd}; csrc/fusion_tail.hip).  ``stage``:
-    'tail1_fwd' | 'tail2_fwd' | 'tail2_bwd' | 'tail1_bwd'; ``dims``: dict(B, D, Da, Hd, nmm, nv, na, eps2); ``tensors``: the
-    DavFusionTail pointer fields by name (torch tensors; the ones a stage does not use may be omitted)."""
-    lib = _lib.load()
-    q = _lib.DavFusionTail()
-    for k in ('B', 'D', 'Da', 'Hd', 'nmm', 'nv', 'na'):
-        setattr(q, k, int(dims[k]))
-    q.eps2 = float(dims.get('eps2', 0.0))
-    for k, t in tensors.items():
-        setattr(q, k, _ptr(t))
-    fn = getattr(lib, 'dav_fusion_' + stage)
-    _lib.check(fn(C.byref(q), _stream()), 'dav_fusion_' + stage)
 
 
 def cast_transpose_grouped(pairs):

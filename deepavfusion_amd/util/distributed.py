@@ -275,9 +275,6 @@ class GradReducer:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             for st in self._streams[bi]:
                 self.comm_stream.wait_stream(st)
-            sw = engine.wgrad_stream(view.device)          # weight gradients are produced on their own stream
-            if sw is not None:
-                self.comm_stream.wait_stream(sw)
             with torch.cuda.stream(self.comm_stream):
                 self._reduce_bucket(view)
         else:                                     # gloo (CPU tests): no AVG op

@@ -102,6 +102,29 @@ class FlatAdamW(torch.optim.Optimizer):
             self.state[p] = dict(step=torch.tensor(0.), exp_avg=self.exp_avg[o:o + p.numel()].view(p.shape),
                                  exp_avg_sq=self.exp_avg_sq[o:o + p.numel()].view(p.shape))
 
+    @classmethod
+    def from_torch(cls, opt: torch.optim.Optimizer, model: Optional[torch.nn.Module] = None) -> 'FlatAdamW':
+        """Adopt a stock ``torch.optim.AdamW`` (train.py:93 builds exactly that): same parameter groups — every key a group carries,
+        incl. the 'pretrained' / 'lr_scale' tags util/lr_sched.py reads — same hyper-parameters, and whatever state it already holds
+        (a resumed run) through its own state_dict, which is also this class's format.  The parameters' storage moves into the flat
+        buffers; the torch optimizer object is not used afterwards."""
+        if not isinstance(opt, torch.optim.AdamW):
+            raise TypeError(f'only torch.optim.AdamW can be adopted into the flat optimizer, got {type(opt).__name__}')
+        d = opt.defaults
+        if d.get('amsgrad') or d.get('maximize'):
+            raise NotImplementedError('FlatAdamW: amsgrad / maximize are not implemented (no reference config sets them)')
+        for g in opt.param_groups:
+            if tuple(g['betas']) != tuple(d['betas']) or g['eps'] != d['eps'] or g.get('amsgrad') or g.get('maximize'):
+                raise NotImplementedError('FlatAdamW: betas / eps must be the same in every parameter group')
+        skip = ('params', 'amsgrad', 'maximize', 'foreach', 'capturable', 'differentiable', 'fused', 'decoupled_weight_decay')
+        groups = [dict({k: v for k, v in g.items() if k not in skip}, params=list(g['params'])) for g in opt.param_groups]
+        had_state = len(opt.state) > 0
+        sd = opt.state_dict() if had_state else None
+        new = cls(groups, lr=d['lr'], betas=tuple(d['betas']), eps=d['eps'], weight_decay=d['weight_decay'], model=model)
+        if had_state:
+            new.load_state_dict(sd)
+        return new
+
     def zero_grad(self, set_to_none: bool = False):
         self.flat.zero_grad()
 
@@ -152,26 +175,6 @@ class FlatAdamW(torch.optim.Optimizer):
                        sumsq_out=self.sumsq if fused_norm_and_zero else None, zero_grad=fused_norm_and_zero,
                        keep_grad=keep_grad if fused_norm_and_zero else None, gscale_dev=gscale_dev)
         engine.invalidate_weight_cache(f.params)      # fp32 masters changed behind torch's back
-
-    def make_range(self, first: int, last: int):
-        """Tables for an AdamW pass over the parameters first..last (inclusive, flat order) only: the segment ends relative to
-        the range's first element (the kernel indexes from the pointers it is given).  Allocates: call OUTSIDE graph capture."""
-        f = self.flat
-        lo, hi = f.offsets[first], int(f.seg_end[last])
-        return dict(first=first, n=last - first + 1, lo=lo, hi=hi, seg_end=(f.seg_end[first:last + 1] - lo).contiguous(),
-                    sumsq=torch.zeros(1, dtype=torch.float32, device=f.flat_p.device))
-
-    def launch_range(self, r, keep_grad=None, gscale_dev=None):
-        """The fused pass of ``launch_step(fused_norm_and_zero=True)`` over one ``make_range`` range (capturable): the same
-        element-wise update, sum(g^2) of the range left in ``r['sumsq']``.  util.misc.GraphedStep issues the ranges whose
-        gradients are final while the rest of the backward is still running."""
-        b1, b2 = self.defaults['betas']
-        f, lo, hi, a = self.flat, r['lo'], r['hi'], r['first']
-        if keep_grad is None:
-            keep_grad = self.keep_grad
-        ops.adamw_flat(f.flat_p[lo:hi], f.flat_g[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.flat_bf16[lo:hi],
-                       r['seg_end'], self._hyper[a:], r['n'], b1, b2, self.defaults['eps'], self._bc, 1.0,
-                       sumsq_out=r['sumsq'], zero_grad=True, keep_grad=keep_grad[a:], gscale_dev=gscale_dev)
 
     @torch.no_grad()
     def load_state_dict(self, state_dict):

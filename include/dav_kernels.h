@@ -37,7 +37,7 @@ typedef struct ihipStream_t* hipStream_t;
 extern "C" {
 #endif
 
-#define DAV_ABI_VERSION 6   /* 2: DavTnProblem.flags, dav_adamw_flat keep_grad + gscale_dev, dav_step_guard; 3: dav_attn_bwd_ctx, dav_add_cast; 4: fused fusion tails, grouped cast-transpose; 5: dav_gemm_tn_grouped_adamw_bf16; 6: dav_gemm_tn_gang_bf16 */
+#define DAV_ABI_VERSION 7   /* 2: DavTnProblem.flags, dav_adamw_flat keep_grad + gscale_dev, dav_step_guard; 3: dav_attn_bwd_ctx, dav_add_cast; 4: fused fusion tails, grouped cast-transpose; 5: dav_gemm_tn_grouped_adamw_bf16; 6: dav_gemm_tn_gang_bf16; 7: the fused fusion tails and dav_gemm_tn_grouped_adamw_bf16 are gone (measured slower, DESIGN_HISTORY section 11) */
 int dav_abi_version(void);
 int dav_build_flags(void);   /* bit 0: experimental build (make EXPERIMENTAL=1): the rejected GEMM tile configurations exist */
 /* text of the last HIP error latched by a kernel launch of the calling thread (diagnostics) */
@@ -93,7 +93,7 @@ typedef struct DavTnProblem {
   float* C; float* bias_grad;         /* fp32 [N, K] (ldc), fp32 [N] or NULL; both accumulated */
   int Mc, N, K, lda, ldb, ldc;
   int a_rowmap[3], b_rowmap[3];
-  int flags;                          /* bit 1 + bits 8..: see dav_gemm_tn_grouped_adamw_bf16.  bit 0: C is WRITTEN, its old contents ignored (the first contribution to a gradient
+  int flags;                          /* bit 0: C is WRITTEN, its old contents ignored (the first contribution to a gradient
                                          that the optimizer pass did not zero-fill, see dav_adamw_flat keep_grad); bias_grad
                                          is accumulated regardless.  Such a problem is never split over the contraction. */
 } DavTnProblem;
@@ -104,26 +104,11 @@ int dav_gemm_tn_grouped_bf16(const DavTnProblem* problems, int count, hipStream_
  * 256 x 256 tiles, one workgroup per CU: every problem's tile grid is cut into gangs of <= 32 tiles that share operand panels, the
  * gangs are dealt out to eight per-XCD ticket queues (longest contraction first) and the workgroups of an XCD draw the tiles of one gang
  * together, so that a panel crosses the fabric once per XCD instead of once per tile.  One owner per tile over the whole contraction:
- * no atomics on C, bit-repeatable.  flags bit 0 as above; bit 1 is not supported (DAV_ERR_SHAPE).  Two problems of one call must not
+ * no atomics on C, bit-repeatable.  flags bit 0 as above; other bits: DAV_ERR_SHAPE.  Two problems of one call must not
  * address the same C.  workspace: caller-owned device memory of dav_gemm_tn_gang_workspace_bytes(problems, count) bytes (0 = invalid
  * problems), 16-byte aligned, written and read on `stream` only (it must stay untouched until the launch has run). */
 size_t dav_gemm_tn_gang_workspace_bytes(const DavTnProblem* problems, int count);
 int dav_gemm_tn_gang_bf16(const DavTnProblem* problems, int count, void* workspace, size_t workspace_bytes, hipStream_t stream);
-
-/* The same launch with the optimizer pass FUSED into it (ABI 5; the captured single-process step of util/misc.py GraphedStep): a problem
- * with flags bit 1 set (legal only together with bit 0, C inside the flat gradient buffer) does not store its gradient tile — the workgroup
- * that owns the tile holds the FINAL gradient of those weights and applies AdamW to them in place: fp32 master, both moments and the bf16
- * mirror at element offset (C - g_base) of the flat buffers, hyper[2 * idx] = {lr, weight_decay} with idx = flags >> 8 (the parameter's
- * row in dav_adamw_flat's table), the arithmetic of dav_adamw_flat in its order (Trainer.step, util/misc.py:96-136 -> torch.optim.AdamW);
- * sum(g^2) of those tiles is ADDED to *sumsq (not zeroed here); gscale_dev as in dav_adamw_flat.  The caller skips these parameters in
- * dav_adamw_flat (keep_grad byte bit 1) — 8 bytes per weight less traffic (the gradient's round trip) and no optimizer kernel running alone
- * behind the backward for them.  Problems without bit 1 behave as in dav_gemm_tn_grouped_bf16. */
-typedef struct DavTnAdamW {
-  const float* g_base; float* p_base; float* m_base; float* v_base; void* bf16_base;
-  const float* hyper; const float* bias_corr; const float* gscale_dev; float* sumsq;
-  float beta1, beta2, eps;
-} DavTnAdamW;
-int dav_gemm_tn_grouped_adamw_bf16(const DavTnProblem* problems, int count, const DavTnAdamW* opt, hipStream_t stream);
 
 /* ---- attention ---------------------------------------------------------------------------- */
 /* softmax(scale * Q K^T) V per (batch, head); element (b, n, h, d) of X is X[b*x_bs + n*x_rs + h*dX + d].
@@ -207,7 +192,7 @@ size_t dav_layernorm_bwd_workspace_bytes(int rows, int D);   /* rows = B * (r0 +
 /* Deferred form: call dav_layernorm_bwd with dgamma = dbeta = NULL and a workspace (only the per-workgroup
  * partial rows are written), then reduce up to 64 such workspaces into their dgamma/dbeta (+=) in ONE launch. */
 /* rows > 0: the LayerNorm backward ran over `rows` rows (its own grid decides how many partial rows the workspace holds);
- * rows < 0 (ABI 4): the workspace holds exactly -rows partial rows [2 D] (dav_fusion_tail2_bwd) */
+ * rows < 0 (ABI 4): the workspace holds exactly -rows partial rows [2 D] */
 typedef struct DavLnReduce { const void* workspace; float* dgamma; float* dbeta; int rows; int D; } DavLnReduce;
 int dav_layernorm_bwd_reduce_grouped(const DavLnReduce* items, int count, hipStream_t stream);
 
@@ -251,58 +236,6 @@ int dav_patch_mse_bwd(const float* img, const float* pred, const float* mask, co
 int dav_pair_expand(const float* Pv, const float* Pa, int B, int nv, int na, int Wd, void* out_bf16, hipStream_t stream);
 int dav_pair_reduce(const void* d_bf16, int B, int nv, int na, int Wd, void* dPv_bf16, void* dPa_bf16, hipStream_t stream);
 
-/* ---- fused "tail" chains of FusionBlock_FactorizedAVInteractions (csrc/fusion_tail.hip; ABI 4) ----------------------
- * Everything behind the block's first-level projections is per sample with 8 .. 32 rows per sample; ONE workgroup owns two
- * samples and walks a whole chain of the reference's small Linear / LayerNorm / GELU stages (models/fusion_blocks.py:46-59
- * proj, :245-252 k / v of the (v, a) pairs, :259-261 proj, :281-288 norm2 + Mlp and the residuals) instead of one batched
- * launch per stage.  The attentions in between stay on dav_attn_*.
- *   dav_fusion_tail1_fwd   o_v, o_a (cross-attention outputs, bf16 [B nv, D] / [B na, D])
- *                          -> xvo_b / xao_b = proj_v(o_v) / proj_a(o_a) (bf16, pre-residual), xmm1 rows [nmm, nF) = that + xmm32 rows
- *                          -> kv_p, ka_p [B 8, Da], vv_p, va_p [B 8, D] fp32 (k / v projections of the two halves, bias in the v half)
- *                          -> Kp [B nv na, Da], Vp [B nv na, D] bf16 (pair p = i na + j: P_v[i] + P_a[j], as dav_pair_expand)
- *   dav_fusion_tail2_fwd   o2 (pair-attention output, bf16 [B nmm, D]) -> xmm1 rows [0, nmm) = proj(o2) + xmm32 rows
- *                          -> h2 = LayerNorm(xmm1; g2, be2, eps2) (bf16 [B nF, D], mean2 / rstd2 [B nF])
- *                          -> u = GELU(fc1 h2), z = GELU'(pre-activation) (bf16 [B nF, Hd]) -> out = fc2 u + xmm1 (fp32 [B, nF, D])
- *   dav_fusion_tail2_bwd   g (fp32 gradient of out) -> gb (its bf16 copy), dz = (gb W2) z, dh2 = dz W1 (bf16),
- *                          g1 = LayerNorm-backward(xmm1, dh2) + g (fp32 + bf16 twin g1b), do2 = g1b rows [0, nmm) Wp (bf16 [B nmm, D]),
- *                          ln2_partial [B / 2][2 D]: per-workgroup dgamma | dbeta sums (dav_layernorm_bwd_reduce_grouped with rows = -(B / 2))
- *   dav_fusion_tail1_bwd   dKp, dVp (bf16, from the pair attention backward) -> dkv_p, dka_p, dvv_p, dva_p (bf16, as dav_pair_reduce)
- *                          -> dxvo_b / dxao_b = g1 rows + dkv_p Wk[:, :D] + dvv_p Wv[:, :D] / the [:, D:] halves (bf16)
- *                          -> dov = dxvo_b Wpv, doa = dxao_b Wpa (bf16: gradients of the cross-attention outputs)
- * W*: bf16 [out, in] weights; W*T: their bf16 transposes [in, out] (the backward contracts over the out features); b*: fp32.
- * Supported (dav_fusion_tail_supported): D = Hd = 768, Da in {192, 768}, tokens (16, 8, 8), B even; anything else returns
- * DAV_ERR_SHAPE and the caller uses the per-stage entry points.  Weight gradients are NOT produced here: every (dy, input)
- * operand pair they need is an output above and goes to dav_gemm_tn_grouped_bf16 as before. */
-typedef struct DavFusionTail {
-  int B, D, Da, Hd, nmm, nv, na;
-  float eps2;
-  const void *Wpv, *Wpa, *Wk, *Wv, *Wp, *W1, *W2;
-  const void *WpvT, *WpaT, *WkT, *WvT, *WpT, *W1T, *W2T;
-  const float *bpv, *bpa, *bk, *bv, *bp, *b1, *b2, *g2, *be2;
-  const float* xmm32;
-  const void *o_v, *o_a;
-  void *xvo_b, *xao_b;
-  float *kv_p, *ka_p, *vv_p, *va_p;
-  void *Kp, *Vp;
-  float* xmm1;
-  const void* o2;
-  void *h2, *z, *u;
-  float *mean2, *rstd2;
-  float* out;
-  const float* g;
-  void *gb, *dz, *dh2;
-  float* g1;
-  void *g1b, *do2;
-  float* ln2_partial;
-  const void *dKp, *dVp;
-  void *dkv_p, *dka_p, *dvv_p, *dva_p, *dxvo_b, *dxao_b, *dov, *doa;
-} DavFusionTail;
-int dav_fusion_tail_supported(int D, int Da, int Hd, int nmm, int nv, int na, int B);
-int dav_fusion_tail1_fwd(const DavFusionTail* p, hipStream_t stream);
-int dav_fusion_tail2_fwd(const DavFusionTail* p, hipStream_t stream);
-int dav_fusion_tail2_bwd(const DavFusionTail* p, hipStream_t stream);
-int dav_fusion_tail1_bwd(const DavFusionTail* p, hipStream_t stream);
-
 /* ---- casts, grad norm, optimizer ----------------------------------------------------------- */
 int dav_cast_bf16(const float* x, void* y_bf16, long n, hipStream_t stream);
 /* out = a + b (fp32, n % 4 == 0) and out_bf16 = bf16(out) in one pass: the gradient w.r.t. the fusion tokens is the sum of what the
@@ -322,8 +255,7 @@ int dav_l2norm(const float* x, long n, float scale, float* out, void* workspace,
  * util/misc.py:151-163 is its square root), (b) rewrite the bf16 weight mirror p_bf16, (c) zero the gradients
  * (Trainer.zero_grad) — one trip over the buffers instead of three.  keep_grad (NULL or one byte per segment): segments
  * with a non-zero byte are NOT zero-filled — their next gradient will be written, not accumulated (DavTnProblem.flags bit 0),
- * which saves the fill here and the read there; byte bit 1 (ABI 5): the segment is skipped altogether — the weight-gradient launch
- * that computed its gradient has already updated it (dav_gemm_tn_grouped_adamw_bf16).  All accesses are 16-byte ones: the buffers must be
+ * which saves the fill here and the read there; byte bit 1: the segment is skipped altogether.  All accesses are 16-byte ones: the buffers must be
  * 16-byte aligned (p_bf16 8-byte), n and every seg_end a multiple of 4 (FlatParams aligns segments to 64 elements).
  * gscale_dev (optional): device scalar from dav_step_guard, see there. */
 int dav_adamw_flat(float* p, float* g, float* m, float* v, void* p_bf16, long n, const long* seg_end, const float* hyper,

@@ -27,30 +27,9 @@ _FILE_RANK = {
 DEFAULT_TIMEOUT_S = 420            # hard per-test limit (pytest-timeout); spawning tests set their own, shorter, limits
 
 
-# Tests that start a fresh interpreter (a second `import torch`: seconds on most boxes, MINUTES on some — the GPU suite of the same tree took
-# 590 s on one box and 1339 s on another, all of the difference in these).  They are variants / end-to-end extras behind the in-process
-# parity tests; past this many seconds of session time they skip themselves (with the reason) instead of pushing the suite beyond the
-# driver's limit.  DAV_TEST_BUDGET_S overrides; 0 = no valve.
-SUBPROCESS_BUDGET_S = float(os.environ.get('DAV_TEST_BUDGET_S', '780'))
-_SESSION_T0 = [None]
-
-
-def pytest_sessionstart(session):
-    import time
-    _SESSION_T0[0] = time.time()
-
-
-def pytest_runtest_setup(item):
-    import time
-    if item.get_closest_marker('fresh_process') is not None and SUBPROCESS_BUDGET_S > 0 and _SESSION_T0[0] is not None:
-        spent = time.time() - _SESSION_T0[0]
-        if spent > SUBPROCESS_BUDGET_S:
-            pytest.skip(f'fresh-process test skipped: {spent:.0f} s of session time spent (budget {SUBPROCESS_BUDGET_S:.0f} s, DAV_TEST_BUDGET_S)')
-
-
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
-    config.addinivalue_line('markers', 'fresh_process: starts another interpreter; skips itself once the session is past its time budget')
+    config.addinivalue_line('markers', 'fresh_process: starts another interpreter (a second `import torch`: seconds on most boxes, a minute on some); never skipped')
     config.addinivalue_line('markers', 'timeout: per-test limit (pytest-timeout)')
 
 
@@ -86,16 +65,3 @@ def _collect_between_tests():
     yield
     if mode == 'collect':
         gc.collect()
-
-
-def pytest_sessionfinish(session, exitstatus):
-    """The oracle steps tests/test_hip_parity.py hands to its child processes (~1 GB at B = 64) do not outlive the session that wrote them."""
-    if os.environ.get('DAV_TEST_ORACLE_FROM_CACHE'):
-        return                                   # a child: the files belong to its parent
-    import glob
-    import tempfile
-    for f in glob.glob(os.path.join(tempfile.gettempdir(), f'dav_oracle_step_{os.getuid()}_*.pt')):
-        try:
-            os.remove(f)
-        except OSError:
-            pass

@@ -48,14 +48,15 @@ def register_archs():
 
 
 ARCH_OF = {'micro': 'vit_micro', 'micro_token': 'vit_micro', 'micro_dense': 'vit_micro', 'micro_swin': 'vit_micro', 'tiny': 'vit_tiny',
-           'base': 'vit_base'}
+           'base': 'vit_base', 'base_as': 'vit_base', 'large': 'vit_large'}
 
 
 def build_reference(name):
     cfg = CONFIGS[name]
+    pt = None if ARCH_OF[name] == 'vit_large' else ''       # models/vits.py:150-151: vit_large asserts on anything but None
     enc = DeepAVFusion(
-        image_arch=ARCH_OF[name], image_pretrained='', image_size=cfg.image_size,
-        audio_arch=ARCH_OF[name], audio_pretrained='', audio_size=cfg.audio_size,
+        image_arch=ARCH_OF[name], image_pretrained=pt, image_size=cfg.image_size,
+        audio_arch=ARCH_OF[name], audio_pretrained=pt, audio_size=cfg.audio_size,
         fusion_arch=cfg.fusion_arch, fusion_layers='all', num_fusion_tkns=cfg.fusion_tkns,
         fusion_mlp_ratio=cfg.fusion_mlp_ratio, fusion_attn_ratio=cfg.fusion_attn_ratio,
         fusion_num_heads=cfg.fusion_num_heads)
@@ -255,6 +256,43 @@ def gen_e2e(name, B, seed, keep_preds):
     print(f'e2e[{name}] loss_image={float(li):.6f} loss_audio={float(la):.6f} gnorm={float(out["grad_norm_total"]):.6f}')
 
 
+def _compact_grads(model, out, full_max=256, budget=150000):
+    """Every parameter's gradient norm, the total norm, every SMALL gradient in full and a strided sample of every large one
+    (the stride — odd, so that it walks across rows — keeps the samples of all large gradients together near ``budget`` floats)."""
+    total = sum(p.numel() for p in model.parameters() if p.grad is not None and p.numel() > full_max)
+    stride = max(97, total // budget) | 1
+    names, norms = [], []
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        names.append(n)
+        norms.append(float(p.grad.double().norm()))
+        g = p.grad.detach().reshape(-1)
+        out['grad.' + n] = (g if g.numel() <= full_max else g[::stride]).numpy().astype(np.float32).copy()
+    out['grad_names'] = np.array(names)
+    out['grad_norms'] = np.array(norms, dtype=np.float64)
+    out['grad_stride'] = np.int64(stride)
+    out['grad_full_max'] = np.int64(full_max)
+
+
+def gen_e2e_full(name, B, seed):
+    """The BASELINE.json configurations at their published widths (ViT-B cfg 2 / cfg 3, ViT-L cfg 4), small batch: what the imported
+    reference computes — losses, strided prediction samples, every gradient's norm, small gradients in full and a strided sample of
+    the large ones (the fixture stays near 1 MB)."""
+    cfg, model, sd = build_reference(name)
+    image, audio, ni, na = O.synthetic_batch(cfg, B, seed=seed)
+    model.zero_grad()
+    with InjectNoise([ni, na]):
+        li, la, pi, pa = model(image, audio)
+    (li + la).backward()
+    out = {'loss_image': li.detach().numpy(), 'loss_audio': la.detach().numpy(), 'B': np.int64(B), 'seed': np.int64(seed),
+           'pred_image_sub': pi.detach().numpy()[:, ::5, ::11].copy(), 'pred_audio_sub': pa.detach().numpy()[:, ::5, ::11].copy(),
+           'grad_norm_total': np.float64(ref_misc.get_grad_norm_(model.parameters()).item())}
+    _compact_grads(model, out)
+    np.savez_compressed(os.path.join(OUT, f'e2e_{name}.npz'), **out)
+    print(f'e2e_full[{name}] B={B} loss_image={float(li):.6f} loss_audio={float(la):.6f} gnorm={float(out["grad_norm_total"]):.6f}')
+
+
 class _NS(dict):
     """attribute + .get() access, enough for util/lr_sched.py's ``args.opt``."""
     __getattr__ = dict.__getitem__
@@ -378,16 +416,21 @@ def gen_video(name, B, seed):
     out.update(x_video=xv.detach().numpy(), x_audio=xa.detach().numpy(), x_fusion=xf.detach().numpy(),
                loss_sum=np.float64((xv.sum() + xa.sum() + xf.sum()).item()),        # the reference probe's loss (:185)
                loss_probe=np.float64(loss.item()))
-    names, norms = [], []
-    for n, p in model.named_parameters():
-        if p.grad is not None:
-            names.append(n)
-            norms.append(float(p.grad.double().norm()))
-    out['grad_names'] = np.array(names)
-    out['grad_norms'] = np.array(norms, dtype=np.float64)
-    for n in ('fusion_tokens', 'video.patch_embed.proj.weight', 'video.blocks.0.attn.qkv.bias', 'audio.patch_embed.proj.bias',
-              'fusion_blocks.1.attn.k.weight', 'video.norm.weight'):
-        out['grad.' + n] = dict(model.named_parameters())[n].grad.numpy().copy()
+    if name == 'video_base':                                      # full width: compact form (see gen_e2e_full)
+        _compact_grads(model, out)
+        for k in ('x_video', 'x_audio', 'x_fusion'):
+            out[k + '_sub'] = out.pop(k)[:, ::3, ::7].copy()
+    else:
+        names, norms = [], []
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                names.append(n)
+                norms.append(float(p.grad.double().norm()))
+        out['grad_names'] = np.array(names)
+        out['grad_norms'] = np.array(norms, dtype=np.float64)
+        for n in ('fusion_tokens', 'video.patch_embed.proj.weight', 'video.blocks.0.attn.qkv.bias', 'audio.patch_embed.proj.bias',
+                  'fusion_blocks.1.attn.k.weight', 'video.norm.weight'):
+            out['grad.' + n] = dict(model.named_parameters())[n].grad.numpy().copy()
     # embeddings per layer (return_embs=True) of a second call pin that surface too
     with torch.no_grad():
         embs = model(video, audio, return_embs=True)[3]
@@ -461,7 +504,10 @@ if __name__ == '__main__':
             'droppath': gen_droppath,
             'e2e_micro_token': lambda: gen_e2e('micro_token', 3, 23, False),
             'e2e_micro_dense': lambda: gen_e2e('micro_dense', 3, 24, False),
-            'e2e_micro_swin': lambda: gen_e2e('micro_swin', 2, 25, True)}
+            'e2e_micro_swin': lambda: gen_e2e('micro_swin', 2, 25, True),
+            # the published configurations at full width (BASELINE.json configs[1] .. [4]), small batches
+            'e2e_base': lambda: gen_e2e_full('base', 2, 51), 'e2e_base_as': lambda: gen_e2e_full('base_as', 2, 52),
+            'e2e_large': lambda: gen_e2e_full('large', 1, 53), 'video_base': lambda: gen_video('video_base', 1, 54)}
     if a.curve:
         jobs = {'curve': gen_curve}
     for k, f in jobs.items():

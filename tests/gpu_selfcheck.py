@@ -254,6 +254,62 @@ def gemm_tn():
     report('gemm_tn rowmaps+ldc', rel(Cw, ref), 2e-4)
 
 
+@check
+def gemm_tn_gang():
+    """dav_gemm_tn_gang_bf16: the queued weight gradients of several layers as one persistent launch of 256 x 256 tiles."""
+    # odd K-tile counts (Mc = 64 * odd), N / K below, across and beyond one tile, ragged last tiles, a long contraction
+    shapes = [(512, 768, 768), (3136, 192, 768), (4032, 2304, 768), (3136, 768, 3072), (640, 8, 264), (14592, 512, 1536), (2048, 520, 776),
+              (64, 256, 256), (192, 1032, 40), (5184, 2304, 768), (6080, 3072, 1024)]
+    for mode in ('accumulate', 'written', 'mixed'):
+        probs, refs = [], []
+        for i, (Mc, N, K) in enumerate(shapes):
+            A, Bm = rnd(Mc, N, dtype=BF16, seed=160 + i), rnd(Mc, K, dtype=BF16, seed=170 + i)
+            ow = mode == 'written' or (mode == 'mixed' and i % 2 == 0)
+            C = torch.full((N, K), float('nan') if ow else 0.25, device=dev)
+            bg = torch.full((N,), 0.5, device=dev) if i % 3 != 1 else None
+            probs.append(dict(A=A, B=Bm, Mc=Mc, N=N, K=K, C=C, lda=N, ldb=K, ldc=K, bias_grad=bg, overwrite=ow))
+            refs.append((C, (0.0 if ow else 0.25) + A.float().t() @ Bm.float(), bg, None if bg is None else 0.5 + A.float().sum(0)))
+        ops.gemm_tn_gang(probs)
+        for i, (C, rc, bg, rb) in enumerate(refs):
+            report(f'gemm_tn_gang {mode} #{i} {shapes[i]} C', rel(C, rc), 2e-4)
+            if bg is not None:
+                report(f'gemm_tn_gang {mode} #{i} bias', rel(bg, rb), 2e-4)
+    # bit-repeatable whoever draws which ticket: the same launch twice, written tiles
+    Cs = []
+    for _ in range(2):
+        for pr in probs:
+            pr['overwrite'] = True
+            pr['C'] = torch.empty_like(pr['C'])
+        ops.gemm_tn_gang(probs)
+        torch.cuda.synchronize()
+        Cs.append([pr['C'].clone() for pr in probs])
+    report('gemm_tn_gang bit-repeatable', float(max((a != b).sum() for a, b in zip(*Cs))), 0.0)
+    # row maps on both operands + a column block of a wider gradient (ldc), rows-per-batch below and above 64
+    for (Bsz, rpb, tot, offa, offb, N, K) in [(16, 12, 20, 3, 8, 320, 136), (8, 81, 95, 14, 0, 768, 512), (64, 8, 40, 32, 0, 264, 768)]:
+        Af, Bf = rnd(Bsz * tot, N, dtype=BF16, seed=113), rnd(Bsz * tot, K, dtype=BF16, seed=114)
+        Mc = Bsz * rpb
+        if Mc % 64:
+            continue
+        As = Af.view(Bsz, tot, N)[:, offa:offa + rpb].reshape(-1, N)
+        Bs = Bf.view(Bsz, tot, K)[:, offb:offb + rpb].reshape(-1, K)
+        Cw = torch.zeros(N, 2 * K, device=dev)
+        ops.gemm_tn_gang([dict(A=Af, B=Bf, Mc=Mc, N=N, K=K, C=Cw.view(-1)[K:], lda=N, ldb=K, ldc=2 * K, a_rowmap=(rpb, tot, offa),
+                               b_rowmap=(rpb, tot, offb), bias_grad=None)])
+        ref = torch.zeros_like(Cw)
+        ref[:, K:] = As.float().t() @ Bs.float()
+        report(f'gemm_tn_gang rowmaps+ldc rpb={rpb}', rel(Cw, ref), 2e-4)
+    # a few hundred problems in one launch (several table-writer launches)
+    many, refs = [], []
+    for i in range(150):
+        Mc, N, K = 64 * (1 + i % 5), 8 * (1 + (7 * i) % 60), 8 * (1 + (11 * i) % 70)
+        A, Bm = rnd(Mc, N, dtype=BF16, seed=300 + i), rnd(Mc, K, dtype=BF16, seed=500 + i)
+        C = torch.zeros(N, K, device=dev)
+        many.append(dict(A=A, B=Bm, Mc=Mc, N=N, K=K, C=C, lda=N, ldb=K, ldc=K, bias_grad=None, overwrite=bool(i & 1)))
+        refs.append(A.float().t() @ Bm.float())
+    ops.gemm_tn_gang(many)
+    report('gemm_tn_gang 150 problems', max(rel(pr['C'], r) for pr, r in zip(many, refs)), 2e-4)
+
+
 def ref_attn(q, k, v, scale):
     s = (q @ k.transpose(-2, -1)) * scale
     return s.softmax(-1) @ v

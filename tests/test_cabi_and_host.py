@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in include/dav_kernels.h but not exported'
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.dav_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.dav_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_no_cpu_fallback():
@@ -245,7 +245,8 @@ def test_every_entry_point_rejects_empty_input_with_the_documented_code():
     lib = _lib.load()
     host_only = {'dav_abi_version', 'dav_build_flags', 'dav_last_error_string', 'dav_tune', 'dav_nt_issue_log', 'dav_nt_tune_set', 'dav_batch_begin',
                  'dav_batch_lane', 'dav_batch_region', 'dav_batch_skip', 'dav_batch_suspend', 'dav_batch_end', 'dav_batch_abort',
-                 'dav_batch_stats', 'dav_layernorm_bwd_workspace_bytes', 'dav_l2norm_workspace_bytes', 'dav_fusion_tail_supported'}
+                 'dav_batch_stats', 'dav_layernorm_bwd_workspace_bytes', 'dav_l2norm_workspace_bytes',
+                 'dav_gemm_tn_gang_workspace_bytes'}
     kernels = sorted(set(_lib.SIGNATURES) - host_only)
     assert len(kernels) >= 40
     for name in kernels:
@@ -295,6 +296,20 @@ def test_error_codes_for_dtype_alignment_and_workspace():
     args[8] = p(4096)                                                          # dy_bf16
     args[-3], args[-2] = p(8192), C.c_size_t(need - 1)                         # workspace, workspace_bytes
     assert lib.dav_layernorm_bwd(*args) == -3
+    # dav_gemm_tn_gang_bf16(problems, count, workspace, workspace_bytes, stream): the workspace query prices header + problem table +
+    # one ticket per 256 x 256 tile; a smaller workspace, a misaligned one and a problem asking for the fused optimizer pass are refused
+    pr = (_lib.DavTnProblem * 2)()
+    for q, (N, K) in zip(pr, ((768, 3072), (192, 264))):
+        q.A, q.B, q.C = 4096, 8192, 12288
+        q.Mc, q.N, q.K, q.lda, q.ldb, q.ldc = 3136, N, K, N, K, K
+    need = lib.dav_gemm_tn_gang_workspace_bytes(pr, 2)
+    assert need == 128 + 2 * 96 + 8 * (3 * 12 + 1 * 2)
+    assert lib.dav_gemm_tn_gang_bf16(pr, 2, p(1 << 20), C.c_size_t(need - 1), None) == -3
+    assert lib.dav_gemm_tn_gang_bf16(pr, 2, p((1 << 20) + 4), C.c_size_t(need), None) == -5
+    pr[1].flags = 3
+    assert lib.dav_gemm_tn_gang_workspace_bytes(pr, 2) == 0 and lib.dav_gemm_tn_gang_bf16(pr, 2, p(1 << 20), C.c_size_t(need), None) == -1
+    pr[1].flags, pr[1].Mc = 0, 100
+    assert lib.dav_gemm_tn_gang_workspace_bytes(pr, 2) == 0
     assert _lib.ERRORS[-2] and _lib.ERRORS[-3] and _lib.ERRORS[-5]
 
 
@@ -338,56 +353,6 @@ def test_written_first_contribution_bookkeeping(monkeypatch):
     with E.deferred_wgrads():
         E._DEFERRED.append(prob(0, 64))
     assert launches and not launches[0][0].get('overwrite')
-
-
-def test_fused_adamw_bookkeeping(monkeypatch):
-    """engine.flush_wgrads under fused_adamw_begin(): which weight-gradient problems carry their weight's AdamW update
-    (DavTnProblem.flags bit 1) — only WRITTEN full-weight problems of weights that see exactly ONE problem per step (counted in a warm-up
-    pass by wgrad_contrib_begin / _end).  Pure host logic, the grouped launch is intercepted."""
-    from deepavfusion_amd import engine as E, ops
-    launches = []
-    monkeypatch.setattr(ops, 'gemm_tn_grouped', lambda probs, opt=None: launches.append(([dict(p) for p in probs], opt)))
-    lin = [torch.nn.Linear(8, 8) for _ in range(4)]
-    g = [torch.zeros(8, 8) for _ in range(4)]
-
-    def prob(i, mc, full=True):
-        return dict(A=None, B=None, Mc=mc, N=8, K=8 if full else 4, C=g[i], lda=8, ldb=8, ldc=8, bias_grad=None, ready=(),
-                    gbase=g[i].data_ptr(), weight=lin[i].weight if full else None)
-
-    def one_step():
-        with E.deferred_wgrads():
-            E._DEFERRED.extend([prob(0, 128), prob(1, 64), prob(1, 192), prob(2, 64, full=False)])      # 1: two problems; 2: a column block
-            E.flush_wgrads()
-            E._DEFERRED.append(prob(3, 64))
-    # warm-up pass: count
-    E.wgrad_contrib_begin()
-    one_step()
-    contrib = E.wgrad_contrib_end()
-    assert E._CONTRIB is None
-    assert contrib[g[0].data_ptr()] == 1 and contrib[g[1].data_ptr()] == 2 and contrib[g[2].data_ptr()] >= 2 and contrib[g[3].data_ptr()] == 1
-    allowed = {id(lin[i].weight) for i in range(4) if contrib[g[i].data_ptr()] == 1}
-    assert allowed == {id(lin[0].weight), id(lin[3].weight)}
-    # captured pass: written-first + fused
-    launches.clear()
-    opt = dict(tag='the optimizer buffers')
-    E.wgrad_overwrite_begin()
-    E.fused_adamw_begin(opt, {id(lin[i].weight): 10 + i for i in range(4)}, allowed)
-    one_step()
-    used = E.fused_adamw_end()
-    E.wgrad_overwrite_end()
-    assert E._FUSED is None
-    assert all(o is opt for _, o in launches)
-    flat = {(p['C'].data_ptr(), p['Mc']): p for l, _ in launches for p in l}
-    assert flat[(g[0].data_ptr(), 128)].get('fused_idx') == 10 and flat[(g[3].data_ptr(), 64)].get('fused_idx') == 13
-    assert all(flat[k].get('fused_idx') is None for k in flat if k[0] in (g[1].data_ptr(), g[2].data_ptr()))
-    assert all(p.get('overwrite') for p in flat.values() if p.get('fused_idx') is not None)            # a fused tile is a written one
-    assert {id(p) for p in used} == allowed
-    # outside the bracket nothing is fused and the launch is called without the optimizer buffers
-    launches.clear()
-    monkeypatch.setattr(ops, 'gemm_tn_grouped', lambda probs: launches.append([dict(p) for p in probs]))
-    with E.deferred_wgrads():
-        E._DEFERRED.append(prob(0, 64))
-    assert launches and launches[0][0].get('fused_idx') is None
 
 
 def test_bench_starts_its_own_ranks_when_launched_plainly():

@@ -175,6 +175,62 @@ def test_end_to_end(golden, name):
     assert abs(total - float(g['grad_norm_total'])) < 1e-4 * float(g['grad_norm_total'])
 
 
+def _sampled(gradient, g):
+    """the compact form of tests/golden/gen_golden.py::_compact_grads: small gradients in full, a strided sample of large ones"""
+    flat = gradient.detach().reshape(-1)
+    return (flat if flat.numel() <= int(g['grad_full_max']) else flat[::int(g['grad_stride'])]).numpy()
+
+
+@pytest.mark.parametrize('name', ['base', 'base_as', 'large'])
+def test_published_configs_at_full_width(golden, name):
+    """BASELINE.json configs[1] / [2] / [3] at their published widths and depths (ViT-B, ViT-B with the AudioSet fusion widths, ViT-L),
+    batch 2 / 2 / 1: the oracle against what the imported reference computed (losses, prediction samples, every gradient's norm,
+    sampled gradients) — the pin of the restatement at the sizes the GPU numbers are published for."""
+    g = golden(f'e2e_{name}')
+    cfg = CONFIGS[name]
+    sd = {k: v.clone().requires_grad_(k not in O.FROZEN and not O.is_buffer(k)) for k, v in O.closed_form_state(cfg, 0).items()}
+    image, audio, ni, na = O.synthetic_batch(cfg, int(g['B']), seed=int(g['seed']))
+    li, la, pi, pa, aux = O.avmae_forward(sd, cfg, image, audio, ni, na)
+    close(li.detach().numpy(), g['loss_image'])
+    close(la.detach().numpy(), g['loss_audio'])
+    close(pi.detach().numpy()[:, ::5, ::11], g['pred_image_sub'], rtol=1e-4)
+    close(pa.detach().numpy()[:, ::5, ::11], g['pred_audio_sub'], rtol=1e-4)
+    (li + la).backward()
+    norms = dict(zip(g['grad_names'].tolist(), g['grad_norms'].tolist()))
+    assert set(norms) == {k for k, v in sd.items() if v.requires_grad}
+    for k, ref in norms.items():
+        got = float(sd[k].grad.double().norm())
+        assert abs(got - ref) <= 5e-4 * max(ref, 1e-6) + 1e-6, (k, got, ref)
+        a, b = _sampled(sd[k].grad, g).astype(np.float64), g['grad.' + k].astype(np.float64)
+        # (exactly-zero gradients — the key biases, softmax shift invariance — are rounding noise on both sides: absolute floor)
+        assert np.abs(a - b).max() <= 5e-4 * np.abs(b).max() + 1e-7 * float(g['grad_norm_total']), (k, np.abs(a - b).max(), np.abs(b).max())
+    total = T.global_grad_norm([v.grad for v in sd.values() if v.grad is not None])
+    assert abs(total - float(g['grad_norm_total'])) < 1e-4 * float(g['grad_norm_total'])
+
+
+def test_video_base_at_full_width(golden):
+    """BASELINE.json configs[4] (ViT-B video early fusion, 8 x 224 x 224 clip + 3 s of audio) at B = 1 through the reference."""
+    g = golden('e2e_video_base')
+    cfg = CONFIGS['video_base']
+    sd = {k: v.clone().requires_grad_(k not in O.FROZEN) for k, v in O.closed_form_state(cfg, 0).items()}
+    video, audio = O.synthetic_video_batch(cfg, int(g['B']), seed=int(g['seed']))
+    xv, xa, xf = O.video_earlyfusion_forward(sd, cfg, video, audio)
+    for got, key in ((xv, 'x_video_sub'), (xa, 'x_audio_sub'), (xf, 'x_fusion_sub')):
+        close(got.detach().numpy()[:, ::3, ::7], g[key], rtol=1e-4)
+    w = probe_weights([xv.shape, xa.shape, xf.shape], int(g['seed']) + 1)
+    loss = (xv * w[0]).sum() + (xa * w[1]).sum() + (xf * w[2]).sum()
+    assert abs(float(loss) - float(g['loss_probe'])) < 2e-4 * abs(float(g['loss_probe']))
+    loss.backward()
+    norms = dict(zip(g['grad_names'].tolist(), g['grad_norms'].tolist()))
+    assert set(norms) == {k for k, v in sd.items() if v.requires_grad}
+    gtot = float(np.sqrt(sum(v * v for v in norms.values())))
+    for k, ref in norms.items():
+        got = float(sd[k].grad.double().norm())
+        assert abs(got - ref) <= 5e-4 * max(ref, 1e-6) + 1e-5, (k, got, ref)
+        a, b = _sampled(sd[k].grad, g).astype(np.float64), g['grad.' + k].astype(np.float64)
+        assert np.abs(a - b).max() <= 5e-4 * np.abs(b).max() + 1e-7 * gtot, (k, np.abs(a - b).max(), np.abs(b).max())
+
+
 def probe_weights(shapes, seed):
     rs = np.random.RandomState(seed)
     return [torch.from_numpy(rs.standard_normal(tuple(s)).astype(np.float32)) for s in shapes]

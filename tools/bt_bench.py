@@ -9,13 +9,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+import _libsel  # noqa: E402,F401
 from deepavfusion_amd import _lib  # noqa: E402
-if os.environ.get('DAV_BENCH_LIB'):
-    _lib.LIB_PATH = os.environ['DAV_BENCH_LIB']
-    import ctypes
-    _lib.ABI_VERSION = ctypes.CDLL(_lib.LIB_PATH).dav_abi_version()
-    for k in [k for k in _lib.SIGNATURES if not hasattr(ctypes.CDLL(_lib.LIB_PATH), k)]:
-        del _lib.SIGNATURES[k]
 from deepavfusion_amd import ops  # noqa: E402
 
 dev = torch.device('cuda')

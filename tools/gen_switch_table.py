@@ -24,37 +24,26 @@ S = {
     'DAV_STREAMS': ('1', 'schedule', "0: everything on the current stream (serial schedule; tools/instep_gemm_bound.py uses it)", 'tools/instep_gemm_bound.py (profiles/r04_gemm_instep_bound.txt)'),
     'DAV_DEC_STREAMS': ('0', 'schedule', "lanes schedule only: 1 = the two decoders on two streams all the same", '- (A/B in DESIGN_HISTORY section 4)'),
     'DAV_DEC_WGRAD_JOINT': ('1', 'schedule', "both decoders' weight-gradient problems in one grouped launch after both backward passes", 'test_baseline_config_shapes_vs_oracle (default path)'),
-    'DAV_WGRAD_SIDE': ('0', 'schedule', "1: captured step: a layer's grouped weight-gradient launch goes out on a side stream (parallel graph branch) instead of between two layers of the input-gradient chain (profiles/r04_wgrad_side.txt)", 'test_wgrad_side_stream_equals_the_serial_placement'),
-    'DAV_WGRAD_SIDE_PRIO': ('0', 'schedule', "dispatch priority of that stream (-1 high)", '- (A/B in profiles/r04_wgrad_side.txt)'),
-    'DAV_WGRAD_STREAM': ('0', 'schedule', "1: weight-gradient GEMMs on their own stream (measured slower)", '- (A/B in DESIGN_HISTORY)'),
+    'DAV_WGRAD_GANG': ('1', 'kernel', "weight gradients of a flush as ONE gang-scheduled launch of 256 x 256 tiles (dav_gemm_tn_gang_bf16: per-XCD ticket queues of tiles that share operand panels); 0 = the 128 x 128 grouped kernel, one launch per layer (profiles/r05_tn_gang_*.txt)", 'test_gang_weight_gradients_equal_the_grouped_kernel_and_the_oracle, test_baseline_config_shapes_vs_oracle (default path), tools/tn_gang_bench.py check()'),
+    'DAV_WGRAD_GANG_MIN_TILES': ('128', 'kernel', "flushes with fewer 256 x 256 tiles than this keep the 128 x 128 grouped kernel (a persistent grid of one workgroup per CU needs tiles to balance)", 'test_gang_weight_gradients_equal_the_grouped_kernel_and_the_oracle'),
+    'DAV_WGRAD_MERGE': ('0 (all layers of a captured segment)', 'schedule', "encoder layers whose queued weight gradients share one launch (n > 0: a flush every n layers)", 'test_gang_weight_gradients_equal_the_grouped_kernel_and_the_oracle (1 and 0)'),
+    'DAV_TN_GANG_DEBUG': ('0', 'debug', "dav_gemm_tn_gang_bf16 timing ablations: 2 = no epilogue, 4 = no MFMAs, 8 / 16 = queue chosen by block id / by a deliberately wrong placement instead of the hardware XCC id", '- (tools/tn_gang_bench.py, profiles/r05_tn_gang_*.txt)'),
+    'DAV_TN_GANG_WGS': ('CU count', 'kernel', "persistent workgroups of the gang launch", '- (tuning knob)'),
     'DAV_GROUPED_WGRAD': ('1', 'kernel', "0: one weight-gradient launch per Linear instead of one grouped launch per layer", 'test_batch64_grouped_wgrad_path_vs_oracle (default), gpu_selfcheck gemm_tn family'),
     'DAV_WGRAD_OVERWRITE': ('1', 'kernel', "captured step: the first weight-gradient contribution to a Linear weight WRITES its tile (AdamW skips that zero-fill); 0 = accumulate / zero-fill", 'test_written_first_gradients_equal_accumulated_ones'),
     'DAV_ADD_CAST': ('1', 'kernel', "sum of the fusion tokens' two gradient streams + its bf16 copy in one pass (dav_add_cast); 0 = torch add", 'test_end_to_end_vs_oracle_and_golden (default path)'),
     'DAV_ATTN_CTX': ('1', 'kernel', "the dQ kernel zero-fills the q slots of the fusion-token context rows (dav_attn_bwd_ctx); 0 = a torch fill pass", 'gpu_selfcheck attention family, e2e tests'),
     'DAV_ATTN_PAIR': ('1', 'kernel', "d = 32 attention: adjacent heads on the same XCD (pair_heads); 0 = linear (batch, head) order", 'gpu_selfcheck attention family (both orders)'),
-    'DAV_ATTN_FUSED_BWD': ('0', 'kernel', "1: d = 32 attention backward as ONE kernel from one recomputation of the probabilities (attn_bwd_fused_body; no faster: profiles/r04_attn_fused_bwd.txt)", 'test_opt_in_fused_attention_backward_matches_reference'),
-    'DAV_FUSION_TAIL': ('0', 'kernel', "1: the fused tail chains of the factorised fusion block (csrc/fusion_tail.hip: 15 -> 9 launches per layer; slower inside the step, profiles/r04_fusion_tails.txt)", 'test_fusion_tails_equal_the_per_stage_launches_and_the_oracle, test_whole_step_with_the_opt_in_fused_fusion_tails_vs_oracle'),
     'DAV_FUSION_PRIO': ('0', 'schedule', "dispatch priority of the fusion block's stream (-1 = high, 1 = low; profiles/r04_fusion_tails.txt, r04_stream_priority_ab.txt)", '- (A/B only)'),
     'DAV_NT_TUNE': ('1', 'kernel', "0: ignore the tuned tile-configuration table (deepavfusion_amd/tuning/nt_gfx950.json), rules only", 'test_nt_tuning_table_loads_and_rejects_malformed_blobs, test_baseline_config_shapes_vs_oracle[large-32] (entries must fire)'),
     'DAV_NT_TUNE_FILE': ('tuning/nt_gfx950.json', 'kernel', "another tuned table", 'test_nt_tuning_table_loads_and_rejects_malformed_blobs'),
     'DAV_NT_WIDE': ('1', 'kernel', "0: no 128 x 256 tiles for the K <= 512 wide-output GEMMs (rule of nt2_issue_auto)", 'gpu_selfcheck gemm_nt family (explicit configurations)'),
-    'DAV_NT_PERSIST': ('0', 'kernel', "n: single NT launches of the 128 x 128 / 128 x 64 / 64 x 64 tiles run on at most n 8-wave workgroup slots, each workgroup walking several tiles (gemm_nt2_persist_kernel); a wash in the step (profiles/r04_nt_persist.txt)", '- (same body; GPU parity subset run with it, profiles/r04_nt_persist.txt)'),
     'DAV_NT_SMALL': ('5', 'kernel', "tile configuration of launches below DAV_NT_T5 tiles: 5 = 64 x 64 two-stage ring, 7 = four-stage ring", 'gpu_selfcheck gemm_nt family'),
     'DAV_NT_T5': ('100', 'kernel', "tile-count threshold between the 64 x 64 and the 128 x 64 configurations", '- (tuning knob)'),
     'DAV_NT_T8': ('400', 'kernel', "tile-count threshold between the 128 x 64 and the 128 x 128 configurations", '- (tuning knob)'),
-    'DAV_NT256': ('0', 'kernel', "1: the 256 x 256 NT body (configuration 60) by rule (faster alone, slower in the step: profiles/r03_nt256_instep_ab.txt)", 'test_bench_workload_with_the_opt_in_256_tile_kernels_vs_oracle'),
-    'DAV_NT256_N': ('1024', 'kernel', "minimum output width for the DAV_NT256 rule", 'test_bench_workload_with_the_opt_in_256_tile_kernels_vs_oracle'),
-    'DAV_NT256_TILES': ('150', 'kernel', "minimum 256 x 256 tile count for the DAV_NT256 rule", 'test_bench_workload_with_the_opt_in_256_tile_kernels_vs_oracle'),
     'DAV_NT_LD': ('0', 'kernel', "EXPERIMENTAL builds only: loader-wave variant (configuration 51) in place of configuration 3", '- (make EXPERIMENTAL=1)'),
-    'DAV_TN256': ('0', 'kernel', "EXPERIMENTAL builds only (round 4): 1 = the persistent 256 x 256 stream-K weight-gradient kernel (slower: atomics)", 'test_tn256_weight_gradient_kernel_matches_reference (EXPERIMENTAL builds)'),
-    'DAV_TN256_MIN': ('512', 'kernel', "EXPERIMENTAL builds only: K-tile pairs below which DAV_TN256 falls back to the 128 x 128 kernel", 'test_tn256_weight_gradient_kernel_matches_reference (EXPERIMENTAL builds)'),
-    'DAV_TN_TILE': ('128', 'kernel', "EXPERIMENTAL builds only: 256 / 257 = 256 x 128 owner-per-tile weight-gradient tiles on 64-row x 2 / 32-row x 3 rings (slower: profiles/r04_tn256x128.txt)", '- (gpu_selfcheck gemm_tn family run with it, profiles/r04_tn256x128.txt)'),
     'DAV_TN_XCD': ('1', 'kernel', "weight-gradient tiles: one contiguous run of each problem's tiles per XCD; 0 = every 8th tile", 'gpu_selfcheck gemm_tn family'),
-    'DAV_EARLY_ADAMW': ('0', 'optimizer', "1: AdamW on ranges of the flat buffer as their gradients become final, on a side stream (slower)", 'test_early_adamw_ranges_equal_the_single_pass'),
-    'DAV_FUSED_ADAMW': ('0', 'optimizer', "1: captured single-process step: a Linear weight whose one weight-gradient problem is a written tile set is updated by the workgroups that own those tiles (dav_gemm_tn_grouped_adamw_bf16); the optimizer kernel covers the rest (profiles/r04_fused_adamw.txt)", 'test_fused_adamw_equals_the_optimizer_kernel'),
-    'DAV_DEFER_ADAMW': ('0', 'optimizer', "1: the update with step i's gradients runs at the top of replay i + 1, layer by layer on a side stream under that replay's forward; GraphedStep.flush() applies the last one (profiles/r04_defer_adamw.txt)", 'test_deferred_adamw_equals_the_plain_schedule'),
     'DAV_ADAMW_WGS': ('0 (whole grid)', 'optimizer', "cap on the AdamW kernel's workgroups (a narrow grid trickles beside other work instead of evicting it)", '- (element-wise grid-stride loop; profiles/r04_defer_adamw.txt)'),
-    'DAV_EARLY_ADAMW_CUTS': ('depth,9,6,3,1', 'optimizer', "layers after which DAV_EARLY_ADAMW launches a range", 'test_early_adamw_ranges_equal_the_single_pass'),
     'DAV_SEGMENTS': ('0 (1 graph; 5 when data-parallel)', 'dp', "graphs per captured step (any run)", 'test_segmented_graph_step_matches_single_graph_and_schedules_every_bucket'),
     'DAV_DP_SEGMENTS': ('5', 'dp', "graphs per captured data-parallel step, between which finished gradient buckets are reduced", 'test_dp_switches_over_one_rank_rccl'),
     'DAV_DP_ALGO': ('allreduce', 'dp', "allreduce | rs_ag (reduce-scatter + all-gather per bucket)", 'test_dp_switches_world2_and_world4_gloo, test_dp_switches_over_one_rank_rccl'),

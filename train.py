@@ -195,8 +195,6 @@ def train_one_epoch(loader, trainer, epoch, device, args, graphed=None, frontend
                   f'amp_scale {amp_scale}  lr {lr:.3e}  {seen / (time.time() - t0):.1f} pairs/s/GPU')
         if args.debug and step == 100:
             break
-    if graphed is not None:
-        graphed.flush()              # (deferred AdamW: the last step's update, before anything reads the parameters)
     trainer.zero_grad()
 
 
