@@ -1413,6 +1413,8 @@ void nt2_issue_auto(const void* const* params_in, int n, hipStream_t stream) {
   else if (cfg == 3 && wide && t256 >= 512 && nt_wide_on()) cfg = 44;
 #ifdef DAV_EXPERIMENTAL
   if (cfg == 3 && nt_ld_on()) cfg = 51;
+  static const bool nt_pipe = [] { const char* e = getenv("DAV_NT_PIPE"); return e && e[0] == '1'; }();      // A/B only: the software-pipelined k-loop in place of configuration 3
+  if (cfg == 3 && nt_pipe) cfg = 31;
 #endif
   if (cfg == 60 && !all256) cfg = 3;                     // (an explicit or tuned 60 on a group the 256 x 256 body cannot take)
   nt_log_issue(cfg, BT, params, n);
@@ -1423,6 +1425,7 @@ void nt2_issue_auto(const void* const* params_in, int n, hipStream_t stream) {
     case 43: nt2_issue<256, 128, 4, 2, 3, BT, 32>(params, n, stream); break;      // (43 / 46: tools/mix_sweep.py candidates)
     case 46: nt2_issue<128, 256, 2, 4, 2, BT, 32>(params, n, stream); break;
 #ifdef DAV_EXPERIMENTAL
+    case 31: nt2_issue<128, 128, 2, 4, 2, BT, 64, 1>(params, n, stream); break;      // software-pipelined k-loop
     case 50: nt2_issue<128, 128, 4, 2, 2, BT, 64, 2>(params, n, stream); break;      // + two loader waves
     case 51: nt2_issue<128, 128, 4, 2, 2, BT, 64, 4>(params, n, stream); break;      // + four
 #endif

@@ -18,6 +18,9 @@
 // Tried and dropped (profiles/r05_tn_gang_2_asm_reads_prefetch.txt): group 0 owning the whole LDS-DMA stream while group 1 prefetches
 // the panels into L2 a few K-tiles ahead (the gang's tiles wait out the fabric latency of a shared line together) — 2238 vs 1954 us
 // on the 12 encoder layers: four DMA pieces per wave and interval cost group 0 more than the warm L2 returns.
+// Also tried: issuing an interval's DMA at its top (the slot it restages went free at the barrier just passed) instead of behind the
+// fragment reads — 2427 vs 2156 us (decoders), 2212 vs 2084 us (12 encoder layers): the issue slots delay the MFMAs by more than the
+// extra flight time returns.
 // One owner per tile, whole contraction, fixed order: no atomics on the gradient, results independent of who drew which ticket.
 // The merged launch (a dozen layers' problems) is what makes whole tiles per workgroup balance: ~4000 tiles over 256 CUs.
 //

@@ -205,6 +205,116 @@ def test_segment_schedule_world4_gloo():
     assert res[0][1] == [b for s in res[0][2] for b in s]                 # buckets go out segment by segment
 
 
+def _avmae_equiv_worker(rank, world, port, q):
+    """SURVEY.md section 8(e) (reference util/misc.py:32-34, 144-148): N ranks, each with its own slice of a global batch and the same
+    injected masking noise, through the real DataParallel wrapper + GradReducer + the captured step's segment schedule
+    (gradients appear segment by segment — decoders, then encoder layers last to first — and the buckets a segment completes are
+    all-reduced between segments)  ==  one rank on the concatenated batch.  The AVMAE arithmetic on the CPU is the oracle's (the
+    product model has no CPU path); parameters, flat buffers, buckets and collectives are the product's."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    import re
+    from deepavfusion_amd.build_model import build_avmae
+    from deepavfusion_amd.configs import CONFIGS
+    from deepavfusion_amd.util.distributed import DataParallel
+    from deepavfusion_amd.util.flat import FlatParams
+    from deepavfusion_amd.util.misc import segment_cuts
+    from oracle import avmae_oracle as O
+    from oracle.configs import CONFIGS as OC
+    cfg = OC['micro']
+    model = build_avmae(CONFIGS['micro'])
+    sd0 = O.closed_form_state(cfg, 0)
+    if rank:                                          # a rank that was initialised differently: the wrapper broadcasts rank 0's
+        sd0 = {k: (v + 0.01 if v.is_floating_point() and k not in O.FROZEN else v) for k, v in sd0.items()}
+    model.load_state_dict(sd0, strict=True)
+    flat = FlatParams(reversed(list(model.parameters())))
+    dp = DataParallel(model, flat, bucket_mb=0.05, first_bucket_mb=0.01)
+    dp.reducer.comm_stream = None
+    red = dp.reducer
+    names = {id(p): n for n, p in model.named_parameters()}
+    depth = len(model.encoder.image.blocks)
+    cuts = segment_cuts(depth, depth + 1)             # a cut behind the decoders and behind every layer but the last
+
+    def layer_of(n):                                  # where the backward finishes a gradient: decoders first, layer 0 and the embeddings last
+        if not n.startswith('encoder.'):
+            return depth
+        m = re.search(r'blocks\.(\d+)\.', n)
+        return int(m.group(1)) if m else (depth - 1 if 'norm' in n else 0)
+    B_per = 3
+    image, audio, ni, na = O.synthetic_batch(cfg, B_per * world, seed=91)
+
+    def oracle_grads(sl):
+        sd = {n: p.detach().clone().requires_grad_(p.requires_grad) for n, p in model.named_parameters()}
+        sd.update({k: v for k, v in model.state_dict().items() if k not in sd})
+        li, la, _, _, _ = O.avmae_forward(sd, cfg, image[sl], audio[sl], ni[sl], na[sl])
+        (li + la).backward()
+        return {n: v.grad for n, v in sd.items() if getattr(v, 'grad', None) is not None}, float(li + la)
+    # capture-time bookkeeping of GraphedStep: which buckets does each segment complete?
+    order = sorted(flat.params, key=lambda p: -layer_of(names[id(p)]))
+    pending = [len(b[2]) for b in red.buckets]
+    sched, seg, last = [[] for _ in range(len(cuts) + 1)], 0, depth
+    for p in order:
+        l = layer_of(names[id(p)])
+        if l != last and last in cuts:
+            seg += 1
+        last = l
+        bi = red._bucket_of[id(p)]
+        pending[bi] -= 1
+        if pending[bi] == 0:
+            sched[seg].append(bi)
+    assert sorted(b for s_ in sched for b in s_) == list(range(len(red.buckets)))
+    # the data-parallel step on this rank's slice
+    g_rank, loss_rank = oracle_grads(slice(rank * B_per, (rank + 1) * B_per))
+    flat.zero_grad()
+    red.begin_backward()
+    seg, last = 0, depth
+    for p in order:
+        l = layer_of(names[id(p)])
+        if l != last and last in cuts:
+            red.launch_buckets(sched[seg])
+            seg += 1
+        last = l
+        p.grad.add_(g_rank[names[id(p)]])
+    red.launch_buckets(sched[seg])
+    red.finish()
+    g_dp = flat.flat_g.clone()
+    t = torch.tensor([loss_rank])
+    dist.all_reduce(t)
+    # one rank, concatenated batch (every sample masks the same number of patches: the global masked mean is the mean of the ranks')
+    g_all, loss_all = oracle_grads(slice(0, B_per * world))
+    flat.zero_grad()
+    for p in flat.params:
+        p.grad.add_(g_all[names[id(p)]])
+    assert abs(float(t) / world - loss_all) < 1e-5 * abs(loss_all)
+    assert torch.allclose(g_dp, flat.flat_g, rtol=2e-4, atol=1e-6 * float(flat.flat_g.abs().max())), float((g_dp - flat.flat_g).abs().max())
+    q.put((rank, list(red.launch_order), sched))
+    dist.destroy_process_group()
+
+
+def test_avmae_dp_equivalence_world2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_avmae_equiv_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.daemon = True
+        p.start()
+    try:
+        for p in procs:
+            p.join(timeout=240)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+                p.join(5)
+                if p.is_alive():
+                    p.kill()
+    res = [q.get(timeout=5) for _ in range(world)]
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2]              # same collective order and schedule on every rank
+    assert res[0][1] == [b for s in res[0][2] for b in s]                 # buckets go out segment by segment
+
+
 def _switch_worker(rank, world, port, q, algo, bf16):
     """DAV_DP_ALGO / DAV_DP_BF16 / DAV_DP_BUCKET_MB (README "Data-parallel switches"): every combination must produce the
     group average in every gradient element — bucket lengths that are not multiples of the world size included (rs_ag reduces
