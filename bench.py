@@ -259,7 +259,8 @@ def main():
         red.skip_collectives = False
         comm = {'ms_per_step_no_collectives': round(float(t_nc), 3), 'comm_ms_exposed': round(ms - float(t_nc), 3),
                 'algo': red.algo, 'bf16_wire': red.bf16_wire, 'buckets': len(red.buckets), 'segments': getattr(gs, 'n_seg', None),
-                'grad_bytes': int(red.flat.flat_g.numel() * 4)}
+                'grad_bytes': int(red.flat.flat_g.numel() * 4), 'rccl_ranks': torch.distributed.get_world_size(),
+                'backend': torch.distributed.get_backend()}
     if rank != 0:
         return 0
 
@@ -566,6 +567,17 @@ def main():
         tc = time.perf_counter() - t_start
         result['cpu_baseline'] = {'value': round(Bc * n_done / tc, 3), 'unit': 'AV-pairs/s', 'cores': cores, 'kind': 'port',
                                   'sample': f'{n_done} fp32 oracle steps (fwd+bwd+AdamW) at B={Bc}, same shapes'}
+        if cores > 1:                       # "also report a 1-thread number" — one step of one pair
+            torch.set_num_threads(1)
+            im1, au1, ni1, na1 = O.synthetic_batch(ocfg, 1, seed=8)
+            t1 = time.perf_counter()
+            li, la = O.avmae_forward(sd, ocfg, im1, au1, ni1, na1)[:2]
+            (li + la).backward()
+            optc.step()
+            optc.zero_grad()
+            result['cpu_baseline']['one_thread'] = {'value': round(1.0 / (time.perf_counter() - t1), 3), 'unit': 'AV-pairs/s', 'cores': 1,
+                                                    'sample': '1 fp32 oracle step (fwd+bwd+AdamW) at B=1'}
+            torch.set_num_threads(cores)
     try:                                    # RCCL's version banner sits in C stdio's buffer: push it out BEFORE the JSON line
         import ctypes
         ctypes.CDLL(None).fflush(None)

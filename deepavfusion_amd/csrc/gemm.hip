@@ -2143,7 +2143,7 @@ int tn_gang_check(const DavTnProblem* probs, int count) {
   if (count <= 0 || count > 4096) return DAV_ERR_SHAPE;
   for (int i = 0; i < count; ++i) {
     const DavTnProblem& q = probs[i];
-    if (q.Mc <= 0 || (q.Mc & 63) || q.N <= 0 || q.K <= 0 || (q.N & 7) || (q.K & 7) || (q.lda & 7) || (q.ldb & 7)) return DAV_ERR_SHAPE;
+    if (q.Mc <= 0 || q.N <= 0 || q.K <= 0 || (q.N & 7) || (q.K & 7) || (q.lda & 7) || (q.ldb & 7)) return DAV_ERR_SHAPE;      // (any contraction length: the ragged last K-tile reads zeros)
     if (q.N > (32767 << 8) || q.K > (32767 << 8) || (q.flags & ~1)) return DAV_ERR_SHAPE;
     if (((uintptr_t)q.A | (uintptr_t)q.B | (uintptr_t)q.C) & 15 || (q.ldc & 3)) return DAV_ERR_ALIGN;
   }

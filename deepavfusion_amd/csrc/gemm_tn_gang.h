@@ -97,7 +97,7 @@ __device__ __forceinline__ void tng_tile(const TNParams& p, const int bn, const 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int n0 = bn << 8, k0 = bk << 8;
-  const int nk = p.Mc >> 6;
+  const int nk = (p.Mc + 63) >> 6;                          // a ragged last K-tile (Mc % 64 != 0: B x tokens at batch 32, 81 / 95 rows per sample) reads zeros for its missing A rows
   const int kend = (nk + 1) & ~1;                           // K-tiles [0, kend); an odd count is padded with one K-tile of zeros on the A side
   const uint32_t amagic = p.amap.rpb > 0 ? (uint32_t)(0x100000000ull / (uint32_t)p.amap.rpb) : 0u;
   const uint32_t bmagic = p.bmap.rpb > 0 ? (uint32_t)(0x100000000ull / (uint32_t)p.bmap.rpb) : 0u;
@@ -123,9 +123,10 @@ __device__ __forceinline__ void tng_tile(const TNParams& p, const int bn, const 
     const int ktc = pad ? nk - 1 : kt;
 #pragma unroll
     for (int ee = 0; ee < 2; ++ee) {
-      const int m = ktc * 64 + krow[ee];
+      const int m0 = ktc * 64 + krow[ee];
+      const int m = m0 < p.Mc ? m0 : p.Mc - 1;              // (rows past the end: A reads zeros, B any valid row)
       const bf16_t* src;
-      if (isA) src = pad ? reinterpret_cast<const bf16_t*>(g_tng_zeros) + (lane & 15) * 8 : p.A + tng_row(m, p.amap, amagic) * p.lda + a_col[h];
+      if (isA) src = (pad || m0 >= p.Mc) ? reinterpret_cast<const bf16_t*>(g_tng_zeros) + (lane & 15) * 8 : p.A + tng_row(m, p.amap, amagic) * p.lda + a_col[h];
       else src = p.B + tng_row(m, p.bmap, bmagic) * p.ldb + b_col[h];
       __builtin_amdgcn_global_load_lds(GLB_PTR(void, src), LDS_PTR(void, slot + ee * 1024), 16, 0, 0);
     }

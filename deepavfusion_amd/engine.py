@@ -407,7 +407,14 @@ def _flush_wgrads_now():
         if WGRAD_GANG and PRECISION == 'bf16' and sum(-(-pr['N'] // 256) * -(-pr['K'] // 256) for pr in now) >= WGRAD_GANG_MIN_TILES:
             ops.gemm_tn_gang(now)          # one persistent launch of 256 x 256 tiles, gangs of panel-sharing tiles per XCD
         else:
-            ops.gemm_tn_grouped(now)
+            grouped = [pr for pr in now if pr['Mc'] % 64 == 0 or pr['A'].dtype == F32]
+            if grouped:
+                ops.gemm_tn_grouped(grouped)
+            for pr in now:                 # (a ragged contraction in a flush too small for the gang launch: the one-problem kernel)
+                if pr['Mc'] % 64 and pr['A'].dtype != F32:
+                    ops.gemm_tn(pr['A'], pr['B'], pr['Mc'], pr['N'], pr['K'], pr['C'], lda=pr['lda'], ldb=pr['ldb'], ldc=pr['ldc'],
+                                a_rowmap=pr.get('a_rowmap'), b_rowmap=pr.get('b_rowmap'), beta=0 if pr.get('overwrite') else 1,
+                                bias_grad=pr.get('bias_grad'))
         for pr in now:
             _ready(*pr['ready'])
         probs = later
@@ -496,7 +503,7 @@ def lin_bwd(lin, dy, a, M, *, dy_rowmap=None, a_rowmap=None, lda=None, need_dx=T
     gwv = gw.view(N, -1)
     Cw = gwv if w_col_off == 0 else gwv.view(-1)[w_col_off:]
     gb = gbuf(lin.bias) if (use_bias and lin.bias is not None) else None
-    if _DEFERRED is not None and M % 64 == 0 and N % 8 == 0 and K % 8 == 0:
+    if _DEFERRED is not None and N % 8 == 0 and K % 8 == 0 and (M % 64 == 0 or (WGRAD_GANG and PRECISION == 'bf16')):
         # weight gradients are off the dependency chain: queue them and launch ONE grouped GEMM per flush
         _DEFERRED.append(dict(A=dy, B=a, Mc=M, N=N, K=K, C=Cw, lda=N, ldb=lda if lda is not None else K, ldc=Kfull,
                               a_rowmap=dy_rowmap, b_rowmap=a_rowmap, bias_grad=gb,

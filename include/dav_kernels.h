@@ -104,7 +104,8 @@ int dav_gemm_tn_grouped_bf16(const DavTnProblem* problems, int count, hipStream_
  * 256 x 256 tiles, one workgroup per CU: every problem's tile grid is cut into gangs of <= 32 tiles that share operand panels, the
  * gangs are dealt out to eight per-XCD ticket queues (longest contraction first) and the workgroups of an XCD draw the tiles of one gang
  * together, so that a panel crosses the fabric once per XCD instead of once per tile.  One owner per tile over the whole contraction:
- * no atomics on C, bit-repeatable.  flags bit 0 as above; other bits: DAV_ERR_SHAPE.  Two problems of one call must not
+ * no atomics on C, bit-repeatable.  Any Mc > 0 (a contraction that is not a multiple of 64 rows — B x tokens at batch 32 — is padded with
+ * zeros on the fly).  flags bit 0 as above; other bits: DAV_ERR_SHAPE.  Two problems of one call must not
  * address the same C.  workspace: caller-owned device memory of dav_gemm_tn_gang_workspace_bytes(problems, count) bytes (0 = invalid
  * problems), 16-byte aligned, written and read on `stream` only (it must stay untouched until the launch has run). */
 size_t dav_gemm_tn_gang_workspace_bytes(const DavTnProblem* problems, int count);

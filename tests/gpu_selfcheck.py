@@ -259,7 +259,8 @@ def gemm_tn_gang():
     """dav_gemm_tn_gang_bf16: the queued weight gradients of several layers as one persistent launch of 256 x 256 tiles."""
     # odd K-tile counts (Mc = 64 * odd), N / K below, across and beyond one tile, ragged last tiles, a long contraction
     shapes = [(512, 768, 768), (3136, 192, 768), (4032, 2304, 768), (3136, 768, 3072), (640, 8, 264), (14592, 512, 1536), (2048, 520, 776),
-              (64, 256, 256), (192, 1032, 40), (5184, 2304, 768), (6080, 3072, 1024)]
+              (64, 256, 256), (192, 1032, 40), (5184, 2304, 768), (6080, 3072, 1024),
+              (2592, 1024, 1024), (3040, 1024, 3072), (1568, 4096, 1024), (40, 264, 520), (200, 8, 8), (63 * 8, 768, 192)]      # ragged: Mc % 64 != 0
     for mode in ('accumulate', 'written', 'mixed'):
         probs, refs = [], []
         for i, (Mc, N, K) in enumerate(shapes):
@@ -689,7 +690,7 @@ def main():
         if ':' in kv:
             from deepavfusion_amd import _lib
             _lib.check(_lib.load().dav_tune(int(kv.split(':')[0]), int(kv.split(':')[1])), 'dav_tune')
-    for fn in (gemm_nt, gemm_tn, attention, layernorm, masking, misc_kernels, patch_gather3d):
+    for fn in (gemm_nt, gemm_tn, gemm_tn_gang, attention, window_attention, layernorm, masking, misc_kernels, patch_gather3d):
         if flt in fn.__name__:
             fn()
     bad = [r for r in RESULTS if not r[3]]

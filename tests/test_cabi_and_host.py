@@ -308,7 +308,10 @@ def test_error_codes_for_dtype_alignment_and_workspace():
     assert lib.dav_gemm_tn_gang_bf16(pr, 2, p((1 << 20) + 4), C.c_size_t(need), None) == -5
     pr[1].flags = 3
     assert lib.dav_gemm_tn_gang_workspace_bytes(pr, 2) == 0 and lib.dav_gemm_tn_gang_bf16(pr, 2, p(1 << 20), C.c_size_t(need), None) == -1
-    pr[1].flags, pr[1].Mc = 0, 100
+    pr[1].flags, pr[1].Mc = 0, 100                                       # a ragged contraction (not a multiple of 64 rows) is fine here ...
+    assert lib.dav_gemm_tn_gang_workspace_bytes(pr, 2) == need
+    assert lib.dav_gemm_tn_grouped_bf16(pr, 2, None) == -1                # ... and refused by the 128 x 128 grouped kernel
+    pr[1].Mc = 0
     assert lib.dav_gemm_tn_gang_workspace_bytes(pr, 2) == 0
     assert _lib.ERRORS[-2] and _lib.ERRORS[-3] and _lib.ERRORS[-5]
 

@@ -41,6 +41,7 @@ S = {
     'DAV_NT_SMALL': ('5', 'kernel', "tile configuration of launches below DAV_NT_T5 tiles: 5 = 64 x 64 two-stage ring, 7 = four-stage ring", 'gpu_selfcheck gemm_nt family'),
     'DAV_NT_T5': ('100', 'kernel', "tile-count threshold between the 64 x 64 and the 128 x 64 configurations", '- (tuning knob)'),
     'DAV_NT_T8': ('400', 'kernel', "tile-count threshold between the 128 x 64 and the 128 x 128 configurations", '- (tuning knob)'),
+    'DAV_NT_PIPE': ('0', 'kernel', "EXPERIMENTAL builds only: software-pipelined k-loop (configuration 31) in place of configuration 3 (faster alone, +0.6 ms in the step: profiles/r05_experiments.txt)", '- (make EXPERIMENTAL=1)'),
     'DAV_NT_LD': ('0', 'kernel', "EXPERIMENTAL builds only: loader-wave variant (configuration 51) in place of configuration 3", '- (make EXPERIMENTAL=1)'),
     'DAV_TN_XCD': ('1', 'kernel', "weight-gradient tiles: one contiguous run of each problem's tiles per XCD; 0 = every 8th tile", 'gpu_selfcheck gemm_tn family'),
     'DAV_ADAMW_WGS': ('0 (whole grid)', 'optimizer', "cap on the AdamW kernel's workgroups (a narrow grid trickles beside other work instead of evicting it)", '- (element-wise grid-stride loop; profiles/r04_defer_adamw.txt)'),
