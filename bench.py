@@ -150,9 +150,6 @@ def main():
             _lib.load().dav_tune(int(kv.split(':')[0]), int(kv.split(':')[1]))
     cfg = CONFIGS[a.config]
     B = a.batch or (32 if cfg.embed_dim >= 1024 else 64)
-    # placement experiment (profiles/r04_placement_sweep.txt): identical captured steps time up to 0.6 ms apart depending on where
-    # the allocator puts their buffers; DAV_BENCH_SHIFT_MB=x holds x MB in front of everything this process allocates
-    _shift = [torch.empty(int(float(kv) * 2 ** 20), dtype=torch.uint8, device=dev) for kv in os.environ.get('DAV_BENCH_SHIFT_MB', '').split(',') if kv]
     torch.manual_seed(0)                                   # identical init on every rank (then broadcast anyway)
     model = build_avmae(cfg).to(dev)
     nd = [n for n, p in model.named_parameters() if 'bias' in n or 'norm' in n]                 # train.py:89

@@ -29,8 +29,8 @@ def _streams(dev):
         return main, main, main
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     if key not in _SIDE_STREAMS:
-        prio = int(os.environ.get('DAV_FUSION_PRIO', '0'))        # < 0: the fusion block's stream gets a higher dispatch priority
-        _SIDE_STREAMS[key] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev, priority=prio))
+        # (a higher dispatch priority for the fusion block's stream costs 9 ms per step: profiles/r04_stream_priority_ab.txt)
+        _SIDE_STREAMS[key] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
     sa, sf = _SIDE_STREAMS[key]
     return main, sa, sf
 
@@ -399,7 +399,7 @@ def avmae_fwd(model, image, audio, noise_i, noise_a):
     nF = enc.fusion_tokens.shape[1]
     dec_i, dec_a = model.decoder('image'), model.decoder('audio')
     main, sa, _ = _streams(image.device)
-    lanes = t_enc['lanes'] and os.environ.get('DAV_DEC_STREAMS', '0') != '1'      # the two decoders follow the encoder's schedule
+    lanes = t_enc['lanes']                                                        # the two decoders follow the encoder's schedule
     if lanes:
         with E.batch() as bt:                 # the two MAE decoders (models/avmae.py:147-180) in lockstep
             bt.lane()
@@ -422,8 +422,8 @@ def avmae_fwd(model, image, audio, noise_i, noise_a):
     return (loss_i, loss_a, pred_i, pred_a), tape, aux
 
 
-_DEC_WGRAD_JOINT = os.environ.get('DAV_DEC_WGRAD_JOINT', '1') != '0'
-_ADD_CAST = os.environ.get('DAV_ADD_CAST', '1') != '0'
+_DEC_WGRAD_JOINT = True
+_ADD_CAST = True
 
 
 def avmae_bwd(model, t, g_li, g_la, g_pi=None, g_pa=None, layer_cb=None):

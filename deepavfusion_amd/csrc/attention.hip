@@ -44,7 +44,7 @@ struct AttnParams {
   long dq_bs, dk_bs, dv_bs;
   int dq_rs, dk_rs, dv_rs;
   int debug;          // DAV_ATTN_DEBUG ablations (timing experiments only): 1 = no tile loop, 2 = no staging
-  int pair;           // narrow heads: adjacent heads on the same XCD (pair_heads); DAV_ATTN_PAIR=0 switches it off
+  int pair;           // narrow heads: adjacent heads on the same XCD (pair_heads)
   // additive score bias (window attention, models/swin.py:66-80): bias[b % bias_nb][h][q][0 .. bias_ld) in LOG2 units (already
   // multiplied by log2 e), bias_ld = Nk rounded up to 32 with zero padding; dS (backward, optional): gradient of the biased
   // logits [B][H][Nq][bias_ld] in natural units, what the relative-position table's gradient is reduced from
@@ -960,7 +960,7 @@ extern "C" int dav_attn_bias_fwd(const void* Q, const void* K, const void* V, vo
   if (!bias_ok(bias, bias_nb, bias_ld, nullptr, B, Nk)) return DAV_ERR_SHAPE;
   AttnParams p = {};
   p.debug = attn_debug();
-  { static const int pr = [] { const char* e = getenv("DAV_ATTN_PAIR"); return e ? atoi(e) : 1; }(); p.pair = pr; }
+  p.pair = 1;
   p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (bf16_t*)O; p.LSE = LSE;
   p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.q_bs = q_bs; p.k_bs = k_bs; p.v_bs = v_bs; p.o_bs = o_bs;
   p.q_rs = q_rs; p.k_rs = k_rs; p.v_rs = v_rs; p.o_rs = o_rs; p.scale = scale;
@@ -1000,7 +1000,7 @@ static int attn_bwd_any(const void* Q, const void* K, const void* V, const void*
   AttnParams p = {};
   p.dq_ctx = dq_ctx_rows;
   p.debug = attn_debug();
-  { static const int pr = [] { const char* e = getenv("DAV_ATTN_PAIR"); return e ? atoi(e) : 1; }(); p.pair = pr; }
+  p.pair = 1;
   p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.Of = (const bf16_t*)O; p.O = nullptr;
   p.dO = (const bf16_t*)dO; p.LSE = const_cast<float*>(LSE); p.Delta = Delta;
   p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV;

@@ -1375,12 +1375,9 @@ static int nt_tuned_lookup(bool bt, const void* const* params, int n) {
   return it == nt_tuned.end() ? 0 : it->second;
 }
 
-// DAV_NT_WIDE=0 switches the 128 x 256 configuration off (A/B timing of the same box)
-[[maybe_unused]] static bool nt_ld_on() { static const bool on = [] { const char* e = getenv("DAV_NT_LD"); return e && e[0] == '1'; }(); return on; }
 // 256 x 256 tiles (configuration 60): an explicit / tunable configuration only.  Alone on the GPU it is 7-25 % faster than 128 x 128 /
 // 128 x 256 on every wide shape of the step, but as a rule it made the step 0.25 ms SLOWER in every schedule (round 3, same-box
 // alternation, profiles/r03_nt256_instep_ab.txt): a workgroup that owns 128 KB of LDS keeps the other streams' kernels off its CU.
-static bool nt_wide_on() { static const bool on = [] { const char* e = getenv("DAV_NT_WIDE"); return !(e && e[0] == '0'); }(); return on; }
 
 // Recorded with the tile configuration left open: chosen at issue time from the tile count of the WHOLE group.
 template <bool BT>
@@ -1410,11 +1407,12 @@ void nt2_issue_auto(const void* const* params_in, int n, hipStream_t stream) {
   const int tuned = forced ? 0 : nt_tuned_lookup(BT, params, n);
   if (forced) cfg = forced;
   else if (tuned) cfg = tuned;
-  else if (cfg == 3 && wide && t256 >= 512 && nt_wide_on()) cfg = 44;
+  else if (cfg == 3 && wide && t256 >= 512) cfg = 44;
 #ifdef DAV_EXPERIMENTAL
-  if (cfg == 3 && nt_ld_on()) cfg = 51;
-  static const bool nt_pipe = [] { const char* e = getenv("DAV_NT_PIPE"); return e && e[0] == '1'; }();      // A/B only: the software-pipelined k-loop in place of configuration 3
-  if (cfg == 3 && nt_pipe) cfg = 31;
+  // (A/B of round 5, profiles/r05_experiments.txt: configurations 31 — software-pipelined k-loop — and 51 — loader waves — in place of 3
+  // are 6-26 % faster alone and +0.6 / +1.9 ms in the step; DAV_NT_ALT=31 / 51 reproduces it in an EXPERIMENTAL build)
+  static const int nt_alt = getenv("DAV_NT_ALT") ? atoi(getenv("DAV_NT_ALT")) : 0;
+  if (cfg == 3 && (nt_alt == 31 || nt_alt == 51)) cfg = nt_alt;
 #endif
   if (cfg == 60 && !all256) cfg = 3;                     // (an explicit or tuned 60 on a group the 256 x 256 body cannot take)
   nt_log_issue(cfg, BT, params, n);
@@ -1854,9 +1852,8 @@ int nt_auto_config_tiles(long t128, bool narrow) {
   // 64x64, 4 waves.  A few dozen tiles alone on the GPU (the fusion block's projections: weights last touched a step ago)
   // get the FOUR-stage ring — three k-steps of prefetch cover the HBM miss a two-stage ring exposes at every k-step (15 us in
   // the step vs 7 us with warm operands); from ~250 tiles of 64x64 on the 64 KB ring costs occupancy instead (3136x768x3072
-  // alone: 40.5 vs 32.7 us).  DAV_NT_SMALL=5 forces the two-stage ring.
-  static const int small_cfg = getenv("DAV_NT_SMALL") ? atoi(getenv("DAV_NT_SMALL")) : 5;      // round 3, stream schedule: the two-stage ring is -0.18 ms per step (same-box alternation); 7 = the four-stage ring
-  static const int t5 = getenv("DAV_NT_T5") ? atoi(getenv("DAV_NT_T5")) : 100, t8 = getenv("DAV_NT_T8") ? atoi(getenv("DAV_NT_T8")) : 400;
+  // alone: 40.5 vs 32.7 us).
+  constexpr int small_cfg = 5, t5 = 100, t8 = 400;      // (round 3, stream schedule: the two-stage ring for the small launches is -0.18 ms per step; 7 = the four-stage ring)
   if (narrow || t128 < t5) return (small_cfg == 5 || t128 > 64) ? 5 : 7;
   if (t128 < t8) return 8;                   // 128x64, 4 waves
   return 3;                                   // 128x128, 8 waves (2 x 4)
@@ -1911,9 +1908,6 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
   if (b_kn) {
     if (!vec_ok) return DAV_ERR_SHAPE;
     if (cfg == 0) cfg = nt_auto_config(M, N, K);       // (only reached with the variant bits set; the open choice returned above)
-#ifdef DAV_EXPERIMENTAL
-    if (cfg == 3 && nt_ld_on()) cfg = 51;
-#endif
     if (cfg == 60 && !nt256_ok(p)) return DAV_ERR_SHAPE;
     switch (cfg) {
       case 60: launch_nt256<true>(p, stream); break;
@@ -1939,9 +1933,6 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
   }
   if (vec_ok && !(variant & 15)) {
     if (cfg == 0) cfg = nt_auto_config(M, N, K);
-#ifdef DAV_EXPERIMENTAL
-    if (cfg == 3 && nt_ld_on()) cfg = 51;
-#endif
     if (cfg == 60 && !nt256_ok(p)) return DAV_ERR_SHAPE;
     switch (cfg) {
       case 60: launch_nt256<false>(p, stream); return dav_launch_status();
@@ -2089,8 +2080,7 @@ static int tn_grouped_impl(const DavTnProblem* probs, int count, hipStream_t str
   // (round 3: -21 % memory-side fetch, -5 % kernel time, -0.2 ms per step on two boxes.  Cutting the WHOLE launch's unit sequence
   // into eight equal-work ranges, one per XCD, took the fetch down 3 x (33.5 -> 11.5 GB per step) and the kernel time UP 6 %:
   // profiles/r03_step_traffic.txt — what bounded this kernel was not the fabric but a compiler-inserted drain of its own DMA, see tn2_tr)
-  static const int xcd_runs = getenv("DAV_TN_XCD") ? atoi(getenv("DAV_TN_XCD")) != 0 : 1;
-  g.count = count | (xcd_runs ? TN_XCD_RUNS : 0);
+  g.count = count | TN_XCD_RUNS;
   // 4 x 2 waves (32 x 64 wave tiles): +1 % over 2 x 4 in the step; thinner or deeper rings (32-row stages x 3 / 4, 64-row x 3),
   // 4-wave workgroups, three workgroups per CU, 256 x 128 owner-per-tile tiles (round 4) and a 256 x 256 stream-K form with fp32
   // atomics (round 3) were all measured slower (profiles/r02_tn_ring_variants.txt, r04_tn256x128.txt, r03_tn256_group_bench.txt)
@@ -2204,7 +2194,6 @@ extern "C" int dav_gemm_tn_gang_bf16(const DavTnProblem* probs, int count, void*
   static const int n_wg = [] {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (getenv("DAV_TN_GANG_WGS")) cus = atoi(getenv("DAV_TN_GANG_WGS"));
     return cus > 0 ? cus : 256;
   }();
   const long tiles = q_start[8];

@@ -688,10 +688,6 @@ extern "C" int dav_adamw_flat(float* p, float* g, float* m, float* v, void* p_bf
   if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15 || ((uintptr_t)p_bf16 & 7)) return DAV_ERR_ALIGN;
   if (sumsq_out) HIP_CHECK_RET(hipMemsetAsync(sumsq_out, 0, sizeof(float), stream));
   long g2 = (n + 4095) / 4096; g2 = g2 > 16384 ? 16384 : g2;
-  // DAV_ADAMW_WGS=<n>: at most n workgroups (grid-stride over the rest).  For an update that runs BESIDE other work (the deferred
-  // AdamW of util.misc.GraphedStep): a grid that fills every CU evicts the forward's kernels for its duration, a narrow one trickles.
-  static const long cap = [] { const char* e = getenv("DAV_ADAMW_WGS"); return e ? atol(e) : 0L; }();
-  if (cap > 0 && g2 > cap) g2 = cap;
   DAV_LAUNCH(adamw_flat_kernel, dim3((int)g2), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, n, seg_end, hyper, nseg,
                      beta1, beta2, eps, bias_corr, grad_scale, sumsq_out, zero_grad, keep_grad, gscale_dev);
   return dav_launch_status();

@@ -73,7 +73,7 @@ BATCH_STATS = [0, 0]          # launches recorded / issued since the last reset 
 #             launches (the fusion block's projections / cross-attentions / LayerNorms) and the layer's grouped weight gradients.
 #   lanes     the two tower blocks (the two decoders) as LANES of one launch batch on the main stream — equal-rank kernels merged
 #             into grouped grids — with the fusion block on its own stream beside them (DAV_FUSION_STREAM=0: as a third lane
-#             of the batch, the towers idling through its extra steps: everything on ONE queue; DAV_DEC_STREAMS=1: the decoders
+#             of the batch, the towers idling through its extra steps: everything on ONE queue; (round 3 also ran the decoders
 #             on two streams all the same).
 # BATCH_POLICY 'auto' (default): streams, unless DAV_LANE_MIN_ROWS=n asks for lanes from n rows (B x tokens per tower block)
 # upwards; 'on' (DAV_BATCH=1): lanes always; 'off' (DAV_BATCH=0): streams and no launch batching at all.
@@ -289,15 +289,15 @@ class region:
 # ------------------------------------------------------------------------------------------------
 # deferred weight gradients: inside `deferred_wgrads()` lin_bwd only records its wgrad problem;
 # `flush_wgrads()` launches everything recorded so far as one grouped GEMM (dav_gemm_tn_grouped_bf16)
-# and then reports the parameters ready.  DAV_GROUPED_WGRAD=0 restores one launch per weight.
+# and then reports the parameters ready.
 # ------------------------------------------------------------------------------------------------
-# DAV_WGRAD_GANG (default 1): a flush with at least DAV_WGRAD_GANG_MIN_TILES 256 x 256 tiles goes out as ONE gang-scheduled launch
+# DAV_WGRAD_GANG (default 1): a flush with at least WGRAD_GANG_MIN_TILES 256 x 256 tiles goes out as ONE gang-scheduled launch
 # (dav_gemm_tn_gang_bf16); 0 = the 128 x 128 grouped kernel, <= 40 problems per launch.  DAV_WGRAD_MERGE (default 0 = all): encoder
 # layers whose weight gradients share a launch — the flush after a layer's backward is skipped unless the layer closes a group (or a
 # captured segment: ``WGRAD_FLUSH_LAYERS``, set by util.misc.GraphedStep to its cuts).  A whole tile per workgroup only balances
 # when thousands of tiles share a launch (profiles/r05_tn_gang_*.txt: 12 launches 2.83 ms, one launch 1.95 ms).
 WGRAD_GANG = os.environ.get('DAV_WGRAD_GANG', '1') != '0'
-WGRAD_GANG_MIN_TILES = int(os.environ.get('DAV_WGRAD_GANG_MIN_TILES', '128'))
+WGRAD_GANG_MIN_TILES = 128
 WGRAD_MERGE = int(os.environ.get('DAV_WGRAD_MERGE', '0'))
 WGRAD_FLUSH_LAYERS = set()
 
@@ -318,7 +318,7 @@ class deferred_wgrads:
     def __enter__(self):
         global _DEFERRED, _DEFERRED_LN
         self.prev = (_DEFERRED, _DEFERRED_LN)
-        on = os.environ.get('DAV_GROUPED_WGRAD', '1') != '0'
+        on = True
         _DEFERRED = [] if on else None
         _DEFERRED_LN = [] if on else None
         return self
@@ -531,7 +531,7 @@ def attention_fwd(q, k, v, B, H, Nq, Nk, dqk, dv, scale, q_bs, q_rs, k_bs, k_rs,
     return O, LSE
 
 
-_ATTN_CTX = os.environ.get('DAV_ATTN_CTX', '1') != '0'      # 0: a torch fill pass zeroes the context rows' dq slots (rounds 1-2)
+_ATTN_CTX = True      # (False: a torch fill pass zeroes the context rows' dq slots, rounds 1-2)
 
 
 def attention_bwd(q, k, v, O, dO, LSE, dq, dk, dvv, B, H, Nq, Nk, dqk, dv, scale, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs,
@@ -1120,7 +1120,7 @@ FUSION_IDLE_FWD, FUSION_IDLE_BWD = 4, 6
 def fusion_block_batchable(fb, dp=None):
     """True when the block's forward / backward consist of library launches only, i.e. may run as a lane of a launch batch
     (the factorised block without DropPath; the token / dense blocks and DropPath use torch ops between kernels)."""
-    return dp is None and getattr(fb, 'arch', 'factorized_mmi') == 'factorized_mmi' and os.environ.get('DAV_BATCH_FUSION_LANE', '1') != '0'
+    return dp is None and getattr(fb, 'arch', 'factorized_mmi') == 'factorized_mmi'
 
 
 def fusion_block_fwd(fb, x_f, x_i, x_a, heads, tkns, dp=None):

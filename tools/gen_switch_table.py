@@ -20,31 +20,14 @@ S = {
     'DAV_BATCH': ('auto', 'schedule', "launch batching policy (engine.BATCH_POLICY): unset = one HIP stream per independent chain with batched regions; 1 = the towers / decoders as lanes of one launch batch; 0 = no batching at all", 'test_lane_batched_and_stream_schedules_agree, test_full_size_step_is_schedule_independent_and_repeatable'),
     'DAV_LANE_MIN_ROWS': ('2^30', 'schedule', "with DAV_BATCH unset: lanes from this many rows (B x tokens per tower block) upwards", 'test_lane_batched_and_stream_schedules_agree (policy values)'),
     'DAV_FUSION_STREAM': ('1', 'schedule', "lanes schedule only: the fusion block on its own stream (1) or as a third lane of the batch (0)", 'bench.py roofline.lanes_schedule (runs it), test_full_size_step...'),
-    'DAV_BATCH_FUSION_LANE': ('1', 'schedule', "0: the fusion block never joins a launch batch as a lane", '- (diagnostic)'),
     'DAV_STREAMS': ('1', 'schedule', "0: everything on the current stream (serial schedule; tools/instep_gemm_bound.py uses it)", 'tools/instep_gemm_bound.py (profiles/r04_gemm_instep_bound.txt)'),
-    'DAV_DEC_STREAMS': ('0', 'schedule', "lanes schedule only: 1 = the two decoders on two streams all the same", '- (A/B in DESIGN_HISTORY section 4)'),
-    'DAV_DEC_WGRAD_JOINT': ('1', 'schedule', "both decoders' weight-gradient problems in one grouped launch after both backward passes", 'test_baseline_config_shapes_vs_oracle (default path)'),
     'DAV_WGRAD_GANG': ('1', 'kernel', "weight gradients of a flush as ONE gang-scheduled launch of 256 x 256 tiles (dav_gemm_tn_gang_bf16: per-XCD ticket queues of tiles that share operand panels); 0 = the 128 x 128 grouped kernel, one launch per layer (profiles/r05_tn_gang_*.txt)", 'test_gang_weight_gradients_equal_the_grouped_kernel_and_the_oracle, test_baseline_config_shapes_vs_oracle (default path), tools/tn_gang_bench.py check()'),
-    'DAV_WGRAD_GANG_MIN_TILES': ('128', 'kernel', "flushes with fewer 256 x 256 tiles than this keep the 128 x 128 grouped kernel (a persistent grid of one workgroup per CU needs tiles to balance)", 'test_gang_weight_gradients_equal_the_grouped_kernel_and_the_oracle'),
     'DAV_WGRAD_MERGE': ('0 (all layers of a captured segment)', 'schedule', "encoder layers whose queued weight gradients share one launch (n > 0: a flush every n layers)", 'test_gang_weight_gradients_equal_the_grouped_kernel_and_the_oracle (1 and 0)'),
     'DAV_TN_GANG_DEBUG': ('0', 'debug', "dav_gemm_tn_gang_bf16 timing ablations: 2 = no epilogue, 4 = no MFMAs, 8 / 16 = queue chosen by block id / by a deliberately wrong placement instead of the hardware XCC id", '- (tools/tn_gang_bench.py, profiles/r05_tn_gang_*.txt)'),
-    'DAV_TN_GANG_WGS': ('CU count', 'kernel', "persistent workgroups of the gang launch", '- (tuning knob)'),
-    'DAV_GROUPED_WGRAD': ('1', 'kernel', "0: one weight-gradient launch per Linear instead of one grouped launch per layer", 'test_batch64_grouped_wgrad_path_vs_oracle (default), gpu_selfcheck gemm_tn family'),
     'DAV_WGRAD_OVERWRITE': ('1', 'kernel', "captured step: the first weight-gradient contribution to a Linear weight WRITES its tile (AdamW skips that zero-fill); 0 = accumulate / zero-fill", 'test_written_first_gradients_equal_accumulated_ones'),
-    'DAV_ADD_CAST': ('1', 'kernel', "sum of the fusion tokens' two gradient streams + its bf16 copy in one pass (dav_add_cast); 0 = torch add", 'test_end_to_end_vs_oracle_and_golden (default path)'),
-    'DAV_ATTN_CTX': ('1', 'kernel', "the dQ kernel zero-fills the q slots of the fusion-token context rows (dav_attn_bwd_ctx); 0 = a torch fill pass", 'gpu_selfcheck attention family, e2e tests'),
-    'DAV_ATTN_PAIR': ('1', 'kernel', "d = 32 attention: adjacent heads on the same XCD (pair_heads); 0 = linear (batch, head) order", 'gpu_selfcheck attention family (both orders)'),
-    'DAV_FUSION_PRIO': ('0', 'schedule', "dispatch priority of the fusion block's stream (-1 = high, 1 = low; profiles/r04_fusion_tails.txt, r04_stream_priority_ab.txt)", '- (A/B only)'),
+    'DAV_NT_ALT': ('0', 'kernel', "EXPERIMENTAL builds only: 31 / 51 = the software-pipelined / loader-wave body in place of configuration 3 (faster alone, +0.6 / +1.9 ms in the step: profiles/r05_experiments.txt)", '- (make EXPERIMENTAL=1)'),
     'DAV_NT_TUNE': ('1', 'kernel', "0: ignore the tuned tile-configuration table (deepavfusion_amd/tuning/nt_gfx950.json), rules only", 'test_nt_tuning_table_loads_and_rejects_malformed_blobs, test_baseline_config_shapes_vs_oracle[large-32] (entries must fire)'),
     'DAV_NT_TUNE_FILE': ('tuning/nt_gfx950.json', 'kernel', "another tuned table", 'test_nt_tuning_table_loads_and_rejects_malformed_blobs'),
-    'DAV_NT_WIDE': ('1', 'kernel', "0: no 128 x 256 tiles for the K <= 512 wide-output GEMMs (rule of nt2_issue_auto)", 'gpu_selfcheck gemm_nt family (explicit configurations)'),
-    'DAV_NT_SMALL': ('5', 'kernel', "tile configuration of launches below DAV_NT_T5 tiles: 5 = 64 x 64 two-stage ring, 7 = four-stage ring", 'gpu_selfcheck gemm_nt family'),
-    'DAV_NT_T5': ('100', 'kernel', "tile-count threshold between the 64 x 64 and the 128 x 64 configurations", '- (tuning knob)'),
-    'DAV_NT_T8': ('400', 'kernel', "tile-count threshold between the 128 x 64 and the 128 x 128 configurations", '- (tuning knob)'),
-    'DAV_NT_PIPE': ('0', 'kernel', "EXPERIMENTAL builds only: software-pipelined k-loop (configuration 31) in place of configuration 3 (faster alone, +0.6 ms in the step: profiles/r05_experiments.txt)", '- (make EXPERIMENTAL=1)'),
-    'DAV_NT_LD': ('0', 'kernel', "EXPERIMENTAL builds only: loader-wave variant (configuration 51) in place of configuration 3", '- (make EXPERIMENTAL=1)'),
-    'DAV_TN_XCD': ('1', 'kernel', "weight-gradient tiles: one contiguous run of each problem's tiles per XCD; 0 = every 8th tile", 'gpu_selfcheck gemm_tn family'),
-    'DAV_ADAMW_WGS': ('0 (whole grid)', 'optimizer', "cap on the AdamW kernel's workgroups (a narrow grid trickles beside other work instead of evicting it)", '- (element-wise grid-stride loop; profiles/r04_defer_adamw.txt)'),
     'DAV_SEGMENTS': ('0 (1 graph; 5 when data-parallel)', 'dp', "graphs per captured step (any run)", 'test_segmented_graph_step_matches_single_graph_and_schedules_every_bucket'),
     'DAV_DP_SEGMENTS': ('5', 'dp', "graphs per captured data-parallel step, between which finished gradient buckets are reduced", 'test_dp_switches_over_one_rank_rccl'),
     'DAV_DP_ALGO': ('allreduce', 'dp', "allreduce | rs_ag (reduce-scatter + all-gather per bucket)", 'test_dp_switches_world2_and_world4_gloo, test_dp_switches_over_one_rank_rccl'),
@@ -53,7 +36,6 @@ S = {
     'DAV_DP_BF16': ('0', 'dp', "1 (NOT the reference's arithmetic): gradient buckets reduced as bf16 on the wire", 'test_dp_switches_world2_and_world4_gloo, test_dp_switches_over_one_rank_rccl'),
     'DAV_FORCE_DIST': ('0', 'harness', "1: build the data-parallel machinery on a 1-rank process group (tests / tools on one GPU)", 'test_dp_step_over_one_rank_rccl'),
     'DAV_DIST_TIMEOUT_S': ('1800', 'dp', "process-group timeout in seconds", '- (init_distributed_mode)'),
-    'DAV_BENCH_SHIFT_MB': ('', 'harness', "bench.py: hold this many MB (comma list = several blocks) in front of every allocation of the process (buffer-placement experiment, profiles/r04_placement_sweep.txt)", '- (bench only)'),
     'DAV_TUNE': ('', 'harness', "bench.py: comma list knob:value for dav_tune (launch-geometry experiments)", '- (bench only)'),
     'DAV_DUMP_MIX': ('', 'harness', "bench.py: file that receives the recorded launch mix of one step (tools/mix_sweep.py input)", '- (bench only)'),
     'DAV_BENCH_SPAWN_DRY': ('0', 'harness', "bench.py: CPU test hook of the rank spawner (no GPU call)", 'test_bench_starts_its_own_ranks_when_launched_plainly'),
