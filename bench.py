@@ -412,16 +412,18 @@ def main():
                 in_step = {'what': 'the same launches timed inside one eager step of the default stream schedule (HIP event pair per launch on its own stream; other streams\' kernels run beside it)',
                            'launches': len(pairs), 'avg_launch_us': round(us / len(pairs), 2), 'achieved': round(fl_s / (us * 1e-6) / 1e12, 1),
                            'frac': round(fl_s / (us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), 'ms_per_step': round(us * 1e-3, 3)}
-        traffic = None          # HBM bytes per launch: offline rocprofv3 PMC passes over THIS replay (profiles/), only for the profiled workload
+        traffic = traffic_source = None          # HBM bytes per launch: offline rocprofv3 PMC passes over THIS replay (profiles/), only for the profiled workload
         tf = os.path.join(ROOT, 'profiles', 'dominant_kernel_traffic.json')
         if os.path.exists(tf):
             rec = json.load(open(tf)).get(f'{a.config}_b{B}', {})
             traffic = rec.get('hbm_bytes_per_launch')
+            traffic_source = rec.get('source')
         result['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_nt2_kernel / gemm_nt2_grouped_kernel, the launches of >= 400 tile equivalents exactly as the step issues them (default stream schedule: one launch per tower GEMM), each with its tile configuration (128x128 dominant; 128x256 per the rules / tuned table): forward + b_kn dgrad',
                               'launches_by_config': {str(c): sum(1 for cc, _b, _p in big if cc == c) for c in sorted({cc for cc, _b, _p in big})},
                               'achieved': round(ach, 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                               'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': traffic,
-                              'traffic_note': 'offline rocprofv3 --pmc FETCH_SIZE (x2, gfx950 note) + WRITE_SIZE over this replay; null unless profiled for this workload',
+                              'traffic_source': traffic_source,
+                              'traffic_note': 'offline rocprofv3 --pmc FETCH_SIZE (x2, gfx950 note) + WRITE_SIZE over this replay (the committed files named in traffic_source: a constant of the tree, not of this run); null unless profiled for this workload',
                               'algorithmic_bytes_per_launch': int(sum(2.0 * (M * K + N * K + M * N) for _c, _b, probs in big for (M, N, K) in probs) / len(big)),
                               'launches_per_step': len(big), 'problems_per_step': sum(len(pr) for _c, _b, pr in big),
                               'avg_launch_us': round(total_ms * 1e3 / len(big), 2),

@@ -297,7 +297,7 @@ class region:
 # captured segment: ``WGRAD_FLUSH_LAYERS``, set by util.misc.GraphedStep to its cuts).  A whole tile per workgroup only balances
 # when thousands of tiles share a launch (profiles/r05_tn_gang_*.txt: 12 launches 2.83 ms, one launch 1.95 ms).
 WGRAD_GANG = os.environ.get('DAV_WGRAD_GANG', '1') != '0'
-WGRAD_GANG_MIN_TILES = 128
+WGRAD_GANG_MIN_TILES = 512      # (one ViT-B layer = 346 tiles: 193 us on the 128 x 128 kernel, 202 us as a gang launch; two layers 386 vs 347 us)
 WGRAD_MERGE = int(os.environ.get('DAV_WGRAD_MERGE', '0'))
 WGRAD_FLUSH_LAYERS = set()
 
@@ -404,7 +404,8 @@ def _flush_wgrads_now():
                     _OVERWRITE['touched'].add(pr.get('gbase', key))
                 if pr['overwrite']:
                     _OVERWRITE['params'][id(pr['weight'])] = pr['weight']
-        if WGRAD_GANG and PRECISION == 'bf16' and sum(-(-pr['N'] // 256) * -(-pr['K'] // 256) for pr in now) >= WGRAD_GANG_MIN_TILES:
+        if WGRAD_GANG and PRECISION == 'bf16' and (sum(-(-pr['N'] // 256) * -(-pr['K'] // 256) for pr in now) >= WGRAD_GANG_MIN_TILES
+                                                   or any(pr['Mc'] % 64 for pr in now)):      # (a ragged contraction has no other fast kernel)
             ops.gemm_tn_gang(now)          # one persistent launch of 256 x 256 tiles, gangs of panel-sharing tiles per XCD
         else:
             grouped = [pr for pr in now if pr['Mc'] % 64 == 0 or pr['A'].dtype == F32]

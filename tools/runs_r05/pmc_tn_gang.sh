@@ -1,6 +1,6 @@
 # rocprofv3 counter passes over the 12 encoder layers' weight gradients: 128 x 128 grouped (12 launches) vs gang (one launch)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-out=gpurun_out/r05/pmc_tn_gang; mkdir -p $out; rm -f $out/summary.txt
+out=gpurun_out/r05/pmc_tn_gang_tmp; mkdir -p $out; rm -f $out/summary.txt
 i=0
 for set in "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1))
