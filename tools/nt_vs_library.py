@@ -21,6 +21,7 @@ import _libsel  # noqa: E402,F401
 from deepavfusion_amd import ops   # noqa: E402
 
 dev = torch.device('cuda')
+MIN_LAUNCH_TILES = int(os.environ.get('NTL_MIN_TILES', '150'))      # (the bench's "dominant kernel" set is >= 400 tile equivalents per launch)
 NSETS = 4                       # operand sets rotated per call: no launch finds its own operands in L2
 
 
@@ -75,19 +76,20 @@ for path in sys.argv[1:]:
     for ent in mix:
         cfg, b_kn, probs = ent[0], ent[1], ent[2]
         tiles = sum(-(-m // 128) * -(-n // 128) for (m, n, k) in probs)
-        if tiles < 400:                     # the bench's "dominant kernel" set: launches of >= 400 tile equivalents
+        if tiles < MIN_LAUNCH_TILES:
             continue
         for (m, n, k) in probs:
             if -(-m // 128) * -(-n // 128) < 100:
                 continue                    # (small members of a grouped launch)
             key = (m, n, k, b_kn)
-            shapes[key] = shapes.get(key, 0) + 1
+            c = shapes.setdefault(key, [0, set()])
+            c[0] += 1; c[1].add(cfg)
     print(f'# {path}: {len(shapes)} distinct big NT shapes (launch count per step in the last column)')
-    print(f'# {"M x N x K":>22} {"form":>5} {"product us":>10} {"TF":>6} {"cfg 60 us":>10} {"library us":>10} {"TF":>6} {"product / library":>8} {"n":>4}')
+    print(f'# {"M x N x K":>22} {"form":>5} {"product us":>10} {"TF":>6} {"cfg 60 us":>10} {"library us":>10} {"TF":>6} {"product / library":>8} {"n":>4}   tile configuration(s) in the step')
     tot = [0.0, 0.0]
-    for (m, n, k, b_kn), cnt in sorted(shapes.items(), key=lambda kv: -kv[1] * kv[0][0] * kv[0][1] * kv[0][2]):
+    for (m, n, k, b_kn), (cnt, cfgs) in sorted(shapes.items(), key=lambda kv: -kv[1][0] * kv[0][0] * kv[0][1] * kv[0][2]):
         t0, t60, tl = one(m, n, k, b_kn)
         gf = 2.0 * m * n * k / 1e6
         tot[0] += t0 * cnt; tot[1] += tl * cnt
-        print(f'  {f"{m} x {n} x {k}":>22} {"b_kn" if b_kn else "nt":>5} {t0:10.1f} {gf / t0:6.0f} {t60:10.1f} {tl:10.1f} {gf / tl:6.0f} {t0 / tl:8.2f} {cnt:4d}')
+        print(f'  {f"{m} x {n} x {k}":>22} {"b_kn" if b_kn else "nt":>5} {t0:10.1f} {gf / t0:6.0f} {t60:10.1f} {tl:10.1f} {gf / tl:6.0f} {t0 / tl:8.2f} {cnt:4d}   cfg {sorted(cfgs)}')
     print(f'# weighted by launch count: product {tot[0] / 1e3:.2f} ms, library {tot[1] / 1e3:.2f} ms per step  (ratio {tot[0] / max(tot[1], 1e-9):.2f})')

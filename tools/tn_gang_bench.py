@@ -11,6 +11,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+import _libsel  # noqa: E402,F401
 from deepavfusion_amd import ops  # noqa: E402
 
 dev = torch.device('cuda')
