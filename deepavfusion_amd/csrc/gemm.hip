@@ -1919,6 +1919,7 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
 #ifdef DAV_EXPERIMENTAL      // measured and rejected configurations: kept for the tools that reproduce the measurements
       case 50: launch_nt2<128, 128, 4, 2, 2, true, 64, 2>(p, stream); break;
       case 51: launch_nt2<128, 128, 4, 2, 2, true, 64, 4>(p, stream); break;
+      case 52: launch_nt2<192, 128, 4, 2, 2, true>(p, stream); break;      // 192-row tiles, 2 x 80 KB per CU (round 5: -15..30 % alone on the M = 22528 / 3136 shapes, +0.1..0.3 ms in the step)
       case 31: launch_nt2<128, 128, 2, 4, 2, true, 64, 1>(p, stream); break;
       case 32: launch_nt3<true>(p, stream); break;
       case 40: launch_nt2<256, 128, 4, 4, 3, true>(p, stream); break;      // 16 waves, one workgroup per CU, 3 x 48 KB ring
@@ -1970,6 +1971,7 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
       case 2: launch_nt2<128, 128, 2, 2, 3>(p, stream); return dav_launch_status();
       case 50: launch_nt2<128, 128, 4, 2, 2, false, 64, 2>(p, stream); return dav_launch_status();
       case 51: launch_nt2<128, 128, 4, 2, 2, false, 64, 4>(p, stream); return dav_launch_status();
+      case 52: launch_nt2<192, 128, 4, 2, 2>(p, stream); return dav_launch_status();
       case 4: launch_nt2<128, 128, 2, 4, 3>(p, stream); return dav_launch_status();
       case 48: launch_nt2<128, 128, 4, 2, 4>(p, stream); return dav_launch_status();      // 4 x 32 KB ring, one workgroup per CU (in-flight depth experiment)
       case 6: launch_nt2<64, 64, 2, 2, 3>(p, stream); return dav_launch_status();
