@@ -28,7 +28,7 @@ for (M, N, K) in [(5184, 2304, 768), (6080, 2304, 768), (4032, 3072, 768), (5184
 
 # weight-gradient shapes (C[N, K] = A[Mc, N]^T . B[Mc, K]): what the vendor library reaches on single problems of the grouped launches
 print('--- TN (weight gradient) shapes')
-for (Mc, N, K) in [(22528, 2048, 512), (22528, 512, 2048), (22528, 1536, 512), (6080, 2304, 768), (4032, 768, 3072), (3136, 3072, 768), (5184, 768, 768)]:
+for (Mc, N, K) in [(22528, 2048, 512), (22528, 512, 2048), (22528, 1536, 512), (6080, 2304, 768), (4032, 768, 3072), (3136, 3072, 768), (5184, 768, 768), (4096, 4096, 4096), (8192, 4096, 4096)]:
     sets = [(torch.randn(Mc, N, device=dev).bfloat16(), torch.randn(Mc, K, device=dev).bfloat16()) for _ in range(4)]
     outs = [torch.empty(N, K, device=dev, dtype=torch.bfloat16) for _ in range(4)]
     it = [0]

@@ -5,6 +5,8 @@ import json, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+import _libsel  # noqa: F401  (DAV_BENCH_LIB: an experiment build with DAV_TN_GANG_WGS = persistent workgroups of the gang launch)
 from deepavfusion_amd import ops
 dev = torch.device('cuda')
 mix = json.load(open(os.path.join(ROOT, 'profiles', 'r02_step_launch_mix.json')))['tn']
