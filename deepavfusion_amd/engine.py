@@ -318,9 +318,7 @@ class deferred_wgrads:
     def __enter__(self):
         global _DEFERRED, _DEFERRED_LN
         self.prev = (_DEFERRED, _DEFERRED_LN)
-        on = True
-        _DEFERRED = [] if on else None
-        _DEFERRED_LN = [] if on else None
+        _DEFERRED, _DEFERRED_LN = [], []
         return self
 
     def __exit__(self, *exc):
@@ -369,10 +367,6 @@ def deferred_operands_to(stream):
 
 def flush_wgrads():
     """Launch the queued weight-gradient problems on the current stream (their operands must be complete on it)."""
-    _flush_wgrads_now()
-
-
-def _flush_wgrads_now():
     if _DEFERRED_LN:
         items = list(_DEFERRED_LN)
         del _DEFERRED_LN[:]
