@@ -414,16 +414,23 @@ def main():
                            'frac': round(fl_s / (us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), 'ms_per_step': round(us * 1e-3, 3)}
         traffic = traffic_source = None          # HBM bytes per launch: offline rocprofv3 PMC passes over THIS replay (profiles/), only for the profiled workload
         tf = os.path.join(ROOT, 'profiles', 'dominant_kernel_traffic.json')
+        from deepavfusion_amd._lib import kernel_source_hash
+        src_hash = kernel_source_hash()
+        traffic_note = ('offline rocprofv3 --pmc FETCH_SIZE (x2, gfx950 note) + WRITE_SIZE over this replay (the committed files named in traffic_source: a constant '
+                        'of the tree, not of this run — reported only while the kernel sources and the tuned table still hash to what was profiled); null unless profiled for this workload')
         if os.path.exists(tf):
             rec = json.load(open(tf)).get(f'{a.config}_b{B}', {})
-            traffic = rec.get('hbm_bytes_per_launch')
             traffic_source = rec.get('source')
+            if rec.get('kernel_source_hash') == src_hash:
+                traffic = rec.get('hbm_bytes_per_launch')
+            elif rec:
+                traffic_note = f'STALE, not reported: the kernel sources / tuned table changed since the PMC passes ({rec.get("kernel_source_hash")} -> {src_hash}); re-run tools/collect_r05.sh'
         result['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_nt2_kernel / gemm_nt2_grouped_kernel, the launches of >= 400 tile equivalents exactly as the step issues them (default stream schedule: one launch per tower GEMM), each with its tile configuration (128x128 dominant; 128x256 per the rules / tuned table): forward + b_kn dgrad',
                               'launches_by_config': {str(c): sum(1 for cc, _b, _p in big if cc == c) for c in sorted({cc for cc, _b, _p in big})},
                               'achieved': round(ach, 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                               'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': traffic,
                               'traffic_source': traffic_source,
-                              'traffic_note': 'offline rocprofv3 --pmc FETCH_SIZE (x2, gfx950 note) + WRITE_SIZE over this replay (the committed files named in traffic_source: a constant of the tree, not of this run); null unless profiled for this workload',
+                              'traffic_note': traffic_note,
                               'algorithmic_bytes_per_launch': int(sum(2.0 * (M * K + N * K + M * N) for _c, _b, probs in big for (M, N, K) in probs) / len(big)),
                               'launches_per_step': len(big), 'problems_per_step': sum(len(pr) for _c, _b, pr in big),
                               'avg_launch_us': round(total_ms * 1e3 / len(big), 2),
@@ -432,7 +439,7 @@ def main():
         st = os.path.join(ROOT, 'profiles', 'step_traffic.json')        # offline rocprofv3 FETCH_SIZE / WRITE_SIZE passes over the whole step
         if os.path.exists(st):
             rec = json.load(open(st)).get(f'{a.config}_b{B}')
-            if rec:
+            if rec and rec.get('kernel_source_hash') == src_hash:      # (a constant of the tree like roofline.traffic: dropped when stale)
                 result['step_fabric'] = {'GB_per_step': rec['GB_per_step'], 'GBps': round(rec['GB_per_step'] / (ms * 1e-3), 0),
                                          'hbm_frac_of_8TBps': round(rec['GB_per_step'] / (ms * 1e-3) / HBM_PEAK_GBS, 3), 'source': rec.get('source')}
         # the same kernel in the LANES schedule (engine.BATCH_POLICY 'on', three lanes on one queue: the towers' and the fusion

@@ -132,6 +132,20 @@ def load():
     return lib
 
 
+def kernel_source_hash():
+    """sha1 over the kernel sources and the tuned tile-configuration table: the PMC-derived constants under profiles/ (HBM traffic of the
+    dominant kernel, fabric bytes per step) carry the hash of the tree they were measured on, and bench.py reports them only while it
+    still matches (tools/traffic_json.py, tools/step_traffic.py write it)."""
+    import glob
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(here, 'csrc', '*.hip')) + glob.glob(os.path.join(here, 'csrc', '*.h'))) + [os.path.join(here, 'tuning', 'nt_gfx950.json')]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
 NT_TUNING_PATH = os.environ.get('DAV_NT_TUNE_FILE') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuning', 'nt_gfx950.json')
 
 

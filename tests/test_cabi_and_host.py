@@ -473,3 +473,17 @@ def test_switch_table_is_complete_and_current():
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'gen_switch_table.py'), '--check'], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
+
+
+def test_profiled_traffic_constants_belong_to_this_tree():
+    """bench.py's roofline.traffic and step_fabric are PMC-derived constants read from profiles/*.json; each record carries the hash of
+    the kernel sources + tuned table it was measured on (deepavfusion_amd._lib.kernel_source_hash) and bench.py drops a stale one.
+    The committed records of the bench workload must be current, or the driver's line would carry nulls."""
+    import json
+    from deepavfusion_amd._lib import kernel_source_hash
+    h = kernel_source_hash()
+    assert h == kernel_source_hash() and len(h) == 16
+    for name in ('dominant_kernel_traffic.json', 'step_traffic.json'):
+        rec = json.load(open(os.path.join(ROOT, 'profiles', name)))['base_b64']
+        assert rec.get('kernel_source_hash') == h, (f'profiles/{name} was measured on another version of the kernels / tuned table: '
+                                                     're-run tools/collect_r05.sh quick on the GPU box and tools/traffic_json.py')

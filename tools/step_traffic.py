@@ -3,7 +3,7 @@
 misses: Infinity-Cache hits are included, MI355X_MICROARCH.md "HBM") and the rate they imply — from two rocprofv3 --pmc passes
 (FETCH_SIZE, WRITE_SIZE; kernels run one at a time under counter collection) over `bench.py --no-graph --no-roofline`.
 FETCH_SIZE is doubled (gfx950 note of the guide); both are KiB.  Steps = launches of adamw_flat_kernel.
-Usage: step_traffic.py fetch_counter_collection.csv write_counter_collection.csv"""
+Usage: step_traffic.py fetch_counter_collection.csv write_counter_collection.csv [out.json key [source text]]"""
 import csv
 import re
 import sys
@@ -48,8 +48,12 @@ for t, k, n, f, w in rows[:45]:
 if len(sys.argv) > 4:                                # step_traffic.py fetch.csv write.csv <out.json> <key>: totals for bench.py's step_fabric field
     import json
     import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from deepavfusion_amd._lib import kernel_source_hash
     path, key = sys.argv[3], sys.argv[4]
     j = json.load(open(path)) if os.path.exists(path) else {'_comment': 'memory-side traffic of one whole training step (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes over bench.py --no-graph; Infinity-Cache hits included); tools/step_traffic.sh; key = <config>_b<batch>'}
     j[key] = {'GB_per_step': round((FF + WW) / 1e9, 2), 'fetched_GB': round(FF / 1e9, 2), 'written_GB': round(WW / 1e9, 2),
-              'serialised_kernel_ms': round(T / 1e6, 2), 'source': 'profiles/r04_step_traffic.txt (tools/step_traffic.sh)'}
+              'serialised_kernel_ms': round(T / 1e6, 2),
+              'source': sys.argv[5] if len(sys.argv) > 5 else 'profiles/r05_step_traffic.txt (tools/collect_r05.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py --no-graph)',
+              'kernel_source_hash': kernel_source_hash()}
     json.dump(j, open(path, 'w'), indent=1)

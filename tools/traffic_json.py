@@ -12,6 +12,8 @@ import sys
 d, key = sys.argv[1], sys.argv[2]
 pre = sys.argv[3] if len(sys.argv) > 3 else 'r02'
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from deepavfusion_amd._lib import kernel_source_hash  # noqa: E402
 
 
 def fam(n):
@@ -45,6 +47,7 @@ j = json.load(open(path))
 j[key] = {'fetch_kib_per_launch_raw': {k: F[k] for k in fams}, 'write_kib_per_launch': {k: W[k] for k in fams},
           'launches_profiled': {k: calls[k] for k in fams}, 'fetch_kib_per_launch_raw_weighted': round(fetch, 1),
           'write_kib_per_launch_weighted': round(write, 1), 'hbm_bytes_per_launch': int((2 * fetch + write) * 1024),
-          'source': f'profiles/{pre}_pmc_FETCH_SIZE.txt, profiles/{pre}_pmc_WRITE_SIZE.txt, profiles/{pre}_roofline_kernel_stats.csv (launch counts); tools/traffic_json.py'}
+          'source': f'profiles/{pre}_pmc_FETCH_SIZE.txt, profiles/{pre}_pmc_WRITE_SIZE.txt, profiles/{pre}_roofline_kernel_stats.csv (launch counts); tools/traffic_json.py',
+          'kernel_source_hash': kernel_source_hash()}
 json.dump(j, open(path, 'w'), indent=1)
 print(key, tot, 'launches:', round(fetch), 'KiB fetched (raw),', round(write), 'KiB written ->', j[key]['hbm_bytes_per_launch'], 'bytes per launch')
