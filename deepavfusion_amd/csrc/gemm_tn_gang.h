@@ -72,6 +72,8 @@ __global__ __launch_bounds__(64) void gemm_tn_gang_write_kernel(const TGWrite w)
 }
 
 // row of token m under a row map, without an integer division: q = m / rpb through a multiply-high and one correction
+// (magic = floor(2^32 / rpb) estimates q or q - 1 for every m < 2^32; rpb = 1 would need 2^32 itself: 2^32 - 1 gives m - 1, corrected too)
+__device__ __forceinline__ uint32_t tng_magic(int rpb) { return rpb > 1 ? (uint32_t)(0x100000000ull / (uint32_t)rpb) : rpb == 1 ? 0xffffffffu : 0u; }
 __device__ __forceinline__ long tng_row(int m, const RowMap& r, uint32_t magic) {
   if (r.rpb <= 0) return (long)m;
   int q = (int)__umulhi((uint32_t)m, magic);
@@ -99,8 +101,7 @@ __device__ __forceinline__ void tng_tile(const TNParams& p, const int bn, const 
   const int n0 = bn << 8, k0 = bk << 8;
   const int nk = (p.Mc + 63) >> 6;                          // a ragged last K-tile (Mc % 64 != 0: B x tokens at batch 32, 81 / 95 rows per sample) reads zeros for its missing A rows
   const int kend = (nk + 1) & ~1;                           // K-tiles [0, kend); an odd count is padded with one K-tile of zeros on the A side
-  const uint32_t amagic = p.amap.rpb > 0 ? (uint32_t)(0x100000000ull / (uint32_t)p.amap.rpb) : 0u;
-  const uint32_t bmagic = p.bmap.rpb > 0 ? (uint32_t)(0x100000000ull / (uint32_t)p.bmap.rpb) : 0u;
+  const uint32_t amagic = tng_magic(p.amap.rpb), bmagic = tng_magic(p.bmap.rpb);
 
   // ---- LDS-DMA sources.  Piece e of this wave = token rows (2 wave + e) * 4 + (lane >> 4) of the K-tile, 16-byte chunk lane & 15
   // of the 256-byte image row; the image's 32-byte granule g holds source granule g ^ 2 (row & 3).

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised shape fuzz of the C-ABI kernels against torch fp32 references (companion of tests/gpu_selfcheck.py, which uses
-fixed shape lists).  Usage: python tests/gpu_fuzz.py [seed] [n_gemm] [n_attn] [n_ln]"""
+fixed shape lists).  Usage: python tests/gpu_fuzz.py [seed] [n_gemm] [n_attn] [n_ln] [n_gang]"""
 import os
 import random
 import sys
@@ -147,14 +147,57 @@ def fuzz_ln(rng, n):
         check(tag + ' dbeta', rel(db, bp.grad), 3e-4)
 
 
+def fuzz_gang(rng, n):
+    """dav_gemm_tn_gang_bf16 on random problem LISTS: 1 .. 90 problems per launch, contraction lengths from one row to a few thousand
+    (mostly ragged), N / K any multiple of 8 (below, across and beyond one 256 x 256 tile), written and accumulated tiles mixed, bias
+    gradients on some, row maps (rows-per-batch windows of a taller tensor) on some operands, column blocks of a wider gradient."""
+    for it in range(n):
+        probs, refs = [], []
+        for j in range(rng.choice([1, 1, 2, 3, 5, 8, 13, 24, 24, 45, 90])):      # (> 28 problems: several table-writer launches)
+            N = 8 * rng.choice([1, 2, 31, 32, 33, 64, 96, 100, rng.randint(1, 130)])
+            K = 8 * rng.choice([1, 3, 32, 33, 64, 65, 96, rng.randint(1, 130)])
+            mapped = rng.random() < 0.35
+            if mapped:
+                Bsz, tot = rng.choice([1, 2, 7, 16, 32]), rng.randint(2, 120)
+                rpb = rng.randint(1, tot)
+                offa, offb = rng.randint(0, tot - rpb), rng.randint(0, tot - rpb)
+                Mc = Bsz * rpb
+                Af, Bf = torch.randn(Bsz * tot, N, device=dev).to(BF16), torch.randn(Bsz * tot, K, device=dev).to(BF16)
+                As = Af.view(Bsz, tot, N)[:, offa:offa + rpb].reshape(-1, N)
+                Bs = Bf.view(Bsz, tot, K)[:, offb:offb + rpb].reshape(-1, K)
+                maps = dict(a_rowmap=(rpb, tot, offa), b_rowmap=(rpb, tot, offb))
+            else:
+                Mc = rng.choice([1, 7, 63, 64, 65, 128, 200, 640, 1000, rng.randint(1, 3000)])
+                Af = As = torch.randn(Mc, N, device=dev).to(BF16)
+                Bf = Bs = torch.randn(Mc, K, device=dev).to(BF16)
+                maps = dict(a_rowmap=None, b_rowmap=None)
+            ow = rng.random() < 0.5
+            wide = rng.random() < 0.25                      # the problem's gradient is a column block of a wider tensor
+            ldc = K + (8 * rng.randint(1, 20) if wide else 0)
+            Cw = torch.full((N, ldc), 0.25, device=dev)
+            if ow:
+                Cw[:, :K] = float('nan')
+            bg = torch.full((N,), 0.5, device=dev) if rng.random() < 0.4 else None
+            probs.append(dict(A=Af, B=Bf, Mc=Mc, N=N, K=K, C=Cw, lda=N, ldb=K, ldc=ldc, bias_grad=bg, overwrite=ow, **maps))
+            ref = torch.full((N, ldc), 0.25, device=dev)
+            ref[:, :K] = (0.0 if ow else 0.25) + As.float().t() @ Bs.float()
+            refs.append((Cw, ref, bg, None if bg is None else 0.5 + As.float().sum(0), (Mc, N, K, mapped, ow, wide)))
+        ops.gemm_tn_gang(probs)
+        for j, (C, rc, bg, rb, what) in enumerate(refs):
+            check(f'gang #{it}.{j} {what} C', rel(C, rc), 2e-4)
+            if bg is not None:
+                check(f'gang #{it}.{j} {what} bias', rel(bg, rb), 2e-4)
+
+
 if __name__ == '__main__':
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-    ng, na, nl = (int(sys.argv[i]) if len(sys.argv) > i else d for i, d in ((2, 150), (3, 60), (4, 60)))
+    ng, na, nl, ngg = (int(sys.argv[i]) if len(sys.argv) > i else d for i, d in ((2, 150), (3, 60), (4, 60), (5, 60)))
     rng = random.Random(seed)
     torch.manual_seed(seed)
     fuzz_gemm(rng, ng)
     fuzz_attn(rng, na)
     fuzz_ln(rng, nl)
+    fuzz_gang(rng, ngg)
     print(f'fuzz seed {seed}: {len(FAILS)} failures')
     for f in FAILS[:20]:
         print('  ', f)

@@ -288,9 +288,7 @@ def gemm_tn_gang():
     # row maps on both operands + a column block of a wider gradient (ldc), rows-per-batch below and above 64
     for (Bsz, rpb, tot, offa, offb, N, K) in [(16, 12, 20, 3, 8, 320, 136), (8, 81, 95, 14, 0, 768, 512), (64, 8, 40, 32, 0, 264, 768)]:
         Af, Bf = rnd(Bsz * tot, N, dtype=BF16, seed=113), rnd(Bsz * tot, K, dtype=BF16, seed=114)
-        Mc = Bsz * rpb
-        if Mc % 64:
-            continue
+        Mc = Bsz * rpb                    # (8 x 81 = 648 rows: a ragged contraction THROUGH a row map — ViT-L's towers at small batch)
         As = Af.view(Bsz, tot, N)[:, offa:offa + rpb].reshape(-1, N)
         Bs = Bf.view(Bsz, tot, K)[:, offb:offb + rpb].reshape(-1, K)
         Cw = torch.zeros(N, 2 * K, device=dev)
