@@ -2161,7 +2161,6 @@ extern "C" int dav_gemm_tn_gang_bf16(const DavTnProblem* probs, int count, void*
   tn_gang_plan(probs, count, items, q_start);
   static const int dbg = getenv("DAV_TN_GANG_DEBUG") ? atoi(getenv("DAV_TN_GANG_DEBUG")) & 30 : 0;
   // the tables go to the workspace through kernel arguments, <= TG_WCH problems / TG_WIT gangs per writer launch
-  size_t ii = 0;
   bool header = true;
   std::vector<std::vector<const TGPlanItem*>> by_prob(count);
   for (const TGPlanItem& it : items) by_prob[it.prob].push_back(&it);
@@ -2176,19 +2175,19 @@ extern "C" int dav_gemm_tn_gang_bf16(const DavTnProblem* probs, int count, void*
     const TGWrite wl = w;
     DAV_LAUNCH(gemm_tn_gang_write_kernel, dim3(wl.item_count + 1), dim3(64), 0, stream, wl);
   };
-  (void)ii;
   reset(0);
   for (int i = 0; i < count; ++i) {
-    if ((int)by_prob[i].size() > TG_WIT) return DAV_ERR_SHAPE;
-    if (w.prob_count == TG_WCH || w.item_count + (int)by_prob[i].size() > TG_WIT) { flush(); reset(i); }
+    if (w.prob_count == TG_WCH) { flush(); reset(i); }
     const DavTnProblem& q = probs[i];
     TNParams& p = w.prob[w.prob_count++];
     p.A = (const bf16_t*)q.A; p.B = (const bf16_t*)q.B; p.Mc = q.Mc; p.N = q.N; p.K = q.K; p.lda = q.lda; p.ldb = q.ldb;
     p.amap = RowMap{q.a_rowmap[0], q.a_rowmap[1], q.a_rowmap[2]};
     p.bmap = RowMap{q.b_rowmap[0], q.b_rowmap[1], q.b_rowmap[2]};
     p.C = q.C; p.ldc = q.ldc; p.beta = (q.flags & 1) ? 0 : 1; p.bias_grad = q.bias_grad; p.debug_plain_store = 0; p.splits = 1;
-    for (const TGPlanItem* it : by_prob[i])
+    for (const TGPlanItem* it : by_prob[i]) {      // (a very wide weight has more gangs than one writer launch carries: its tickets span several)
+      if (w.item_count == TG_WIT) { flush(); reset(i + 1); }
       w.item[w.item_count++] = TGItem{i, q_start[it->queue] + it->first, (it->r0 << 16) | it->c0, (it->nr << 16) | it->nc};
+    }
   }
   flush();
   static bool big = false;

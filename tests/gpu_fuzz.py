@@ -156,6 +156,8 @@ def fuzz_gang(rng, n):
         for j in range(rng.choice([1, 1, 2, 3, 5, 8, 13, 24, 24, 45, 90])):      # (> 28 problems: several table-writer launches)
             N = 8 * rng.choice([1, 2, 31, 32, 33, 64, 96, 100, rng.randint(1, 130)])
             K = 8 * rng.choice([1, 3, 32, 33, 64, 65, 96, rng.randint(1, 130)])
+            if rng.random() < 0.06:              # a weight of more than 32 tiles: the planner cuts its tile grid into several gangs
+                N, K = 8 * rng.randint(260, 520), 8 * rng.randint(130, 400)
             mapped = rng.random() < 0.35
             if mapped:
                 Bsz, tot = rng.choice([1, 2, 7, 16, 32]), rng.randint(2, 120)

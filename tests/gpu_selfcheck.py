@@ -307,6 +307,15 @@ def gemm_tn_gang():
         refs.append(A.float().t() @ Bm.float())
     ops.gemm_tn_gang(many)
     report('gemm_tn_gang 150 problems', max(rel(pr['C'], r) for pr, r in zip(many, refs)), 2e-4)
+    # one very wide weight: 50 x 50 tiles = 104 gangs, more than one table-writer launch carries (its tickets span two), beside a small one
+    A, Bm = rnd(64, 12800, dtype=BF16, seed=700), rnd(64, 12800, dtype=BF16, seed=701)
+    A2, B2 = rnd(100, 264, dtype=BF16, seed=702), rnd(100, 40, dtype=BF16, seed=703)
+    Cbig, C2 = torch.empty(12800, 12800, device=dev), torch.zeros(264, 40, device=dev)
+    ops.gemm_tn_gang([dict(A=A, B=Bm, Mc=64, N=12800, K=12800, C=Cbig, lda=12800, ldb=12800, ldc=12800, bias_grad=None, overwrite=True),
+                      dict(A=A2, B=B2, Mc=100, N=264, K=40, C=C2, lda=264, ldb=40, ldc=40, bias_grad=None)])
+    report('gemm_tn_gang 12800 x 12800 weight (104 gangs)', rel(Cbig, A.float().t() @ Bm.float()), 2e-4)
+    report('gemm_tn_gang ... and the problem after it', rel(C2, A2.float().t() @ B2.float()), 2e-4)
+    del Cbig
 
 
 def ref_attn(q, k, v, scale):
