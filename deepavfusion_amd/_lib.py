@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, 'libdavfusion_hip.so')
 
 _p, _i, _l, _f, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 
-ABI_VERSION = 7      # DAV_ABI_VERSION of include/dav_kernels.h this package was written against (struct layouts, signatures)
+ABI_VERSION = 8      # DAV_ABI_VERSION of include/dav_kernels.h this package was written against (struct layouts, signatures)
 
 # name -> argtypes (must match include/dav_kernels.h)
 SIGNATURES = {
@@ -26,6 +26,13 @@ SIGNATURES = {
     'dav_last_error_string': [],
     'dav_tune': [_i, _i],
     'dav_gemm_nt_bf16': [_p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _f, _i, _p],
+    'dav_gemm_nt_ln_bf16': [_p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _f, _i, _p, _p],
+    'dav_ln_fold_grouped': [_p, _i, _p],
+    'dav_rowstats_cast': [_p, _l, _i, _i, _i, _p, _p, _p],
+    'dav_layernorm_bwd_twin': [_p, _l, _p, _i, _p, _l, _p, _i, _i, _i, _f, _p, _p, _p, _p,
+                               _p, _l, _i, _p, _l, _p, _l,
+                               _p, _l, _i, _p, _l, _p, _l,
+                               _p, _p, _p, _p, _sz, _p],
     'dav_nt_issue_log': [_i, _p, _i],
     'dav_nt_tune_set': [_p, _i],
     'dav_gemm_tn_bf16': [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _i, _p, _i, _p],
@@ -95,6 +102,16 @@ SIGNATURES = {
 
 class DavLnReduce(C.Structure):
     _fields_ = [('workspace', C.c_void_p), ('dgamma', C.c_void_p), ('dbeta', C.c_void_p), ('rows', C.c_int), ('D', C.c_int)]
+
+
+class DavNtLn(C.Structure):
+    _fields_ = [('stats', C.c_void_p), ('stats2', C.c_void_p), ('A2', C.c_void_p), ('ln_c', C.c_void_p), ('eps', C.c_float),
+                ('a_r0', C.c_int), ('a_r1', C.c_int), ('stats_out', C.c_void_p), ('twin_out', C.c_void_p), ('ld_twin', C.c_int)]
+
+
+class DavLnFold(C.Structure):
+    _fields_ = [('w', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p), ('bias', C.c_void_p),
+                ('w_ln_bf16', C.c_void_p), ('ln_c', C.c_void_p), ('ln_d', C.c_void_p), ('N', C.c_int), ('K', C.c_int)]
 
 
 class DavTranspose(C.Structure):

@@ -79,12 +79,20 @@ def _vis(enc):
 # encoder (models/deepavfusion.py:88-118)
 # ------------------------------------------------------------------------------------------------
 def encoder_fwd(enc, image, audio, ik32, ak32, want_f32=False, collect_embs=False):
+    with E.fold_scope(enc):          # (a no-op inside avmae_fwd's scope)
+        return _encoder_fwd(enc, image, audio, ik32, ak32, want_f32, collect_embs)
+
+
+def _encoder_fwd(enc, image, audio, ik32, ak32, want_f32=False, collect_embs=False):
     B = image.shape[0]
     vis = _vis(enc)
     x_i, t_pi = E.patch_embed_fwd(vis, image, ik32)
     x_a, t_pa = E.patch_embed_fwd(enc.audio, audio, ak32)
     x_f = enc.fusion_tokens.detach().expand(B, -1, -1).clone(memory_format=torch.contiguous_format)   # never an alias of the parameter (B == 1)
     Hi, Ha, Hf = vis.num_heads, enc.audio.num_heads, enc.fusion_num_heads
+    if E.ln_fuse_ok(x_f.shape[2]):      # twin + row statistics of the layer inputs, made once before the three chains of a layer fork
+        for x in (x_i, x_a, x_f):
+            E.ensure_tw(x)
     layers, embs = [], []
     main, sa, sf = _streams(image.device)
     batched = _batched(B * (x_i.shape[1] + x_f.shape[1]))          # rows of the (smaller) visual tower's blocks
@@ -376,7 +384,8 @@ class _FusionBlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        dx_f, dx_i, dx_a = E.fusion_block_bwd(ctx.fb, ctx.tape, g.contiguous(), None)
+        with E.deferred_wgrads():
+            dx_f, dx_i, dx_a = E.fusion_block_bwd(ctx.fb, ctx.tape, g.contiguous(), None)
         return (None, dx_f, dx_i, dx_a) + (None,) * ctx.np
 
 
@@ -389,6 +398,11 @@ def fusion_block(fb, xmm, xv, xa):
 # the whole AVMAE step (models/avmae.py:216-236)
 # ------------------------------------------------------------------------------------------------
 def avmae_fwd(model, image, audio, noise_i, noise_a):
+    with E.fold_scope(model):      # the gamma-folded weights behind the LayerNorms: one grouped refresh per step
+        return _avmae_fwd(model, image, audio, noise_i, noise_a)
+
+
+def _avmae_fwd(model, image, audio, noise_i, noise_a):
     enc = model.encoder
     B = image.shape[0]
     Li, La = model.image_gs[0] * model.image_gs[1], model.audio_gs[0] * model.audio_gs[1]

@@ -47,6 +47,19 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// mean / rstd of one row from its ns = D / 64 partial sums, by the FOUR adjacent lanes q = 0..3 of a row: lane q sums the slots
+// q, q + 4, ... in order, then the four sums are combined as (0 + 1) + (2 + 3).  Every user of the statistics (the consuming GEMM,
+// the LayerNorm backward) goes through this function, so forward and backward see the same bits.
+__device__ __forceinline__ float2 dav_ln_row_stats(const float2* sp, int ns, int q, int D, float eps) {
+  float a1 = 0.f, a2 = 0.f;
+  for (int s_ = q; s_ < ns; s_ += 4) { const float2 t = sp[s_]; a1 += t.x; a2 += t.y; }
+  a1 += __shfl_xor(a1, 1, 64); a2 += __shfl_xor(a2, 1, 64);
+  a1 += __shfl_xor(a1, 2, 64); a2 += __shfl_xor(a2, 2, 64);
+  const float inv = 1.0f / (float)D;
+  const float mean = a1 * inv;
+  return float2{mean, rsqrtf(fmaxf(a2 * inv - mean * mean, 0.f) + eps)};
+}
+
 // exact (erf) GELU and its derivative, as nn.GELU() default
 // Exact (erf) GELU and its derivative from ONE exponential: erf through Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7,
 // far inside the bf16 the results are stored in) — erf(|x|) = 1 - poly(t) e^{-x^2}, t = 1 / (1 + p|x|); with x = z / sqrt(2)

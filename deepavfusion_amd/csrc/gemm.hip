@@ -45,7 +45,30 @@ struct NTParams {
   float alpha;
   int debug;                     // timing experiments only (DAV_NT_DEBUG): 1 = epilogue without global stores, 2 = no epilogue, 4 = no fragment reads / MFMAs
   int force_cfg;                 // host side only: tile configuration asked for explicitly (0 = chosen per group at issue time)
+  // ---- LayerNorm folded into the GEMM (dav_gemm_nt_ln_bf16, DavNtLn) ----
+  // consumer: A holds the RAW rows (bf16 twin of the fp32 residual stream), B = gamma-scaled weights; the epilogue turns the
+  // accumulator into rstd[m] * (acc - mean[m] * ln_c[n]) + bias[n].  Row statistics come as per-row partial sums over 64-column
+  // slots, ln_st[row * (K / 64) + s] = {sum x, sum x^2}; a_r0 > 0: the rows of a batch element are a_r0 rows of (A, ln_st)
+  // followed by a_r1 rows of (A2, ln_st2), both dense.
+  const float* ln_st; const float* ln_st2; const bf16_t* A2; const float* ln_c; float ln_eps; int a_r0, a_r1;
+  // producer: per-row partial sums of the final fp32 value over 64-column slots (row index = the C row) and its bf16 twin
+  float* st_out; bf16_t* tw_out; int ldtw;
 };
+// row of the A operand / of its statistics partials (NS = K / 64 float2 per row)
+__device__ __forceinline__ const bf16_t* nt_a_row(const NTParams& p, int gm) {
+  if (p.a_r0 > 0) {
+    const int R = p.a_r0 + p.a_r1, b = gm / R, i = gm - b * R;
+    return i < p.a_r0 ? p.A + ((long)b * p.a_r0 + i) * p.lda : p.A2 + ((long)b * p.a_r1 + (i - p.a_r0)) * p.lda;
+  }
+  return p.A + map_row(gm, p.amap) * p.lda;
+}
+__device__ __forceinline__ const float2* nt_stat_row(const NTParams& p, int gm, int ns) {
+  if (p.a_r0 > 0) {
+    const int R = p.a_r0 + p.a_r1, b = gm / R, i = gm - b * R;
+    return reinterpret_cast<const float2*>(i < p.a_r0 ? p.ln_st + ((long)b * p.a_r0 + i) * ns * 2 : p.ln_st2 + ((long)b * p.a_r1 + (i - p.a_r0)) * ns * 2);
+  }
+  return reinterpret_cast<const float2*>(p.ln_st + map_row(gm, p.amap) * ns * 2);
+}
 
 struct TNParams {                     // (pointers first: 96 bytes, 40 of them fit the grouped kernels' by-value table)
   const bf16_t* A; const bf16_t* B;   // A[Mc, N] (lda), B[Mc, K] (ldb)
@@ -366,10 +389,31 @@ __device__ __forceinline__ void nt_epilogue(const NTParams& p, f32x4 (&acc)[FM][
 // row straight from registers: no LDS round trip, no waits.  Measured on the LDS-staged epilogue above (DAV_NT_DEBUG):
 // 31 % of the 11264 x 2304 x 768 GEMM and 45 % of the K = 512 decoder GEMMs were epilogue, more than half of it the
 // registers -> LDS -> registers transposition.
-template <int FM, int FN, int WTM, int WTN>
-__device__ __forceinline__ void nt_epilogue_t(const NTParams& p, f32x4 (&acc)[FM][FN], int m0, int n0, int wm, int wn, int lane) {
+// LayerNorm consumer: v = rstd[m] * (alpha acc - mean[m] * c[n]) for one fragment.  mean / rstd (ln_mr[BM]) and c (the tile's BN
+// values behind them) come from LDS at the point of use; without a LayerNorm the operands are the identity (0, 1, 0) — a select on six
+// scalars instead of control flow around the 64 accumulator registers (which made hipcc keep two copies of them: 230 bytes of scratch).
+template <int BM>
+__device__ __forceinline__ float4 nt_ln_frag(const f32x4& a, float alpha, bool lnc, const float2* ln_mr, int ml, int nl) {
+  const float2 mr = lnc ? ln_mr[ml] : float2{0.f, 1.f};
+  const float4 c = lnc ? *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(ln_mr + BM) + nl) : float4{0.f, 0.f, 0.f, 0.f};
+  float4 v;
+  v.x = mr.y * (a[0] * alpha - mr.x * c.x); v.y = mr.y * (a[1] * alpha - mr.x * c.y);
+  v.z = mr.y * (a[2] * alpha - mr.x * c.z); v.w = mr.y * (a[3] * alpha - mr.x * c.w);
+  return v;
+}
+
+// LayerNorm folded in (DavNtLn): consumer — ln_mr[tile row] = {mean, rstd} (LDS), the accumulator becomes rstd * (acc - mean * c[n]);
+// producer — per-row partial sums {sum v, sum v^2} of the FINAL value over 64-column slots (p.st_out, row = the C row) and its bf16
+// twin (p.tw_out): what the next GEMM consumes instead of a LayerNorm output.  A wave tile narrower than a slot (WTN == 32)
+// combines the waves of a slot through LDS in a fixed order (no atomics: bit-repeatable).
+template <int FM, int FN, int WTM, int WTN, int BM = 0, int BN = 0, int WN_ = 1>
+__device__ __forceinline__ void nt_epilogue_t(const NTParams& p, f32x4 (&acc)[FM][FN], int m0, int n0, int wm, int wn, int lane,
+                                              const float2* ln_mr = nullptr, char* smem = nullptr, int tid = 0) {
   if (p.debug & 2) return;
   const int fr = lane & 15, fg = lane >> 4;
+  constexpr bool PROD = BM > 0 && FM * FN <= 8;      // producer side: wave tiles up to 32 x 64 (the 64 x 64 ones have no register to spare: nt_ln_producer_cfg)
+  const bool lnp = PROD && p.st_out != nullptr;
+  const bool lnc = BM > 0 && p.ln_st != nullptr;
   // Every global READ of the epilogue (bias, residual, aux) is requested for a batch of fragments (2 x FN, or FN for the
   // 64-wide wave tiles) before the first one is used: written fragment by fragment the compiler has to wait for each load
   // right where it stands (a store to C may alias the next residual), i.e. one memory latency per read — sixteen of them in
@@ -409,13 +453,19 @@ __device__ __forceinline__ void nt_epilogue_t(const NTParams& p, f32x4 (&acc)[FM
       const int i = i0 + ii;
       const int m = m0 + wm * WTM + i * 16 + fr;
       if (!mok[ii]) continue;
+      float ps1 = 0.f, ps2 = 0.f;
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         const int n = n0 + wn * WTN + j * 16 + fg * 4;
         if (!nok[j]) continue;
         float4 v;
-        v.x = acc[i][j][0] * p.alpha + bv[j].x; v.y = acc[i][j][1] * p.alpha + bv[j].y;
-        v.z = acc[i][j][2] * p.alpha + bv[j].z; v.w = acc[i][j][3] * p.alpha + bv[j].w;
+        if constexpr (BM > 0) {
+          v = nt_ln_frag<BM>(acc[i][j], p.alpha, lnc, ln_mr, wm * WTM + i * 16 + fr, wn * WTN + j * 16 + fg * 4);
+          v.x += bv[j].x; v.y += bv[j].y; v.z += bv[j].z; v.w += bv[j].w;
+        } else {
+          v.x = acc[i][j][0] * p.alpha + bv[j].x; v.y = acc[i][j][1] * p.alpha + bv[j].y;
+          v.z = acc[i][j][2] * p.alpha + bv[j].z; v.w = acc[i][j][3] * p.alpha + bv[j].w;
+        }
         if (p.debug & 1) { if (v.x == 123.456f) reinterpret_cast<float*>(p.C)[0] = v.y; continue; }
         if (p.c2_mode == 1) {
           uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
@@ -456,6 +506,40 @@ __device__ __forceinline__ void nt_epilogue_t(const NTParams& p, f32x4 (&acc)[FM
           uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
           *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
         }
+        if (PROD && p.tw_out) {
+          uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
+          *reinterpret_cast<uint2*>(p.tw_out + crow[ii] * p.ldtw + n) = w;
+        }
+        if (lnp) {
+          ps1 += (v.x + v.y) + (v.z + v.w);
+          ps2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+      }
+      if (lnp) {       // the four lanes (fg = 0..3) that hold a row's columns of this wave tile
+        ps1 += __shfl_xor(ps1, 16, 64); ps2 += __shfl_xor(ps2, 16, 64);
+        ps1 += __shfl_xor(ps1, 32, 64); ps2 += __shfl_xor(ps2, 32, 64);
+        if (fg == 0) {
+          if constexpr (WTN >= 64) {
+            static_assert(WTN == 64 || BM == 0, "one 64-column slot per wave tile");
+            reinterpret_cast<float2*>(p.st_out)[crow[ii] * (p.N >> 6) + ((n0 + wn * WTN) >> 6)] = float2{ps1, ps2};
+          } else {
+            reinterpret_cast<float2*>(smem)[(wm * WTM + i * 16 + fr) * WN_ + wn] = float2{ps1, ps2};
+          }
+        }
+      }
+    }
+  }
+  if constexpr (PROD && WTN < 64) {
+    static_assert(WTN == 32 || BM == 0, "two wave tiles per 64-column slot");
+    if (lnp) {                                         // (uniform per launch: every wave of the workgroup gets here)
+      __syncthreads();
+      constexpr int SPT = BN / 64;                     // slots per tile
+      if (tid < BM * SPT) {
+        const int ml = tid % BM, sl = tid / BM, m = m0 + ml;
+        if (m < p.M) {
+          const float2 a = reinterpret_cast<const float2*>(smem)[ml * WN_ + 2 * sl], b = reinterpret_cast<const float2*>(smem)[ml * WN_ + 2 * sl + 1];
+          reinterpret_cast<float2*>(p.st_out)[map_row(m, p.cmap) * (p.N >> 6) + (n0 >> 6) + sl] = float2{a.x + b.x, a.y + b.y};
+        }
       }
     }
   }
@@ -482,9 +566,10 @@ __device__ __forceinline__ bool nt_staged_ok(const NTParams& p) {
 // after the other, the twin's packed values waiting in registers.
 template <int BM, int BN, int NTHREADS, int FM, int FN, int WTM, int WTN, bool SPLIT = false>
 __device__ __forceinline__ void nt_epilogue_s(const NTParams& p, f32x4 (&acc)[FM][FN], char* lds, int m0, int n0, int wm, int wn,
-                                              int lane, int tid) {
+                                              int lane, int tid, const float2* ln_mr = nullptr) {
   constexpr int RB = BN * 2 + 16;                         // padded tile row (16: keeps the b128 row reads aligned)
   const int fr = lane & 15, fg = lane >> 4;
+  const bool lnc = ln_mr != nullptr && p.ln_st != nullptr;      // LayerNorm consumer (see nt_epilogue_t)      // LayerNorm consumer (see nt_epilogue_t)
   char* img2 = SPLIT ? lds : lds + BM * RB;
   uint2 w2r[SPLIT ? FM : 1][SPLIT ? FN : 1];
   // all global reads of the elementwise part (bias per fragment column, aux per fragment) go out before the first use: one
@@ -516,8 +601,13 @@ __device__ __forceinline__ void nt_epilogue_s(const NTParams& p, f32x4 (&acc)[FM
       const int n = n0 + nl;
       float4 v;
       const bool ok = m < p.M && n < p.N;
-      v.x = acc[i][j][0] * p.alpha + bv[j].x; v.y = acc[i][j][1] * p.alpha + bv[j].y;
-      v.z = acc[i][j][2] * p.alpha + bv[j].z; v.w = acc[i][j][3] * p.alpha + bv[j].w;
+      if (ln_mr != nullptr) {
+        v = nt_ln_frag<BM>(acc[i][j], p.alpha, lnc, ln_mr, ml, nl);
+        v.x += bv[j].x; v.y += bv[j].y; v.z += bv[j].z; v.w += bv[j].w;
+      } else {
+        v.x = acc[i][j][0] * p.alpha + bv[j].x; v.y = acc[i][j][1] * p.alpha + bv[j].y;
+        v.z = acc[i][j][2] * p.alpha + bv[j].z; v.w = acc[i][j][3] * p.alpha + bv[j].w;
+      }
       uint2 w2 = uint2{0, 0};
       if (p.c2_mode == 1) { w2.x = pack2bf(v.x, v.y); w2.y = pack2bf(v.z, v.w); }
       if (p.act == 1) {
@@ -577,6 +667,16 @@ __device__ __forceinline__ void nt_epilogue_s(const NTParams& p, f32x4 (&acc)[FM
     }
   }
 }
+
+// ring / epilogue image of a workgroup; the BM row statistics (float2 mean, rstd) of a LayerNorm-consuming GEMM sit behind it
+template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK>
+constexpr size_t nt2_lds_bytes() {
+  constexpr size_t ring = (size_t)STAGES * (BM + BN) * BK * 2;
+  constexpr size_t epi = (size_t)(nt_epi_split<BM, BN>() ? 1 : 2) * nt_stage_bytes<BM, BN>();
+  return ring > epi ? ring : epi;
+}
+template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK>
+constexpr size_t nt2_lds_alloc() { return nt2_lds_bytes<BM, BN, WM_, WN_, STAGES, BT, BK>() + (size_t)BM * 8 + (size_t)BN * 4; }
 
 #include "gemm_nt256.h"
 #include "gemm_tn_gang.h"
@@ -688,13 +788,30 @@ __device__ __forceinline__ void nt2_body(const NTParams& p, int bid, int tid_in 
   // 16-byte-slot XOR swizzle of the row-major tiles: 128-byte rows (BK 64) / 64-byte rows (BK 32)
   auto rswz = [](int row) { return BK == 64 ? ((row >> 1) & 7) : ((0 - (row >> 2)) & 3); };
 
+  // LayerNorm consumer (p.ln_st): the row statistics of this tile's BM rows — mean, rstd out of the K / 64 partial sums per row —
+  // are formed once per workgroup into LDS behind the ring / epilogue image, by four lanes per row (dav_ln_row_stats: the same
+  // summation order as the LayerNorm backward), before anything else of the tile is live in registers; the epilogue reads them after
+  // the barrier that ends the k-loop.  (The loads are older in the vmcnt queue than every DMA piece: the counted waits of the k-loop
+  // stay what they were.)
+  float2* ln_mr = reinterpret_cast<float2*>(smem + nt2_lds_bytes<BM, BN, WM_, WN_, STAGES, BT, BK>());
+  if (!BT && p.ln_st != nullptr) {
+    const int ns = p.K >> 6;
+    for (int r = tid >> 2; r < BM; r += NT >> 2) {
+      int gm = m0 + r; gm = gm < p.M ? gm : p.M - 1;
+      const float2 mr = dav_ln_row_stats(nt_stat_row(p, gm, ns), ns, tid & 3, p.K, p.ln_eps);
+      if ((tid & 3) == 0) ln_mr[r] = mr;
+    }
+    float* ln_cv = reinterpret_cast<float*>(ln_mr + BM);
+    for (int c = tid; c < BN; c += NT) ln_cv[c] = n0 + c < p.N ? p.ln_c[n0 + c] : 0.f;
+  }
+
   const bf16_t* a_src[A_CH];
   const bf16_t* b_src[B_CH];
 #pragma unroll
   for (int i = 0; i < (PIPE >= 2 ? 0 : A_CH); ++i) {
     const int c = tid + NT * i, row = c / ACPR, ls = (c % ACPR) ^ rswz(row);
     int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;
-    a_src[i] = p.A + map_row(gm, p.amap) * p.lda + ls * 8;
+    a_src[i] = (BT ? p.A + map_row(gm, p.amap) * p.lda : nt_a_row(p, gm)) + ls * 8;
   }
   // B tile: NT mode = [BN rows][BK k] (as A); BT mode (B given as [K, N], the dgrad reading W itself) =
   // [64 k rows][BN cols] (BN*2-byte rows) read back with the transposing ds_read_b64_tr_b16.
@@ -942,8 +1059,10 @@ __device__ __forceinline__ void nt2_body(const NTParams& p, int bid, int tid_in 
     }
     return;
   }
-  if (nt_staged_ok(p)) nt_epilogue_s<BM, BN, NT, FM, FN, WTM, WTN, nt_epi_split<BM, BN>()>(p, acc, smem, m0, n0, wm, wn, lane, tid);
-  else nt_epilogue_t<FM, FN, WTM, WTN>(p, acc, m0, n0, wm, wn, lane);
+  // (the LayerNorm forms exist in the forward [N, K] kernels only: the input-gradient kernels are what they were)
+  if (nt_staged_ok(p)) nt_epilogue_s<BM, BN, NT, FM, FN, WTM, WTN, nt_epi_split<BM, BN>()>(p, acc, smem, m0, n0, wm, wn, lane, tid, BT ? nullptr : ln_mr);
+  else if constexpr (BT) nt_epilogue_t<FM, FN, WTM, WTN>(p, acc, m0, n0, wm, wn, lane);
+  else nt_epilogue_t<FM, FN, WTM, WTN, BM, BN, WN_>(p, acc, m0, n0, wm, wn, lane, ln_mr, smem, tid);
 }
 
 #ifdef DAV_EXPERIMENTAL
@@ -1180,13 +1299,6 @@ __global__ __launch_bounds__((WM_* WN_ + (PIPE >= 2 ? PIPE : 0)) * 64, PIPE == 4
   nt2_body<BM, BN, WM_, WN_, STAGES, BT, BK, false, PIPE>(g.prob[pi], (int)blockIdx.x - g.first_block[pi]);
 }
 
-template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK>
-constexpr size_t nt2_lds_bytes() {
-  constexpr size_t ring = (size_t)STAGES * (BM + BN) * BK * 2;
-  constexpr size_t epi = (size_t)(nt_epi_split<BM, BN>() ? 1 : 2) * nt_stage_bytes<BM, BN>();
-  return ring > epi ? ring : epi;
-}
-
 template <bool BT, int EK>
 __global__ __launch_bounds__(512) void gemm_nt256_grouped_kernel(const NTGroup g) {
   int pi = 0;
@@ -1291,7 +1403,7 @@ void launch_nt3(const NTParams& p, hipStream_t stream) {
 template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK, int PIPE = 0>
 void nt2_issue(const void* const* params, int n, hipStream_t stream) {
   constexpr int NT = (WM_ * WN_ + (PIPE >= 2 ? PIPE : 0)) * 64;      // + the loader waves
-  constexpr size_t lds = nt2_lds_bytes<BM, BN, WM_, WN_, STAGES, BT, BK>();
+  constexpr size_t lds = nt2_lds_alloc<BM, BN, WM_, WN_, STAGES, BT, BK>();
   auto kern = gemm_nt2_kernel<BM, BN, WM_, WN_, STAGES, BT, BK, PIPE>;
   auto gkern = gemm_nt2_grouped_kernel<BM, BN, WM_, WN_, STAGES, BT, BK, PIPE>;
   static bool big = false;
@@ -1379,6 +1491,8 @@ static int nt_tuned_lookup(bool bt, const void* const* params, int n) {
 // 128 x 256 on every wide shape of the step, but as a rule it made the step 0.25 ms SLOWER in every schedule (round 3, same-box
 // alternation, profiles/r03_nt256_instep_ab.txt): a workgroup that owns 128 KB of LDS keeps the other streams' kernels off its CU.
 
+static bool nt_ln_producer_cfg(int cfg) { return cfg == 3 || cfg == 5 || cfg == 7 || cfg == 8; }
+
 // Recorded with the tile configuration left open: chosen at issue time from the tile count of the WHOLE group.
 template <bool BT>
 void nt2_issue_auto(const void* const* params_in, int n, hipStream_t stream) {
@@ -1390,8 +1504,10 @@ void nt2_issue_auto(const void* const* params_in, int n, hipStream_t stream) {
   bool wide = true;
   bool narrow = true;
   bool all256 = true;                                     // every problem can go through the 256 x 256 body and is wide enough for it
+  bool ln_prod = false;                                   // a problem of the group writes row statistics / a twin (DavNtLn producer)
   for (int i = 0; i < n; ++i) {
     const NTParams& p = *(const NTParams*)params[i];
+    ln_prod = ln_prod || p.st_out || p.tw_out;
     all256 = all256 && nt256_ok(p);
     t128 += (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     t256 += (long)((p.M + 127) / 128) * ((p.N + 255) / 256);
@@ -1415,6 +1531,7 @@ void nt2_issue_auto(const void* const* params_in, int n, hipStream_t stream) {
   if (cfg == 3 && (nt_alt == 31 || nt_alt == 51)) cfg = nt_alt;
 #endif
   if (cfg == 60 && !all256) cfg = 3;                     // (an explicit or tuned 60 on a group the 256 x 256 body cannot take)
+  if (ln_prod && !nt_ln_producer_cfg(cfg)) cfg = 3;      // row statistics come out of the 32 x 64 / 32 x 32 wave tiles only
   nt_log_issue(cfg, BT, params, n);
   switch (cfg) {
     case 60: nt256_issue<BT>(params, n, stream); break;
@@ -1865,11 +1982,36 @@ int nt_auto_config(int M, int N, int K) {
 
 }  // namespace
 
+static int nt_entry(const void* A, const void* B, int M, int N, int K, int lda, int ldb,
+                    const int* a_rowmap, const float* bias, int act, const void* aux, int ldaux,
+                    const float* res, int ldres, const int* res_rowmap, const int* res_rows,
+                    void* C, int ldc, int c_is_bf16, const int* c_rowmap, void* C2, int ldc2, int c2_mode,
+                    int beta, float alpha, int variant, const DavNtLn* ln, hipStream_t stream);
+
 extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int K, int lda, int ldb,
                                 const int* a_rowmap, const float* bias, int act, const void* aux, int ldaux,
                                 const float* res, int ldres, const int* res_rowmap, const int* res_rows,
                                 void* C, int ldc, int c_is_bf16, const int* c_rowmap, void* C2, int ldc2, int c2_mode,
                                 int beta, float alpha, int variant, hipStream_t stream) {
+  return nt_entry(A, B, M, N, K, lda, ldb, a_rowmap, bias, act, aux, ldaux, res, ldres, res_rowmap, res_rows, C, ldc, c_is_bf16, c_rowmap,
+                  C2, ldc2, c2_mode, beta, alpha, variant, nullptr, stream);
+}
+
+extern "C" int dav_gemm_nt_ln_bf16(const void* A, const void* B, int M, int N, int K, int lda, int ldb,
+                                   const int* a_rowmap, const float* bias, int act, const void* aux, int ldaux,
+                                   const float* res, int ldres, const int* res_rowmap, const int* res_rows,
+                                   void* C, int ldc, int c_is_bf16, const int* c_rowmap, void* C2, int ldc2, int c2_mode,
+                                   int beta, float alpha, int variant, const DavNtLn* ln, hipStream_t stream) {
+  if (!ln) return DAV_ERR_SHAPE;
+  return nt_entry(A, B, M, N, K, lda, ldb, a_rowmap, bias, act, aux, ldaux, res, ldres, res_rowmap, res_rows, C, ldc, c_is_bf16, c_rowmap,
+                  C2, ldc2, c2_mode, beta, alpha, variant, ln, stream);
+}
+
+static int nt_entry(const void* A, const void* B, int M, int N, int K, int lda, int ldb,
+                    const int* a_rowmap, const float* bias, int act, const void* aux, int ldaux,
+                    const float* res, int ldres, const int* res_rowmap, const int* res_rows,
+                    void* C, int ldc, int c_is_bf16, const int* c_rowmap, void* C2, int ldc2, int c2_mode,
+                    int beta, float alpha, int variant, const DavNtLn* ln, hipStream_t stream) {
   const int b_kn = (variant >> 12) & 1;   // bit 12: B is [K, N] row-major (dgrad reading W itself)
   variant &= 0xfff;
   if (M <= 0 || N <= 0 || K <= 0 || (K & 7) || (lda & 7) || (ldb & 7)) return DAV_ERR_SHAPE;
@@ -1888,10 +2030,36 @@ extern "C" int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int 
   p.beta = beta; p.alpha = alpha; p.b_kn = b_kn;
   static const int nt_debug = getenv("DAV_NT_DEBUG") ? atoi(getenv("DAV_NT_DEBUG")) : 0;
   p.debug = nt_debug;
+  p.ln_st = p.ln_st2 = nullptr; p.A2 = nullptr; p.ln_c = nullptr; p.ln_eps = 0.f; p.a_r0 = p.a_r1 = 0;
+  p.st_out = nullptr; p.tw_out = nullptr; p.ldtw = 0;
   const bool glds_ok = (K & 63) == 0;
   const bool vec_ok = glds_ok && (N & 3) == 0 && (ldc & 3) == 0 && (!res || (ldres & 3) == 0) && (!C2 || (ldc2 & 3) == 0) &&
                       (!aux || (ldaux & 3) == 0) && !(((uintptr_t)C | (uintptr_t)C2 | (uintptr_t)res) & 15) && !((uintptr_t)aux & 7);
   int cfg = variant >> 4;
+  const bool ln_use = ln && (ln->stats || ln->stats_out || ln->twin_out);
+  if (ln_use) {
+    // LayerNorm folded in: the second-generation bodies with 128-wide (or narrower) wave grids only, tile choice left open
+    if (!vec_ok || b_kn || (variant & 15) || !(cfg == 0 || cfg == 3 || cfg == 5 || cfg == 7 || cfg == 8 || cfg == 43 || cfg == 44 || cfg == 45 || cfg == 46)) return DAV_ERR_SHAPE;
+    if (ln->stats) {
+      if (!ln->ln_c || K > 1024 || alpha != 1.0f || !(ln->eps > 0.f) || (((uintptr_t)ln->stats | (uintptr_t)ln->ln_c) & 15)) return DAV_ERR_SHAPE;
+      if (ln->a_r0 < 0 || ln->a_r1 < 0) return DAV_ERR_SHAPE;
+      if (ln->a_r0 > 0) {
+        if (ln->a_r1 <= 0 || !ln->A2 || !ln->stats2 || a_rowmap || M % (ln->a_r0 + ln->a_r1)) return DAV_ERR_SHAPE;
+        if (((uintptr_t)ln->A2 & 15) || ((uintptr_t)ln->stats2 & 7)) return DAV_ERR_ALIGN;
+      }
+      p.ln_st = ln->stats; p.ln_st2 = ln->stats2; p.A2 = (const bf16_t*)ln->A2; p.ln_c = ln->ln_c; p.ln_eps = ln->eps;
+      p.a_r0 = ln->a_r0; p.a_r1 = ln->a_r0 > 0 ? ln->a_r1 : 0;
+    } else if (ln->a_r0 || ln->A2) {
+      return DAV_ERR_SHAPE;
+    }
+    if (ln->stats_out || ln->twin_out) {
+      if (!C || c_is_bf16 || (N & 63)) return DAV_ERR_SHAPE;                 // statistics of the fp32 result, whole 64-column slots
+      if (cfg != 0 && !nt_ln_producer_cfg(cfg)) return DAV_ERR_SHAPE;
+      if (ln->twin_out && ((ln->ld_twin & 3) || ln->ld_twin < N)) return DAV_ERR_SHAPE;
+      if (((uintptr_t)ln->stats_out | (uintptr_t)ln->twin_out) & 7) return DAV_ERR_ALIGN;
+      p.st_out = ln->stats_out; p.tw_out = (bf16_t*)ln->twin_out; p.ldtw = ln->ld_twin;
+    }
+  }
   const bool groupable_cfg = cfg == 0 || cfg == 60 || cfg == 3 || cfg == 5 || cfg == 7 || cfg == 8 || cfg == 50 || cfg == 51 || cfg == 43 || cfg == 44 || cfg == 45 || cfg == 46;
   p.force_cfg = cfg;
   if (vec_ok && groupable_cfg && !(variant & 15) && davb::recording()) {
@@ -2159,7 +2327,13 @@ extern "C" int dav_gemm_tn_gang_bf16(const DavTnProblem* probs, int count, void*
   std::vector<TGPlanItem> items;
   int q_start[9];
   tn_gang_plan(probs, count, items, q_start);
+  // product builds honour the PLACEMENT bits only (8 / 16: same results, other queues); the ablations that make every weight
+  // gradient wrong (2 = no epilogue, 4 = no MFMAs) exist in EXPERIMENTAL builds (tools/runs_r05/gang_ablate.sh)
+#ifdef DAV_EXPERIMENTAL
   static const int dbg = getenv("DAV_TN_GANG_DEBUG") ? atoi(getenv("DAV_TN_GANG_DEBUG")) & 30 : 0;
+#else
+  static const int dbg = getenv("DAV_TN_GANG_DEBUG") ? atoi(getenv("DAV_TN_GANG_DEBUG")) & 24 : 0;
+#endif
   // the tables go to the workspace through kernel arguments, <= TG_WCH problems / TG_WIT gangs per writer launch
   bool header = true;
   std::vector<std::vector<const TGPlanItem*>> by_prob(count);
@@ -2190,13 +2364,22 @@ extern "C" int dav_gemm_tn_gang_bf16(const DavTnProblem* probs, int count, void*
     }
   }
   flush();
-  static bool big = false;
-  if (!big) { (void)hipFuncSetAttribute((const void*)gemm_tn_gang_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); big = true; }
-  static const int n_wg = [] {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    return cus > 0 ? cus : 256;
-  }();
+  // per device (a process may drive several): the > 64 KB dynamic-LDS opt-in and the CU count the persistent grid is sized from
+  static std::mutex dev_mu;
+  static int dev_cus[64] = {0};
+  int n_wg = 256;
+  {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return DAV_ERR_HIP;
+    std::lock_guard<std::mutex> lk(dev_mu);
+    if (!dev_cus[dev]) {
+      if (hipFuncSetAttribute((const void*)gemm_tn_gang_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DAV_ERR_HIP;
+      int cus = 256;
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      dev_cus[dev] = cus > 0 ? cus : 256;
+    }
+    n_wg = dev_cus[dev];
+  }
   const long tiles = q_start[8];
   const int grid = (int)std::min<long>(n_wg, tiles);
   DAV_LAUNCH(gemm_tn_gang_kernel, dim3(grid), dim3(512), TNG_LDS, stream, (char*)workspace, count, dbg);

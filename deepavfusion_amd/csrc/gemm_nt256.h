@@ -31,6 +31,7 @@ constexpr size_t NT256_LDS = 131072;
 
 __host__ __device__ inline bool nt256_ok(const NTParams& p) {
   if ((p.K & 127) || (p.N & 7)) return false;
+  if (p.ln_st || p.st_out || p.tw_out || p.a_r0) return false;      // LayerNorm folded in: the 128-wide bodies only
   if (p.C && (p.ldc & (p.c_bf16 ? 7 : 3))) return false;
   if (p.C2 && (p.ldc2 & 7)) return false;
   if (p.res && (p.ldres & 3)) return false;

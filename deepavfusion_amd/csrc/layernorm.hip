@@ -47,6 +47,12 @@ struct LNBwd {
   const float *gamma, *mean, *rstd;
   float *dgamma, *dbeta;   // accumulated
   float* partial;          // workspace [gridDim.x][2*D]
+  // LayerNorm folded away on the forward path (dav_layernorm_bwd_twin): x as bf16 twin + statistics partials, h_out = gamma xhat + beta
+  const bf16_t *xb0, *xb1;   // twin rows of the two segments (batch strides s0.bs / s1.bs); null = the fp32 sources above
+  const float *st0, *st1;    // {sum, sum of squares} per 64-column slot, row (b * bs / D + r)
+  const float* beta;
+  bf16_t* h_out;             // [B*R, D] or null
+  float eps;
 };
 
 template <int MAXC>
@@ -148,9 +154,20 @@ __device__ __forceinline__ void ln_bwd_body(const LNBwd& p, const int vbid, cons
     const int b = row / R, j = row % R;
     const bool seg0 = j < p.s0.rows;
     const int jj = seg0 ? j : j - p.s0.rows;
-    const float* x = seg0 ? p.s0.x + b * p.s0.bs + (long)jj * p.D : p.s1.x + b * p.s1.bs + (long)jj * p.D;
+    const float* x = p.xb0 ? nullptr : (seg0 ? p.s0.x + b * p.s0.bs + (long)jj * p.D : p.s1.x + b * p.s1.bs + (long)jj * p.D);
     const LNDst& d = seg0 ? p.d0 : p.d1;
-    const float mean = p.mean[row], rstd = p.rstd[row];
+    const bf16_t* xb = nullptr;
+    float mean, rstd;
+    if (p.xb0) {
+      const LNSeg& sg = seg0 ? p.s0 : p.s1;
+      xb = (seg0 ? p.xb0 : p.xb1) + b * sg.bs + (long)jj * p.D;
+      const int ns = p.D >> 6;
+      const float2* sp = reinterpret_cast<const float2*>(seg0 ? p.st0 : p.st1) + ((long)b * (sg.bs / p.D) + jj) * ns;
+      const float2 mr = dav_ln_row_stats(sp, ns, lane & 3, p.D, p.eps);      // (every group of four lanes forms the same value)
+      mean = mr.x; rstd = mr.y;
+    } else {
+      mean = p.mean[row]; rstd = p.rstd[row];
+    }
     float4 xh[MAXC], gy[MAXC], rv[MAXC];
     float s1 = 0.f, s2 = 0.f;
     // the residual-gradient row is fetched together with x / dy (one memory latency per row instead of two: the second pass
@@ -161,7 +178,14 @@ __device__ __forceinline__ void ln_bwd_body(const LNBwd& p, const int vbid, cons
       const int c = lane + 64 * i;
       if (c < nch) {
         rv[i] = rr ? reinterpret_cast<const float4*>(rr)[c] : float4{0.f, 0.f, 0.f, 0.f};
-        const float4 xv = reinterpret_cast<const float4*>(x)[c];
+        float4 xv;
+        if (xb) {
+          const uint2 w = reinterpret_cast<const uint2*>(xb)[c];
+          xv.x = __uint_as_float(w.x << 16); xv.y = __uint_as_float(w.x & 0xffff0000u);
+          xv.z = __uint_as_float(w.y << 16); xv.w = __uint_as_float(w.y & 0xffff0000u);
+        } else {
+          xv = reinterpret_cast<const float4*>(x)[c];
+        }
         float4 dyv = float4{0.f, 0.f, 0.f, 0.f};
         if (p.dy) {
           const uint2 w = reinterpret_cast<const uint2*>(p.dy + (long)row * p.D)[c];
@@ -180,6 +204,13 @@ __device__ __forceinline__ void ln_bwd_body(const LNBwd& p, const int vbid, cons
         gy[i].x = dyv.x * gm.x; gy[i].y = dyv.y * gm.y; gy[i].z = dyv.z * gm.z; gy[i].w = dyv.w * gm.w;
         s1 += gy[i].x + gy[i].y + gy[i].z + gy[i].w;
         s2 += gy[i].x * xh[i].x + gy[i].y * xh[i].y + gy[i].z * xh[i].z + gy[i].w * xh[i].w;
+        if (p.h_out) {          // the consuming Linear's weight-gradient operand: LayerNorm output, re-made here
+          const float4 bt = reinterpret_cast<const float4*>(p.beta)[c];
+          uint2 w;
+          w.x = pack2bf(xh[i].x * gm.x + bt.x, xh[i].y * gm.y + bt.y);
+          w.y = pack2bf(xh[i].z * gm.z + bt.z, xh[i].w * gm.w + bt.w);
+          reinterpret_cast<uint2*>(p.h_out + (long)row * p.D)[c] = w;
+        }
       }
     }
     s1 = wave_sum(s1) / p.D;
@@ -441,6 +472,7 @@ extern "C" int dav_layernorm_bwd(const float* x0, long x0_bs, int r0, const floa
   p.dy = (const bf16_t*)dy_bf16; p.dy32 = dy_f32; p.gamma = gamma; p.mean = mean; p.rstd = rstd;
   p.dgamma = dgamma; p.dbeta = dbeta;
   p.partial = (float*)workspace;
+  p.xb0 = p.xb1 = nullptr; p.st0 = p.st1 = nullptr; p.beta = nullptr; p.h_out = nullptr; p.eps = 0.f;
   const int grid = ln_bwd_grid(B * (r0 + r1));
   const int nch = (D / 4 + 63) / 64;
   if (nch <= 1) ln_dispatch<LNBwd, ln_bwd_issue<1>>(p, stream);
@@ -449,5 +481,147 @@ extern "C" int dav_layernorm_bwd(const float* x0, long x0_bs, int r0, const floa
   else if (nch == 4) ln_dispatch<LNBwd, ln_bwd_issue<4>>(p, stream);
   else ln_dispatch<LNBwd, ln_bwd_issue<8>>(p, stream);
   if (dgamma) DAV_LAUNCH(ln_bwd_reduce_kernel, dim3((2 * D + 63) / 64), dim3(1024), 0, stream, (const float*)workspace, grid, D, dgamma, dbeta);
+  return dav_launch_status();
+}
+
+extern "C" int dav_layernorm_bwd_twin(const void* xb0, long xb0_bs, const float* st0, int r0, const void* xb1, long xb1_bs, const float* st1,
+                                      int r1, int B, int D, float eps, const void* dy_bf16, const float* dy_f32, const float* gamma,
+                                      const float* beta,
+                                      float* dx0, long dx0_bs, int acc0, const float* res0, long res0_bs, void* dx0_bf16, long dx0_bf_bs,
+                                      float* dx1, long dx1_bs, int acc1, const float* res1, long res1_bs, void* dx1_bf16, long dx1_bf_bs,
+                                      void* h_out_bf16, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                                      hipStream_t stream) {
+  if (B <= 0 || D <= 0 || (D & 63) || D > 1024 || r0 <= 0 || r1 < 0 || !(eps > 0.f)) return DAV_ERR_SHAPE;
+  if (!xb0 || !st0 || (r1 > 0 && (!xb1 || !st1)) || !gamma) return DAV_ERR_SHAPE;
+  if (!dy_bf16 && !dy_f32) return DAV_ERR_SHAPE;
+  if (h_out_bf16 && !beta) return DAV_ERR_SHAPE;
+  if ((xb0_bs % D) || (r1 > 0 && (xb1_bs % D))) return DAV_ERR_SHAPE;          // the statistics rows follow the twin's row numbering
+  if (((uintptr_t)xb0 | (uintptr_t)xb1 | (uintptr_t)st0 | (uintptr_t)st1 | (uintptr_t)h_out_bf16) & 7) return DAV_ERR_ALIGN;
+  if (workspace && workspace_bytes < dav_layernorm_bwd_workspace_bytes(B * (r0 + r1), D)) return DAV_ERR_WORKSPACE;
+  if (dgamma && !workspace) return DAV_ERR_WORKSPACE;
+  LNBwd p;
+  p.s0 = LNSeg{nullptr, xb0_bs, r0}; p.s1 = LNSeg{nullptr, xb1_bs, r1}; p.B = B; p.D = D;
+  p.d0 = LNDst{dx0, dx0_bs, r0, acc0, res0, res0_bs, (bf16_t*)dx0_bf16, dx0_bf_bs};
+  p.d1 = LNDst{dx1, dx1_bs, r1, acc1, res1, res1_bs, (bf16_t*)dx1_bf16, dx1_bf_bs};
+  p.dy = (const bf16_t*)dy_bf16; p.dy32 = dy_f32; p.gamma = gamma; p.mean = nullptr; p.rstd = nullptr;
+  p.dgamma = dgamma; p.dbeta = dbeta;
+  p.partial = (float*)workspace;
+  p.xb0 = (const bf16_t*)xb0; p.xb1 = (const bf16_t*)xb1; p.st0 = st0; p.st1 = st1; p.beta = beta; p.h_out = (bf16_t*)h_out_bf16; p.eps = eps;
+  const int grid = ln_bwd_grid(B * (r0 + r1));
+  const int nch = (D / 4 + 63) / 64;
+  if (nch <= 1) ln_dispatch<LNBwd, ln_bwd_issue<1>>(p, stream);
+  else if (nch == 2) ln_dispatch<LNBwd, ln_bwd_issue<2>>(p, stream);
+  else if (nch == 3) ln_dispatch<LNBwd, ln_bwd_issue<3>>(p, stream);
+  else ln_dispatch<LNBwd, ln_bwd_issue<4>>(p, stream);
+  if (dgamma) DAV_LAUNCH(ln_bwd_reduce_kernel, dim3((2 * D + 63) / 64), dim3(1024), 0, stream, (const float*)workspace, grid, D, dgamma, dbeta);
+  return dav_launch_status();
+}
+
+// ---- LayerNorm folded into its neighbour GEMMs: weight fold and stand-alone row statistics ------------------------------------
+namespace {
+
+constexpr int FOLD_MAX = 48;
+struct FoldItem { const float* w; const float *gamma, *beta, *bias; bf16_t* wl; float *c, *d; int N, K; };
+struct FoldGroup { FoldItem it[FOLD_MAX]; int first_row[FOLD_MAX + 1]; int count; };
+static_assert(sizeof(FoldGroup) <= 4096, "kernel argument block");
+
+// one wave per output row n (w = the fp32 master: ONE rounding, like the plain bf16 mirror): w_ln[n, :] = bf16(gamma * w[n, :]), c[n] = sum of the ROUNDED products (what the GEMM really contracts
+// with, so that acc - mean * c is an exact centring), d[n] = bias[n] + sum beta * w[n, :]
+__global__ __launch_bounds__(256) void ln_fold_kernel(const FoldGroup g) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= g.first_row[g.count]) return;
+  int pi = 0;
+  while (pi + 1 < g.count && row >= g.first_row[pi + 1]) ++pi;
+  const FoldItem it = g.it[pi];
+  const int n = row - g.first_row[pi];
+  const float* w = it.w + (long)n * it.K;
+  bf16_t* wl = it.wl + (long)n * it.K;
+  float c = 0.f, d = 0.f;
+  for (int k = lane * 8; k < it.K; k += 512) {
+    const float4 w0 = *reinterpret_cast<const float4*>(w + k), w1 = *reinterpret_cast<const float4*>(w + k + 4);
+    const float4 g0 = *reinterpret_cast<const float4*>(it.gamma + k), g1 = *reinterpret_cast<const float4*>(it.gamma + k + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(it.beta + k), b1 = *reinterpret_cast<const float4*>(it.beta + k + 4);
+    const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    uint4 o;
+    o.x = pack2bf(wv[0] * gv[0], wv[1] * gv[1]); o.y = pack2bf(wv[2] * gv[2], wv[3] * gv[3]);
+    o.z = pack2bf(wv[4] * gv[4], wv[5] * gv[5]); o.w = pack2bf(wv[6] * gv[6], wv[7] * gv[7]);
+    *reinterpret_cast<uint4*>(wl + k) = o;
+    c += (__uint_as_float(o.x << 16) + __uint_as_float(o.x & 0xffff0000u)) + (__uint_as_float(o.y << 16) + __uint_as_float(o.y & 0xffff0000u)) +
+         (__uint_as_float(o.z << 16) + __uint_as_float(o.z & 0xffff0000u)) + (__uint_as_float(o.w << 16) + __uint_as_float(o.w & 0xffff0000u));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d += wv[e] * bv[e];
+  }
+  c = wave_sum(c);
+  d = wave_sum(d);
+  if (lane == 0) {
+    it.c[n] = c;
+    it.d[n] = d + (it.bias ? it.bias[n] : 0.f);
+  }
+}
+
+struct RowStat { const float* x; long bs; int B, rows, D; bf16_t* tw; float* st; };
+
+// one wave per row: lane l holds columns [4 l + 256 i, 4 l + 256 i + 4); a 64-column slot = 16 consecutive lanes of one chunk i
+template <int MAXC>
+__global__ __launch_bounds__(256) void rowstats_cast_kernel(const RowStat p) {
+  const int lane = threadIdx.x & 63;
+  const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int total = p.B * p.rows, nch = p.D >> 2, ns = p.D >> 6;
+  for (int row = gw; row < total; row += nwaves) {
+    const int b = row / p.rows, r = row % p.rows;
+    const float* x = p.x + b * p.bs + (long)r * p.D;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      float s1 = 0.f, s2 = 0.f;
+      if (c < nch) {
+        const float4 v = reinterpret_cast<const float4*>(x)[c];
+        uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
+        reinterpret_cast<uint2*>(p.tw + (long)row * p.D)[c] = w;
+        s1 = (v.x + v.y) + (v.z + v.w);
+        s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+      const int slot = 4 * i + (lane >> 4);
+      if ((lane & 15) == 0 && slot < ns) reinterpret_cast<float2*>(p.st)[(long)row * ns + slot] = float2{s1, s2};
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int dav_ln_fold_grouped(const DavLnFold* items, int count, hipStream_t stream) {
+  if (count <= 0 || count > FOLD_MAX || !items) return DAV_ERR_SHAPE;
+  FoldGroup g;
+  int first = 0;
+  for (int i = 0; i < count; ++i) {
+    const DavLnFold& q = items[i];
+    if (q.N <= 0 || q.K <= 0 || (q.K & 7) || !q.w || !q.gamma || !q.beta || !q.w_ln_bf16 || !q.ln_c || !q.ln_d) return DAV_ERR_SHAPE;
+    if (((uintptr_t)q.w | (uintptr_t)q.w_ln_bf16 | (uintptr_t)q.gamma | (uintptr_t)q.beta) & 15) return DAV_ERR_ALIGN;
+    g.it[i] = FoldItem{q.w, q.gamma, q.beta, q.bias, (bf16_t*)q.w_ln_bf16, q.ln_c, q.ln_d, q.N, q.K};
+    g.first_row[i] = first;
+    first += q.N;
+  }
+  for (int i = count; i <= FOLD_MAX; ++i) g.first_row[i] = first;
+  g.count = count;
+  const FoldGroup gl = g;
+  DAV_LAUNCH(ln_fold_kernel, dim3((first + 3) / 4), dim3(256), 0, stream, gl);
+  return dav_launch_status();
+}
+
+extern "C" int dav_rowstats_cast(const float* x, long x_bs, int B, int rows, int D, void* twin_bf16, float* stats, hipStream_t stream) {
+  if (B <= 0 || rows <= 0 || D <= 0 || (D & 63) || D > 1024 || !x || !twin_bf16 || !stats) return DAV_ERR_SHAPE;
+  if (((uintptr_t)x & 15) || ((uintptr_t)twin_bf16 & 7) || ((uintptr_t)stats & 7) || (x_bs & 3)) return DAV_ERR_ALIGN;
+  const RowStat p{x, x_bs, B, rows, D, (bf16_t*)twin_bf16, stats};
+  const int grid = ln_grid(B * rows);
+  const int nch = (D / 4 + 63) / 64;
+  if (nch <= 1) DAV_LAUNCH(rowstats_cast_kernel<1>, dim3(grid), dim3(256), 0, stream, p);
+  else if (nch == 2) DAV_LAUNCH(rowstats_cast_kernel<2>, dim3(grid), dim3(256), 0, stream, p);
+  else if (nch == 3) DAV_LAUNCH(rowstats_cast_kernel<3>, dim3(grid), dim3(256), 0, stream, p);
+  else DAV_LAUNCH(rowstats_cast_kernel<4>, dim3(grid), dim3(256), 0, stream, p);
   return dav_launch_status();
 }

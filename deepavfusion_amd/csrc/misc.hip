@@ -437,8 +437,7 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
     for (int it = 0; it < 4; ++it, i += 1024) {
       if (i >= n) break;
       while (s + 1 < nseg && i >= seg_end[s]) ++s;
-      const unsigned char kg = keep_grad ? keep_grad[s] : 0;            // (fetched with the segment's hyper-parameters)
-      if (kg & 2) continue;               // updated by the weight-gradient launch that computed its gradient (dav_gemm_tn_grouped_adamw_bf16)
+      const unsigned char kg = keep_grad ? keep_grad[s] : 0;            // strictly 0 / 1 (fetched with the segment's hyper-parameters)
       const float lr = hyper[2 * s], wd = hyper[2 * s + 1];
       const bool fill = zero_grad && !kg;
       const float decay = 1.f - lr * wd, step = lr / bc1;

@@ -236,6 +236,7 @@ def invalidate_weight_cache(params):
     """The fp32 masters changed behind torch's version counters (optimizer kernel, flat-buffer cast): un-managed bf16 copies
     become stale; optimizer-managed mirrors were rewritten by the same kernel and are stamped in sync; transposed copies of
     either kind are re-derived on next use."""
+    bump_fold_generation()
     for p in params:
         c = p.__dict__.get('_dav_cache')
         if c is not None:
@@ -262,6 +263,128 @@ def refresh_weight_cache(module: torch.nn.Module):
 
 def _e(shape, dtype, dev):
     return torch.empty(shape, dtype=dtype, device=dev)
+
+
+# ------------------------------------------------------------------------------------------------
+# LayerNorm folded into the GEMMs either side of it (dav_gemm_nt_ln_bf16; DAV_LN_FUSE=0 keeps the LayerNorm kernels).
+# Every fp32 residual-stream tensor carries a bf16 TWIN and its row-statistics partials ({sum, sum of squares} per 64-column slot),
+# written by the epilogue of the GEMM that produced it (``lin_fwd_tw``) or by ``ensure_tw``; the Linear behind a LayerNorm contracts
+# the RAW twin with gamma-folded weights and normalises in its epilogue (``lin_fwd_ln``).  No LayerNorm-forward launch and no
+# normalised tensor in memory on the forward path; the LayerNorm backward re-makes the weight-gradient operand from the twin
+# (``ln_bwd_tw``: h_out).  The reference lines: timm Block norms (models/vits.py:32-34, models/avmae.py:53-57), the fusion blocks'
+# norm1_img / norm1_aud / norm2 (models/fusion_blocks.py:281-288), decoder_norm -> decoder_pred (models/avmae.py:177-178).
+# norm1_mm of the fusion blocks stays a kernel: its OUTPUT is the residual base (norm-then-residual, :281-283).
+# ------------------------------------------------------------------------------------------------
+LN_FUSE = os.environ.get('DAV_LN_FUSE', '1') != '0'
+
+
+def set_ln_fuse(on: bool):
+    """Tests run one model with the LayerNorms folded into their neighbour GEMMs and with the LayerNorm kernels."""
+    global LN_FUSE
+    LN_FUSE = bool(on)
+
+
+def ln_fuse_ok(D: int) -> bool:
+    return LN_FUSE and PRECISION == 'bf16' and D % 64 == 0 and D <= 1024
+
+
+def tw_of(x):
+    """(bf16 twin [rows, D], statistics partials [rows, D / 64, 2]) attached to the fp32 activation ``x``, or None."""
+    return getattr(x, '_dav_tw', None)
+
+
+def tw_set(x, xb, st):
+    x._dav_tw = (xb, st)
+    return x
+
+
+def ensure_tw(x):
+    """The twin + statistics of a contiguous fp32 activation [B, rows, D]: as attached by its producer, else made here
+    (dav_rowstats_cast: the patch tokens of another API, the expanded fusion tokens, the un-shuffled decoder input)."""
+    t = tw_of(x)
+    if t is None:
+        B, r, D = x.shape
+        xb, st = _e((B * r, D), BF16, x.device), _e((B * r, D // 64, 2), F32, x.device)
+        ops.rowstats_cast(x, r * D, B, r, D, xb, st)
+        t = x._dav_tw = (xb, st)
+    return t
+
+
+class _Fold:
+    """gamma-folded bf16 copy of a Linear's weight behind a LayerNorm + the two epilogue vectors (dav_ln_fold_grouped)."""
+    __slots__ = ('wl', 'c', 'd', 'stamp', 'lin', 'norm')
+
+
+_FOLD_SCOPE = None          # dict id(weight) -> _Fold of the model whose forward is running (filled lazily; refreshed as ONE launch)
+
+
+_FOLD_GEN = [0]             # bumped whenever fp32 masters change behind torch's version counters (optimizer kernel, graph replay)
+
+
+def bump_fold_generation():
+    _FOLD_GEN[0] += 1
+
+
+def _fold_stamp(lin, norm):
+    ps = (lin.weight, norm.weight, norm.bias) + ((lin.bias,) if lin.bias is not None else ())
+    return (_FOLD_GEN[0],) + tuple((p._version, p.data_ptr()) for p in ps)
+
+
+def _fold_items(folds):
+    return [(f.lin.weight.detach().view(f.lin.weight.shape[0], -1), f.norm.weight.detach(), f.norm.bias.detach(),
+             f.lin.bias.detach() if f.lin.bias is not None else None, f.wl, f.c, f.d) for f in folds]
+
+
+def ln_fold(lin, norm):
+    """-> _Fold of (lin, norm), brought up to date when a master changed (optimizer step, load_state_dict)."""
+    f = lin.weight.__dict__.get('_dav_fold')
+    if f is None or f.norm is not norm or f.wl.device != lin.weight.device:
+        f = _Fold()
+        N, K = lin.weight.shape[0], lin.weight.numel() // lin.weight.shape[0]
+        dev = lin.weight.device
+        f.wl, f.c, f.d, f.stamp, f.lin, f.norm = _e((N, K), BF16, dev), _e((N,), F32, dev), _e((N,), F32, dev), None, lin, norm
+        lin.weight.__dict__['_dav_fold'] = f
+    if _FOLD_SCOPE is not None:
+        _FOLD_SCOPE[id(lin.weight)] = f
+    stamp = _fold_stamp(lin, norm)
+    if f.stamp != stamp:
+        with ops.unbatched():
+            ops.ln_fold_grouped(_fold_items([f]))
+        f.stamp = stamp
+    return f
+
+
+class fold_scope:
+    """``with fold_scope(model):`` around a forward: the folds the model has used so far are refreshed by ONE grouped launch when any
+    master changed since (every training step) — always inside a stream capture, so that a replayed graph re-folds from the weights the
+    captured optimizer pass wrote; folds met for the first time are made on the spot and join the scope."""
+
+    def __init__(self, root):
+        self.root = root
+
+    def __enter__(self):
+        global _FOLD_SCOPE
+        self.prev = _FOLD_SCOPE
+        if self.prev is not None or not (LN_FUSE and PRECISION == 'bf16'):
+            return self
+        scope = self.root.__dict__.setdefault('_dav_fold_scope', {})
+        _FOLD_SCOPE = scope
+        folds = list(scope.values())
+        if folds:
+            capturing = folds[0].wl.is_cuda and torch.cuda.is_current_stream_capturing()
+            stamps = [_fold_stamp(f.lin, f.norm) for f in folds]
+            todo = folds if capturing else [f for f, s_ in zip(folds, stamps) if f.stamp != s_]
+            if todo:
+                with ops.unbatched():
+                    ops.ln_fold_grouped(_fold_items(todo))
+                for f in todo:
+                    f.stamp = _fold_stamp(f.lin, f.norm)
+        return self
+
+    def __exit__(self, *exc):
+        global _FOLD_SCOPE
+        _FOLD_SCOPE = self.prev
+        return False
 
 
 class region:
@@ -474,7 +597,7 @@ def lin_fwd(lin, a, M, *, a_rowmap=None, lda=None, act=0, res=None, res_rowmap=N
 
 def lin_bwd(lin, dy, a, M, *, dy_rowmap=None, a_rowmap=None, lda=None, need_dx=True, gelu_aux=None, dx=None, dx_bf16=True,
             dx_rowmap=None, dx_beta=0, dx_C2=None, dx_c2_mode=0, w_col_off=0, k=None, use_bias=True, final=True,
-            dx_res=None, dx_res_rowmap=None):
+            dx_res=None, dx_res_rowmap=None, wgrad=True):
     """Backward of lin_fwd: dx = dy @ W (optionally * GELU'(aux)), dW += dy^T a, db += colsum(dy).
 
     dy: bf16 [*, N]; a: bf16 [*, K] (the forward input).  Returns dx (bf16 [M, K] unless given)."""
@@ -494,6 +617,16 @@ def lin_bwd(lin, dy, a, M, *, dy_rowmap=None, a_rowmap=None, lda=None, need_dx=T
                     aux=gelu_aux, ldaux=K, res=dx_res, ldres=K, res_rowmap=dx_res_rowmap,
                     C_out=dx, ldc=K, c_bf16=dx.dtype == BF16, c_rowmap=dx_rowmap, beta=dx_beta,
                     C2=dx_C2, ldc2=K, c2_mode=dx_c2_mode, variant=variant)
+    if wgrad:
+        lin_wgrad(lin, dy, a, M, dy_rowmap=dy_rowmap, a_rowmap=a_rowmap, lda=lda, w_col_off=w_col_off, k=k, use_bias=use_bias, final=final)
+    return dx
+
+
+def lin_wgrad(lin, dy, a, M, *, dy_rowmap=None, a_rowmap=None, lda=None, w_col_off=0, k=None, use_bias=True, final=True):
+    """The weight-gradient half of lin_bwd: dW += dy^T a, db += colsum(dy) (queued inside ``deferred_wgrads()``).  On its own for the
+    Linears behind a folded LayerNorm, whose operand ``a`` only exists once the LayerNorm backward has re-made it (ln_bwd_tw)."""
+    N, Kfull = lin.weight.shape[0], lin.weight.numel() // lin.weight.shape[0]
+    K = Kfull if k is None else k
     gw = gbuf(lin.weight)
     gwv = gw.view(N, -1)
     Cw = gwv if w_col_off == 0 else gwv.view(-1)[w_col_off:]
@@ -505,14 +638,64 @@ def lin_bwd(lin, dy, a, M, *, dy_rowmap=None, a_rowmap=None, lda=None, need_dx=T
                               ready=(lin.weight, lin.bias) if final else (),
                               gbase=gwv.data_ptr(),
                               weight=lin.weight if (w_col_off == 0 and K == Kfull) else None))      # full weight: may be written
-        return dx
+        return
     if _OVERWRITE is not None:
         _OVERWRITE['touched'].add(gwv.data_ptr())
     ops.gemm_tn(dy, a, M, N, K, Cw, lda=N, ldb=lda if lda is not None else K, ldc=Kfull, a_rowmap=dy_rowmap,
                 b_rowmap=a_rowmap, beta=1, bias_grad=gb)
     if final:
         _ready(lin.weight, lin.bias)
-    return dx
+
+
+def lin_fwd_ln(lin, norm, eps, t0, M, *, t1=None, r0=0, r1=0, a_rowmap=None, act=0, out_bf16=True, out=None, C2=None, c2_mode=0):
+    """lin(norm(x)) with the LayerNorm folded into the GEMM (dav_gemm_nt_ln_bf16): t0 = (twin, statistics) of x.  With t1 the rows of
+    a batch element are r0 rows of t0 followed by r1 rows of t1 — norm(cat((x_fusion, x_mod))) of models/deepavfusion.py:104-105."""
+    f = ln_fold(lin, norm)
+    N, K = f.wl.shape
+    if out is None:
+        out = _e((M, N), BF16 if out_bf16 else F32, f.wl.device)
+    ln = dict(stats=t0[1], ln_c=f.c, eps=eps)
+    if t1 is not None:
+        ln.update(A2=t1[0], stats2=t1[1], a_r0=r0, a_r1=r1)
+    ops.gemm_nt_ln(t0[0], f.wl, M, N, K, ln=ln, a_rowmap=a_rowmap, bias=f.d, act=act, C_out=out, c_bf16=out.dtype == BF16,
+                   C2=C2, ldc2=N, c2_mode=c2_mode)
+    return out
+
+
+def lin_fwd_tw(lin, a, M, res, *, res_rowmap=None, res_rows=None, out=None, tw=None, c_rowmap=None, C2=None, c2_mode=0, rows_out=None):
+    """res + lin(a) in fp32 together with its bf16 twin and row-statistics partials, all from the one epilogue -> (out, (twin, stats)).
+    ``out`` / ``tw`` given: several GEMMs fill row groups of one activation through ``c_rowmap`` (the fusion block's three proj)."""
+    W = wcache(lin.weight)
+    N, K = W.shape
+    dev = a.device
+    R = M if rows_out is None else rows_out
+    if out is None:
+        out = _e((R, N), F32, dev)
+    if tw is None:
+        tw = (_e((R, N), BF16, dev), _e((R, N // 64, 2), F32, dev))
+    ops.gemm_nt_ln(a, W, M, N, K, prod=dict(stats_out=tw[1], twin_out=tw[0], ld_twin=N), bias=lin.bias, res=res, ldres=N,
+                   res_rowmap=res_rowmap, res_rows=res_rows, C_out=out, c_rowmap=c_rowmap, C2=C2, ldc2=N, c2_mode=c2_mode)
+    return out, tw
+
+
+def ln_bwd_tw(norm, eps, t0, r0, t1, r1, B, dy_bf16=None, dy_f32=None, *, h_out=None, dx0=None, acc0=0, res0=None, dx0_bf16=None,
+              dx1=None, acc1=0, res1=None, dx1_bf16=None):
+    """Backward of a LayerNorm that was folded away on the forward path (dav_layernorm_bwd_twin): x comes as twin + statistics
+    (t0: r0 rows | t1: r1 rows per batch element, both dense), ``h_out`` receives the LayerNorm OUTPUT — the operand of the consuming
+    Linear's weight gradient."""
+    D = norm.weight.shape[0]
+    if t0 is None:
+        t0, r0, t1, r1 = t1, r1, None, 0
+        dx0, acc0, res0, dx0_bf16, dx1, acc1, res1, dx1_bf16 = dx1, acc1, res1, dx1_bf16, None, 0, None, None
+    ops.layernorm_bwd_twin(t0[0], r0 * D, t0[1], r0, t1[0] if t1 is not None else None, r1 * D, t1[1] if t1 is not None else None, r1,
+                           B, D, eps, dy_bf16, dy_f32, norm.weight, norm.bias,
+                           dx0, r0 * D, acc0, res0, r0 * D, dx0_bf16, r0 * D,
+                           dx1, r1 * D, acc1, res1, r1 * D, dx1_bf16, r1 * D,
+                           h_out=h_out, dgamma=gbuf(norm.weight), dbeta=gbuf(norm.bias), defer=_DEFERRED_LN)
+    if _DEFERRED_LN is None:
+        _ready(norm.weight, norm.bias)
+    else:
+        _DEFERRED_LN_READY.append((norm.weight, norm.bias))
 
 
 def attention_fwd(q, k, v, B, H, Nq, Nk, dqk, dv, scale, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, dev):
@@ -572,6 +755,8 @@ def block_fwd(blk, x_mod, x_fus, heads, eps, dp=None, idle_before_mlp=0):
     nF = x_fus.shape[1] if x_fus is not None else 0
     R, hd, dev = nF + n, D // heads, x_mod.device
     M, Mq = B * R, B * n
+    if dp is None and ln_fuse_ok(D):
+        return _block_fwd_ln(blk, x_mod, x_fus, heads, eps, idle_before_mlp)
     h1, _, st1 = ln_fwd(blk.norm1, x_fus, x_mod, B, eps)
     qkv = lin_fwd(blk.attn.qkv, h1, M, out_bf16=True)                                       # [B*R, 3D]
     o, lse = attention_fwd((qkv, nF * 3 * D), (qkv, D), (qkv, 2 * D), B, heads, n, R, hd, hd, hd ** -0.5,
@@ -585,6 +770,34 @@ def block_fwd(blk, x_mod, x_fus, heads, eps, dp=None, idle_before_mlp=0):
     x2 = _res_add(blk.mlp.fc2, u, Mq, x1, B, n, D, None if dp is None else dp[1]).view(B, n, D)
     tape = dict(x_mod=x_mod, x_fus=x_fus, h1=h1, st1=st1, qkv=qkv, o=o, lse=lse, x1=x1, h2=h2, st2=st2, z=z, u=u,
                 heads=heads, nF=nF, dp=dp)
+    return x2, tape
+
+
+def _block_fwd_ln(blk, x_mod, x_fus, heads, eps, idle_before_mlp=0):
+    """block_fwd with both LayerNorms folded into the GEMMs around them: qkv / fc1 contract the raw twins of their inputs, proj / fc2
+    write the twin + row statistics of the residual stream they produce.  Saved for the backward: twins and statistics instead of the
+    two normalised tensors and the two fp32 residual tensors."""
+    B, n, D = x_mod.shape
+    nF = x_fus.shape[1] if x_fus is not None else 0
+    R, hd, dev = nF + n, D // heads, x_mod.device
+    M, Mq = B * R, B * n
+    tm = ensure_tw(x_mod)
+    tf = ensure_tw(x_fus) if nF else None
+    if nF:
+        qkv = lin_fwd_ln(blk.attn.qkv, blk.norm1, eps, tf, M, t1=tm, r0=nF, r1=n)            # [B*R, 3D]
+    else:
+        qkv = lin_fwd_ln(blk.attn.qkv, blk.norm1, eps, tm, M)
+    o, lse = attention_fwd((qkv, nF * 3 * D), (qkv, D), (qkv, 2 * D), B, heads, n, R, hd, hd, hd ** -0.5,
+                           R * 3 * D, 3 * D, R * 3 * D, 3 * D, R * 3 * D, 3 * D, dev)
+    x1, tw1 = lin_fwd_tw(blk.attn.proj, o, Mq, x_mod)
+    lane_skip(idle_before_mlp)
+    Hd = blk.mlp.fc1.weight.shape[0]
+    z = _e((Mq, Hd), BF16, dev)
+    u = lin_fwd_ln(blk.mlp.fc1, blk.norm2, eps, tw1, Mq, act=1, C2=z, c2_mode=4)
+    x2, tw2 = lin_fwd_tw(blk.mlp.fc2, u, Mq, x1)
+    x2 = tw_set(x2.view(B, n, D), *tw2)
+    tape = dict(ln_fused=True, eps=eps, x_mod=x_mod, x_fus=x_fus, tm=tm, tf=tf, tw1=tw1, qkv=qkv, o=o, lse=lse, z=z, u=u,
+                heads=heads, nF=nF, dp=None)
     return x2, tape
 
 
@@ -611,11 +824,18 @@ def block_bwd_head(blk, t, g2, g2b, idle_before_attn=0):
         ops.rows_scale_cast(g2, dp[1], B, n, D, g2b)
     elif g2b is None:
         g2b = to_bf16(g2)
+    fused = t.get('ln_fused', False)
     dz = lin_bwd(blk.mlp.fc2, g2b, t['u'], Mq, gelu_aux=t['z'])                              # [Mq, Hd] bf16 (already * GELU')
-    dh2 = lin_bwd(blk.mlp.fc1, dz, t['h2'], Mq)
     g1 = _e((B, n, D), F32, dev)
     g1b = _e((Mq, D), BF16, dev)
-    ln_bwd(blk.norm2, None, t['x1'], B, t['st2'], dy_bf16=dh2, dx1=g1, res1=g2, dx1_bf16=g1b)
+    if fused:       # the norm2 backward re-makes fc1's weight-gradient operand (the LayerNorm output) from the twin of x1
+        dh2 = lin_bwd(blk.mlp.fc1, dz, None, Mq, wgrad=False)
+        h2 = _e((Mq, D), BF16, dev)
+        ln_bwd_tw(blk.norm2, t['eps'], None, 0, t['tw1'], n, B, dy_bf16=dh2, h_out=h2, dx1=g1, res1=g2, dx1_bf16=g1b)
+        lin_wgrad(blk.mlp.fc1, dz, h2, Mq)
+    else:
+        dh2 = lin_bwd(blk.mlp.fc1, dz, t['h2'], Mq)
+        ln_bwd(blk.norm2, None, t['x1'], B, t['st2'], dy_bf16=dh2, dx1=g1, res1=g2, dx1_bf16=g1b)
     if dp is not None:
         ops.rows_scale_cast(g1, dp[0], B, n, D, g1b)
     do = lin_bwd(blk.attn.proj, g1b, t['o'], Mq)
@@ -631,6 +851,9 @@ def block_bwd_head(blk, t, g2, g2b, idle_before_attn=0):
                   (dqkv, nF * 3 * D), (dqkv, D), (dqkv, 2 * D), B, heads, n, R, hd, hd, hd ** -0.5,
                   R * 3 * D, 3 * D, R * 3 * D, 3 * D, R * 3 * D, 3 * D,
                   R * 3 * D, 3 * D, R * 3 * D, 3 * D, R * 3 * D, 3 * D, dq_ctx_rows=nF if ctx_in_kernel else 0)
+    if fused:
+        dh1 = lin_bwd(blk.attn.qkv, dqkv, None, M, wgrad=False)
+        return dict(dh1=dh1, g1=g1, dqkv=dqkv)
     dh1 = lin_bwd(blk.attn.qkv, dqkv, t['h1'], M)
     return dict(dh1=dh1, g1=g1)
 
@@ -640,6 +863,23 @@ def block_bwd_tail(blk, t, st, *, dx_fus=None, dx_fus_acc=0, dx_mod=None, dx_mod
     B, n, D = x_mod.shape
     dev = x_mod.device
     dh1, g1 = st['dh1'], st['g1']
+    if t.get('ln_fused', False):
+        h1 = _e((B * (nF + n), D), BF16, dev)
+        if not need_dx:
+            ln_bwd_tw(blk.norm1, t['eps'], t['tf'], nF, t['tm'], n, B, dy_bf16=dh1, h_out=h1)
+            lin_wgrad(blk.attn.qkv, st['dqkv'], h1, B * (nF + n))
+            return None, None, None
+        if dx_mod is None:
+            dx_mod = _e((B, n, D), F32, dev)
+            dx_mod_acc = 0
+        dx_mod_b = _e((B * n, D), BF16, dev)
+        if nF > 0 and dx_fus is None:
+            dx_fus = _e((B, nF, D), F32, dev)
+            dx_fus_acc = 0
+        ln_bwd_tw(blk.norm1, t['eps'], t['tf'], nF, t['tm'], n, B, dy_bf16=dh1, h_out=h1, dx0=dx_fus, acc0=dx_fus_acc,
+                  dx1=dx_mod, acc1=dx_mod_acc, res1=g1, dx1_bf16=dx_mod_b)
+        lin_wgrad(blk.attn.qkv, st['dqkv'], h1, B * (nF + n))
+        return dx_mod, dx_mod_b, dx_fus
     if not need_dx:
         ln_bwd(blk.norm1, x_fus, x_mod, B, t['st1'], dy_bf16=dh1)
         return None, None, None
@@ -671,16 +911,26 @@ def _factorized_fwd(fb, x_f, x_i, x_a, heads, tkns, dp=None):
     dev, at = x_f.device, fb.attn
     Da, hd = at.q.weight.shape[0], D // heads
     rm2, rmv, rma = (nmm, nF, 0), (nv, nF, nmm), (na, nF, nmm + nv)
+    fused = ln_fuse_ok(D)      # norm1_img / norm1_aud / norm2 folded into the kv / fc1 GEMMs; norm1_mm's OUTPUT is the residual base: a kernel
     # norm-then-residual: the residual base is the NORMED xmm (models/fusion_blocks.py:281-283)
-    with region():
+    if fused:
+        ti, ta = ensure_tw(x_i), ensure_tw(x_a)        # (the towers' twins of the same layer inputs)
         xmm_b, xmm32, st_mm = ln_fwd(fb.norm1_mm, None, x_f, B, want_f32=True)
-        xv_b, _, st_v = ln_fwd(fb.norm1_img, None, x_i, B)
-        xa_b, _, st_a = ln_fwd(fb.norm1_aud, None, x_a, B)
+        xv_b = xa_b = st_v = st_a = None
+    else:
+        with region():
+            xmm_b, xmm32, st_mm = ln_fwd(fb.norm1_mm, None, x_f, B, want_f32=True)
+            xv_b, _, st_v = ln_fwd(fb.norm1_img, None, x_i, B)
+            xa_b, _, st_a = ln_fwd(fb.norm1_aud, None, x_a, B)
     with region():      # CrossAttention q / kv (models/fusion_blocks.py:46-59) of both aggregations + the pair query
         q_v = lin_fwd(at.attn_v.q, xmm_b, B * nv, a_rowmap=rmv, out_bf16=True)               # [B*nv, D]
-        kv_v = lin_fwd(at.attn_v.kv, xv_b, B * nI, out_bf16=True)                            # [B*nI, 2D]
         q_a = lin_fwd(at.attn_a.q, xmm_b, B * na, a_rowmap=rma, out_bf16=True)
-        kv_a = lin_fwd(at.attn_a.kv, xa_b, B * nA, out_bf16=True)
+        if fused:
+            kv_v = lin_fwd_ln(at.attn_v.kv, fb.norm1_img, fb.norm1_img.eps, ti, B * nI)          # [B*nI, 2D]
+            kv_a = lin_fwd_ln(at.attn_a.kv, fb.norm1_aud, fb.norm1_aud.eps, ta, B * nA)
+        else:
+            kv_v = lin_fwd(at.attn_v.kv, xv_b, B * nI, out_bf16=True)
+            kv_a = lin_fwd(at.attn_a.kv, xa_b, B * nA, out_bf16=True)
         q2 = lin_fwd(at.q, xmm_b, B * nmm, a_rowmap=rm2, out_bf16=True)                      # [B*nmm, Da]
     with region():
         o_v, lse_v = attention_fwd((q_v, 0), (kv_v, 0), (kv_v, D), B, heads, nv, nI, hd, hd, hd ** -0.5,
@@ -692,9 +942,15 @@ def _factorized_fwd(fb, x_f, x_i, x_a, heads, tkns, dp=None):
     # proj of the two aggregations: fp32 result lands in its rows of xmm1 (+ normed-xmm residual),
     # bf16 twin of the pre-residual value feeds the pair projections
     xvo_b, xao_b = _e((B * nv, D), BF16, dev), _e((B * na, D), BF16, dev)
+    xmm1_2d = xmm1.view(B * nF, D)
+    tw1 = (_e((B * nF, D), BF16, dev), _e((B * nF, D // 64, 2), F32, dev)) if fused else None      # twin + statistics of xmm1, by row group
     with region():
-        lin_fwd(at.attn_v.proj, o_v, B * nv, res=xmm32, res_rowmap=rmv, out=xmm1, c_rowmap=rmv, C2=xvo_b, c2_mode=2)
-        lin_fwd(at.attn_a.proj, o_a, B * na, res=xmm32, res_rowmap=rma, out=xmm1, c_rowmap=rma, C2=xao_b, c2_mode=2)
+        if fused:
+            lin_fwd_tw(at.attn_v.proj, o_v, B * nv, xmm32, res_rowmap=rmv, out=xmm1_2d, tw=tw1, c_rowmap=rmv, C2=xvo_b, c2_mode=2)
+            lin_fwd_tw(at.attn_a.proj, o_a, B * na, xmm32, res_rowmap=rma, out=xmm1_2d, tw=tw1, c_rowmap=rma, C2=xao_b, c2_mode=2)
+        else:
+            lin_fwd(at.attn_v.proj, o_v, B * nv, res=xmm32, res_rowmap=rmv, out=xmm1, c_rowmap=rmv, C2=xvo_b, c2_mode=2)
+            lin_fwd(at.attn_a.proj, o_a, B * na, res=xmm32, res_rowmap=rma, out=xmm1, c_rowmap=rma, C2=xao_b, c2_mode=2)
     # all (v, a) pairs: Linear(cat(xv_i, xa_j)) = W[:, :D] xv_i + W[:, D:] xa_j + b  (never materialised)
     with region():
         kv_p = lin_fwd(at.k, xvo_b, B * nv, k=D)
@@ -709,15 +965,22 @@ def _factorized_fwd(fb, x_f, x_i, x_a, heads, tkns, dp=None):
     scale = hd ** -0.5                                                                       # NOT (Da/heads)^-0.5 (:220-222)
     o2, lse2 = attention_fwd((q2, 0), (Kp, 0), (Vp, 0), B, heads, nmm, P, Da // heads, hd, scale,
                              nmm * Da, Da, P * Da, Da, P * D, D, dev)
-    lin_fwd(at.proj, o2, B * nmm, res=xmm32, res_rowmap=rm2, out=xmm1, c_rowmap=rm2)
-    h2, _, st2 = ln_fwd(fb.norm2, None, xmm1, B)
     Hd = fb.mlp.fc1.weight.shape[0]
     z = _e((B * nF, Hd), BF16, dev)
-    u = lin_fwd(fb.mlp.fc1, h2, B * nF, act=1, out_bf16=True, C2=z, c2_mode=4)
-    out = lin_fwd(fb.mlp.fc2, u, B * nF, res=xmm1).view(B, nF, D)
+    if fused:
+        lin_fwd_tw(at.proj, o2, B * nmm, xmm32, res_rowmap=rm2, out=xmm1_2d, tw=tw1, c_rowmap=rm2)
+        u = lin_fwd_ln(fb.mlp.fc1, fb.norm2, fb.norm2.eps, tw1, B * nF, act=1, C2=z, c2_mode=4)
+        out, two = lin_fwd_tw(fb.mlp.fc2, u, B * nF, xmm1_2d)
+        out = tw_set(out.view(B, nF, D), *two)
+        h2 = st2 = None
+    else:
+        lin_fwd(at.proj, o2, B * nmm, res=xmm32, res_rowmap=rm2, out=xmm1, c_rowmap=rm2)
+        h2, _, st2 = ln_fwd(fb.norm2, None, xmm1, B)
+        u = lin_fwd(fb.mlp.fc1, h2, B * nF, act=1, out_bf16=True, C2=z, c2_mode=4)
+        out = lin_fwd(fb.mlp.fc2, u, B * nF, res=xmm1).view(B, nF, D)
     tape = dict(dp=None, x_f=x_f, x_i=x_i, x_a=x_a, xmm_b=xmm_b, st_mm=st_mm, xv_b=xv_b, st_v=st_v, xa_b=xa_b, st_a=st_a, cv=cv, ca=ca,
                 xvo_b=xvo_b, xao_b=xao_b, Kp=Kp, Vp=Vp, q2=q2, o2=o2, lse2=lse2, xmm1=xmm1, h2=h2, st2=st2, z=z, u=u,
-                heads=heads, tkns=tkns)
+                heads=heads, tkns=tkns, ln_fused=fused, ti=ti if fused else None, ta=ta if fused else None, tw1=tw1)
     return out, tape
 
 
@@ -739,10 +1002,16 @@ def _factorized_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
     if gb is None:
         gb = to_bf16(g)
     dz = lin_bwd(fb.mlp.fc2, gb, t['u'], B * nF, gelu_aux=t['z'])
-    dh2 = lin_bwd(fb.mlp.fc1, dz, t['h2'], B * nF)
     g1 = _e((B, nF, D), F32, dev)                 # gradient at xmm1 = residual-path gradient of the normed xmm
     g1b = _e((B * nF, D), BF16, dev)
-    ln_bwd(fb.norm2, None, t['xmm1'], B, t['st2'], dy_bf16=dh2, dx1=g1, res1=g, dx1_bf16=g1b)
+    if t.get('ln_fused', False):
+        dh2 = lin_bwd(fb.mlp.fc1, dz, None, B * nF, wgrad=False)
+        h2 = _e((B * nF, D), BF16, dev)
+        ln_bwd_tw(fb.norm2, fb.norm2.eps, None, 0, t['tw1'], nF, B, dy_bf16=dh2, h_out=h2, dx1=g1, res1=g, dx1_bf16=g1b)
+        lin_wgrad(fb.mlp.fc1, dz, h2, B * nF)
+    else:
+        dh2 = lin_bwd(fb.mlp.fc1, dz, t['h2'], B * nF)
+        ln_bwd(fb.norm2, None, t['xmm1'], B, t['st2'], dy_bf16=dh2, dx1=g1, res1=g, dx1_bf16=g1b)
     # d(normed xmm) from the three projections of its row groups lands in one bf16 buffer
     dxmm_b = _e((B * nF, D), BF16, dev)
     # --- pair attention branch (rows [0, nmm)) ---
@@ -796,11 +1065,12 @@ def _factorized_bwd_cross(fb, t, g1, dov, doa, dxmm_b, dx_i, dx_a):
             attention_bwd((ca['q'], 0), (ca['kv'], 0), (ca['kv'], D), ca['o'], doa, ca['lse'], (dq_a, 0), (dkv_a, 0), (dkv_a, D),
                           B, heads, na, nA, hd, hd, hd ** -0.5, na * D, D, nA * 2 * D, 2 * D, nA * 2 * D, 2 * D,
                           na * D, D, nA * 2 * D, 2 * D, nA * 2 * D, 2 * D, part=part, Delta=del_a)
+    fused = t.get('ln_fused', False)
     with region():
         lin_bwd(at.attn_v.q, dq_v, t['xmm_b'], B * nv, a_rowmap=rmv, dx=dxmm_b, dx_rowmap=rmv)
         lin_bwd(at.attn_a.q, dq_a, t['xmm_b'], B * na, a_rowmap=rma, dx=dxmm_b, dx_rowmap=rma)
-        dxv_b = lin_bwd(at.attn_v.kv, dkv_v, t['xv_b'], B * nI)
-        dxa_b = lin_bwd(at.attn_a.kv, dkv_a, t['xa_b'], B * nA)
+        dxv_b = lin_bwd(at.attn_v.kv, dkv_v, t['xv_b'], B * nI, wgrad=not fused)
+        dxa_b = lin_bwd(at.attn_a.kv, dkv_a, t['xa_b'], B * nA, wgrad=not fused)
     # --- the three input LayerNorms ---
     acc_i, acc_a = (1 if dx_i is not None else 0), (1 if dx_a is not None else 0)
     if dx_i is None:
@@ -809,9 +1079,17 @@ def _factorized_bwd_cross(fb, t, g1, dov, doa, dxmm_b, dx_i, dx_a):
         dx_a = _e((B, nA, D), F32, dev)
     dx_f = _e((B, nF, D), F32, dev)
     with region():
-        ln_bwd(fb.norm1_img, None, x_i, B, t['st_v'], dy_bf16=dxv_b, dx1=dx_i, acc1=acc_i)
-        ln_bwd(fb.norm1_aud, None, x_a, B, t['st_a'], dy_bf16=dxa_b, dx1=dx_a, acc1=acc_a)
+        if fused:      # (folded on the forward path: the backward re-makes the kv projections' weight-gradient operands)
+            hv, ha = _e((B * nI, D), BF16, dev), _e((B * nA, D), BF16, dev)
+            ln_bwd_tw(fb.norm1_img, fb.norm1_img.eps, None, 0, t['ti'], nI, B, dy_bf16=dxv_b, h_out=hv, dx1=dx_i, acc1=acc_i)
+            ln_bwd_tw(fb.norm1_aud, fb.norm1_aud.eps, None, 0, t['ta'], nA, B, dy_bf16=dxa_b, h_out=ha, dx1=dx_a, acc1=acc_a)
+        else:
+            ln_bwd(fb.norm1_img, None, x_i, B, t['st_v'], dy_bf16=dxv_b, dx1=dx_i, acc1=acc_i)
+            ln_bwd(fb.norm1_aud, None, x_a, B, t['st_a'], dy_bf16=dxa_b, dx1=dx_a, acc1=acc_a)
         ln_bwd(fb.norm1_mm, None, x_f, B, t['st_mm'], dy_bf16=dxmm_b, dy_f32=g1, dx1=dx_f)
+    if fused:
+        lin_wgrad(at.attn_v.kv, dkv_v, hv, B * nI)
+        lin_wgrad(at.attn_a.kv, dkv_a, ha, B * nA)
     return dx_f, dx_i, dx_a
 
 
@@ -1172,8 +1450,14 @@ def patch_embed_fwd(vit, img, ids_keep32):
     Wb = wcache(pe.proj.weight)
     tok = _e((B, nk, D), F32, img.device)
     pos_by_id = ids_keep32 is not None and not clip
-    ops.gemm_nt(A, Wb, B * nk, D, K, bias=pe.proj.bias, res=vit.pos_embed, ldres=D,
-                res_rows=ids_keep32 if pos_by_id else None, res_rowmap=None if pos_by_id else (L, 0, 0), C_out=tok)
+    if ln_fuse_ok(D) and K % 64 == 0:      # the tokens' twin + row statistics for the first block's folded norm1 (and the fusion block's norm1_*)
+        tw = (_e((B * nk, D), BF16, img.device), _e((B * nk, D // 64, 2), F32, img.device))
+        ops.gemm_nt_ln(A, Wb, B * nk, D, K, prod=dict(stats_out=tw[1], twin_out=tw[0], ld_twin=D), bias=pe.proj.bias, res=vit.pos_embed,
+                       ldres=D, res_rows=ids_keep32 if pos_by_id else None, res_rowmap=None if pos_by_id else (L, 0, 0), C_out=tok)
+        tw_set(tok, *tw)
+    else:
+        ops.gemm_nt(A, Wb, B * nk, D, K, bias=pe.proj.bias, res=vit.pos_embed, ldres=D,
+                    res_rows=ids_keep32 if pos_by_id else None, res_rowmap=None if pos_by_id else (L, 0, 0), C_out=tok)
     return tok, dict(A=A, nk=nk)
 
 
@@ -1211,6 +1495,12 @@ def decoder_fwd(dec, x_b, xf_b, ids_restore32, B, nk, nF):
         tapes.append(bt)
     # decoder_norm + pred on the patch rows only (x[:, nF:]) — the LN reads them through the batch stride
     D_ = Dd
+    if not swin and ln_fuse_ok(Dd):       # decoder_norm folded into decoder_pred: the head contracts the twin's patch rows through a row map
+        tw_last = ensure_tw(x)
+        pred = lin_fwd_ln(dec.pred, dec.norm, dec.norm.eps, tw_last, B * L, a_rowmap=(L, nF + L, nF), out_bf16=False)
+        P = pred.shape[1]
+        tape = dict(x_b=x_b, xf_b=xf_b, tapes=tapes, tw_last=tw_last, ln_fused=True, ids_restore32=ids_restore32, nk=nk, nF=nF, L=L)
+        return pred.view(B, L, P), tape
     hN = _e((B * L, D_), BF16, dev)
     mean, rstd = _e((B * L,), F32, dev), _e((B * L,), F32, dev)
     xs = x.view(-1)[nF * Dd:]
@@ -1225,15 +1515,25 @@ def decoder_bwd(dec, t, dpred_b, ids_keep32, B):
     nk, nF, L = t['nk'], t['nF'], t['L']
     Dd = dec.embed.weight.shape[0]
     dev = dpred_b.device
-    dhN = lin_bwd(dec.pred, dpred_b, t['hN'], B * L)
+    fused = t.get('ln_fused', False)
+    dhN = lin_bwd(dec.pred, dpred_b, None if fused else t['hN'], B * L, wgrad=not fused)
     g = _e((B, nF + L, Dd), F32, dev)                  # the LayerNorm backward writes the L patch rows; the fusion rows carry no
     gb = _e((B * (nF + L), Dd), BF16, dev)             # gradient from the head (models/avmae.py:173 drops them)
     g[:, :nF].zero_()
     gb.view(B, nF + L, Dd)[:, :nF].zero_()
-    xs = t['x_last'].view(-1)[nF * Dd:]
-    ops.layernorm_bwd(xs, (nF + L) * Dd, L, None, 0, 0, B, Dd, dhN, None, dec.norm.weight, t['stN'][0], t['stN'][1],
-                      g.view(-1)[nF * Dd:], (nF + L) * Dd, 0, None, 0, gb.view(-1)[nF * Dd:], (nF + L) * Dd,
-                      None, 0, 0, None, 0, None, 0, gbuf(dec.norm.weight), gbuf(dec.norm.bias))
+    if fused:
+        xb, st = t['tw_last']
+        hN = _e((B * L, Dd), BF16, dev)
+        ops.layernorm_bwd_twin((xb, nF * Dd), (nF + L) * Dd, (st, nF * (Dd // 64) * 2), L, None, 0, None, 0, B, Dd, dec.norm.eps,
+                               dhN, None, dec.norm.weight, dec.norm.bias,
+                               (g, nF * Dd), (nF + L) * Dd, 0, None, 0, (gb, nF * Dd), (nF + L) * Dd,
+                               h_out=hN, dgamma=gbuf(dec.norm.weight), dbeta=gbuf(dec.norm.bias))
+        lin_wgrad(dec.pred, dpred_b, hN, B * L)
+    else:
+        xs = t['x_last'].view(-1)[nF * Dd:]
+        ops.layernorm_bwd(xs, (nF + L) * Dd, L, None, 0, 0, B, Dd, dhN, None, dec.norm.weight, t['stN'][0], t['stN'][1],
+                          g.view(-1)[nF * Dd:], (nF + L) * Dd, 0, None, 0, gb.view(-1)[nF * Dd:], (nF + L) * Dd,
+                          None, 0, 0, None, 0, None, 0, gbuf(dec.norm.weight), gbuf(dec.norm.bias))
     _ready(dec.norm.weight, dec.norm.bias)
     swin = getattr(dec, 'arch', 'plain') == 'swin'
     for blk, bt in zip(reversed(list(dec.blocks)), reversed(t['tapes'])):

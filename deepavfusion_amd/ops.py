@@ -117,6 +117,73 @@ def gemm_nt(A, B, M, N, K, *, lda=None, ldb=None, a_rowmap=None, bias=None, act=
                                     _ptr(C2), ldc2, c2_mode, beta, float(alpha), variant, _stream()), 'dav_gemm_nt_bf16')
 
 
+def gemm_nt_ln(A, B, M, N, K, *, ln=None, prod=None, lda=None, ldb=None, a_rowmap=None, bias=None, act=0, aux=None, ldaux=0, res=None,
+               ldres=0, res_rowmap=None, res_rows=None, C_out=None, ldc=None, c_bf16=False, c_rowmap=None, C2=None, ldc2=0,
+               c2_mode=0, beta=0, variant=0):
+    """dav_gemm_nt_ln_bf16 (bf16 path only).  ``ln`` = dict(stats, ln_c, eps[, A2, stats2, a_r0, a_r1]): A holds RAW twin rows, B the
+    gamma-folded weight, ``bias`` the folded bias (consumer side).  ``prod`` = dict(stats_out=..., twin_out=..., ld_twin=...):
+    row-statistics partials + bf16 twin of the fp32 result (producer side)."""
+    lib = _lib.load()
+    q = _lib.DavNtLn()
+    if ln is not None:
+        q.stats, q.ln_c, q.eps = _ptr(ln['stats']), _ptr(ln['ln_c']), float(ln['eps'])
+        q.stats2, q.A2 = _ptr(ln.get('stats2')), _ptr(ln.get('A2'))
+        q.a_r0, q.a_r1 = int(ln.get('a_r0', 0)), int(ln.get('a_r1', 0))
+    if prod is not None:
+        q.stats_out, q.twin_out, q.ld_twin = _ptr(prod.get('stats_out')), _ptr(prod.get('twin_out')), int(prod.get('ld_twin', N))
+    _lib.check(lib.dav_gemm_nt_ln_bf16(_ptr(A), _ptr(B), M, N, K, lda if lda is not None else K, ldb if ldb is not None else K,
+                                       _rm(a_rowmap), _ptr(bias), act, _ptr(aux), ldaux, _ptr(res), ldres, _rm(res_rowmap),
+                                       _ptr(res_rows), _ptr(C_out), ldc if ldc is not None else N, int(c_bf16), _rm(c_rowmap),
+                                       _ptr(C2), ldc2, c2_mode, beta, 1.0, variant, C.byref(q), _stream()), 'dav_gemm_nt_ln_bf16')
+
+
+LN_FOLD_MAX = 48          # dav_ln_fold_grouped: pairs per launch
+
+
+def ln_fold_grouped(items):
+    """items: [(w fp32 [N, K], gamma, beta, bias or None, w_ln_bf16, ln_c, ln_d), ...] (dav_ln_fold_grouped)."""
+    lib = _lib.load()
+    for i in range(0, len(items), LN_FOLD_MAX):
+        chunk = items[i:i + LN_FOLD_MAX]
+        arr = (_lib.DavLnFold * len(chunk))()
+        for q, (w, g, b, bias, wl, c, d) in zip(arr, chunk):
+            q.w, q.gamma, q.beta, q.bias, q.w_ln_bf16, q.ln_c, q.ln_d = _ptr(w), _ptr(g), _ptr(b), _ptr(bias), _ptr(wl), _ptr(c), _ptr(d)
+            q.N, q.K = int(w.shape[0]), int(w.shape[1])
+        _lib.check(lib.dav_ln_fold_grouped(arr, len(chunk), _stream()), 'dav_ln_fold_grouped')
+
+
+def rowstats_cast(x, x_bs, B, rows, D, twin, stats):
+    """bf16 twin + per-row {sum, sum of squares} partials over 64-column slots of fp32 rows (dav_rowstats_cast)."""
+    _lib.check(_lib.load().dav_rowstats_cast(_ptr(x), x_bs, B, rows, D, _ptr(twin), _ptr(stats), _stream()), 'dav_rowstats_cast')
+
+
+def layernorm_bwd_twin(xb0, xb0_bs, st0, r0, xb1, xb1_bs, st1, r1, B, D, eps, dy_bf16, dy_f32, gamma, beta,
+                       dx0=None, dx0_bs=0, acc0=0, res0=None, res0_bs=0, dx0_bf16=None, dx0_bf_bs=0,
+                       dx1=None, dx1_bs=0, acc1=0, res1=None, res1_bs=0, dx1_bf16=None, dx1_bf_bs=0, h_out=None, dgamma=None, dbeta=None,
+                       defer=None):
+    """dav_layernorm_bwd_twin; xb* / st* / dx* may be (tensor, element offset) pairs.  ``defer`` as layernorm_bwd."""
+    lib = _lib.load()
+
+    def po(t):
+        if t is None:
+            return None
+        if isinstance(t, tuple):
+            return _ptr(t[0]) + t[0].element_size() * t[1]
+        return _ptr(t)
+    ws = None
+    if dgamma is not None:
+        ws = torch.empty(lib.dav_layernorm_bwd_workspace_bytes(B * (r0 + r1), D) // 4, dtype=F32, device=dgamma.device)
+        if defer is not None:
+            defer.append((ws, dgamma, dbeta, B * (r0 + r1), D))
+            dgamma = dbeta = None
+    _lib.check(lib.dav_layernorm_bwd_twin(po(xb0), xb0_bs, po(st0), r0, po(xb1), xb1_bs, po(st1), r1, B, D, float(eps),
+                                          _ptr(dy_bf16), _ptr(dy_f32), _ptr(gamma), _ptr(beta),
+                                          po(dx0), dx0_bs, acc0, po(res0), res0_bs, po(dx0_bf16), dx0_bf_bs,
+                                          po(dx1), dx1_bs, acc1, po(res1), res1_bs, po(dx1_bf16), dx1_bf_bs,
+                                          _ptr(h_out), _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel() * 4 if ws is not None else 0,
+                                          _stream()), 'dav_layernorm_bwd_twin')
+
+
 def nt_issue_log(enable=None, with_flags=False):
     """enable True / False: start (clearing) / stop logging the NT launches the library issues; None: fetch the log as a
     list of (cfg, b_kn, [(M, N, K), ...]) — one entry per launch (grouped launches have several problems); with_flags adds a

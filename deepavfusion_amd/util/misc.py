@@ -337,6 +337,7 @@ class GraphedStep:
             self.reducer.finish()
             self.opt_graph.replay()
         self.opt.flat.stale = self.kept_params > 0
+        engine.bump_fold_generation()          # the replayed optimizer pass moved the masters: gamma-folded weight copies are re-made on next eager use
         self.tr.n_steps += 1
         return self.loss_image, self.loss_audio, self.grad_norm
 

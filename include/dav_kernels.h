@@ -37,7 +37,7 @@ typedef struct ihipStream_t* hipStream_t;
 extern "C" {
 #endif
 
-#define DAV_ABI_VERSION 7   /* 2: DavTnProblem.flags, dav_adamw_flat keep_grad + gscale_dev, dav_step_guard; 3: dav_attn_bwd_ctx, dav_add_cast; 4: fused fusion tails, grouped cast-transpose; 5: dav_gemm_tn_grouped_adamw_bf16; 6: dav_gemm_tn_gang_bf16; 7: the fused fusion tails and dav_gemm_tn_grouped_adamw_bf16 are gone (measured slower, DESIGN_HISTORY section 11) */
+#define DAV_ABI_VERSION 8   /* 8: LayerNorm folded into the GEMMs either side of it (dav_gemm_nt_ln_bf16, dav_ln_fold_grouped, dav_rowstats_cast, dav_layernorm_bwd_twin); 2: DavTnProblem.flags, dav_adamw_flat keep_grad + gscale_dev, dav_step_guard; 3: dav_attn_bwd_ctx, dav_add_cast; 4: fused fusion tails, grouped cast-transpose; 5: dav_gemm_tn_grouped_adamw_bf16; 6: dav_gemm_tn_gang_bf16; 7: the fused fusion tails and dav_gemm_tn_grouped_adamw_bf16 are gone (measured slower, DESIGN_HISTORY section 11) */
 int dav_abi_version(void);
 int dav_build_flags(void);   /* bit 0: experimental build (make EXPERIMENTAL=1): the rejected GEMM tile configurations exist */
 /* text of the last HIP error latched by a kernel launch of the calling thread (diagnostics) */
@@ -63,6 +63,30 @@ int dav_gemm_nt_bf16(const void* A, const void* B, int M, int N, int K, int lda,
                      const float* bias, int act, const void* aux, int ldaux, const float* res, int ldres,
                      const int* res_rowmap, const int* res_rows, void* C, int ldc, int c_is_bf16, const int* c_rowmap,
                      void* C2, int ldc2, int c2_mode, int beta, float alpha, int variant, hipStream_t stream);
+
+/* dav_gemm_nt_bf16 with the LayerNorm between two GEMMs folded into them (ABI 8) — timm Block.norm1 / norm2 in front of attn.qkv /
+ * mlp.fc1 (models/vits.py:32-34, models/avmae.py:53-57, 83-87), norm1_img / norm1_aud / norm2 of the fusion blocks
+ * (models/fusion_blocks.py:281-288), decoder_norm in front of decoder_pred (models/avmae.py:59-60,177-178): no LayerNorm launch and no
+ * normalised tensor in memory on the forward path.
+ *  PRODUCER side (stats_out / twin_out; C must be fp32, N % 64 == 0): besides C the epilogue writes, for every row, the partial sums
+ *   stats_out[crow * (N / 64) + s] = {sum, sum of squares} of the FINAL fp32 values of columns [64 s, 64 s + 64) (crow = the C row after
+ *   c_rowmap) and the bf16 twin twin_out[crow * ld_twin + n] of the final value.  Fixed summation order, no atomics.
+ *  CONSUMER side (stats): A holds RAW rows — such a twin — and B the weight with the LayerNorm's gamma folded in (dav_ln_fold_grouped:
+ *   B[n, k] = bf16(gamma[k] W[n, k]) from the fp32 master W, ln_c[n] = sum_k B[n, k], bias := b[n] + sum_k beta[k] W[n, k]); the epilogue starts from
+ *   v = rstd[m] * (acc[m, n] - mean[m] * ln_c[n]) + bias[n] with mean / rstd formed from the K / 64 partial sums of row m
+ *   (mean = sum / K, var = sumsq / K - mean^2 clamped at 0, rstd = 1 / sqrt(var + eps)); K % 64 == 0, K <= 1024, alpha == 1.
+ *   The statistics row of A row m is the physical A row (through a_rowmap).  a_r0 > 0: every batch element's rows are a_r0 rows of
+ *   (A, stats) followed by a_r1 rows of (A2, stats2), both dense and with row stride lda — the cat((x_fusion, x_mod)) of
+ *   models/deepavfusion.py:104-105; a_rowmap must be NULL and M a multiple of a_r0 + a_r1.
+ * Everything else as dav_gemm_nt_bf16 (b_kn and explicit first-generation variants are refused). */
+typedef struct DavNtLn {
+  const float* stats; const float* stats2; const void* A2; const float* ln_c; float eps; int a_r0, a_r1;   /* consumer */
+  float* stats_out; void* twin_out; int ld_twin;                                                          /* producer */
+} DavNtLn;
+int dav_gemm_nt_ln_bf16(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const int* a_rowmap,
+                        const float* bias, int act, const void* aux, int ldaux, const float* res, int ldres,
+                        const int* res_rowmap, const int* res_rows, void* C, int ldc, int c_is_bf16, const int* c_rowmap,
+                        void* C2, int ldc2, int c2_mode, int beta, float alpha, int variant, const DavNtLn* ln, hipStream_t stream);
 
 /* Diagnostics for benchmarks: log which launches the NT family issues (grouped or single).  enable 1 / 0 with out == NULL
  * starts (and clears) / stops logging (process-wide: autograd runs the backward on its own thread); with out != NULL the log is copied: entries of
@@ -197,6 +221,33 @@ size_t dav_layernorm_bwd_workspace_bytes(int rows, int D);   /* rows = B * (r0 +
 typedef struct DavLnReduce { const void* workspace; float* dgamma; float* dbeta; int rows; int D; } DavLnReduce;
 int dav_layernorm_bwd_reduce_grouped(const DavLnReduce* items, int count, hipStream_t stream);
 
+/* ---- LayerNorm folded into its neighbour GEMMs (ABI 8; see dav_gemm_nt_ln_bf16) ------------------------------------------- */
+/* Per (Linear, LayerNorm-in-front-of-it) pair, from the fp32 master weight w [N, K] (one rounding, as for the plain bf16 mirror):
+ * w_ln[n, k] = bf16(gamma[k] * w[n, k]), ln_c[n] = sum_k float(w_ln[n, k]) (the ROUNDED values the GEMM contracts with: acc - mean * ln_c
+ * is an exact centring), ln_d[n] = (bias ? bias[n] : 0) + sum_k beta[k] * w[n, k].  One launch for up to 48 pairs (one wave per output
+ * row); the table is read on the host during the call only.  K % 8 == 0. */
+typedef struct DavLnFold {
+  const float* w; const float* gamma; const float* beta; const float* bias;   /* [N, K] fp32, [K], [K], [N] or NULL */
+  void* w_ln_bf16; float* ln_c; float* ln_d;                                   /* [N, K] bf16, [N], [N] */
+  int N, K;
+} DavLnFold;
+int dav_ln_fold_grouped(const DavLnFold* items, int count, hipStream_t stream);
+/* Row statistics + bf16 twin of an fp32 activation that no GEMM epilogue produced (the decoder input after the un-shuffle, the
+ * expanded fusion tokens, DropPath outputs): rows r of [B][rows][D] at x + b * x_bs + r * D (x_bs in elements, 0 = broadcast) ->
+ * twin[(b * rows + r) * D + ...] bf16, stats[(b * rows + r) * (D / 64) + s] = {sum, sum of squares} over columns [64 s, 64 s + 64).
+ * D % 64 == 0, D <= 1024. */
+int dav_rowstats_cast(const float* x, long x_bs, int B, int rows, int D, void* twin_bf16, float* stats, hipStream_t stream);
+/* dav_layernorm_bwd for a LayerNorm that was folded away on the forward path: x comes as the bf16 twin (two dense segments per batch
+ * element, batch strides in elements as there) with its statistics partials (st*: row b * (st*_bs / D) + r), mean / rstd are re-formed
+ * as dav_gemm_nt_ln_bf16 forms them, and h_out (optional, bf16 [B * (r0 + r1), D]) receives gamma * xhat + beta — the operand the weight
+ * gradient of the consuming Linear contracts with, produced here instead of being kept from the forward.  Everything else as
+ * dav_layernorm_bwd (dgamma / dbeta partial rows in `workspace`, reduced by dav_layernorm_bwd_reduce_grouped or at once). */
+int dav_layernorm_bwd_twin(const void* xb0, long xb0_bs, const float* st0, int r0, const void* xb1, long xb1_bs, const float* st1, int r1,
+                           int B, int D, float eps, const void* dy_bf16, const float* dy_f32, const float* gamma, const float* beta,
+                           float* dx0, long dx0_bs, int acc0, const float* res0, long res0_bs, void* dx0_bf16, long dx0_bf_bs,
+                           float* dx1, long dx1_bs, int acc1, const float* res1, long res1_bs, void* dx1_bf16, long dx1_bf_bs,
+                           void* h_out_bf16, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, hipStream_t stream);
+
 /* ---- masking / gather / scatter ------------------------------------------------------------ */
 /* AVMAE.random_masking (models/avmae.py:120-142) for given noise [N,L]: argsort twice, keep the first
  * len_keep, un-shuffled 0/1 mask.  Bit-exact with torch.argsort for tie-free noise. */
@@ -256,7 +307,7 @@ int dav_l2norm(const float* x, long n, float scale, float* out, void* workspace,
  * util/misc.py:151-163 is its square root), (b) rewrite the bf16 weight mirror p_bf16, (c) zero the gradients
  * (Trainer.zero_grad) — one trip over the buffers instead of three.  keep_grad (NULL or one byte per segment): segments
  * with a non-zero byte are NOT zero-filled — their next gradient will be written, not accumulated (DavTnProblem.flags bit 0),
- * which saves the fill here and the read there; byte bit 1: the segment is skipped altogether.  All accesses are 16-byte ones: the buffers must be
+ * which saves the fill here and the read there (values other than 0 / 1 are not defined).  All accesses are 16-byte ones: the buffers must be
  * 16-byte aligned (p_bf16 8-byte), n and every seg_end a multiple of 4 (FlatParams aligns segments to 64 elements).
  * gscale_dev (optional): device scalar from dav_step_guard, see there. */
 int dav_adamw_flat(float* p, float* g, float* m, float* v, void* p_bf16, long n, const long* seg_end, const float* hyper,

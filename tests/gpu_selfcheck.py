@@ -524,6 +524,171 @@ def layernorm():
         report(tag + ' dbeta', rel(db, bp.grad), 1e-4)
 
 
+def _slot_stats(x):
+    """[rows, D] fp32 -> [rows, D/64, 2] {sum, sum of squares} per 64-column slot (float64 reference)"""
+    r, D = x.shape
+    v = x.double().view(r, D // 64, 64)
+    return torch.stack([v.sum(-1), (v * v).sum(-1)], -1)
+
+
+@check
+def ln_fused():
+    """LayerNorm folded into the GEMMs either side of it (dav_gemm_nt_ln_bf16, dav_ln_fold_grouped, dav_rowstats_cast,
+    dav_layernorm_bwd_twin) against torch fp32 / fp64 on the same operands."""
+    ln = torch.nn.functional.layer_norm
+    # 1. stand-alone row statistics + twin (incl. a broadcast source: batch stride 0)
+    for (B, rows, D, bs) in [(3, 7, 128, None), (2, 81, 768, None), (4, 16, 512, 0), (2, 5, 1024, None), (64, 49, 768, None)]:
+        x = rnd(B if bs is None else 1, rows, D, seed=41) + 0.3
+        tw = torch.empty(B * rows, D, device=dev, dtype=BF16)
+        st = torch.empty(B * rows, D // 64, 2, device=dev)
+        ops.rowstats_cast(x, rows * D if bs is None else 0, B, rows, D, tw, st)
+        xe = x.expand(B, rows, D).reshape(B * rows, D)
+        report(f'rowstats B{B} r{rows} D{D} twin', float((tw.float() - xe.to(BF16).float()).abs().max()), 0.0)
+        report(f'rowstats B{B} r{rows} D{D} sums', rel(st, _slot_stats(xe)), 2e-6)
+    # 2. weight fold
+    items, refs = [], []
+    for (N, K, has_b) in [(2304, 768, True), (1536, 512, True), (96, 64, False), (3072, 1024, True), (40, 192, True)]:
+        w = rnd(N, K, scale=0.05, seed=42)
+        g, bt = rnd(K, seed=43) * 0.2 + 1, rnd(K, seed=44) * 0.2
+        bias = rnd(N, seed=45) if has_b else None
+        wl, c, d = torch.empty(N, K, device=dev, dtype=BF16), torch.empty(N, device=dev), torch.empty(N, device=dev)
+        items.append((w, g, bt, bias, wl, c, d))
+        wl_ref = (w * g).to(BF16)
+        refs.append((wl_ref, wl_ref.double().sum(1), (w.double() * bt.double()).sum(1) + (bias.double() if has_b else 0)))
+    ops.ln_fold_grouped(items)
+    for (w, g, bt, bias, wl, c, d), (wl_ref, c_ref, d_ref) in zip(items, refs):
+        tag = f'ln_fold {w.shape[0]}x{w.shape[1]}'
+        report(tag + ' w_ln', float((wl.float() - wl_ref.float()).abs().max()), 0.0)
+        report(tag + ' c', rel(c, c_ref), 2e-6)
+        report(tag + ' d', rel(d, d_ref), 2e-6)
+    # 3. producer side: statistics partials + twin of the fp32 result, through row maps, in every tile configuration that has them
+    for (M, N, K, cfg, cmap) in [(3136, 768, 768, 0, None), (3136, 768, 768, 3, None), (1024, 768, 3072, 8, None), (130, 512, 512, 7, None),
+                                 (260, 512, 2048, 5, None), (22528, 512, 2048, 0, None), (64 * 8, 768, 768, 0, (8, 16, 4)), (200, 192, 192, 0, None),
+                                 (4096, 1024, 1024, 3, None)]:
+        A, Bm = rnd(M, K, dtype=BF16, seed=46), rnd(N, K, dtype=BF16, scale=0.05, seed=47)
+        bias = rnd(N, seed=48)
+        rows_out = M if cmap is None else (M // cmap[0]) * cmap[1]
+        res = rnd(rows_out, N, seed=49)
+        C = torch.zeros(rows_out, N, device=dev)
+        tw = torch.zeros(rows_out, N, device=dev, dtype=BF16)
+        st = torch.zeros(rows_out, N // 64, 2, device=dev)
+        ops.gemm_nt_ln(A, Bm, M, N, K, prod=dict(stats_out=st, twin_out=tw, ld_twin=N), bias=bias, res=res, ldres=N, res_rowmap=cmap,
+                       C_out=C, c_rowmap=cmap, variant=cfg << 4)
+        ref = A.float() @ Bm.float().t() + bias
+        if cmap is None:
+            want = ref + res
+            got, gtw, gst = C, tw, st
+        else:
+            rpb, bs_, off = cmap
+            idx = (torch.arange(M, device=dev) // rpb) * bs_ + off + torch.arange(M, device=dev) % rpb
+            want = ref + res[idx]
+            got, gtw, gst = C[idx], tw[idx], st[idx]
+        tag = f'nt_ln producer {M}x{N}x{K} cfg{cfg}{" rowmap" if cmap else ""}'
+        report(tag + ' C', rel(got, want), 1e-4)
+        report(tag + ' twin', float((gtw.float() - got.to(BF16).float()).abs().max()), 0.0)
+        report(tag + ' sums', rel(gst, _slot_stats(got)), 5e-6)
+    # 4. consumer side: raw twin + partials + folded weight == LayerNorm -> Linear
+    for (B, r0, r1, D, N, cfg, act, c_bf16) in [(64, 16, 49, 768, 2304, 0, 0, True), (64, 0, 49, 768, 3072, 0, 1, True), (8, 0, 352, 512, 1536, 44, 0, True),
+                                                (8, 0, 352, 512, 2048, 44, 1, True), (4, 0, 320, 512, 256, 0, 0, False), (2, 5, 12, 192, 576, 0, 0, True),
+                                                (64, 0, 49, 768, 1536, 45, 0, True), (3, 0, 50, 1024, 3072, 3, 0, True), (16, 16, 64, 768, 2304, 8, 0, True),
+                                                (2, 0, 33, 128, 64, 7, 0, False)]:
+        R = r0 + r1
+        M = B * R
+        eps = 1e-6 if D != 512 else 1e-5
+        x0 = (rnd(B, max(r0, 1), D, seed=51) * 1.3 + 0.2)[:, :r0].contiguous() if r0 else None
+        x1 = (rnd(B, r1, D, seed=52) * 0.7 - 0.1)
+        w32 = rnd(N, D, scale=0.05, seed=53)            # fp32 master; the un-fused path contracts with its bf16 mirror
+        w = w32.to(BF16)
+        g, bt, bias = rnd(D, seed=54) * 0.2 + 1, rnd(D, seed=55) * 0.2, rnd(N, seed=56)
+        wl, c, d = torch.empty_like(w), torch.empty(N, device=dev), torch.empty(N, device=dev)
+        ops.ln_fold_grouped([(w32, g, bt, bias, wl, c, d)])
+        segs = []
+        for xs, r in ((x0, r0), (x1, r1)):
+            if xs is None:
+                continue
+            tw = torch.empty(B * r, D, device=dev, dtype=BF16)
+            st = torch.empty(B * r, D // 64, 2, device=dev)
+            ops.rowstats_cast(xs, r * D, B, r, D, tw, st)
+            segs.append((tw, st, r))
+        xc = torch.cat([t for t in (x0, x1) if t is not None], 1)
+        h = ln(xc, (D,), g, bt, eps).view(M, D)
+        ref = h @ w32.t() + bias
+        pre = ref
+        if act == 1:
+            ref = torch.nn.functional.gelu(ref)
+        out = torch.empty(M, N, device=dev, dtype=BF16 if c_bf16 else F32)
+        Z = torch.empty(M, N, device=dev, dtype=BF16) if act == 1 else None
+        lnd = dict(stats=segs[0][1], ln_c=c, eps=eps)
+        if len(segs) == 2:
+            lnd.update(A2=segs[1][0], stats2=segs[1][1], a_r0=r0, a_r1=r1)
+        ops.gemm_nt_ln(segs[0][0], wl, M, N, D, ln=lnd, bias=d, act=act, C_out=out, c_bf16=c_bf16, C2=Z, ldc2=N, c2_mode=4 if act == 1 else 0,
+                       variant=cfg << 4)
+        tag = f'nt_ln consumer B{B} {r0}+{r1} D{D} N{N} cfg{cfg} act{act}'
+        report(tag, rel(out, ref), 6e-3)
+        if Z is not None:
+            xg = pre.clone().requires_grad_(True)
+            torch.nn.functional.gelu(xg).sum().backward()
+            report(tag + " gelu'twin", float((Z.float() - xg.grad).abs().max()), 2e-2)
+        # against the un-fused product path on the same operands (LayerNorm kernel -> bf16 -> GEMM): both are bf16-operand results
+        y = torch.empty(M, D, device=dev, dtype=BF16)
+        mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+        a0, a1 = (x0, x1) if x0 is not None else (x1, None)
+        n0, n1 = (r0, r1) if x0 is not None else (r1, 0)
+        ops.layernorm_fwd(a0, n0 * D, n0, a1, n1 * D if a1 is not None else 0, n1, B, D, g, bt, eps, y, None, mean, rstd)
+        out2 = torch.empty(M, N, device=dev)
+        ops.gemm_nt(y, w, M, N, D, bias=bias, act=act, C_out=out2)
+        report(tag + ' vs unfused (fp32 ref distance ratio)', rel(out, ref) / max(rel(out2, ref), 1e-9), 1.3)
+    # 4b. consumer through a row map (the decoder head reads x[:, nF:])
+    B, nF, L, D, N = 4, 8, 96, 512, 256
+    x = rnd(B, nF + L, D, seed=57)
+    tw, st = torch.empty(B * (nF + L), D, device=dev, dtype=BF16), torch.empty(B * (nF + L), D // 64, 2, device=dev)
+    ops.rowstats_cast(x, (nF + L) * D, B, nF + L, D, tw, st)
+    w = rnd(N, D, scale=0.05, seed=58)
+    g, bt, bias = rnd(D, seed=59) * 0.2 + 1, rnd(D, seed=60) * 0.2, rnd(N, seed=61)
+    wl, c, d = torch.empty(N, D, device=dev, dtype=BF16), torch.empty(N, device=dev), torch.empty(N, device=dev)
+    ops.ln_fold_grouped([(w, g, bt, bias, wl, c, d)])
+    out = torch.empty(B * L, N, device=dev)
+    ops.gemm_nt_ln(tw, wl, B * L, N, D, ln=dict(stats=st, ln_c=c, eps=1e-5), a_rowmap=(L, nF + L, nF), bias=d, C_out=out)
+    ref = ln(x[:, nF:], (D,), g, bt, 1e-5).reshape(B * L, D) @ w.t() + bias
+    report('nt_ln consumer rowmap', rel(out, ref), 6e-3)
+    # 5. backward from the twin: exact against autograd ON THE TWIN'S VALUES, h_out = the LayerNorm output
+    for (B, r0, r1, D) in [(3, 4, 9, 128), (2, 0, 81, 768), (64, 16, 49, 768), (2, 0, 228, 512), (2, 3, 3, 1024)]:
+        R = r0 + r1
+        eps = 1e-6
+        xs = [(rnd(B, r, D, seed=62 + i) * (1 + i) + 0.1 * i) for i, r in enumerate((r0, r1)) if r]
+        twins = []
+        for xx in xs:
+            r = xx.shape[1]
+            tw, st = torch.empty(B * r, D, device=dev, dtype=BF16), torch.empty(B * r, D // 64, 2, device=dev)
+            ops.rowstats_cast(xx, r * D, B, r, D, tw, st)
+            twins.append((tw, st, r))
+        g, bt = rnd(D, seed=33) * 0.1 + 1, rnd(D, seed=34) * 0.1
+        xc = torch.cat([tw.float().view(B, r, D) for (tw, st, r) in twins], 1).clone().requires_grad_(True)
+        gp, bp = g.clone().requires_grad_(True), bt.clone().requires_grad_(True)
+        ref = ln(xc, (D,), gp, bp, eps)
+        dy, dy32 = rnd(B * R, D, dtype=BF16, seed=35), rnd(B * R, D, seed=36)
+        ref.backward((dy.float() + dy32).view(B, R, D))
+        (t0, s0, n0) = twins[0]
+        (t1, s1, n1) = twins[1] if len(twins) == 2 else (None, None, 0)
+        dx0 = torch.full((B, n0, D), 1.0, device=dev)
+        res0 = rnd(B, n0, D, seed=37)
+        tw0 = torch.empty(B, n0, D, device=dev, dtype=BF16)
+        dx1 = torch.empty(B, max(n1, 1), D, device=dev)[:, :n1].contiguous() if n1 else None
+        dg, db = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+        h = torch.empty(B * R, D, device=dev, dtype=BF16)
+        ops.layernorm_bwd_twin(t0, n0 * D, s0, n0, t1, n1 * D, s1, n1, B, D, eps, dy, dy32, g, bt,
+                               dx0, n0 * D, 1, res0, n0 * D, tw0, n0 * D, dx1, n1 * D, 0, None, 0, None, 0, h_out=h, dgamma=dg, dbeta=db)
+        tag = f'ln_bwd_twin B{B} {r0}+{r1} D{D}'
+        # (the statistics are those of the fp32 rows, x itself their bf16 rounding: mean / rstd differ from the twin's own by ~1e-3 relative)
+        report(tag + ' dx0(acc+res)', rel(dx0, xc.grad[:, :n0] + 1.0 + res0), 3e-3)
+        report(tag + ' dx0 twin', rel(tw0, xc.grad[:, :n0] + 1.0 + res0), 6e-3)
+        if n1:
+            report(tag + ' dx1', rel(dx1, xc.grad[:, n0:]), 3e-3)
+        report(tag + ' dgamma', rel(dg, gp.grad), 3e-3)
+        report(tag + ' dbeta', rel(db, bp.grad), 1e-4)
+        report(tag + ' h_out', rel(h, ref.detach().view(-1, D)), 6e-3)
+
+
 @check
 def masking():
     g = np.load(os.path.join(ROOT, 'tests', 'golden', 'masking.npz'))
@@ -697,7 +862,7 @@ def main():
         if ':' in kv:
             from deepavfusion_amd import _lib
             _lib.check(_lib.load().dav_tune(int(kv.split(':')[0]), int(kv.split(':')[1])), 'dav_tune')
-    for fn in (gemm_nt, gemm_tn, gemm_tn_gang, attention, window_attention, layernorm, masking, misc_kernels, patch_gather3d):
+    for fn in (gemm_nt, gemm_tn, gemm_tn_gang, attention, window_attention, layernorm, ln_fused, masking, misc_kernels, patch_gather3d):
         if flt in fn.__name__:
             fn()
     bad = [r for r in RESULTS if not r[3]]

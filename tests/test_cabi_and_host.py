@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in include/dav_kernels.h but not exported'
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.dav_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.dav_abi_version() == _lib.ABI_VERSION == 8
 
 
 def test_no_cpu_fallback():
