@@ -259,7 +259,8 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, enc, image, audio, ik32, ak32, return_embs, need_tape, *params):
         ctx.set_materialize_grads(False)
-        _, f32s, embs, tape = encoder_fwd(enc, image, audio, ik32, ak32, want_f32=True, collect_embs=return_embs)
+        with E.ln_fuse_for(need_tape):
+            _, f32s, embs, tape = encoder_fwd(enc, image, audio, ik32, ak32, want_f32=True, collect_embs=return_embs)
         ctx.enc, ctx.tape = enc, (tape if need_tape else None)
         B = image.shape[0]
         outs = [x.view(B, -1, x.shape[-1]) for x in f32s]
@@ -499,7 +500,8 @@ class _AVMAEFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, image, audio, noise_i, noise_a, need_tape, *params):
         ctx.set_materialize_grads(False)
-        outs, tape, aux = avmae_fwd(model, image, audio, noise_i, noise_a)
+        with E.ln_fuse_for(need_tape):
+            outs, tape, aux = avmae_fwd(model, image, audio, noise_i, noise_a)
         ctx.model, ctx.tape, ctx.np = model, (tape if need_tape else None), len(params)
         model._last_masks = aux
         return outs

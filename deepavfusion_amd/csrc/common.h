@@ -52,7 +52,11 @@ __device__ __forceinline__ float wave_max(float v) {
 // the LayerNorm backward) goes through this function, so forward and backward see the same bits.
 __device__ __forceinline__ float2 dav_ln_row_stats(const float2* sp, int ns, int q, int D, float eps) {
   float a1 = 0.f, a2 = 0.f;
-  for (int s_ = q; s_ < ns; s_ += 4) { const float2 t = sp[s_]; a1 += t.x; a2 += t.y; }
+  float2 t[4];                                   // ns <= 16: all of a lane's slots requested before the first is used
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t[i] = q + 4 * i < ns ? sp[q + 4 * i] : float2{0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a1 += t[i].x; a2 += t[i].y; }
   a1 += __shfl_xor(a1, 1, 64); a2 += __shfl_xor(a2, 1, 64);
   a1 += __shfl_xor(a1, 2, 64); a2 += __shfl_xor(a2, 2, 64);
   const float inv = 1.0f / (float)D;

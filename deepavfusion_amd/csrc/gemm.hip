@@ -452,12 +452,14 @@ __device__ __forceinline__ void nt_epilogue_t(const NTParams& p, f32x4 (&acc)[FM
     for (int ii = 0; ii < IH; ++ii) {
       const int i = i0 + ii;
       const int m = m0 + wm * WTM + i * 16 + fr;
-      if (!mok[ii]) continue;
+      const bool rowok = mok[ii];            // (no early exit from the row: the twin patch below is a whole-wave affair)
       float ps1 = 0.f, ps2 = 0.f;
+      uint2 twv[FN];
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         const int n = n0 + wn * WTN + j * 16 + fg * 4;
-        if (!nok[j]) continue;
+        twv[j] = uint2{0, 0};
+        if (!nok[j] || !rowok) continue;
         float4 v;
         if constexpr (BM > 0) {
           v = nt_ln_frag<BM>(acc[i][j], p.alpha, lnc, ln_mr, wm * WTM + i * 16 + fr, wn * WTN + j * 16 + fg * 4);
@@ -506,19 +508,40 @@ __device__ __forceinline__ void nt_epilogue_t(const NTParams& p, f32x4 (&acc)[FM
           uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
           *reinterpret_cast<uint2*>(p.C2 + (long)m * p.ldc2 + n) = w;
         }
-        if (PROD && p.tw_out) {
-          uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
-          *reinterpret_cast<uint2*>(p.tw_out + crow[ii] * p.ldtw + n) = w;
+        if constexpr (PROD) {
+          if (p.tw_out) {
+            uint2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
+            if constexpr (FN == 4) twv[j] = w;          // written below as whole 128-byte row segments
+            else *reinterpret_cast<uint2*>(p.tw_out + crow[ii] * p.ldtw + n) = w;
+          }
         }
         if (lnp) {
           ps1 += (v.x + v.y) + (v.z + v.w);
           ps2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         }
       }
+      if constexpr (PROD && FN == 4) {
+        // twin of a 64-column wave tile: lane (fr, fg) holds 4 bf16 of each of the four 16-column fragments — stored as they stand
+        // that is 32 contiguous bytes per row and instruction (partial-line writes: +25 % on the K = 512 GEMMs).  The 16 x 64 block goes
+        // through a wave-private LDS patch (the ring is free by now; 144-byte rows) and leaves as whole 128-byte row segments, eight
+        // lanes per row.
+        if (p.tw_out) {                      // (uniform: every lane of the wave gets here — rows beyond M are masked at the store)
+          char* patch = smem + (tid >> 6) * (16 * 144);
+#pragma unroll
+          for (int j = 0; j < FN; ++j) *reinterpret_cast<uint2*>(patch + fr * 144 + j * 32 + fg * 8) = twv[j];
+          const int pr = lane >> 3, pc = lane & 7;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int mr_ = m0 + wm * WTM + i * 16 + pr + 8 * h;
+            const uint4 w = *reinterpret_cast<const uint4*>(patch + (pr + 8 * h) * 144 + pc * 16);
+            if (mr_ < p.M) *reinterpret_cast<uint4*>(p.tw_out + map_row(mr_, p.cmap) * p.ldtw + n0 + wn * WTN + pc * 8) = w;
+          }
+        }
+      }
       if (lnp) {       // the four lanes (fg = 0..3) that hold a row's columns of this wave tile
         ps1 += __shfl_xor(ps1, 16, 64); ps2 += __shfl_xor(ps2, 16, 64);
         ps1 += __shfl_xor(ps1, 32, 64); ps2 += __shfl_xor(ps2, 32, 64);
-        if (fg == 0) {
+        if (fg == 0 && rowok) {
           if constexpr (WTN >= 64) {
             static_assert(WTN == 64 || BM == 0, "one 64-column slot per wave tile");
             reinterpret_cast<float2*>(p.st_out)[crow[ii] * (p.N >> 6) + ((n0 + wn * WTN) >> 6)] = float2{ps1, ps2};
@@ -675,8 +698,27 @@ constexpr size_t nt2_lds_bytes() {
   constexpr size_t epi = (size_t)(nt_epi_split<BM, BN>() ? 1 : 2) * nt_stage_bytes<BM, BN>();
   return ring > epi ? ring : epi;
 }
+// LayerNorm consumer: BM x {mean, rstd} + BN x c.  Normally behind the ring / image and filled in the prologue (latency under the first
+// tiles' flight); where those bytes would cost a workgroup per CU (64 x 64 tiles: five 32 KB rings fill the 160 KB exactly) they go
+// into the part of the ring the epilogue image leaves free and are filled when the k-loop is over (LN_LATE).
+template <int BM, int BN>
+constexpr size_t nt2_ln_bytes() { return (size_t)BM * 8 + (size_t)BN * 4; }
 template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK>
-constexpr size_t nt2_lds_alloc() { return nt2_lds_bytes<BM, BN, WM_, WN_, STAGES, BT, BK>() + (size_t)BM * 8 + (size_t)BN * 4; }
+constexpr bool nt2_ln_late() {
+  constexpr size_t base = nt2_lds_bytes<BM, BN, WM_, WN_, STAGES, BT, BK>();
+  constexpr size_t ring = (size_t)STAGES * (BM + BN) * BK * 2;
+  constexpr size_t epi = (size_t)(nt_epi_split<BM, BN>() ? 1 : 2) * nt_stage_bytes<BM, BN>();
+  return (160 * 1024) / base != (160 * 1024) / (base + nt2_ln_bytes<BM, BN>()) && ring >= epi + nt2_ln_bytes<BM, BN>();
+}
+template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK>
+constexpr size_t nt2_ln_offset() {
+  constexpr size_t epi = (size_t)(nt_epi_split<BM, BN>() ? 1 : 2) * nt_stage_bytes<BM, BN>();
+  return nt2_ln_late<BM, BN, WM_, WN_, STAGES, BT, BK>() ? epi : nt2_lds_bytes<BM, BN, WM_, WN_, STAGES, BT, BK>();
+}
+template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK>
+constexpr size_t nt2_lds_alloc() {
+  return nt2_lds_bytes<BM, BN, WM_, WN_, STAGES, BT, BK>() + (nt2_ln_late<BM, BN, WM_, WN_, STAGES, BT, BK>() || BT ? 0 : nt2_ln_bytes<BM, BN>());
+}
 
 #include "gemm_nt256.h"
 #include "gemm_tn_gang.h"
@@ -788,23 +830,8 @@ __device__ __forceinline__ void nt2_body(const NTParams& p, int bid, int tid_in 
   // 16-byte-slot XOR swizzle of the row-major tiles: 128-byte rows (BK 64) / 64-byte rows (BK 32)
   auto rswz = [](int row) { return BK == 64 ? ((row >> 1) & 7) : ((0 - (row >> 2)) & 3); };
 
-  // LayerNorm consumer (p.ln_st): the row statistics of this tile's BM rows — mean, rstd out of the K / 64 partial sums per row —
-  // are formed once per workgroup into LDS behind the ring / epilogue image, by four lanes per row (dav_ln_row_stats: the same
-  // summation order as the LayerNorm backward), before anything else of the tile is live in registers; the epilogue reads them after
-  // the barrier that ends the k-loop.  (The loads are older in the vmcnt queue than every DMA piece: the counted waits of the k-loop
-  // stay what they were.)
-  float2* ln_mr = reinterpret_cast<float2*>(smem + nt2_lds_bytes<BM, BN, WM_, WN_, STAGES, BT, BK>());
-  if (!BT && p.ln_st != nullptr) {
-    const int ns = p.K >> 6;
-    for (int r = tid >> 2; r < BM; r += NT >> 2) {
-      int gm = m0 + r; gm = gm < p.M ? gm : p.M - 1;
-      const float2 mr = dav_ln_row_stats(nt_stat_row(p, gm, ns), ns, tid & 3, p.K, p.ln_eps);
-      if ((tid & 3) == 0) ln_mr[r] = mr;
-    }
-    float* ln_cv = reinterpret_cast<float*>(ln_mr + BM);
-    for (int c = tid; c < BN; c += NT) ln_cv[c] = n0 + c < p.N ? p.ln_c[n0 + c] : 0.f;
-  }
-
+  float2* ln_mr = reinterpret_cast<float2*>(smem + nt2_ln_offset<BM, BN, WM_, WN_, STAGES, BT, BK>());      // LayerNorm consumer: see below
+  constexpr bool LN_LATE = nt2_ln_late<BM, BN, WM_, WN_, STAGES, BT, BK>();
   const bf16_t* a_src[A_CH];
   const bf16_t* b_src[B_CH];
 #pragma unroll
@@ -854,6 +881,22 @@ __device__ __forceinline__ void nt2_body(const NTParams& p, int bid, int tid_in 
     for (int s = 0; s < STAGES - 1; ++s)
       if (s < nk) dma_tile(s);
   }
+  // LayerNorm consumer (p.ln_st): the row statistics of this tile's BM rows — mean, rstd out of the K / 64 partial sums per row —
+  // are formed once per workgroup into LDS behind the ring / epilogue image, by four lanes per row (dav_ln_row_stats: the same
+  // summation order as the LayerNorm backward), and the tile's BN values of c behind them; the epilogue reads both after the barrier
+  // that ends the k-loop.  The loads go out BEHIND the ring's first DMA pieces (their latency lies under the first tiles' flight; the
+  // compiler's wait for them drains the DMA queue once, where the k-loop's first wait would drain most of it anyway).
+  auto ln_stats_to_lds = [&]() {
+    const int ns = p.K >> 6;
+    for (int r = tid >> 2; r < BM; r += NT >> 2) {
+      int gm = m0 + r; gm = gm < p.M ? gm : p.M - 1;
+      const float2 mr = dav_ln_row_stats(nt_stat_row(p, gm, ns), ns, tid & 3, p.K, p.ln_eps);
+      if ((tid & 3) == 0) ln_mr[r] = mr;
+    }
+    float* ln_cv = reinterpret_cast<float*>(ln_mr + BM);
+    for (int c = tid; c < BN; c += NT) ln_cv[c] = n0 + c < p.N ? p.ln_c[n0 + c] : 0.f;
+  };
+  if (!BT && !LN_LATE && p.ln_st != nullptr) ln_stats_to_lds();
 
   const int fr = lane & 15, fg = lane >> 4;
   uint32_t bt_base[FN];
@@ -1058,6 +1101,10 @@ __device__ __forceinline__ void nt2_body(const NTParams& p, int bid, int tid_in 
       out[9] = __builtin_amdgcn_s_getreg(63492);    // HW_REG_HW_ID (id 4), all 32 bits: ((32-1) << 11) | 4
     }
     return;
+  }
+  if (!BT && LN_LATE && p.ln_st != nullptr) {      // (uniform per launch)
+    ln_stats_to_lds();
+    __syncthreads();
   }
   // (the LayerNorm forms exist in the forward [N, K] kernels only: the input-gradient kernels are what they were)
   if (nt_staged_ok(p)) nt_epilogue_s<BM, BN, NT, FM, FN, WTM, WTN, nt_epi_split<BM, BN>()>(p, acc, smem, m0, n0, wm, wn, lane, tid, BT ? nullptr : ln_mr);
@@ -2055,8 +2102,8 @@ static int nt_entry(const void* A, const void* B, int M, int N, int K, int lda, 
     if (ln->stats_out || ln->twin_out) {
       if (!C || c_is_bf16 || (N & 63)) return DAV_ERR_SHAPE;                 // statistics of the fp32 result, whole 64-column slots
       if (cfg != 0 && !nt_ln_producer_cfg(cfg)) return DAV_ERR_SHAPE;
-      if (ln->twin_out && ((ln->ld_twin & 3) || ln->ld_twin < N)) return DAV_ERR_SHAPE;
-      if (((uintptr_t)ln->stats_out | (uintptr_t)ln->twin_out) & 7) return DAV_ERR_ALIGN;
+      if (ln->twin_out && ((ln->ld_twin & 7) || ln->ld_twin < N)) return DAV_ERR_SHAPE;
+      if (((uintptr_t)ln->stats_out & 7) || ((uintptr_t)ln->twin_out & 15)) return DAV_ERR_ALIGN;
       p.st_out = ln->stats_out; p.tw_out = (bf16_t*)ln->twin_out; p.ldtw = ln->ld_twin;
     }
   }

@@ -154,37 +154,36 @@ __device__ __forceinline__ void ln_bwd_body(const LNBwd& p, const int vbid, cons
     const int b = row / R, j = row % R;
     const bool seg0 = j < p.s0.rows;
     const int jj = seg0 ? j : j - p.s0.rows;
-    const float* x = p.xb0 ? nullptr : (seg0 ? p.s0.x + b * p.s0.bs + (long)jj * p.D : p.s1.x + b * p.s1.bs + (long)jj * p.D);
+    const LNSeg& sg = seg0 ? p.s0 : p.s1;
     const LNDst& d = seg0 ? p.d0 : p.d1;
-    const bf16_t* xb = nullptr;
-    float mean, rstd;
-    if (p.xb0) {
-      const LNSeg& sg = seg0 ? p.s0 : p.s1;
-      xb = (seg0 ? p.xb0 : p.xb1) + b * sg.bs + (long)jj * p.D;
-      const int ns = p.D >> 6;
+    const bool tw = p.xb0 != nullptr;            // x as bf16 twin + statistics partials (the LayerNorm was folded away on the forward path)
+    const float* x = tw ? nullptr : sg.x + b * sg.bs + (long)jj * p.D;
+    const bf16_t* xb = tw ? (seg0 ? p.xb0 : p.xb1) + b * sg.bs + (long)jj * p.D : nullptr;
+    // every global read of the row — statistics, x, dy, the residual gradient — is requested before the first one is used: one memory
+    // latency per row
+    float2 stp[4];
+    float mean = 0.f, rstd = 0.f;
+    const int ns = p.D >> 6;
+    if (tw) {
       const float2* sp = reinterpret_cast<const float2*>(seg0 ? p.st0 : p.st1) + ((long)b * (sg.bs / p.D) + jj) * ns;
-      const float2 mr = dav_ln_row_stats(sp, ns, lane & 3, p.D, p.eps);      // (every group of four lanes forms the same value)
-      mean = mr.x; rstd = mr.y;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) stp[i] = (lane & 3) + 4 * i < ns ? sp[(lane & 3) + 4 * i] : float2{0.f, 0.f};
     } else {
       mean = p.mean[row]; rstd = p.rstd[row];
     }
     float4 xh[MAXC], gy[MAXC], rv[MAXC];
-    float s1 = 0.f, s2 = 0.f;
-    // the residual-gradient row is fetched together with x / dy (one memory latency per row instead of two: the second pass
-    // would otherwise issue its loads only after the two wave reductions)
     const float* rr = (d.dx && d.res) ? d.res + b * d.res_bs + (long)jj * p.D : nullptr;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
       const int c = lane + 64 * i;
       if (c < nch) {
         rv[i] = rr ? reinterpret_cast<const float4*>(rr)[c] : float4{0.f, 0.f, 0.f, 0.f};
-        float4 xv;
-        if (xb) {
+        if (tw) {
           const uint2 w = reinterpret_cast<const uint2*>(xb)[c];
-          xv.x = __uint_as_float(w.x << 16); xv.y = __uint_as_float(w.x & 0xffff0000u);
-          xv.z = __uint_as_float(w.y << 16); xv.w = __uint_as_float(w.y & 0xffff0000u);
+          xh[i].x = __uint_as_float(w.x << 16); xh[i].y = __uint_as_float(w.x & 0xffff0000u);
+          xh[i].z = __uint_as_float(w.y << 16); xh[i].w = __uint_as_float(w.y & 0xffff0000u);
         } else {
-          xv = reinterpret_cast<const float4*>(x)[c];
+          xh[i] = reinterpret_cast<const float4*>(x)[c];
         }
         float4 dyv = float4{0.f, 0.f, 0.f, 0.f};
         if (p.dy) {
@@ -196,16 +195,42 @@ __device__ __forceinline__ void ln_bwd_body(const LNBwd& p, const int vbid, cons
           const float4 t = reinterpret_cast<const float4*>(p.dy32 + (long)row * p.D)[c];
           dyv.x += t.x; dyv.y += t.y; dyv.z += t.z; dyv.w += t.w;
         }
-        const float4 gm = gmv[i];
-        xh[i].x = (xv.x - mean) * rstd; xh[i].y = (xv.y - mean) * rstd;
-        xh[i].z = (xv.z - mean) * rstd; xh[i].w = (xv.w - mean) * rstd;
+        gy[i] = dyv;
+      }
+    }
+    if (tw) {      // the same arithmetic, in the same order, as the consuming GEMM (dav_ln_row_stats): four lanes per row there, every group of four here
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a1 += stp[i].x; a2 += stp[i].y; }
+      a1 += __shfl_xor(a1, 1, 64); a2 += __shfl_xor(a2, 1, 64);
+      a1 += __shfl_xor(a1, 2, 64); a2 += __shfl_xor(a2, 2, 64);
+      const float inv = 1.0f / (float)p.D;
+      mean = a1 * inv;
+      rstd = rsqrtf(fmaxf(a2 * inv - mean * mean, 0.f) + p.eps);
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        const float4 gm = gmv[i], dyv = gy[i];
+        xh[i].x = (xh[i].x - mean) * rstd; xh[i].y = (xh[i].y - mean) * rstd;
+        xh[i].z = (xh[i].z - mean) * rstd; xh[i].w = (xh[i].w - mean) * rstd;
         dg[i].x += dyv.x * xh[i].x; dg[i].y += dyv.y * xh[i].y; dg[i].z += dyv.z * xh[i].z; dg[i].w += dyv.w * xh[i].w;
         db[i].x += dyv.x; db[i].y += dyv.y; db[i].z += dyv.z; db[i].w += dyv.w;
         gy[i].x = dyv.x * gm.x; gy[i].y = dyv.y * gm.y; gy[i].z = dyv.z * gm.z; gy[i].w = dyv.w * gm.w;
         s1 += gy[i].x + gy[i].y + gy[i].z + gy[i].w;
         s2 += gy[i].x * xh[i].x + gy[i].y * xh[i].y + gy[i].z * xh[i].z + gy[i].w * xh[i].w;
-        if (p.h_out) {          // the consuming Linear's weight-gradient operand: LayerNorm output, re-made here
-          const float4 bt = reinterpret_cast<const float4*>(p.beta)[c];
+      }
+    }
+    s1 = wave_sum(s1) / p.D;
+    s2 = wave_sum(s2) / p.D;
+    if (p.h_out) {          // the consuming Linear's weight-gradient operand: LayerNorm output, re-made here
+#pragma unroll
+      for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+          const float4 gm = gmv[i], bt = reinterpret_cast<const float4*>(p.beta)[c];
           uint2 w;
           w.x = pack2bf(xh[i].x * gm.x + bt.x, xh[i].y * gm.y + bt.y);
           w.y = pack2bf(xh[i].z * gm.z + bt.z, xh[i].w * gm.w + bt.w);
@@ -213,8 +238,6 @@ __device__ __forceinline__ void ln_bwd_body(const LNBwd& p, const int vbid, cons
         }
       }
     }
-    s1 = wave_sum(s1) / p.D;
-    s2 = wave_sum(s2) / p.D;
     if (d.dx == nullptr) continue;   // caller does not need this segment's input gradient
     float* dxr = d.dx + b * d.bs + (long)jj * p.D;
     bf16_t* br = d.dx_bf16 ? d.dx_bf16 + b * d.bf_bs + (long)jj * p.D : nullptr;

@@ -275,13 +275,41 @@ def _e(shape, dtype, dev):
 # norm1_img / norm1_aud / norm2 (models/fusion_blocks.py:281-288), decoder_norm -> decoder_pred (models/avmae.py:177-178).
 # norm1_mm of the fusion blocks stays a kernel: its OUTPUT is the residual base (norm-then-residual, :281-283).
 # ------------------------------------------------------------------------------------------------
-LN_FUSE = os.environ.get('DAV_LN_FUSE', '1') != '0'
+# Where it stands (profiles/r06_ln_fuse.txt, ViT-B B = 64, same box): the forward loses its 123 LayerNorm launches and 0.25 ms, but the
+# backward must WRITE the LayerNorm output it no longer finds saved (+2 bytes per element on the serial LayerNorm-backward kernels:
+# +0.5 ms), the producers' epilogues pay 6-20 % for twin + statistics and the weight fold is 0.8 GB per step: 25.8 ms against 25.1 ms.
+# So DAV_LN_FUSE defaults to 'auto': folded when NO backward will follow (eval, kNN probe, encoder-only inference: the forward alone is
+# 2.5 % shorter), the LayerNorm kernels of rounds 1-5 in training steps; '1' folds always, '0' never.
+LN_FUSE_MODE = {'1': 'on', '0': 'off'}.get(os.environ.get('DAV_LN_FUSE', ''), 'auto')
+LN_FUSE = LN_FUSE_MODE == 'on'
 
 
-def set_ln_fuse(on: bool):
-    """Tests run one model with the LayerNorms folded into their neighbour GEMMs and with the LayerNorm kernels."""
-    global LN_FUSE
-    LN_FUSE = bool(on)
+def set_ln_fuse(mode):
+    """'on' | 'off' | 'auto' (True / False = 'on' / 'off'): tests run one model with the LayerNorms folded into their neighbour GEMMs
+    and with the LayerNorm kernels."""
+    global LN_FUSE, LN_FUSE_MODE
+    LN_FUSE_MODE = {True: 'on', False: 'off'}.get(mode, mode)
+    assert LN_FUSE_MODE in ('on', 'off', 'auto')
+    LN_FUSE = LN_FUSE_MODE == 'on'
+
+
+class ln_fuse_for:
+    """``with ln_fuse_for(need_backward):`` around a forward: resolves the 'auto' mode for this pass."""
+
+    def __init__(self, need_backward: bool):
+        self.need = need_backward
+
+    def __enter__(self):
+        global LN_FUSE
+        self.prev = LN_FUSE
+        if LN_FUSE_MODE == 'auto':
+            LN_FUSE = not self.need
+        return self
+
+    def __exit__(self, *exc):
+        global LN_FUSE
+        LN_FUSE = self.prev
+        return False
 
 
 def ln_fuse_ok(D: int) -> bool:
@@ -346,12 +374,23 @@ def ln_fold(lin, norm):
         lin.weight.__dict__['_dav_fold'] = f
     if _FOLD_SCOPE is not None:
         _FOLD_SCOPE[id(lin.weight)] = f
+        if id(f) in _FOLD_PENDING:          # refreshed on the side stream by this step's fold_scope: join it once per consuming stream
+            cur = torch.cuda.current_stream()
+            if cur.cuda_stream not in _FOLD_JOINED:
+                cur.wait_stream(_FOLD_SIDE[0])
+                _FOLD_JOINED.add(cur.cuda_stream)
     stamp = _fold_stamp(lin, norm)
     if f.stamp != stamp:
         with ops.unbatched():
             ops.ln_fold_grouped(_fold_items([f]))
         f.stamp = stamp
     return f
+
+
+FOLD_EARLY = 8              # folds (in order of first use: the first encoder layer's) refreshed on the main stream; the rest beside it
+_FOLD_PENDING = set()       # id(_Fold) of the folds this step's refresh put on the side stream
+_FOLD_JOINED = set()        # streams that have waited for it
+_FOLD_SIDE = [None]
 
 
 class fold_scope:
@@ -361,6 +400,7 @@ class fold_scope:
 
     def __init__(self, root):
         self.root = root
+        self.main = None
 
     def __enter__(self):
         global _FOLD_SCOPE
@@ -375,14 +415,32 @@ class fold_scope:
             stamps = [_fold_stamp(f.lin, f.norm) for f in folds]
             todo = folds if capturing else [f for f, s_ in zip(folds, stamps) if f.stamp != s_]
             if todo:
+                # the first layer's folds at once; the bulk (0.8 GB of traffic) on a side stream under the first layer's kernels —
+                # nothing else runs at the top of a step, on the main stream the refresh was 0.3 ms of step time
+                early, late = todo[:FOLD_EARLY], todo[FOLD_EARLY:]
                 with ops.unbatched():
-                    ops.ln_fold_grouped(_fold_items(todo))
+                    ops.ln_fold_grouped(_fold_items(early))
+                    if late and folds[0].wl.is_cuda and os.environ.get('DAV_STREAMS', '1') != '0':
+                        if _FOLD_SIDE[0] is None:
+                            _FOLD_SIDE[0] = torch.cuda.Stream(folds[0].wl.device)
+                        self.main = torch.cuda.current_stream()
+                        _FOLD_SIDE[0].wait_stream(self.main)
+                        with torch.cuda.stream(_FOLD_SIDE[0]):
+                            ops.ln_fold_grouped(_fold_items(late))
+                        _FOLD_PENDING.update(id(f) for f in late)
+                    elif late:
+                        ops.ln_fold_grouped(_fold_items(late))
                 for f in todo:
                     f.stamp = _fold_stamp(f.lin, f.norm)
         return self
 
     def __exit__(self, *exc):
         global _FOLD_SCOPE
+        if self.prev is None and _FOLD_PENDING:
+            if self.main.cuda_stream not in _FOLD_JOINED:          # (a capture must see every forked stream re-joined)
+                self.main.wait_stream(_FOLD_SIDE[0])
+            _FOLD_PENDING.clear()
+            _FOLD_JOINED.clear()
         _FOLD_SCOPE = self.prev
         return False
 

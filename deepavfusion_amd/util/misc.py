@@ -318,7 +318,8 @@ class GraphedStep:
         B, dev = self.image.shape[0], self.image.device
         Li, La = self.model.image_gs[0] * self.model.image_gs[1], self.model.audio_gs[0] * self.model.audio_gs[1]
         noise_i, noise_a = torch.rand(B, Li, device=dev), torch.rand(B, La, device=dev)
-        outs, tape, aux = self.bridge.avmae_fwd(self.model, self.image, self.audio, noise_i, noise_a)
+        with engine.ln_fuse_for(True):
+            outs, tape, aux = self.bridge.avmae_fwd(self.model, self.image, self.audio, noise_i, noise_a)
         one = torch.ones((), device=dev)
         self.bridge.avmae_bwd(self.model, tape, one, one, layer_cb=layer_cb)
         return outs[0], outs[1]

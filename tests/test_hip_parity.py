@@ -106,6 +106,97 @@ def test_lane_batched_and_stream_schedules_agree():
             assert rel(got[3][n], g) < 1e-5, (policy, n)
 
 
+@pytest.mark.parametrize('name', ['micro', 'tiny'])
+def test_ln_folded_and_layernorm_kernel_paths_agree(golden, name):
+    """engine.LN_FUSE: the LayerNorms folded into the GEMMs either side of them (producer epilogues write twin + row statistics, consumer
+    GEMMs contract the raw twin with gamma-folded weights, the LayerNorm backward re-makes the weight-gradient operand) against the
+    LayerNorm kernels, the oracle and the reference's fixture: same tolerances as every other bf16 path — with non-trivial gamma / beta
+    (the closed-form state has them at 1 / 0), after an optimizer step (the fold must follow the masters), in 'auto' mode (folded only
+    when no backward follows) and through a captured step."""
+    from deepavfusion_amd import engine as E
+    g = golden(f'e2e_{name}')
+    res = {}
+    try:
+        for mode in ('on', 'off'):
+            E.set_ln_fuse(mode)
+            model, sd, cfg, O = _build(name)
+            rs = np.random.RandomState(3)
+            sd2 = {k: (v + torch.from_numpy(rs.standard_normal(tuple(v.shape)).astype(np.float32)) * 0.2) if ('norm' in k and v.dim() == 1) else v
+                   for k, v in sd.items()}
+            model.load_state_dict(sd2, strict=True)
+            image, audio, ni, na = O.synthetic_batch(cfg, int(g['B']), seed=int(g['seed']))
+            args = (image.cuda(), audio.cuda(), torch.from_numpy(ni).cuda(), torch.from_numpy(na).cuda())
+            E.BATCH_STATS[0] = E.BATCH_STATS[1] = 0
+            out = model(*args)
+            (out[0] + out[1]).backward()
+            torch.cuda.synchronize()
+            res[mode] = (out, {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+            if mode == 'on':
+                sdo = {k: v.clone().requires_grad_(k not in O.FROZEN and not O.is_buffer(k)) for k, v in sd2.items()}
+                li, la, pi, pa, aux = O.avmae_forward(sdo, cfg, image, audio, ni, na)
+                (li + la).backward()
+                assert abs(float(out[0]) - float(li)) <= LOSS_RTOL * abs(float(li)) and abs(float(out[1]) - float(la)) <= LOSS_RTOL * abs(float(la))
+                assert rel(out[2], pi) < ACT_TOL and rel(out[3], pa) < ACT_TOL
+                g_all = sum(float(v.grad.double().norm()) ** 2 for v in sdo.values() if v.grad is not None) ** 0.5
+                for n, p in model.named_parameters():
+                    if p.grad is None or any(z in n for z in ZERO_GRADS):
+                        continue
+                    ref = sdo[n].grad
+                    err = float((p.grad.detach().cpu().double() - ref.double()).norm())
+                    assert err <= GRAD_TOL * float(ref.double().norm()) + 1e-4 * g_all, (n, err, float(ref.double().norm()))
+                # the fold follows the masters: one SGD-like nudge of every norm weight and Linear weight, then a no-grad forward in
+                # both modes must still agree
+                with torch.no_grad():
+                    for n, p in model.named_parameters():
+                        if p.requires_grad:
+                            p.add_(torch.sign(p.grad) * 1e-2 * float(p.abs().mean()))
+                    o_on = model(*args)
+                    E.set_ln_fuse('off')
+                    o_off = model(*args)
+                    E.set_ln_fuse('auto')          # no backward follows: folded
+                    o_auto = model(*args)
+                assert abs(float(o_on[0]) - float(o_off[0])) <= LOSS_RTOL * abs(float(o_off[0]))
+                assert rel(o_on[2], o_off[2]) < ACT_TOL and rel(o_on[3], o_off[3]) < ACT_TOL
+                assert torch.equal(o_on[2], o_auto[2]) and torch.equal(o_on[3], o_auto[3])
+    finally:
+        E.set_ln_fuse({'1': 'on', '0': 'off'}.get(os.environ.get('DAV_LN_FUSE', ''), 'auto'))
+    (o1, g1), (o0, g0) = res['on'], res['off']
+    assert abs(float(o1[0]) - float(o0[0])) <= LOSS_RTOL * abs(float(o0[0])) and abs(float(o1[1]) - float(o0[1])) <= LOSS_RTOL * abs(float(o0[1]))
+    assert rel(o1[2], o0[2]) < ACT_TOL and rel(o1[3], o0[3]) < ACT_TOL
+    assert set(g1) == set(g0)
+
+
+def test_ln_folded_captured_step_tracks_the_kernel_path():
+    """A captured training step (hipGraph: forward, backward, AdamW) with the LayerNorms folded: the weight fold is re-made INSIDE the
+    graph from the masters the captured optimizer pass wrote, so ten replays follow the loss curve of the LayerNorm-kernel path."""
+    from deepavfusion_amd import engine as E
+    from deepavfusion_amd.util import lr_sched
+    from deepavfusion_amd.util.flat import FlatAdamW
+    from deepavfusion_amd.util.misc import GraphedStep, Trainer
+    curves = {}
+    try:
+        for mode in ('on', 'off'):
+            E.set_ln_fuse(mode)
+            model, sd, cfg, O = _build('micro')
+            image, audio, ni, na = O.synthetic_batch(cfg, 4, seed=11)
+            nd = [n for n, p in model.named_parameters() if 'bias' in n or 'norm' in n]
+            groups = lr_sched.param_groups_pretrained(model, 0.05, no_weight_decay_list=nd, image_pt='', audio_pt='')
+            opt = FlatAdamW(groups, lr=2e-3, betas=(0.9, 0.95), model=model)
+            tr = Trainer(model, optimizer=opt, accum_iter=1)
+            torch.manual_seed(5)
+            gs = GraphedStep(tr, image.shape, audio.shape, warmup=1)
+            losses = []
+            for _ in range(10):
+                li, la, _ = gs(image.cuda(), audio.cuda())
+                losses.append(float(li) + float(la))
+            curves[mode] = losses
+    finally:
+        E.set_ln_fuse({'1': 'on', '0': 'off'}.get(os.environ.get('DAV_LN_FUSE', ''), 'auto'))
+    assert all(np.isfinite(curves['on'])) and curves['on'][-1] < curves['on'][0]
+    # (the masking noise differs per replay and per run: the curves agree in level, not step by step)
+    assert abs(np.mean(curves['on'][-3:]) - np.mean(curves['off'][-3:])) < 0.1 * abs(np.mean(curves['off'][-3:]))
+
+
 def test_full_size_step_is_schedule_independent_and_repeatable():
     """BASELINE configs[1] at its full size (ViT-B, B = 64 — the bench workload; the oracle would need minutes there): the
     size-independent properties instead.  The step computed as merged-grid lanes on one queue and as three streams with batched

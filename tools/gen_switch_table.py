@@ -25,7 +25,7 @@ S = {
     'DAV_WGRAD_MERGE': ('0 (all layers of a captured segment)', 'schedule', "encoder layers whose queued weight gradients share one launch (n > 0: a flush every n layers)", 'test_gang_weight_gradients_equal_the_grouped_kernel_and_the_oracle (1 and 0)'),
     'DAV_TN_GANG_DEBUG': ('0', 'debug', "dav_gemm_tn_gang_bf16 timing ablations: 2 = no epilogue, 4 = no MFMAs, 8 / 16 = queue chosen by block id / by a deliberately wrong placement instead of the hardware XCC id", '- (tools/tn_gang_bench.py, profiles/r05_tn_gang_*.txt)'),
     'DAV_WGRAD_OVERWRITE': ('1', 'kernel', "captured step: the first weight-gradient contribution to a Linear weight WRITES its tile (AdamW skips that zero-fill); 0 = accumulate / zero-fill", 'test_written_first_gradients_equal_accumulated_ones'),
-    'DAV_LN_FUSE': ('1', 'kernel', "LayerNorms folded into the GEMMs either side of them (dav_gemm_nt_ln_bf16: twin + row statistics from the producer's epilogue, gamma-folded weights in the consumer; no LayerNorm-forward launches); 0 = the LayerNorm kernels of rounds 1-5", 'test_ln_folded_and_layernorm_kernel_paths_agree, test_kernel_family[ln_fused]; every e2e test runs the default'),
+    'DAV_LN_FUSE': ('auto', 'kernel', "LayerNorms folded into the GEMMs either side of them (dav_gemm_nt_ln_bf16: twin + row statistics from the producer's epilogue, gamma-folded weights in the consumer; no LayerNorm-forward launches): auto = when no backward follows (eval / encoder-only inference: forward -2.5 %), the LayerNorm kernels in training steps (the backward would have to re-make the LayerNorm outputs: +0.7 ms per step, profiles/r06_ln_fuse.txt); 1 = always; 0 = never", 'test_ln_folded_and_layernorm_kernel_paths_agree, test_kernel_family[ln_fused]'),
     'DAV_NT_ALT': ('0', 'kernel', "EXPERIMENTAL builds only: 31 / 51 = the software-pipelined / loader-wave body in place of configuration 3 (faster alone, +0.6 / +1.9 ms in the step: profiles/r05_experiments.txt)", '- (make EXPERIMENTAL=1)'),
     'DAV_NT_TUNE': ('1', 'kernel', "0: ignore the tuned tile-configuration table (deepavfusion_amd/tuning/nt_gfx950.json), rules only", 'test_nt_tuning_table_loads_and_rejects_malformed_blobs, test_baseline_config_shapes_vs_oracle[large-32] (entries must fire)'),
     'DAV_NT_TUNE_FILE': ('tuning/nt_gfx950.json', 'kernel', "another tuned table", 'test_nt_tuning_table_loads_and_rejects_malformed_blobs'),
