@@ -923,8 +923,11 @@ def test_written_first_gradients_equal_accumulated_ones(monkeypatch):
         # 1.4e-5 seen once in ~40 runs of the suite
         assert abs(a - b) <= (1e-5 if k <= 3 else 5e-5) * abs(b), losses
     # not bit-equal: a written tile is never split over the contraction, an accumulated one may be (fp32 atomics), and AdamW turns
-    # rounding noise on exactly-zero gradients (key biases) into lr-sized steps; a LOST contribution would show at >= 4e-3
-    assert rel(finals[0], finals[1]) < 2e-4
+    # rounding noise on (near-)zero gradients — key biases, the pair attention's k projection under a near-uniform softmax — into
+    # lr-sized steps of either sign: which sign is decided by the last bit, so the figure moves with any change of rounding anywhere
+    # upstream (1.1e-4 .. 3.9e-4 across the builds of rounds 5-6, all of it in those parameters: tools/runs_r06/wf_probe.py); a LOST
+    # contribution would show at >= 4e-3
+    assert rel(finals[0], finals[1]) < 1e-3
 
 
 def test_trainer_skip_grad_drops_an_outlier_micro_step():
