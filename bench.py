@@ -21,6 +21,12 @@ sys.path.insert(0, ROOT)
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 BIG_LAUNCH_TILES = 400             # launches of >= 400 128x128-tile equivalents: the 8-wave big-tile regime of gemm_nt2_grouped_kernel (csrc/gemm.hip nt_auto_config_tiles)
 HBM_PEAK_GBS = 8000.0
+VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 2      # wave64 VALU instructions per second: 4 SIMD-32 per CU, 2 cycles per instruction (MI355X_MICROARCH.md "Wave scheduling")
+# (plain VALU, transcendental) instructions per 16 x 32 score tile and wave on the HOT path of the key loops (the rescale branch and the
+# padded-key masking excluded), counted in the ISA of this tree: tools/isa_valu_count.py + profiles/r06_attn_valu_isa.txt
+ATTN_VALU_PER_TILE = {(32, 32): {'fwd': (38, 8), 'dq': (28, 8), 'dkv': (44, 8)},
+                      (64, 64): {'fwd': (44, 8), 'dq': (36, 8), 'dkv': (56, 8)},
+                      (16, 64): {'fwd': (44, 8), 'dq': (36, 8), 'dkv': (56, 8)}}
 
 
 def lin(t, i, o):
@@ -254,7 +260,24 @@ def main():
         if world > 1:
             torch.distributed.all_reduce(t_nc, op=torch.distributed.ReduceOp.MAX)
         red.skip_collectives = False
+        # what the data-parallel MACHINERY costs a rank, collectives aside: the segmented replay without collectives against ONE graph of
+        # the same step (segments = 1, also without collectives) — graph cuts, per-segment weight-gradient launches, bucket bookkeeping
+        gs1 = GraphedStep(trainer, image.shape, audio.shape, segments=1)
+        red.skip_collectives = True
+        for _ in range(3):
+            gs1(image, audio)
+        sync()
+        t2 = time.perf_counter()
+        for _ in range(n_nc):
+            gs1(image, audio)
+        sync()
+        t_one = torch.tensor([(time.perf_counter() - t2) / n_nc * 1e3], device=dev, dtype=torch.float64)
+        if world > 1:
+            torch.distributed.all_reduce(t_one, op=torch.distributed.ReduceOp.MAX)
+        red.skip_collectives = False
+        del gs1
         comm = {'ms_per_step_no_collectives': round(float(t_nc), 3), 'comm_ms_exposed': round(ms - float(t_nc), 3),
+                'ms_per_step_one_graph_no_collectives': round(float(t_one), 3), 'single_rank_overhead_ms': round(float(t_nc) - float(t_one), 3),
                 'algo': red.algo, 'bf16_wire': red.bf16_wire, 'buckets': len(red.buckets), 'segments': getattr(gs, 'n_seg', None),
                 'grad_bytes': int(red.flat.flat_g.numel() * 4), 'rccl_ranks': torch.distributed.get_world_size(),
                 'backend': torch.distributed.get_backend()}
@@ -421,11 +444,13 @@ def main():
         if os.path.exists(tf):
             rec = json.load(open(tf)).get(f'{a.config}_b{B}', {})
             traffic_source = rec.get('source')
+            if traffic_source and rec.get('measured_on'):
+                traffic_source += f" [measured {rec['measured_on']}]"
             if rec.get('kernel_source_hash') == src_hash:
                 traffic = rec.get('hbm_bytes_per_launch')
             elif rec:
                 traffic_note = f'STALE, not reported: the kernel sources / tuned table changed since the PMC passes ({rec.get("kernel_source_hash")} -> {src_hash}); re-run tools/collect_r05.sh'
-        result['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_nt2_kernel / gemm_nt2_grouped_kernel, the launches of >= 400 tile equivalents exactly as the step issues them (default stream schedule: one launch per tower GEMM), each with its tile configuration (128x128 dominant; 128x256 per the rules / tuned table): forward + b_kn dgrad',
+        result['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_nt2_kernel / gemm_nt2_grouped_kernel, the launches of >= 400 tile equivalents exactly as the step issues them (default stream schedule: one launch per tower GEMM), each with the tile configuration it runs with in the step (launches_by_config: 3 = 128x128 on a 64-deep two-stage ring, 44 / 46 = 128x256 on three / two 32-deep stages — the majority of the launches —, 8 = 128x64; rules + tuned table): forward + b_kn dgrad',
                               'launches_by_config': {str(c): sum(1 for cc, _b, _p in big if cc == c) for c in sorted({cc for cc, _b, _p in big})},
                               'achieved': round(ach, 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                               'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': traffic,
@@ -441,7 +466,8 @@ def main():
             rec = json.load(open(st)).get(f'{a.config}_b{B}')
             if rec and rec.get('kernel_source_hash') == src_hash:      # (a constant of the tree like roofline.traffic: dropped when stale)
                 result['step_fabric'] = {'GB_per_step': rec['GB_per_step'], 'GBps': round(rec['GB_per_step'] / (ms * 1e-3), 0),
-                                         'hbm_frac_of_8TBps': round(rec['GB_per_step'] / (ms * 1e-3) / HBM_PEAK_GBS, 3), 'source': rec.get('source')}
+                                         'hbm_frac_of_8TBps': round(rec['GB_per_step'] / (ms * 1e-3) / HBM_PEAK_GBS, 3), 'source': rec.get('source'),
+                                         'measured_on': rec.get('measured_on')}
         # the same kernel in the LANES schedule (engine.BATCH_POLICY 'on', three lanes on one queue: the towers' and the fusion
         # block's equal-rank GEMMs merged into one grid): what the kernel reaches with 1400-2400 tiles per launch — reported
         # beside the as-issued figure because the default stream schedule (faster end to end) launches per tower.
@@ -503,10 +529,18 @@ def main():
         ms_tn = time_replay(replay_tn, reps)
         fl_tn = sum(2.0 * Mc * N * K for _k, probs in tn_log for (Mc, N, K) in probs)
         n_gang = sum(1 for k, _p in tn_log if k == 'gang')
+        wtraffic = wsrc = None                  # HBM bytes per gang launch: offline PMC passes over tools/tn_gang_bench.py (profiles/wgrad_traffic.json), hash-guarded like roofline.traffic
+        wt = os.path.join(ROOT, 'profiles', 'wgrad_traffic.json')
+        if os.path.exists(wt):
+            from deepavfusion_amd._lib import kernel_source_hash as _ksh
+            rec = json.load(open(wt)).get(f'{a.config}_b{B}', {})
+            if rec.get('kernel_source_hash') == _ksh():
+                wtraffic = rec.get('hbm_bytes_per_launch')
+                wsrc = f"{rec.get('source')} [measured {rec.get('measured_on')}]; algorithmic bytes per launch {rec.get('algorithmic_bytes_per_launch')}, L2 hit {rec.get('l2_hit_pct')} %"
         result['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'gemm_tn_gang_kernel (256 x 256 tiles, per-XCD ticket queues: both decoders / all encoder layers of a segment per launch)'
                                     + ('' if n_gang == len(tn_log) else ' + gemm_tn_grouped_kernel<128,4,2> for the small flushes'),
                                     'achieved': round(fl_tn / (ms_tn * 1e-3) / 1e12, 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                                    'frac': round(fl_tn / (ms_tn * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
+                                    'frac': round(fl_tn / (ms_tn * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': wtraffic, 'traffic_source': wsrc,
                                     'launches_per_step': len(tn_log), 'gang_launches': n_gang, 'problems_per_step': sum(len(p) for _k, p in tn_log),
                                     'ms_per_step': round(ms_tn, 3),
                                     'note': 'isolated replay of the recorded launches on fresh operands, written (not accumulated) tiles as in the captured step'}
@@ -543,12 +577,28 @@ def main():
                                        Nq * H * dv, H * dv, Nq * H * dv, H * dv, Nq * H * dqk, H * dqk, Nk * H * dqk, H * dqk, Nk * H * dv, H * dv, sc)
             ms_f, ms_b = time_graph(fwd, 20), time_graph(bwd, 20)
             ff = attn(Nq, Nk, dqk, dv) * B_ * H
+            # VALU roofline of the same launches: the key loops' vector instructions per 16 x 32 score tile counted in the ISA
+            # (tools/isa_valu_count.py, hot path: profiles/r06_attn_valu_isa.txt), a transcendental priced at 5/3 of a plain
+            # instruction (MI355X_MICROARCH.md), against 4 SIMD-32 per CU x 256 CUs x 2.4 GHz / 2 cycles per wave instruction
+            tiles = B_ * H * ((Nq + 15) // 16) * ((Nk + 31) // 32)
+            vi = ATTN_VALU_PER_TILE.get((dqk, dv), ATTN_VALU_PER_TILE[(64, 64)])
+            valu_f = tiles * (vi['fwd'][0] + vi['fwd'][1] * 5.0 / 3.0)
+            valu_b = tiles * (vi['dq'][0] + vi['dkv'][0] + (vi['dq'][1] + vi['dkv'][1]) * 5.0 / 3.0)
             entries.append({'what': names[key], 'B': B_, 'heads': H, 'Nq': Nq, 'Nk': Nk, 'dqk': dqk, 'dv': dv,
                             'calls_per_step': cnt, 'fwd_us': round(ms_f * 1e3, 1), 'bwd_us': round(ms_b * 1e3, 1),
                             'fwd_tflops': round(ff / (ms_f * 1e-3) / 1e12, 1), 'bwd_tflops': round(2.5 * ff / (ms_b * 1e-3) / 1e12, 1),
-                            'fwd_frac': round(ff / (ms_f * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)})
+                            'fwd_frac': round(ff / (ms_f * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                            'fwd_valu_frac': round(valu_f / (ms_f * 1e-3) / VALU_PEAK_WAVE_INSTR, 4),
+                            'bwd_valu_frac': round(valu_b / (ms_b * 1e-3) / VALU_PEAK_WAVE_INSTR, 4),
+                            'fwd_mfma_floor_us': round(ff / (MFMA_BF16_PEAK_TFLOPS * 1e12) * 1e6, 1),
+                            'fwd_valu_floor_us': round(valu_f / VALU_PEAK_WAVE_INSTR * 1e6, 1)})
         entries.sort(key=lambda e: -(e['fwd_us'] + e['bwd_us']) * e['calls_per_step']['fwd'])
-        result['roofline_attention'] = {'bound': 'mfma (nominal; softmax VALU work dominates at head widths 16-64, see DESIGN.md section 3)',
+        result['roofline_attention'] = {'bound': 'neither roof: fwd_frac = fraction of the bf16 MFMA peak, fwd_valu_frac / bwd_valu_frac = fraction of the VALU issue peak '
+                                                 '(plain-equivalent wave instructions of the key loops per second / 1.2288e12); at d = 32 the VALU floor is 1.6 x the MFMA floor and both are '
+                                                 'a quarter of the measured time — the kernels are bound by the dependent chain of a wave (MFMA -> max -> cross-lane -> exp -> cvt -> MFMA per 16 x 32 tile) '
+                                                 'at 6 waves per SIMD and by whole-workgroup rounds (1024 (batch, head) workgroups on 768 resident slots at 352 keys): DESIGN.md section 3',
+                                        'valu_peak_wave_instr_per_s': VALU_PEAK_WAVE_INSTR,
+                                        'valu_instr_per_16x32_tile': {f'{k[0]}x{k[1]}': v for k, v in ATTN_VALU_PER_TILE.items()},
                                         'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'kernels': 'attn_fwd / attn_bwd_dq / attn_bwd_dkv (isolated, back to back inside a replayed hipGraph: device time, no host launch path)',
                                         'shapes': entries}
 

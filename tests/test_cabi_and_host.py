@@ -483,7 +483,8 @@ def test_profiled_traffic_constants_belong_to_this_tree():
     from deepavfusion_amd._lib import kernel_source_hash
     h = kernel_source_hash()
     assert h == kernel_source_hash() and len(h) == 16
-    for name in ('dominant_kernel_traffic.json', 'step_traffic.json'):
+    for name in ('dominant_kernel_traffic.json', 'step_traffic.json', 'wgrad_traffic.json'):
         rec = json.load(open(os.path.join(ROOT, 'profiles', name)))['base_b64']
         assert rec.get('kernel_source_hash') == h, (f'profiles/{name} was measured on another version of the kernels / tuned table: '
-                                                     're-run tools/collect_r05.sh quick on the GPU box and tools/traffic_json.py')
+                                                     're-run tools/collect_r06.sh quick on the GPU box and tools/refresh_profiles_r06.sh')
+        assert rec.get('measured_on'), f'profiles/{name}: no record of the box / date the PMC passes ran on'

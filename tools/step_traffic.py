@@ -55,5 +55,6 @@ if len(sys.argv) > 4:                                # step_traffic.py fetch.csv
     j[key] = {'GB_per_step': round((FF + WW) / 1e9, 2), 'fetched_GB': round(FF / 1e9, 2), 'written_GB': round(WW / 1e9, 2),
               'serialised_kernel_ms': round(T / 1e6, 2),
               'source': sys.argv[5] if len(sys.argv) > 5 else 'profiles/r05_step_traffic.txt (tools/collect_r05.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py --no-graph)',
-              'kernel_source_hash': kernel_source_hash()}
+              'kernel_source_hash': kernel_source_hash(),
+              'measured_on': os.environ.get('DAV_MEASURED_ON') or __import__('datetime').date.today().isoformat()}
     json.dump(j, open(path, 'w'), indent=1)

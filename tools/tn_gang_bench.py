@@ -133,6 +133,16 @@ if __name__ == '__main__':
         ops.gemm_tn_gang(flat)
         torch.cuda.synchronize()
         del enc, flat
+    if 'pmc_step' in which:     # the step's two gang launches (decoders, then all encoder layers), once each: what bench.py's roofline_wgrad replays
+        dec = make(launches[0], ow, seed=77)
+        enc = [make(l, ow, seed=i) for i, l in enumerate(launches[2:])]
+        flat = [d for l in enc for d in l]
+        ops.gemm_tn_gang(dec)
+        ops.gemm_tn_gang(flat)
+        torch.cuda.synchronize()
+        alg = [sum(2.0 * (a * b + a * c) + 4.0 * b * c for (a, b, c) in l) for l in (launches[0], [s for l in launches[2:] for s in l])]
+        print('algorithmic bytes per gang launch (bf16 operands once + fp32 gradient written):', [int(x) for x in alg], flush=True)
+        del dec, enc, flat
     if 'big' in which:
         for (Mc, N, K) in ((4096, 4096, 4096), (8192, 4096, 4096)):
             p = make([(Mc, N, K)], True)

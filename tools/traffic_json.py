@@ -14,6 +14,8 @@ pre = sys.argv[3] if len(sys.argv) > 3 else 'r02'
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from deepavfusion_amd._lib import kernel_source_hash  # noqa: E402
+import datetime  # noqa: E402
+MEASURED_ON = os.environ.get('DAV_MEASURED_ON') or datetime.date.today().isoformat()      # "<date>, <device / box>" of the PMC passes (tools/collect_r06.sh sets it on the GPU box)
 
 
 def fam(n):
@@ -48,6 +50,6 @@ j[key] = {'fetch_kib_per_launch_raw': {k: F[k] for k in fams}, 'write_kib_per_la
           'launches_profiled': {k: calls[k] for k in fams}, 'fetch_kib_per_launch_raw_weighted': round(fetch, 1),
           'write_kib_per_launch_weighted': round(write, 1), 'hbm_bytes_per_launch': int((2 * fetch + write) * 1024),
           'source': f'profiles/{pre}_pmc_FETCH_SIZE.txt, profiles/{pre}_pmc_WRITE_SIZE.txt, profiles/{pre}_roofline_kernel_stats.csv (launch counts); tools/traffic_json.py',
-          'kernel_source_hash': kernel_source_hash()}
+          'kernel_source_hash': kernel_source_hash(), 'measured_on': MEASURED_ON}
 json.dump(j, open(path, 'w'), indent=1)
 print(key, tot, 'launches:', round(fetch), 'KiB fetched (raw),', round(write), 'KiB written ->', j[key]['hbm_bytes_per_launch'], 'bytes per launch')
