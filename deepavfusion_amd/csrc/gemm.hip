@@ -452,7 +452,8 @@ __device__ __forceinline__ void nt_epilogue_t(const NTParams& p, f32x4 (&acc)[FM
     for (int ii = 0; ii < IH; ++ii) {
       const int i = i0 + ii;
       const int m = m0 + wm * WTM + i * 16 + fr;
-      const bool rowok = mok[ii];            // (no early exit from the row: the twin patch below is a whole-wave affair)
+      if constexpr (BM == 0) { if (!mok[ii]) continue; }
+      const bool rowok = mok[ii];            // (BM > 0: no early exit from the row — the twin patch below is a whole-wave affair)
       float ps1 = 0.f, ps2 = 0.f;
       uint2 twv[FN];
 #pragma unroll
@@ -589,7 +590,7 @@ __device__ __forceinline__ bool nt_staged_ok(const NTParams& p) {
 // after the other, the twin's packed values waiting in registers.
 template <int BM, int BN, int NTHREADS, int FM, int FN, int WTM, int WTN, bool SPLIT = false>
 __device__ __forceinline__ void nt_epilogue_s(const NTParams& p, f32x4 (&acc)[FM][FN], char* lds, int m0, int n0, int wm, int wn,
-                                              int lane, int tid, const float2* ln_mr = nullptr) {
+                                              int lane, int tid, const float2* ln_mr = nullptr) {      // (ln_mr: a compile-time null in the kernels without the LayerNorm code)
   constexpr int RB = BN * 2 + 16;                         // padded tile row (16: keeps the b128 row reads aligned)
   const int fr = lane & 15, fg = lane >> 4;
   const bool lnc = ln_mr != nullptr && p.ln_st != nullptr;      // LayerNorm consumer (see nt_epilogue_t)      // LayerNorm consumer (see nt_epilogue_t)
@@ -715,9 +716,9 @@ constexpr size_t nt2_ln_offset() {
   constexpr size_t epi = (size_t)(nt_epi_split<BM, BN>() ? 1 : 2) * nt_stage_bytes<BM, BN>();
   return nt2_ln_late<BM, BN, WM_, WN_, STAGES, BT, BK>() ? epi : nt2_lds_bytes<BM, BN, WM_, WN_, STAGES, BT, BK>();
 }
-template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK>
+template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK, bool LNK>
 constexpr size_t nt2_lds_alloc() {
-  return nt2_lds_bytes<BM, BN, WM_, WN_, STAGES, BT, BK>() + (nt2_ln_late<BM, BN, WM_, WN_, STAGES, BT, BK>() || BT ? 0 : nt2_ln_bytes<BM, BN>());
+  return nt2_lds_bytes<BM, BN, WM_, WN_, STAGES, BT, BK>() + (nt2_ln_late<BM, BN, WM_, WN_, STAGES, BT, BK>() || !LNK ? 0 : nt2_ln_bytes<BM, BN>());
 }
 
 #include "gemm_nt256.h"
@@ -776,7 +777,9 @@ __device__ __forceinline__ void nt2_loader(const NTParams& p, int m0, int n0, in
   // the loaders leave here; the barriers of the epilogue count the surviving (compute) waves only
 }
 
-template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK, bool PROF = false, int PIPE = 0>
+// LNK: the instantiation that carries the LayerNorm-folding code (DavNtLn producer / consumer); every launch without such a problem runs
+// the LNK = false kernels, which are instruction for instruction what they were before the folding existed.
+template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK, bool PROF = false, int PIPE = 0, bool LNK = false>
 __device__ __forceinline__ void nt2_body(const NTParams& p, int bid, int tid_in = -1) {
   // PROF (tile configuration 30, tools/gemm_phase_prof.py only): per-wave shader-cycle sums of the k-loop phases —
   // [wait for the DMA, barrier, DMA issue, fragment reads + MFMAs, prologue, epilogue] — written to the int64 buffer
@@ -830,6 +833,7 @@ __device__ __forceinline__ void nt2_body(const NTParams& p, int bid, int tid_in 
   // 16-byte-slot XOR swizzle of the row-major tiles: 128-byte rows (BK 64) / 64-byte rows (BK 32)
   auto rswz = [](int row) { return BK == 64 ? ((row >> 1) & 7) : ((0 - (row >> 2)) & 3); };
 
+  static_assert(!LNK || (!BT && PIPE == 0 && !PROF), "LayerNorm folding: forward [N, K] kernels only");
   float2* ln_mr = reinterpret_cast<float2*>(smem + nt2_ln_offset<BM, BN, WM_, WN_, STAGES, BT, BK>());      // LayerNorm consumer: see below
   constexpr bool LN_LATE = nt2_ln_late<BM, BN, WM_, WN_, STAGES, BT, BK>();
   const bf16_t* a_src[A_CH];
@@ -838,7 +842,7 @@ __device__ __forceinline__ void nt2_body(const NTParams& p, int bid, int tid_in 
   for (int i = 0; i < (PIPE >= 2 ? 0 : A_CH); ++i) {
     const int c = tid + NT * i, row = c / ACPR, ls = (c % ACPR) ^ rswz(row);
     int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;
-    a_src[i] = (BT ? p.A + map_row(gm, p.amap) * p.lda : nt_a_row(p, gm)) + ls * 8;
+    a_src[i] = (LNK ? nt_a_row(p, gm) : p.A + map_row(gm, p.amap) * p.lda) + ls * 8;
   }
   // B tile: NT mode = [BN rows][BK k] (as A); BT mode (B given as [K, N], the dgrad reading W itself) =
   // [64 k rows][BN cols] (BN*2-byte rows) read back with the transposing ds_read_b64_tr_b16.
@@ -896,7 +900,7 @@ __device__ __forceinline__ void nt2_body(const NTParams& p, int bid, int tid_in 
     float* ln_cv = reinterpret_cast<float*>(ln_mr + BM);
     for (int c = tid; c < BN; c += NT) ln_cv[c] = n0 + c < p.N ? p.ln_c[n0 + c] : 0.f;
   };
-  if (!BT && !LN_LATE && p.ln_st != nullptr) ln_stats_to_lds();
+  if (LNK && !LN_LATE && p.ln_st != nullptr) ln_stats_to_lds();
 
   const int fr = lane & 15, fg = lane >> 4;
   uint32_t bt_base[FN];
@@ -1102,13 +1106,12 @@ __device__ __forceinline__ void nt2_body(const NTParams& p, int bid, int tid_in 
     }
     return;
   }
-  if (!BT && LN_LATE && p.ln_st != nullptr) {      // (uniform per launch)
+  if (LNK && LN_LATE && p.ln_st != nullptr) {      // (uniform per launch)
     ln_stats_to_lds();
     __syncthreads();
   }
-  // (the LayerNorm forms exist in the forward [N, K] kernels only: the input-gradient kernels are what they were)
-  if (nt_staged_ok(p)) nt_epilogue_s<BM, BN, NT, FM, FN, WTM, WTN, nt_epi_split<BM, BN>()>(p, acc, smem, m0, n0, wm, wn, lane, tid, BT ? nullptr : ln_mr);
-  else if constexpr (BT) nt_epilogue_t<FM, FN, WTM, WTN>(p, acc, m0, n0, wm, wn, lane);
+  if (nt_staged_ok(p)) nt_epilogue_s<BM, BN, NT, FM, FN, WTM, WTN, nt_epi_split<BM, BN>()>(p, acc, smem, m0, n0, wm, wn, lane, tid, LNK ? ln_mr : nullptr);
+  else if constexpr (!LNK) nt_epilogue_t<FM, FN, WTM, WTN>(p, acc, m0, n0, wm, wn, lane);
   else nt_epilogue_t<FM, FN, WTM, WTN, BM, BN, WN_>(p, acc, m0, n0, wm, wn, lane, ln_mr, smem, tid);
 }
 
@@ -1321,11 +1324,11 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(NTParams p) {
   nt3_body<BT>(p, blockIdx.x);
 }
 // PIPE: two 512-thread workgroups per CU = 4 waves per SIMD -> at most 128 VGPRs (2nd launch-bounds argument = waves per SIMD)
-template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK = 64, int PIPE = 0>
+template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK = 64, int PIPE = 0, bool LNK = false>
 // (4-wave tiles ask for >= 2 waves per SIMD: with one, the register budget is 512 = VGPRs + AGPRs, the compiler puts the accumulators
 // into AGPRs and copies all of them to VGPRs and back around every k-step — 32-64 v_accvgpr moves against 8-16 MFMAs)
 __global__ __launch_bounds__((WM_* WN_ + (PIPE >= 2 ? PIPE : 0)) * 64, PIPE == 4 ? 6 : PIPE == 2 ? 5 : ((PIPE || (WM_ * WN_ == 8 && BM * BN > 128 * 128)) ? 4 : (WM_ * WN_ <= 4 ? 2 : 1))) void gemm_nt2_kernel(NTParams p) {
-  nt2_body<BM, BN, WM_, WN_, STAGES, BT, BK, false, PIPE>(p, blockIdx.x);
+  nt2_body<BM, BN, WM_, WN_, STAGES, BT, BK, false, PIPE, LNK>(p, blockIdx.x);
 }
 
 // Grouped launch: up to NT_GROUP_MAX independent problems (any M / N / K / epilogue, one tile configuration) in ONE grid —
@@ -1339,11 +1342,11 @@ struct NTGroup {
   int count;
 };
 
-template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK = 64, int PIPE = 0>
+template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK = 64, int PIPE = 0, bool LNK = false>
 __global__ __launch_bounds__((WM_* WN_ + (PIPE >= 2 ? PIPE : 0)) * 64, PIPE == 4 ? 6 : PIPE == 2 ? 5 : ((PIPE || (WM_ * WN_ == 8 && BM * BN > 128 * 128)) ? 4 : (WM_ * WN_ <= 4 ? 2 : 1))) void gemm_nt2_grouped_kernel(const NTGroup g) {
   int pi = 0;
   while (pi + 1 < g.count && (int)blockIdx.x >= g.first_block[pi + 1]) ++pi;
-  nt2_body<BM, BN, WM_, WN_, STAGES, BT, BK, false, PIPE>(g.prob[pi], (int)blockIdx.x - g.first_block[pi]);
+  nt2_body<BM, BN, WM_, WN_, STAGES, BT, BK, false, PIPE, LNK>(g.prob[pi], (int)blockIdx.x - g.first_block[pi]);
 }
 
 template <bool BT, int EK>
@@ -1447,12 +1450,23 @@ void launch_nt3(const NTParams& p, hipStream_t stream) {
 }
 
 // launches n >= 1 recorded problems of this tile configuration (davb::GroupFn)
-template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK, int PIPE = 0>
+static bool nt_has_ln(const void* const* params, int n) {
+  for (int i = 0; i < n; ++i) {
+    const NTParams& p = *(const NTParams*)params[i];
+    if (p.ln_st || p.st_out || p.tw_out) return true;
+  }
+  return false;
+}
+
+template <int BM, int BN, int WM_, int WN_, int STAGES, bool BT, int BK, int PIPE = 0, bool LNK = false>
 void nt2_issue(const void* const* params, int n, hipStream_t stream) {
+  if constexpr (!LNK && !BT && PIPE == 0) {      // a problem with a LayerNorm folded in: the kernels that carry that code
+    if (nt_has_ln(params, n)) { nt2_issue<BM, BN, WM_, WN_, STAGES, BT, BK, PIPE, true>(params, n, stream); return; }
+  }
   constexpr int NT = (WM_ * WN_ + (PIPE >= 2 ? PIPE : 0)) * 64;      // + the loader waves
-  constexpr size_t lds = nt2_lds_alloc<BM, BN, WM_, WN_, STAGES, BT, BK>();
-  auto kern = gemm_nt2_kernel<BM, BN, WM_, WN_, STAGES, BT, BK, PIPE>;
-  auto gkern = gemm_nt2_grouped_kernel<BM, BN, WM_, WN_, STAGES, BT, BK, PIPE>;
+  constexpr size_t lds = nt2_lds_alloc<BM, BN, WM_, WN_, STAGES, BT, BK, LNK>();
+  auto kern = gemm_nt2_kernel<BM, BN, WM_, WN_, STAGES, BT, BK, PIPE, LNK>;
+  auto gkern = gemm_nt2_grouped_kernel<BM, BN, WM_, WN_, STAGES, BT, BK, PIPE, LNK>;
   static bool big = false;
   if (lds > 64 * 1024 && !big) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -275,12 +275,14 @@ def _e(shape, dtype, dev):
 # norm1_img / norm1_aud / norm2 (models/fusion_blocks.py:281-288), decoder_norm -> decoder_pred (models/avmae.py:177-178).
 # norm1_mm of the fusion blocks stays a kernel: its OUTPUT is the residual base (norm-then-residual, :281-283).
 # ------------------------------------------------------------------------------------------------
-# Where it stands (profiles/r06_ln_fuse.txt, ViT-B B = 64, same box): the forward loses its 123 LayerNorm launches and 0.25 ms, but the
-# backward must WRITE the LayerNorm output it no longer finds saved (+2 bytes per element on the serial LayerNorm-backward kernels:
-# +0.5 ms), the producers' epilogues pay 6-20 % for twin + statistics and the weight fold is 0.8 GB per step: 25.8 ms against 25.1 ms.
-# So DAV_LN_FUSE defaults to 'auto': folded when NO backward will follow (eval, kNN probe, encoder-only inference: the forward alone is
-# 2.5 % shorter), the LayerNorm kernels of rounds 1-5 in training steps; '1' folds always, '0' never.
-LN_FUSE_MODE = {'1': 'on', '0': 'off'}.get(os.environ.get('DAV_LN_FUSE', ''), 'auto')
+# Where it stands (profiles/r06_ln_fuse.txt, ViT-B B = 64, same box, alternating): the forward loses its 123 LayerNorm launches, but the
+# producers' epilogues pay 6-20 % for twin + statistics, the consumers 0-10 %, the weight fold moves 0.8 GB per step, and the backward
+# must WRITE the LayerNorm outputs it no longer finds saved (+2 bytes per element on the serial LayerNorm-backward kernels): forward alone
+# 8.60 ms against 8.48 ms, the whole step 25.5 ms against 24.8 ms.  The LayerNorm kernels the folding deletes are memory-bound fillers
+# that run beside MFMA-bound GEMMs of the other streams; what replaces them sits in the GEMMs' own epilogues.  So DAV_LN_FUSE defaults to
+# OFF (the LayerNorm kernels of rounds 1-5); '1' folds always, 'auto' folds when no backward follows.  The GEMM kernels that carry the
+# folding code are separate instantiations (gemm.hip LNK): launches without a folded LayerNorm run the kernels of round 5 unchanged.
+LN_FUSE_MODE = {'1': 'on', 'auto': 'auto'}.get(os.environ.get('DAV_LN_FUSE', ''), 'off')
 LN_FUSE = LN_FUSE_MODE == 'on'
 
 
@@ -483,11 +485,19 @@ WGRAD_MERGE = int(os.environ.get('DAV_WGRAD_MERGE', '0'))
 WGRAD_FLUSH_LAYERS = set()
 
 
+WGRAD_EAGER_DP_MERGE = 3      # eager data-parallel backward (a grad-ready hook, no captured segments): layers per weight-gradient launch
+
+
 def wgrad_flush_due(layer: int, depth: int) -> bool:
     """Whether the queued weight gradients go out after encoder layer ``layer``'s backward (layers run depth-1 .. 0)."""
     if not WGRAD_GANG or layer == 0 or layer in WGRAD_FLUSH_LAYERS:
         return True
-    return WGRAD_MERGE > 0 and (depth - layer) % WGRAD_MERGE == 0
+    if WGRAD_MERGE > 0:
+        return (depth - layer) % WGRAD_MERGE == 0
+    # merge-all, but nobody set flush points (an EAGER step; a captured one sets its segment cuts): with a gradient-ready hook
+    # installed (the data-parallel reducer) one launch at layer 0 would report every encoder gradient at the very end — no bucket could
+    # start its all-reduce under the backward — and keep every layer's operands alive until then: a bounded merge instead
+    return _GRAD_READY is not None and not WGRAD_FLUSH_LAYERS and (depth - layer) % WGRAD_EAGER_DP_MERGE == 0
 
 
 _DEFERRED = None

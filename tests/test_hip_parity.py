@@ -159,7 +159,7 @@ def test_ln_folded_and_layernorm_kernel_paths_agree(golden, name):
                 assert rel(o_on[2], o_off[2]) < ACT_TOL and rel(o_on[3], o_off[3]) < ACT_TOL
                 assert torch.equal(o_on[2], o_auto[2]) and torch.equal(o_on[3], o_auto[3])
     finally:
-        E.set_ln_fuse({'1': 'on', '0': 'off'}.get(os.environ.get('DAV_LN_FUSE', ''), 'auto'))
+        E.set_ln_fuse({'1': 'on', 'auto': 'auto'}.get(os.environ.get('DAV_LN_FUSE', ''), 'off'))
     (o1, g1), (o0, g0) = res['on'], res['off']
     assert abs(float(o1[0]) - float(o0[0])) <= LOSS_RTOL * abs(float(o0[0])) and abs(float(o1[1]) - float(o0[1])) <= LOSS_RTOL * abs(float(o0[1]))
     assert rel(o1[2], o0[2]) < ACT_TOL and rel(o1[3], o0[3]) < ACT_TOL
@@ -191,7 +191,7 @@ def test_ln_folded_captured_step_tracks_the_kernel_path():
                 losses.append(float(li) + float(la))
             curves[mode] = losses
     finally:
-        E.set_ln_fuse({'1': 'on', '0': 'off'}.get(os.environ.get('DAV_LN_FUSE', ''), 'auto'))
+        E.set_ln_fuse({'1': 'on', 'auto': 'auto'}.get(os.environ.get('DAV_LN_FUSE', ''), 'off'))
     assert all(np.isfinite(curves['on'])) and curves['on'][-1] < curves['on'][0]
     # (the masking noise differs per replay and per run: the curves agree in level, not step by step)
     assert abs(np.mean(curves['on'][-3:]) - np.mean(curves['off'][-3:])) < 0.1 * abs(np.mean(curves['off'][-3:]))

@@ -22,10 +22,10 @@ S = {
     'DAV_FUSION_STREAM': ('1', 'schedule', "lanes schedule only: the fusion block on its own stream (1) or as a third lane of the batch (0)", 'bench.py roofline.lanes_schedule (runs it), test_full_size_step...'),
     'DAV_STREAMS': ('1', 'schedule', "0: everything on the current stream (serial schedule; tools/instep_gemm_bound.py uses it)", 'tools/instep_gemm_bound.py (profiles/r04_gemm_instep_bound.txt)'),
     'DAV_WGRAD_GANG': ('1', 'kernel', "weight gradients of a flush as ONE gang-scheduled launch of 256 x 256 tiles (dav_gemm_tn_gang_bf16: per-XCD ticket queues of tiles that share operand panels); 0 = the 128 x 128 grouped kernel, one launch per layer (profiles/r05_tn_gang_*.txt)", 'test_gang_weight_gradients_equal_the_grouped_kernel_and_the_oracle, test_baseline_config_shapes_vs_oracle (default path), tools/tn_gang_bench.py check()'),
-    'DAV_WGRAD_MERGE': ('0 (all layers of a captured segment)', 'schedule', "encoder layers whose queued weight gradients share one launch (n > 0: a flush every n layers)", 'test_gang_weight_gradients_equal_the_grouped_kernel_and_the_oracle (1 and 0)'),
+    'DAV_WGRAD_MERGE': ('0 (all layers of a captured segment)', 'schedule', "encoder layers whose queued weight gradients share one launch (n > 0: a flush every n layers); with 0 an EAGER data-parallel backward (grad-ready hook installed, no captured segments) still flushes every 3 layers, so that gradient buckets become ready under the backward and operands are released (engine.WGRAD_EAGER_DP_MERGE)", 'test_gang_weight_gradients_equal_the_grouped_kernel_and_the_oracle (1 and 0)'),
     'DAV_TN_GANG_DEBUG': ('0', 'debug', "dav_gemm_tn_gang_bf16 timing ablations: 2 = no epilogue, 4 = no MFMAs, 8 / 16 = queue chosen by block id / by a deliberately wrong placement instead of the hardware XCC id", '- (tools/tn_gang_bench.py, profiles/r05_tn_gang_*.txt)'),
     'DAV_WGRAD_OVERWRITE': ('1', 'kernel', "captured step: the first weight-gradient contribution to a Linear weight WRITES its tile (AdamW skips that zero-fill); 0 = accumulate / zero-fill", 'test_written_first_gradients_equal_accumulated_ones'),
-    'DAV_LN_FUSE': ('auto', 'kernel', "LayerNorms folded into the GEMMs either side of them (dav_gemm_nt_ln_bf16: twin + row statistics from the producer's epilogue, gamma-folded weights in the consumer; no LayerNorm-forward launches): auto = when no backward follows (eval / encoder-only inference: forward -2.5 %), the LayerNorm kernels in training steps (the backward would have to re-make the LayerNorm outputs: +0.7 ms per step, profiles/r06_ln_fuse.txt); 1 = always; 0 = never", 'test_ln_folded_and_layernorm_kernel_paths_agree, test_kernel_family[ln_fused]'),
+    'DAV_LN_FUSE': ('0', 'kernel', "1: LayerNorms folded into the GEMMs either side of them (dav_gemm_nt_ln_bf16: twin + row statistics from the producer's epilogue, gamma-folded weights in the consumer; no LayerNorm-forward launches, the backward re-makes the LayerNorm outputs for the weight gradients); auto: only when no backward follows; 0 (default): the LayerNorm kernels — the folded step is 0.7 ms slower, the folded forward alone 0.1 ms slower (profiles/r06_ln_fuse.txt)", 'test_ln_folded_and_layernorm_kernel_paths_agree, test_ln_folded_captured_step_tracks_the_kernel_path, test_kernel_family[ln_fused]'),
     'DAV_NT_ALT': ('0', 'kernel', "EXPERIMENTAL builds only: 31 / 51 = the software-pipelined / loader-wave body in place of configuration 3 (faster alone, +0.6 / +1.9 ms in the step: profiles/r05_experiments.txt)", '- (make EXPERIMENTAL=1)'),
     'DAV_NT_TUNE': ('1', 'kernel', "0: ignore the tuned tile-configuration table (deepavfusion_amd/tuning/nt_gfx950.json), rules only", 'test_nt_tuning_table_loads_and_rejects_malformed_blobs, test_baseline_config_shapes_vs_oracle[large-32] (entries must fire)'),
     'DAV_NT_TUNE_FILE': ('tuning/nt_gfx950.json', 'kernel', "another tuned table", 'test_nt_tuning_table_loads_and_rejects_malformed_blobs'),
