@@ -482,7 +482,7 @@ class region:
 WGRAD_GANG = os.environ.get('DAV_WGRAD_GANG', '1') != '0'
 WGRAD_GANG_MIN_TILES = 512      # (one ViT-B layer = 346 tiles: 193 us on the 128 x 128 kernel, 202 us as a gang launch; two layers 386 vs 347 us)
 WGRAD_MERGE = int(os.environ.get('DAV_WGRAD_MERGE', '0'))
-WGRAD_FLUSH_LAYERS = set()
+WGRAD_FLUSH_LAYERS = None      # None: no captured step in progress; a set (possibly empty): the segment cuts of the step being captured
 
 
 WGRAD_EAGER_DP_MERGE = 3      # eager data-parallel backward (a grad-ready hook, no captured segments): layers per weight-gradient launch
@@ -490,14 +490,15 @@ WGRAD_EAGER_DP_MERGE = 3      # eager data-parallel backward (a grad-ready hook,
 
 def wgrad_flush_due(layer: int, depth: int) -> bool:
     """Whether the queued weight gradients go out after encoder layer ``layer``'s backward (layers run depth-1 .. 0)."""
-    if not WGRAD_GANG or layer == 0 or layer in WGRAD_FLUSH_LAYERS:
+    if not WGRAD_GANG or layer == 0 or layer in (WGRAD_FLUSH_LAYERS or ()):
         return True
     if WGRAD_MERGE > 0:
         return (depth - layer) % WGRAD_MERGE == 0
-    # merge-all, but nobody set flush points (an EAGER step; a captured one sets its segment cuts): with a gradient-ready hook
-    # installed (the data-parallel reducer) one launch at layer 0 would report every encoder gradient at the very end — no bucket could
-    # start its all-reduce under the backward — and keep every layer's operands alive until then: a bounded merge instead
-    return _GRAD_READY is not None and not WGRAD_FLUSH_LAYERS and (depth - layer) % WGRAD_EAGER_DP_MERGE == 0
+    # merge-all, and no captured step in progress (a capture declares its segment cuts, an empty set for one graph): with a
+    # gradient-ready hook installed — the data-parallel reducer of an EAGER step — one launch at layer 0 would report every encoder
+    # gradient at the very end (no bucket could start its all-reduce under the backward) and keep every layer's operands alive until
+    # then: a bounded merge instead
+    return _GRAD_READY is not None and WGRAD_FLUSH_LAYERS is None and (depth - layer) % WGRAD_EAGER_DP_MERGE == 0
 
 
 _DEFERRED = None

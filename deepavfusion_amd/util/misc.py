@@ -284,7 +284,7 @@ class GraphedStep:
                 # (also on an exception: a write-first mode left on would make later EAGER backwards overwrite instead of
                 # accumulate the first contribution to every Linear weight's gradient)
                 kept = {id(p) for p in engine.wgrad_overwrite_end()}
-                engine.WGRAD_FLUSH_LAYERS = set()
+                engine.WGRAD_FLUSH_LAYERS = None
             if not self.dist_active:
                 optimizer_pass()
             self.graphs[seg[0]].capture_end()
