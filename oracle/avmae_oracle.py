@@ -566,8 +566,10 @@ def avmae_forward(sd, cfg: PathConfig, image: Tensor, audio: Tensor,
     """
     ik, im, ir = random_masking_from_noise(noise_image, cfg.image_mask_ratio)
     ak, am, ar = random_masking_from_noise(noise_audio, cfg.audio_mask_ratio)
-    ik_t, ir_t, im_t = torch.from_numpy(ik), torch.from_numpy(ir), torch.from_numpy(im)
-    ak_t, ar_t, am_t = torch.from_numpy(ak), torch.from_numpy(ar), torch.from_numpy(am)
+    dev = image.device          # (host by default; the GPU suite also runs this restatement on the device through stock PyTorch fp32 kernels
+    #                              for the bench-size checks, where the host would need minutes)
+    ik_t, ir_t, im_t = torch.from_numpy(ik).to(dev), torch.from_numpy(ir).to(dev), torch.from_numpy(im).to(dev)
+    ak_t, ar_t, am_t = torch.from_numpy(ak).to(dev), torch.from_numpy(ar).to(dev), torch.from_numpy(am).to(dev)
     x_i, x_a, x_f = deepavfusion_forward(sd, cfg, image, audio, ik_t, ak_t, prefix='encoder.')
     pred_i = forward_decoder(x_i, x_f, ir_t, sd, cfg, 'image')
     loss_i = forward_loss(patchify(image, (cfg.patch, cfg.patch)), pred_i, im_t, cfg.image_norm_loss)

@@ -314,6 +314,34 @@ def test_error_codes_for_dtype_alignment_and_workspace():
     pr[1].Mc = 0
     assert lib.dav_gemm_tn_gang_workspace_bytes(pr, 2) == 0
     assert _lib.ERRORS[-2] and _lib.ERRORS[-3] and _lib.ERRORS[-5]
+    # ---- ABI 8: LayerNorm folded into the GEMMs (dav_gemm_nt_ln_bf16 + DavNtLn, dav_rowstats_cast, dav_layernorm_bwd_twin, dav_ln_fold_grouped)
+    ln = _lib.DavNtLn()
+    ntl = dict(nt, a26=C.byref(ln))
+    ln.stats, ln.ln_c, ln.eps = 16384, 20480, 1e-6
+    assert call('dav_gemm_nt_ln_bf16', **{**ntl, 'a4': C.c_int(2048), 'a5': C.c_int(2048), 'a6': C.c_int(2048)}) == -1      # K > 1024: the statistics of a row do not fit the prologue
+    ln.a_r0, ln.a_r1 = 3, 5                                                  # two-source rows without the second source
+    assert call('dav_gemm_nt_ln_bf16', **ntl) == -1
+    ln = _lib.DavNtLn(); ntl = dict(nt, a26=C.byref(ln))
+    ln.stats_out, ln.twin_out, ln.ld_twin = 16384, 20480 + 8, 128            # twin not 16-byte aligned
+    assert call('dav_gemm_nt_ln_bf16', **ntl) == -5
+    ln.twin_out = 20480
+    assert call('dav_gemm_nt_ln_bf16', **{**ntl, 'a18': C.c_int(1)}) == -1   # statistics are those of an fp32 result
+    assert call('dav_gemm_nt_ln_bf16', **{**ntl, 'a25': C.c_int(60 << 4)}) == -1      # producers: the 32 x 64 / 32 x 32 wave tiles only
+    assert call('dav_rowstats_cast', a0=p(4096), a2=C.c_int(2), a3=C.c_int(3), a4=C.c_int(96), a5=p(8192), a6=p(12288)) == -1      # D % 64
+    assert call('dav_rowstats_cast', a0=p(4096), a2=C.c_int(2), a3=C.c_int(3), a4=C.c_int(128), a5=p(8192 + 2), a6=p(12288)) == -5
+    tw = S['dav_layernorm_bwd_twin']
+    args = _zero_args(tw)
+    args[0], args[1], args[2], args[3] = p(4096), C.c_long(7 * 64), p(8192), C.c_int(7)      # xb0, batch stride, st0, r0
+    args[8], args[9], args[10] = C.c_int(4), C.c_int(64), C.c_float(1e-6)                    # B, D, eps
+    args[11], args[13] = p(12288), p(16384)                                                  # dy_bf16, gamma
+    args[-3], args[-2] = p(20480), C.c_size_t(lib.dav_layernorm_bwd_workspace_bytes(4 * 7, 64) - 1)
+    assert lib.dav_layernorm_bwd_twin(*args) == -3
+    fold = (_lib.DavLnFold * 1)()
+    fold[0].w, fold[0].gamma, fold[0].beta, fold[0].w_ln_bf16, fold[0].ln_c, fold[0].ln_d, fold[0].N, fold[0].K = 4096, 8192, 12288, 16384, 20480, 24576, 8, 60
+    assert lib.dav_ln_fold_grouped(fold, 1, None) == -1                      # K % 8
+    fold[0].K, fold[0].w = 64, 4096 + 4
+    assert lib.dav_ln_fold_grouped(fold, 1, None) == -5
+    assert lib.dav_ln_fold_grouped(fold, 49, None) == -1                     # more pairs than one launch carries
 
 
 def test_written_first_contribution_bookkeeping(monkeypatch):

@@ -1368,6 +1368,41 @@ def test_published_sizes_are_batch_consistent(name, batch):
     assert np.median(rels) < ACT_TOL
 
 
+@pytest.mark.parametrize('name,batch', [('base_as', 64), ('large', 32)])
+def test_published_sizes_vs_oracle_on_the_device(name, batch):
+    """``base_as-64`` and ``large-32`` — the sizes profiles/*bench_base_as.json / *bench_large.json are timed at — against the ORACLE
+    itself, run on the GPU: oracle/avmae_oracle.py is plain torch fp32, so with its state dict and inputs on the device it executes on
+    the stock PyTorch-ROCm kernels (hipBLASLt / MIOpen / ATen: nothing of libdavfusion_hip.so) in a few seconds where the host needs
+    minutes.  An implementation independent of the library checks losses, predictions, masking indices and every gradient at the
+    sizes the throughput is published for (the batch-consistency property above compares the library with itself)."""
+    model, sd, cfg, O = _build(name)
+    image, audio, ni, na = O.synthetic_batch(cfg, batch, seed=25)
+    out = model(image.cuda(), audio.cuda(), torch.from_numpy(ni).cuda(), torch.from_numpy(na).cuda())
+    (out[0] + out[1]).backward()
+    torch.cuda.synchronize()
+    prev = torch.backends.cuda.matmul.allow_tf32
+    torch.backends.cuda.matmul.allow_tf32 = False
+    try:
+        sdd = {k: v.cuda() for k, v in sd.items()}
+        li, la, pi, pa, aux, ograd = _oracle_step(O, sdd, cfg, image.cuda(), audio.cuda(), ni, na)
+    finally:
+        torch.backends.cuda.matmul.allow_tf32 = prev
+    for k in ('image_ids_keep', 'audio_ids_keep', 'image_ids_restore', 'audio_ids_restore'):
+        assert np.array_equal(model._last_masks[k].cpu().numpy(), aux[k]), k
+    assert abs(float(out[0]) - float(li)) <= LOSS_RTOL * float(li) and abs(float(out[1]) - float(la)) <= LOSS_RTOL * float(la)
+    assert rel(out[2], pi) < ACT_TOL and rel(out[3], pa) < ACT_TOL
+    g_all = sum(float(v.double().norm()) ** 2 for v in ograd.values()) ** 0.5
+    rels = []
+    for n, p in model.named_parameters():
+        if not p.requires_grad or n.endswith(ZERO_GRADS):
+            continue
+        ref = ograd[n].double()
+        d = float((p.grad.detach().double() - ref).norm())
+        rels.append(d / max(float(ref.norm()), 1e-30))
+        assert d <= GRAD_TOL * float(ref.norm()) + 1e-4 * g_all, (n, d, float(ref.norm()))
+    assert np.median(rels) < ACT_TOL
+
+
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize('name,batch', [('base', 64), ('base_m75', 4), ('base_swin', 2)])
 def test_baseline_config_shapes_vs_oracle(name, batch):
