@@ -535,14 +535,14 @@ __device__ __forceinline__ void nt_epilogue_t(const NTParams& p, f32x4 (&acc)[FM
           for (int h = 0; h < 2; ++h) {
             const int mr_ = m0 + wm * WTM + i * 16 + pr + 8 * h;
             const uint4 w = *reinterpret_cast<const uint4*>(patch + (pr + 8 * h) * 144 + pc * 16);
-            if (mr_ < p.M) *reinterpret_cast<uint4*>(p.tw_out + map_row(mr_, p.cmap) * p.ldtw + n0 + wn * WTN + pc * 8) = w;
+            if (mr_ < p.M && n0 + wn * WTN < p.N) *reinterpret_cast<uint4*>(p.tw_out + map_row(mr_, p.cmap) * p.ldtw + n0 + wn * WTN + pc * 8) = w;      // (N % 64 == 0: a wave tile's 64 columns are in or out together)
           }
         }
       }
       if (lnp) {       // the four lanes (fg = 0..3) that hold a row's columns of this wave tile
         ps1 += __shfl_xor(ps1, 16, 64); ps2 += __shfl_xor(ps2, 16, 64);
         ps1 += __shfl_xor(ps1, 32, 64); ps2 += __shfl_xor(ps2, 32, 64);
-        if (fg == 0 && rowok) {
+        if (fg == 0 && rowok && n0 + wn * WTN < p.N) {
           if constexpr (WTN >= 64) {
             static_assert(WTN == 64 || BM == 0, "one 64-column slot per wave tile");
             reinterpret_cast<float2*>(p.st_out)[crow[ii] * (p.N >> 6) + ((n0 + wn * WTN) >> 6)] = float2{ps1, ps2};
@@ -560,7 +560,7 @@ __device__ __forceinline__ void nt_epilogue_t(const NTParams& p, f32x4 (&acc)[FM
       constexpr int SPT = BN / 64;                     // slots per tile
       if (tid < BM * SPT) {
         const int ml = tid % BM, sl = tid / BM, m = m0 + ml;
-        if (m < p.M) {
+        if (m < p.M && n0 + 64 * sl < p.N) {
           const float2 a = reinterpret_cast<const float2*>(smem)[ml * WN_ + 2 * sl], b = reinterpret_cast<const float2*>(smem)[ml * WN_ + 2 * sl + 1];
           reinterpret_cast<float2*>(p.st_out)[map_row(m, p.cmap) * (p.N >> 6) + (n0 >> 6) + sl] = float2{a.x + b.x, a.y + b.y};
         }

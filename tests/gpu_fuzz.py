@@ -147,6 +147,78 @@ def fuzz_ln(rng, n):
         check(tag + ' dbeta', rel(db, bp.grad), 3e-4)
 
 
+def fuzz_ln_fused(rng, n):
+    """The LayerNorm-folding chain on random shapes: a producer GEMM (fp32 result + residual through an optional row map, any tile
+    configuration that has the statistics) writes twin + row-statistics partials; a consumer GEMM (optionally two twin sources: rows of a
+    stand-alone dav_rowstats_cast in front of the producer's) contracts them with gamma-folded weights; dav_layernorm_bwd_twin re-makes
+    the LayerNorm output.  Each against torch fp32 on the same operands."""
+    ln = torch.nn.functional.layer_norm
+    for it in range(n):
+        D = 64 * rng.choice([1, 2, 3, 8, 12, 16])
+        B = rng.randint(1, 6)
+        r1 = rng.choice([1, 7, 16, 49, 64, 130, rng.randint(1, 300)])
+        r0 = rng.choice([0, 0, 3, 16])
+        Kp = 64 * rng.choice([1, 2, 4, 12])
+        N2 = 8 * rng.choice([8, 24, 96, 288, rng.randint(1, 200)])
+        M1 = B * r1
+        cfg = rng.choice([0, 0, 3, 5, 7, 8])
+        eps = rng.choice([1e-5, 1e-6])
+        # producer: x1 = A . W^T + b + res  (+ twin + statistics)
+        A = torch.randn(M1, Kp, device=dev).to(BF16)
+        W = (torch.randn(D, Kp, device=dev) * 0.05).to(BF16)
+        bias, res = torch.randn(D, device=dev), torch.randn(M1, D, device=dev) * rng.choice([0.1, 1.0, 3.0]) + rng.choice([0.0, 0.5])
+        x1 = torch.empty(M1, D, device=dev)
+        tw1, st1 = torch.empty(M1, D, device=dev, dtype=BF16), torch.empty(M1, D // 64, 2, device=dev)
+        ops.gemm_nt_ln(A, W, M1, D, Kp, prod=dict(stats_out=st1, twin_out=tw1, ld_twin=D), bias=bias, res=res, ldres=D, C_out=x1, variant=cfg << 4)
+        ref1 = A.float() @ W.float().t() + bias + res
+        tag = f'ln_fused B{B} {r0}+{r1} D{D} Kp{Kp} N{N2} cfg{cfg}'
+        check(tag + ' producer C', rel(x1, ref1), 1e-4)
+        check(tag + ' twin', float((tw1.float() - x1.to(BF16).float()).abs().max()), 0.0)
+        v = x1.double().view(M1, D // 64, 64)
+        check(tag + ' sums', rel(st1, torch.stack([v.sum(-1), (v * v).sum(-1)], -1)), 5e-6)
+        # optional first segment from the stand-alone kernel
+        segs = []
+        x0 = None
+        if r0:
+            x0 = torch.randn(B, r0, D, device=dev) * 1.5 + 0.3
+            tw0, st0 = torch.empty(B * r0, D, device=dev, dtype=BF16), torch.empty(B * r0, D // 64, 2, device=dev)
+            ops.rowstats_cast(x0, r0 * D, B, r0, D, tw0, st0)
+            segs.append((tw0, st0, r0))
+        segs.append((tw1, st1, r1))
+        R, M = r0 + r1, B * (r0 + r1)
+        w32 = torch.randn(N2, D, device=dev) * 0.05
+        g, bt, b2 = torch.randn(D, device=dev) * 0.2 + 1, torch.randn(D, device=dev) * 0.2, torch.randn(N2, device=dev)
+        wl, c, d = torch.empty(N2, D, device=dev, dtype=BF16), torch.empty(N2, device=dev), torch.empty(N2, device=dev)
+        ops.ln_fold_grouped([(w32, g, bt, b2, wl, c, d)])
+        xc = torch.cat(([x0] if r0 else []) + [x1.view(B, r1, D)], 1)
+        ref2 = ln(xc, (D,), g, bt, eps).view(M, D) @ w32.t() + b2
+        out = torch.empty(M, N2, device=dev, dtype=BF16 if rng.random() < 0.5 else torch.float32)
+        lnd = dict(stats=segs[0][1], ln_c=c, eps=eps)
+        if r0:
+            lnd.update(A2=segs[1][0], stats2=segs[1][1], a_r0=r0, a_r1=r1)
+        ops.gemm_nt_ln(segs[0][0], wl, M, N2, D, ln=lnd, bias=d, C_out=out, c_bf16=out.dtype == BF16, variant=rng.choice([0, 0, 3, 5, 8, 44]) << 4)
+        check(tag + ' consumer', rel(out, ref2), 1.2e-2)
+        # backward from the twins (reference: autograd on the twins' values)
+        xt = torch.cat([tw.float().view(B, r, D) for (tw, st_, r) in segs], 1).clone().requires_grad_(True)
+        gp, bp = g.clone().requires_grad_(True), bt.clone().requires_grad_(True)
+        refl = ln(xt, (D,), gp, bp, eps)
+        dy = torch.randn(M, D, device=dev).to(BF16)
+        refl.backward(dy.float().view(B, R, D))
+        (t0, s0, n0) = segs[0]
+        (t1, s1, n1) = segs[1] if len(segs) == 2 else (None, None, 0)
+        dx0 = torch.zeros(B, n0, D, device=dev)
+        dx1 = torch.zeros(B, max(n1, 1), D, device=dev)[:, :n1].contiguous() if n1 else None
+        dg, db = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+        h = torch.empty(M, D, device=dev, dtype=BF16)
+        ops.layernorm_bwd_twin(t0, n0 * D, s0, n0, t1, n1 * D, s1, n1, B, D, eps, dy, None, g, bt, dx0, n0 * D, 0, None, 0, None, 0,
+                               dx1, n1 * D, 0, None, 0, None, 0, h_out=h, dgamma=dg, dbeta=db)
+        dxc = torch.cat([t for t in (dx0, dx1) if t is not None], 1)
+        check(tag + ' bwd dx', rel(dxc, xt.grad), 6e-3)           # (statistics of the fp32 rows, x their bf16 rounding)
+        check(tag + ' bwd dgamma', rel(dg, gp.grad), 6e-3)
+        check(tag + ' bwd dbeta', rel(db, bp.grad), 3e-4)
+        check(tag + ' h_out', rel(h, refl.detach().view(M, D)), 8e-3)
+
+
 def fuzz_gang(rng, n):
     """dav_gemm_tn_gang_bf16 on random problem LISTS: 1 .. 90 problems per launch, contraction lengths from one row to a few thousand
     (mostly ragged), N / K any multiple of 8 (below, across and beyond one 256 x 256 tile), written and accumulated tiles mixed, bias
@@ -199,6 +271,7 @@ if __name__ == '__main__':
     fuzz_gemm(rng, ng)
     fuzz_attn(rng, na)
     fuzz_ln(rng, nl)
+    fuzz_ln_fused(rng, nl)
     fuzz_gang(rng, ngg)
     print(f'fuzz seed {seed}: {len(FAILS)} failures')
     for f in FAILS[:20]:
