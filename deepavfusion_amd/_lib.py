@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, 'libdavfusion_hip.so')
 
 _p, _i, _l, _f, _sz = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 
-ABI_VERSION = 8      # DAV_ABI_VERSION of include/dav_kernels.h this package was written against (struct layouts, signatures)
+ABI_VERSION = 9      # DAV_ABI_VERSION of include/dav_kernels.h this package was written against (struct layouts, signatures)
 
 # name -> argtypes (must match include/dav_kernels.h)
 SIGNATURES = {
@@ -46,6 +46,8 @@ SIGNATURES = {
     'dav_attn_bwd_ctx': [_p] * 10 + [_i] * 6 + [_l, _i] * 8 + [_f, _i, _i, _p],
     'dav_attn_bias_fwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _i, _l, _i, _l, _i, _l, _i, _f, _p, _i, _i, _p],
     'dav_attn_bias_bwd': [_p] * 10 + [_i] * 6 + [_l, _i] * 8 + [_f, _p, _i, _i, _p, _i, _p],
+    'dav_attn_drop_fwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _i, _l, _i, _l, _i, _l, _i, _f, _p, _i, _f, _p],
+    'dav_attn_drop_bwd': [_p] * 10 + [_i] * 6 + [_l, _i] * 8 + [_f, _p, _i, _f, _i, _i, _p],
     'dav_window_unfold': [_p, _i, _p, _i, _i, _i, _i, _i, _i, _f, _p, _i, _p],
     'dav_window_fold': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _p],
     'dav_relpos_bias_build': [_p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p],
@@ -64,6 +66,7 @@ SIGNATURES = {
     'dav_rows_gather_cast': [_p, _l, _i, _p, _i, _i, _i, _p, _p],
     'dav_rows_axpy': [_p, _p, _p, _i, _i, _i, _p, _p],
     'dav_rows_scale_cast': [_p, _p, _i, _i, _i, _p, _p],
+    'dav_dropout_rows': [_p, _i, _p, _p, _f, _p, _i, _i, _i, _p, _i, _p],
     'dav_unshuffle_bwd_reduce': [_p, _l, _i, _p, _i, _i, _i, _i, _p, _p, _p],
     'dav_patch_mse_fwd': [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p],
     'dav_patch_mse_bwd': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p],
@@ -79,6 +82,8 @@ SIGNATURES = {
     'dav_attn_bwd_f32': [_p] * 10 + [_i] * 6 + [_l, _i] * 8 + [_f, _i, _p],
     'dav_attn_bias_fwd_f32': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _i, _l, _i, _l, _i, _l, _i, _f, _p, _i, _i, _p],
     'dav_attn_bias_bwd_f32': [_p] * 10 + [_i] * 6 + [_l, _i] * 8 + [_f, _p, _i, _i, _p, _i, _p],
+    'dav_attn_drop_fwd_f32': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _l, _i, _l, _i, _l, _i, _l, _i, _f, _p, _i, _f, _p],
+    'dav_attn_drop_bwd_f32': [_p] * 10 + [_i] * 6 + [_l, _i] * 8 + [_f, _p, _i, _f, _i, _p],
     'dav_patch_gather_f32': [_p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _p],
     'dav_rows_gather_f32': [_p, _l, _i, _p, _i, _i, _i, _p, _l, _p],
     'dav_pair_expand_f32': [_p, _p, _i, _i, _i, _i, _p, _p],

@@ -54,7 +54,16 @@ struct AttnParams {
   // only (the fusion-token context rows of a fused qkv gradient, models/deepavfusion.py:104-105): the dQ kernel zero-fills this
   // head's columns of them, which the qkv weight-gradient / input-gradient GEMMs read (dav_attn_bwd_ctx)
   int dq_ctx;
+  // attention dropout (nn.Dropout on the probabilities, models/fusion_blocks.py:14,25 / timm Attention.attn_drop; fine-tuning only):
+  // keep[b][h][q][0 .. keep_ld) bytes, non-zero = kept; kept probabilities are scaled by keep_scale = 1 / (1 - p) AFTER the row sum
+  // (softmax, then dropout).  keep_ld >= Nk rounded up to 32, a multiple of 4.  Null on the pre-training path.
+  const unsigned char* keep; int keep_ld; float keep_scale;
 };
+__device__ __forceinline__ void keep4(const unsigned char* ptr, float scale, float (&km)[4]) {
+  const uint32_t m = *reinterpret_cast<const uint32_t*>(ptr);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) km[r] = ((m >> (8 * r)) & 0xffu) ? scale : 0.f;
+}
 
 // 16-byte-slot XOR swizzle of a row-major LDS tile, chosen so that BOTH access patterns are conflict-free:
 //  * ds_read_b128 of 16 consecutive rows at one column slot (its real lane groups are {0-3,12-15,20-27}, ...),
@@ -189,7 +198,7 @@ __device__ __forceinline__ float rows_max(float x) {
   return max_raw(__uint_as_float(c[0]), __uint_as_float(c[1]));
 }
 
-template <int DQK, int DV, bool CHUNKED, int QT>
+template <int DQK, int DV, bool CHUNKED, int QT, bool DROP = false>
 __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, const int bh, const int ychunk) {
   constexpr int DQKP = DQK < 32 ? 32 : DQK, KRB = DQKP * 2, KS = DQKP / 32, VC = DV / 16, DVP = DV < 32 ? 32 : DV;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -343,6 +352,17 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, const int bh,
               if constexpr (!MFMA_SUM) ps += st[u][t][r];
             }
           lsum[u] += ps;
+          if constexpr (DROP) {          // dropout on the probabilities (kernels of their own: the pre-training path's are untouched)
+            const int q = (qt + u) * 16 + fr;
+            const unsigned char* kr = p.keep + (((long)b * p.H + h) * p.Nq + (q < p.Nq ? q : p.Nq - 1)) * p.keep_ld + k0 + 4 * g;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              float km[4];
+              keep4(kr + t * 16, p.keep_scale, km);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) st[u][t][r] *= km[r];
+            }
+          }
           pf[u] = pack8(st[u][0], st[u][1]);
           if constexpr (MFMA_SUM) lacc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[u], lacc[u], 0, 0, 0);
         }
@@ -383,7 +403,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, const int bh,
 // backward, part 1: dQ (waves own query tiles) + delta
 // ------------------------------------------------------------------------------------------------
 // QT query tiles per wave: each K / V fragment (and each transposed K fragment for dQ) read from LDS feeds QT MFMAs.
-template <int DQK, int DV, bool CHUNKED, int QT = 1>
+template <int DQK, int DV, bool CHUNKED, int QT = 1, bool DROP = false>
 __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int bh, const int ychunk) {
   if (p.dq_ctx > 0 && (CHUNKED ? ychunk == 0 : true)) {      // this head's dQ slots of the context-only rows (see AttnParams::dq_ctx)
     const int b_ = bh / p.H, h_ = bh % p.H, cpr = DQK / 8;
@@ -503,10 +523,12 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
           const long srow = (((long)b * p.H + h) * p.Nq + (q < p.Nq ? q : p.Nq - 1)) * p.bias_ld + k0 + t * 16 + 4 * g;
           if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + srow - ((long)(b - b % p.bias_nb) * p.H * p.Nq) * p.bias_ld);
           const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+          float km[4] = {1.f, 1.f, 1.f, 1.f};                // attention dropout: dP reaches the softmax backward through the same mask
+          if constexpr (DROP) keep4(p.keep + (((long)b * p.H + h) * p.Nq + (q < p.Nq ? q : p.Nq - 1)) * p.keep_ld + k0 + t * 16 + 4 * g, p.keep_scale, km);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(st[u][t][r], sl2, bb[r] - lse2[u]));
-            st[u][t][r] = pr * (dp[u][t][r] - delta[u]);     // dS^T
+            st[u][t][r] = pr * (dp[u][t][r] * km[r] - delta[u]);     // dS^T
           }
           if (p.dS && qok[u]) *reinterpret_cast<float4*>(p.dS + srow) = float4{st[u][t][0], st[u][t][1], st[u][t][2], st[u][t][3]};
         }
@@ -528,7 +550,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
       for (int c = 0; c < QC; ++c) kta[c] += 32 * KRB;
     }
     };
-    if (!p.bias && !p.dS) key_loop(std::true_type{}); else key_loop(std::false_type{});
+    if (!DROP && !p.bias && !p.dS) key_loop(std::true_type{}); else key_loop(std::false_type{});
     }
 #pragma unroll
     for (int u = 0; u < QT; ++u) {
@@ -552,7 +574,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
 // KT key tiles per wave: every Q / dO fragment read from LDS (the row-major one for S and dP, the transposed one for dV and
 // dK) then feeds KT MFMAs.  With one tile per wave the kernel is bound by the LDS pipe — 16 fragment reads per 8 MFMAs at
 // d = 32, 128 of the CU's LDS cycles per wave-step against 70 VALU and 32 MFMA cycles per SIMD.
-template <int DQK, int DV, bool CHUNKED, int KT = 1>
+template <int DQK, int DV, bool CHUNKED, int KT = 1, bool DROP = false>
 __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int bh, const int ychunk) {
   constexpr int DQKP = DQK < 32 ? 32 : DQK, QRB = DQKP * 2, KS = DQKP / 32, DVP = DV < 32 ? 32 : DV, ORB = DVP * 2, VS = DVP / 32, QC = DQK / 16, VC = DV / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -667,11 +689,20 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
               bb[r] = qg < p.Nq ? p.bias[(((long)(b % p.bias_nb) * p.H + h) * p.Nq + qg) * p.bias_ld + kc] : 0.f;
             }
           }
+          float km[4] = {1.f, 1.f, 1.f, 1.f};                // attention dropout: keep[q][this lane's key], four query rows
+          if constexpr (DROP) {
+            const int key = (kt + u) * 16 + fr, kc = key < p.Nk ? key : p.Nk - 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int qg = qa + t * 16 + 4 * g + r;
+              km[r] = (qg < p.Nq && p.keep[(((long)b * p.H + h) * p.Nq + qg) * p.keep_ld + kc]) ? p.keep_scale : 0.f;
+            }
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][t][r], sl2, bb[r] - lse4[r]));
-            s[u][t][r] = pr;                                 // P[q][key]
-            dp[u][t][r] = pr * (dp[u][t][r] - del4[r]);      // dS[q][key]
+            s[u][t][r] = pr * km[r];                                 // (dropped) P[q][key]: what dV contracts with
+            dp[u][t][r] = pr * (dp[u][t][r] * km[r] - del4[r]);      // dS[q][key]
           }
         }
       }
@@ -704,7 +735,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
       la += 128; da += 128;
     }
     };
-    if (!p.bias) query_loop(std::true_type{}); else query_loop(std::false_type{});
+    if (!DROP && !p.bias) query_loop(std::true_type{}); else query_loop(std::false_type{});
     }
 #pragma unroll
     for (int u = 0; u < KT; ++u) {
@@ -746,9 +777,9 @@ __device__ __forceinline__ int pair_heads(int x, int n) {
 // LDS pipe at one workgroup per CU.  Removed in round 5; DESIGN_HISTORY section 11.)
 
 // ---- kernels: one grid per problem, or (resident variants) several problems in one grid (batch.h) ------------------
-template <int DQK, int DV, bool CHUNKED, int QT>
+template <int DQK, int DV, bool CHUNKED, int QT, bool DROP = false>
 __global__ __launch_bounds__(512) void attn_fwd_kernel(AttnParams p) {
-  attn_fwd_body<DQK, DV, CHUNKED, QT>(p, (DQK <= 32 && p.pair) ? pair_heads(blockIdx.x, gridDim.x) : (int)blockIdx.x, blockIdx.y);
+  attn_fwd_body<DQK, DV, CHUNKED, QT, DROP>(p, (DQK <= 32 && p.pair) ? pair_heads(blockIdx.x, gridDim.x) : (int)blockIdx.x, blockIdx.y);
 }
 // own tiles per wave in the RESIDENT backward kernels.  Two tiles per wave halve the LDS fragment traffic per MFMA; measured
 // on the decoders' d = 32, 228 / 352-row problems it changes nothing (73.5 / 131 us vs 73.3 / 126 us): those kernels are bound
@@ -759,14 +790,14 @@ template <int DQK, int DV> constexpr int bwd_tiles() { return 1; }
 #define DKV32_MIN_BLOCKS 4      // HIP's second __launch_bounds__ argument = WAVES PER SIMD: 4 -> 128 registers and two 8-wave workgroups per CU
                                 // (the d = 32 dK / dV body wants 130: 2 spilled, 12 bytes of scratch per lane); 3 -> no spill, ONE workgroup per CU
 #endif
-template <int DQK, int DV, bool CHUNKED>
+template <int DQK, int DV, bool CHUNKED, bool DROP = false>
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(AttnParams p) {
-  attn_bwd_dq_body<DQK, DV, CHUNKED, CHUNKED ? 1 : bwd_tiles<DQK, DV>()>(p, (DQK <= 32 && p.pair) ? pair_heads(blockIdx.x, gridDim.x) : (int)blockIdx.x, blockIdx.y);
+  attn_bwd_dq_body<DQK, DV, CHUNKED, CHUNKED ? 1 : bwd_tiles<DQK, DV>(), DROP>(p, (DQK <= 32 && p.pair) ? pair_heads(blockIdx.x, gridDim.x) : (int)blockIdx.x, blockIdx.y);
 }
 // (narrow heads: 4 waves per SIMD = two 8-wave workgroups per CU — at 130 registers only ONE fitted, 2 waves per SIMD under a VALU-bound loop)
-template <int DQK, int DV, bool CHUNKED>
-__global__ __launch_bounds__(512, (DQK <= 32 && DV <= 32) ? DKV32_MIN_BLOCKS : 1) void attn_bwd_dkv_kernel(AttnParams p) {
-  attn_bwd_dkv_body<DQK, DV, CHUNKED, CHUNKED ? 1 : bwd_tiles<DQK, DV>()>(p, (DQK <= 32 && p.pair) ? pair_heads(blockIdx.x, gridDim.x) : (int)blockIdx.x, blockIdx.y);
+template <int DQK, int DV, bool CHUNKED, bool DROP = false>
+__global__ __launch_bounds__(512, (DQK <= 32 && DV <= 32 && !DROP) ? DKV32_MIN_BLOCKS : 1) void attn_bwd_dkv_kernel(AttnParams p) {
+  attn_bwd_dkv_body<DQK, DV, CHUNKED, CHUNKED ? 1 : bwd_tiles<DQK, DV>(), DROP>(p, (DQK <= 32 && p.pair) ? pair_heads(blockIdx.x, gridDim.x) : (int)blockIdx.x, blockIdx.y);
 }
 
 constexpr int ATTN_GROUP_MAX = 8;
@@ -906,6 +937,52 @@ int launch_fwd(const AttnParams& p, hipStream_t stream) {
   return dav_launch_status();
 }
 
+// attention dropout (AttnParams::keep): kernels of their own, one problem per launch (never grouped: fine-tuning only)
+template <int DQK, int DV>
+int launch_fwd_drop(const AttnParams& p, hipStream_t stream) {
+  const size_t lds = attn_lds<DQK, DV, 0>(p);
+  const int nw = waves_for(p.Nq);
+  if (lds <= ATTN_RESIDENT_MAX) {
+    if (int rc = raise_lds_cap<attn_fwd_kernel<DQK, DV, false, 1, true>>(lds)) return rc;
+    DAV_LAUNCH((attn_fwd_kernel<DQK, DV, false, 1, true>), dim3(p.B * p.H), dim3(nw * 64), lds, stream, p);
+  } else {
+    const size_t ldc = ATTN_CHUNK * attn_row_bytes<DQK, DV>();
+    if (int rc = raise_lds_cap<attn_fwd_kernel<DQK, DV, true, 1, true>>(ldc)) return rc;
+    DAV_LAUNCH((attn_fwd_kernel<DQK, DV, true, 1, true>), dim3(p.B * p.H, (p.Nq + nw * 16 - 1) / (nw * 16)), dim3(nw * 64), ldc, stream, p);
+  }
+  return dav_launch_status();
+}
+template <int DQK, int DV>
+int launch_bwd_drop(const AttnParams& p, hipStream_t stream, int part) {
+  const size_t row = attn_row_bytes<DQK, DV>();
+  const size_t lds1 = attn_lds<DQK, DV, 1>(p), lds2 = attn_lds<DQK, DV, 2>(p);
+  if (part & 1) {
+    if (lds1 <= ATTN_RESIDENT_MAX) {
+      const int nw = attn_waves<DQK, DV, 1>(p);
+      if (int rc = raise_lds_cap<attn_bwd_dq_kernel<DQK, DV, false, true>>(lds1)) return rc;
+      DAV_LAUNCH((attn_bwd_dq_kernel<DQK, DV, false, true>), dim3(p.B * p.H), dim3(nw * 64), lds1, stream, p);
+    } else {
+      const int nw1 = waves_for(p.Nq);
+      const size_t ldc = ATTN_CHUNK * row;
+      if (int rc = raise_lds_cap<attn_bwd_dq_kernel<DQK, DV, true, true>>(ldc)) return rc;
+      DAV_LAUNCH((attn_bwd_dq_kernel<DQK, DV, true, true>), dim3(p.B * p.H, (p.Nq + nw1 * 16 - 1) / (nw1 * 16)), dim3(nw1 * 64), ldc, stream, p);
+    }
+  }
+  if (part & 2) {
+    if (lds2 <= ATTN_RESIDENT_MAX) {
+      const int nw = attn_waves<DQK, DV, 2>(p);
+      if (int rc = raise_lds_cap<attn_bwd_dkv_kernel<DQK, DV, false, true>>(lds2)) return rc;
+      DAV_LAUNCH((attn_bwd_dkv_kernel<DQK, DV, false, true>), dim3(p.B * p.H), dim3(nw * 64), lds2, stream, p);
+    } else {
+      const int nw2 = waves_for(p.Nk);
+      const size_t ldc = ATTN_CHUNK * (row + 8);
+      if (int rc = raise_lds_cap<attn_bwd_dkv_kernel<DQK, DV, true, true>>(ldc)) return rc;
+      DAV_LAUNCH((attn_bwd_dkv_kernel<DQK, DV, true, true>), dim3(p.B * p.H, (p.Nk + nw2 * 16 - 1) / (nw2 * 16)), dim3(nw2 * 64), ldc, stream, p);
+    }
+  }
+  return dav_launch_status();
+}
+
 template <int DQK, int DV>
 int launch_bwd(const AttnParams& p, hipStream_t stream, int part = 3) {
   const size_t row = attn_row_bytes<DQK, DV>();
@@ -952,13 +1029,42 @@ static bool bias_ok(const float* bias, int bias_nb, int bias_ld, const float* dS
   return bias_nb > 0 && B % bias_nb == 0 && bias_ld >= Nkp && !(bias_ld & 3) && !(((uintptr_t)bias | (uintptr_t)dS) & 15);
 }
 
+static bool keep_ok(const void* keep, int keep_ld, float keep_scale, int Nk) {
+  if (!keep) return true;
+  return keep_ld >= ((Nk + 31) & ~31) && !(keep_ld & 3) && !((uintptr_t)keep & 3) && keep_scale > 0.f;
+}
+
+static int attn_fwd_any(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int Nq,
+                        int Nk, int dqk, int dv, long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs,
+                        long o_bs, int o_rs, float scale, const float* bias, int bias_nb, int bias_ld,
+                        const void* keep, int keep_ld, float keep_scale, hipStream_t stream);
+
 extern "C" int dav_attn_bias_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int Nq,
                                  int Nk, int dqk, int dv, long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs,
                                  long o_bs, int o_rs, float scale, const float* bias, int bias_nb, int bias_ld,
                                  hipStream_t stream) {
+  return attn_fwd_any(Q, K, V, O, LSE, B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, scale, bias, bias_nb, bias_ld,
+                      nullptr, 0, 0.f, stream);
+}
+
+extern "C" int dav_attn_drop_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int Nq,
+                                 int Nk, int dqk, int dv, long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs,
+                                 long o_bs, int o_rs, float scale, const void* keep, int keep_ld, float keep_scale,
+                                 hipStream_t stream) {
+  if (!keep) return DAV_ERR_SHAPE;
+  return attn_fwd_any(Q, K, V, O, LSE, B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, scale, nullptr, 0, 0,
+                      keep, keep_ld, keep_scale, stream);
+}
+
+static int attn_fwd_any(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int Nq,
+                        int Nk, int dqk, int dv, long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs,
+                        long o_bs, int o_rs, float scale, const float* bias, int bias_nb, int bias_ld,
+                        const void* keep, int keep_ld, float keep_scale, hipStream_t stream) {
   if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return DAV_ERR_SHAPE;
   if (!bias_ok(bias, bias_nb, bias_ld, nullptr, B, Nk)) return DAV_ERR_SHAPE;
+  if (!keep_ok(keep, keep_ld, keep_scale, Nk)) return ((uintptr_t)keep & 3) ? DAV_ERR_ALIGN : DAV_ERR_SHAPE;
   AttnParams p = {};
+  p.keep = (const unsigned char*)keep; p.keep_ld = keep_ld; p.keep_scale = keep_scale;
   p.debug = attn_debug();
   p.pair = 1;
   p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (bf16_t*)O; p.LSE = LSE;
@@ -966,6 +1072,13 @@ extern "C" int dav_attn_bias_fwd(const void* Q, const void* K, const void* V, vo
   p.q_rs = q_rs; p.k_rs = k_rs; p.v_rs = v_rs; p.o_rs = o_rs; p.scale = scale;
   p.bias = bias; p.bias_nb = bias_nb; p.bias_ld = bias_ld;
   if (!strides_ok(p, false)) return DAV_ERR_ALIGN;
+  if (p.keep) {
+    if (p.bias) return DAV_ERR_SHAPE;
+    if (dqk == 64 && dv == 64) return launch_fwd_drop<64, 64>(p, stream);
+    if (dqk == 32 && dv == 32) return launch_fwd_drop<32, 32>(p, stream);
+    if (dqk == 16 && dv == 64) return launch_fwd_drop<16, 64>(p, stream);
+    return DAV_ERR_SHAPE;
+  }
   if (dqk == 64 && dv == 64) return launch_fwd<64, 64>(p, stream);
   if (dqk == 32 && dv == 32) return launch_fwd<32, 32>(p, stream);
   if (dqk == 16 && dv == 64) return launch_fwd<16, 64>(p, stream);
@@ -994,10 +1107,12 @@ static int attn_bwd_any(const void* Q, const void* K, const void* V, const void*
                         long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs,
                         long do_bs, int do_rs, long dq_bs, int dq_rs, long dk_bs, int dk_rs, long dv_bs, int dv_rs,
                         float scale, const float* bias, int bias_nb, int bias_ld, float* dS, int dq_ctx_rows, int part,
-                        hipStream_t stream) {
+                        hipStream_t stream, const void* keep = nullptr, int keep_ld = 0, float keep_scale = 0.f) {
   if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0 || part < 1 || part > 3 || dq_ctx_rows < 0) return DAV_ERR_SHAPE;
   if (!bias_ok(bias, bias_nb, bias_ld, dS, B, Nk)) return DAV_ERR_SHAPE;
+  if (!keep_ok(keep, keep_ld, keep_scale, Nk)) return ((uintptr_t)keep & 3) ? DAV_ERR_ALIGN : DAV_ERR_SHAPE;
   AttnParams p = {};
+  p.keep = (const unsigned char*)keep; p.keep_ld = keep_ld; p.keep_scale = keep_scale;
   p.dq_ctx = dq_ctx_rows;
   p.debug = attn_debug();
   p.pair = 1;
@@ -1010,6 +1125,13 @@ static int attn_bwd_any(const void* Q, const void* K, const void* V, const void*
   p.bias = bias; p.bias_nb = bias_nb; p.bias_ld = bias_ld; p.dS = dS;
   p.O = (bf16_t*)O;   // only for the alignment check
   if (!strides_ok(p, true)) return DAV_ERR_ALIGN;
+  if (p.keep) {
+    if (p.bias || p.dS) return DAV_ERR_SHAPE;
+    if (dqk == 64 && dv == 64) return launch_bwd_drop<64, 64>(p, stream, part);
+    if (dqk == 32 && dv == 32) return launch_bwd_drop<32, 32>(p, stream, part);
+    if (dqk == 16 && dv == 64) return launch_bwd_drop<16, 64>(p, stream, part);
+    return DAV_ERR_SHAPE;
+  }
   if (dqk == 64 && dv == 64) return launch_bwd<64, 64>(p, stream, part);
   if (dqk == 32 && dv == 32) return launch_bwd<32, 32>(p, stream, part);
   if (dqk == 16 && dv == 64) return launch_bwd<16, 64>(p, stream, part);
@@ -1034,6 +1156,18 @@ extern "C" int dav_attn_bwd_ctx(const void* Q, const void* K, const void* V, con
                                 float scale, int dq_ctx_rows, int part, hipStream_t stream) {
   return attn_bwd_any(Q, K, V, O, dO, LSE, Delta, dQ, dK, dV, B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs,
                       do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, scale, nullptr, 0, 0, nullptr, dq_ctx_rows, part, stream);
+}
+
+extern "C" int dav_attn_drop_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
+                                 float* Delta, void* dQ, void* dK, void* dV, int B, int H, int Nq, int Nk, int dqk, int dv,
+                                 long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs,
+                                 long do_bs, int do_rs, long dq_bs, int dq_rs, long dk_bs, int dk_rs, long dv_bs, int dv_rs,
+                                 float scale, const void* keep, int keep_ld, float keep_scale, int dq_ctx_rows, int part,
+                                 hipStream_t stream) {
+  if (!keep) return DAV_ERR_SHAPE;
+  return attn_bwd_any(Q, K, V, O, dO, LSE, Delta, dQ, dK, dV, B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs,
+                      do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, scale, nullptr, 0, 0, nullptr, dq_ctx_rows, part, stream,
+                      keep, keep_ld, keep_scale);
 }
 
 extern "C" int dav_attn_bwd_part(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,

@@ -110,7 +110,11 @@ struct AttnF {
   int dq_rs, dk_rs, dv_rs;
   const float* bias; int bias_nb, bias_ld;    // additive logit bias [b % bias_nb][h][q][bias_ld] in NATURAL units; dS as in attention.hip
   float* dS;
+  const unsigned char* keep; int keep_ld; float keep_scale;   // attention dropout: bytes 0/1 [b][h][q][keep_ld], kept probabilities * keep_scale
 };
+__device__ __forceinline__ float attnf_keep(const AttnF& p, int b, int h, int q, int j) {
+  return !p.keep ? 1.f : (p.keep[(((long)b * p.H + h) * p.Nq + q) * p.keep_ld + j] ? p.keep_scale : 0.f);
+}
 __device__ __forceinline__ float attnf_bias(const AttnF& p, int b, int h, int q, int j) {
   return p.bias ? p.bias[(((long)(b % p.bias_nb) * p.H + h) * p.Nq + q) * p.bias_ld + j] : 0.f;
 }
@@ -138,7 +142,8 @@ __global__ __launch_bounds__(128) void attn_fwd_f32_kernel(AttnF p) {
     for (int d = 0; d < p.dqk; ++d) s = fmaf(qr[d], kr[d], s);
     const float e = expf(s * p.scale + attnf_bias(p, b, h, q, j) - mx);
     l += e;
-    for (int d = 0; d < p.dv; ++d) o[d] = fmaf(e, vr[d], o[d]);
+    const float ek = e * attnf_keep(p, b, h, q, j);     // the normaliser sums ALL probabilities; the dropped ones leave only the output
+    for (int d = 0; d < p.dv; ++d) o[d] = fmaf(ek, vr[d], o[d]);
   }
   const float inv = 1.f / l;
   for (int d = 0; d < p.dv; ++d) o[d] *= inv;
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(128) void attn_bwd_dq_f32_kernel(AttnF p) {
     float s = 0.f, dp = 0.f;
     for (int d = 0; d < p.dqk; ++d) s = fmaf(qr[d], kr[d], s);
     for (int d = 0; d < p.dv; ++d) dp = fmaf(dor[d], vr[d], dp);
-    const float dsn = expf(s * p.scale + attnf_bias(p, b, h, q, j) - lse) * (dp - delta);     // d(biased logit)
+    const float dsn = expf(s * p.scale + attnf_bias(p, b, h, q, j) - lse) * (dp * attnf_keep(p, b, h, q, j) - delta);     // d(biased logit)
     if (p.dS) p.dS[(((long)b * p.H + h) * p.Nq + q) * p.bias_ld + j] = dsn;
     const float ds = dsn * p.scale;
     for (int d = 0; d < p.dqk; ++d) dq[d] = fmaf(ds, kr[d], dq[d]);
@@ -191,8 +196,9 @@ __global__ __launch_bounds__(128) void attn_bwd_dkv_f32_kernel(AttnF p) {
     for (int d = 0; d < p.dqk; ++d) s = fmaf(qr[d], kr[d], s);
     for (int d = 0; d < p.dv; ++d) dp = fmaf(dor[d], vr[d], dp);
     const float pr = expf(s * p.scale + attnf_bias(p, b, h, q, j) - p.LSE[si]);
-    const float ds = pr * (dp - p.Delta[si]) * p.scale;
-    for (int d = 0; d < p.dv; ++d) dvv[d] = fmaf(pr, dor[d], dvv[d]);
+    const float km = attnf_keep(p, b, h, q, j);
+    const float ds = pr * (dp * km - p.Delta[si]) * p.scale;
+    for (int d = 0; d < p.dv; ++d) dvv[d] = fmaf(pr * km, dor[d], dvv[d]);
     for (int d = 0; d < p.dqk; ++d) dk[d] = fmaf(ds, qr[d], dk[d]);
   }
 }
@@ -293,18 +299,36 @@ extern "C" int dav_gemm_tn_f32(const float* A, const float* B, int Mc, int N, in
   return dav_launch_status();
 }
 
-extern "C" int dav_attn_bias_fwd_f32(const float* Q, const float* K, const float* V, float* O, float* LSE, int B, int H, int Nq, int Nk,
-                                     int dqk, int dv, long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs,
-                                     int o_rs, float scale, const float* bias, int bias_nb, int bias_ld, hipStream_t stream) {
+static int attnf_fwd(const float* Q, const float* K, const float* V, float* O, float* LSE, int B, int H, int Nq, int Nk,
+                     int dqk, int dv, long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs,
+                     int o_rs, float scale, const float* bias, int bias_nb, int bias_ld, const void* keep, int keep_ld,
+                     float keep_scale, hipStream_t stream) {
   if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0 || dqk <= 0 || dv <= 0) return DAV_ERR_SHAPE;
   if (bias && (bias_nb <= 0 || B % bias_nb || bias_ld < Nk)) return DAV_ERR_SHAPE;
+  if (keep && (keep_ld < Nk || !(keep_scale > 0.f))) return DAV_ERR_SHAPE;
   AttnF p = {};
+  p.keep = (const unsigned char*)keep; p.keep_ld = keep_ld; p.keep_scale = keep_scale;
   p.Q = Q; p.K = K; p.V = V; p.O = O; p.LSE = LSE; p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.dqk = dqk; p.dv = dv;
   p.q_bs = q_bs; p.k_bs = k_bs; p.v_bs = v_bs; p.o_bs = o_bs; p.q_rs = q_rs; p.k_rs = k_rs; p.v_rs = v_rs; p.o_rs = o_rs; p.scale = scale;
   p.bias = bias; p.bias_nb = bias_nb; p.bias_ld = bias_ld;
   const long total = (long)B * H * Nq;
   DAV_LAUNCH(attn_fwd_f32_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, stream, p);
   return dav_launch_status();
+}
+
+extern "C" int dav_attn_bias_fwd_f32(const float* Q, const float* K, const float* V, float* O, float* LSE, int B, int H, int Nq, int Nk,
+                                     int dqk, int dv, long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs,
+                                     int o_rs, float scale, const float* bias, int bias_nb, int bias_ld, hipStream_t stream) {
+  return attnf_fwd(Q, K, V, O, LSE, B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, scale, bias, bias_nb, bias_ld,
+                   nullptr, 0, 0.f, stream);
+}
+
+extern "C" int dav_attn_drop_fwd_f32(const float* Q, const float* K, const float* V, float* O, float* LSE, int B, int H, int Nq, int Nk,
+                                     int dqk, int dv, long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs,
+                                     int o_rs, float scale, const void* keep, int keep_ld, float keep_scale, hipStream_t stream) {
+  if (!keep) return DAV_ERR_SHAPE;
+  return attnf_fwd(Q, K, V, O, LSE, B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, scale, nullptr, 0, 0,
+                   keep, keep_ld, keep_scale, stream);
 }
 
 extern "C" int dav_attn_fwd_f32(const float* Q, const float* K, const float* V, float* O, float* LSE, int B, int H, int Nq, int Nk,
@@ -314,14 +338,17 @@ extern "C" int dav_attn_fwd_f32(const float* Q, const float* K, const float* V, 
                                nullptr, 0, 0, stream);
 }
 
-extern "C" int dav_attn_bias_bwd_f32(const float* Q, const float* K, const float* V, const float* O, const float* dO, const float* LSE,
-                                     float* Delta, float* dQ, float* dK, float* dV, int B, int H, int Nq, int Nk, int dqk, int dv,
-                                     long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, long do_bs,
-                                     int do_rs, long dq_bs, int dq_rs, long dk_bs, int dk_rs, long dv_bs, int dv_rs, float scale,
-                                     const float* bias, int bias_nb, int bias_ld, float* dS, int part, hipStream_t stream) {
+static int attnf_bwd(const float* Q, const float* K, const float* V, const float* O, const float* dO, const float* LSE,
+                     float* Delta, float* dQ, float* dK, float* dV, int B, int H, int Nq, int Nk, int dqk, int dv,
+                     long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, long do_bs,
+                     int do_rs, long dq_bs, int dq_rs, long dk_bs, int dk_rs, long dv_bs, int dv_rs, float scale,
+                     const float* bias, int bias_nb, int bias_ld, float* dS, const void* keep, int keep_ld, float keep_scale,
+                     int part, hipStream_t stream) {
   if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0 || part < 1 || part > 3) return DAV_ERR_SHAPE;
   if (bias ? (bias_nb <= 0 || B % bias_nb || bias_ld < Nk) : dS != nullptr) return DAV_ERR_SHAPE;
+  if (keep && (keep_ld < Nk || !(keep_scale > 0.f))) return DAV_ERR_SHAPE;
   AttnF p = {};
+  p.keep = (const unsigned char*)keep; p.keep_ld = keep_ld; p.keep_scale = keep_scale;
   p.Q = Q; p.K = K; p.V = V; p.O = const_cast<float*>(O); p.LSE = const_cast<float*>(LSE); p.dO = dO; p.Delta = Delta;
   p.dQ = dQ; p.dK = dK; p.dV = dV; p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.dqk = dqk; p.dv = dv;
   p.q_bs = q_bs; p.k_bs = k_bs; p.v_bs = v_bs; p.o_bs = o_bs; p.q_rs = q_rs; p.k_rs = k_rs; p.v_rs = v_rs; p.o_rs = o_rs;
@@ -337,6 +364,25 @@ extern "C" int dav_attn_bias_bwd_f32(const float* Q, const float* K, const float
     DAV_LAUNCH(attn_bwd_dkv_f32_kernel, dim3((unsigned)((total + 127) / 128)), dim3(128), 0, stream, p);
   }
   return dav_launch_status();
+}
+
+extern "C" int dav_attn_bias_bwd_f32(const float* Q, const float* K, const float* V, const float* O, const float* dO, const float* LSE,
+                                     float* Delta, float* dQ, float* dK, float* dV, int B, int H, int Nq, int Nk, int dqk, int dv,
+                                     long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, long do_bs,
+                                     int do_rs, long dq_bs, int dq_rs, long dk_bs, int dk_rs, long dv_bs, int dv_rs, float scale,
+                                     const float* bias, int bias_nb, int bias_ld, float* dS, int part, hipStream_t stream) {
+  return attnf_bwd(Q, K, V, O, dO, LSE, Delta, dQ, dK, dV, B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs,
+                   do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, scale, bias, bias_nb, bias_ld, dS, nullptr, 0, 0.f, part, stream);
+}
+
+extern "C" int dav_attn_drop_bwd_f32(const float* Q, const float* K, const float* V, const float* O, const float* dO, const float* LSE,
+                                     float* Delta, float* dQ, float* dK, float* dV, int B, int H, int Nq, int Nk, int dqk, int dv,
+                                     long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, long do_bs,
+                                     int do_rs, long dq_bs, int dq_rs, long dk_bs, int dk_rs, long dv_bs, int dv_rs, float scale,
+                                     const void* keep, int keep_ld, float keep_scale, int part, hipStream_t stream) {
+  if (!keep) return DAV_ERR_SHAPE;
+  return attnf_bwd(Q, K, V, O, dO, LSE, Delta, dQ, dK, dV, B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs,
+                   do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, scale, nullptr, 0, 0, nullptr, keep, keep_ld, keep_scale, part, stream);
 }
 
 extern "C" int dav_attn_bwd_f32(const float* Q, const float* K, const float* V, const float* O, const float* dO, const float* LSE,

@@ -155,6 +155,47 @@ __global__ __launch_bounds__(256) void rows_scale_cast_kernel(const float* g, co
   }
 }
 
+// Dropout on activations (nn.Dropout of timm Mlp.drop1 / drop2 and of the attention modules' proj_drop: models/fusion_blocks.py:16,29,
+// 44,58,101,116,166,185,233,260; fine-tuning constructors only — every pre-training config has drop = 0), with DropPath folded in:
+//   out[b, r, :] = (res ? res[b, r, :] : 0) + (rowscale ? rowscale[b] : 1) * (keep[b, r, :] ? keep_scale : 0) * in[b, r, :]
+// keep: bytes 0 / 1, [B * rows, D] (null = all kept); in / out bf16 or fp32; out may alias in or res.  The backward of the same
+// step is the same kernel on the gradient (res = null).
+template <bool IN_F32, bool OUT_F32>
+__global__ __launch_bounds__(256) void dropout_rows_kernel(const void* in, const float* res, const unsigned char* keep, float keep_scale,
+                                                           const float* rowscale, int B, int rows, int D, void* out) {
+  const int lane = threadIdx.x & 63;
+  const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int nch = D >> 2;
+  for (int row = gw; row < B * rows; row += nwaves) {
+    const float sb = rowscale ? rowscale[row / rows] : 1.f;
+    const long base = (long)row * D;
+    for (int c = lane; c < nch; c += 64) {
+      float4 a;
+      if (IN_F32) {
+        a = reinterpret_cast<const float4*>((const float*)in + base)[c];
+      } else {
+        const uint2 w = reinterpret_cast<const uint2*>((const bf16_t*)in + base)[c];
+        a = float4{__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16), __uint_as_float(w.y & 0xffff0000u)};
+      }
+      float4 k = float4{sb, sb, sb, sb};
+      if (keep) {
+        const uchar4 m = reinterpret_cast<const uchar4*>(keep + base)[c];
+        const float ks = sb * keep_scale;
+        k = float4{m.x ? ks : 0.f, m.y ? ks : 0.f, m.z ? ks : 0.f, m.w ? ks : 0.f};
+      }
+      float4 r = float4{0.f, 0.f, 0.f, 0.f};
+      if (res) r = reinterpret_cast<const float4*>(res + base)[c];
+      const float4 o = float4{r.x + k.x * a.x, r.y + k.y * a.y, r.z + k.z * a.z, r.w + k.w * a.w};
+      if (OUT_F32) {
+        reinterpret_cast<float4*>((float*)out + base)[c] = o;
+      } else {
+        uint2 w; w.x = pack2bf(o.x, o.y); w.y = pack2bf(o.z, o.w);
+        reinterpret_cast<uint2*>((bf16_t*)out + base)[c] = w;
+      }
+    }
+  }
+}
+
 // batch reductions of the un-shuffle backward: dpos[r] += sum_b dx[b, off+r];  dmask_token += sum over masked rows
 __global__ __launch_bounds__(256) void unshuffle_bwd_reduce_kernel(const float* dx, long dx_bs, int row_off, const int* restore,
                                                                    int B, int L, int nk, int D, float* dpos, float* dmask_token) {
@@ -556,6 +597,21 @@ extern "C" int dav_rows_scale_cast(const float* g, const float* scale, int B, in
   if (B <= 0 || rows <= 0 || D <= 0 || (D & 3)) return DAV_ERR_SHAPE;
   DAV_LAUNCH(rows_scale_cast_kernel, dim3(wave_grid((long)B * rows)), dim3(256), 0, stream, g, scale, B, rows, D,
                      (bf16_t*)out_bf16);
+  return dav_launch_status();
+}
+
+extern "C" int dav_dropout_rows(const void* in, int in_f32, const float* res, const void* keep, float keep_scale, const float* rowscale,
+                                int B, int rows, int D, void* out, int out_f32, hipStream_t stream) {
+  if (B <= 0 || rows <= 0 || D <= 0 || (D & 3)) return DAV_ERR_SHAPE;
+  if (!in || !out) return DAV_ERR_SHAPE;
+  if (keep && !(keep_scale > 0.f)) return DAV_ERR_SHAPE;
+  if (((uintptr_t)in | (uintptr_t)out | (uintptr_t)res) & 7 || ((uintptr_t)keep & 3)) return DAV_ERR_ALIGN;
+  const dim3 grid(wave_grid((long)B * rows)), block(256);
+  const unsigned char* kp = (const unsigned char*)keep;
+  if (in_f32 && out_f32) { DAV_LAUNCH((dropout_rows_kernel<true, true>), grid, block, 0, stream, in, res, kp, keep_scale, rowscale, B, rows, D, out); }
+  else if (in_f32) { DAV_LAUNCH((dropout_rows_kernel<true, false>), grid, block, 0, stream, in, res, kp, keep_scale, rowscale, B, rows, D, out); }
+  else if (out_f32) { DAV_LAUNCH((dropout_rows_kernel<false, true>), grid, block, 0, stream, in, res, kp, keep_scale, rowscale, B, rows, D, out); }
+  else { DAV_LAUNCH((dropout_rows_kernel<false, false>), grid, block, 0, stream, in, res, kp, keep_scale, rowscale, B, rows, D, out); }
   return dav_launch_status();
 }
 

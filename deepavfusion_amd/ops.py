@@ -547,6 +547,41 @@ def rows_scale_cast(g, scale, B, rows, D, out_bf16):
     _lib.check(lib.dav_rows_scale_cast(_ptr(g), _ptr(scale), B, rows, D, _ptr(out_bf16), _stream()), 'dav_rows_scale_cast')
 
 
+def attn_drop_fwd(q_ptr, k_ptr, v_ptr, O, LSE, B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, scale,
+                  keep, keep_ld, keep_scale):
+    """Attention with dropout on the softmax probabilities (dav_attn_drop_fwd / _f32): keep = bytes 0 / 1 [B, H, Nq, keep_ld]."""
+    lib = _lib.load()
+    fn, name = (lib.dav_attn_drop_fwd_f32, 'dav_attn_drop_fwd_f32') if O.dtype == F32 else (lib.dav_attn_drop_fwd, 'dav_attn_drop_fwd')
+    _lib.check(fn(q_ptr, k_ptr, v_ptr, _ptr(O), _ptr(LSE), B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs,
+                  float(scale), _ptr(keep), keep_ld, float(keep_scale), _stream()), name)
+
+
+def attn_drop_bwd(q_ptr, k_ptr, v_ptr, O, dO, LSE, Delta, dq_ptr, dk_ptr, dv_ptr, B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs,
+                  v_bs, v_rs, o_bs, o_rs, do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, scale, keep, keep_ld, keep_scale,
+                  part=3, dq_ctx_rows=0):
+    lib = _lib.load()
+    if O.dtype == F32:
+        if dq_ctx_rows:
+            raise ValueError('the fp32 attention kernels have no context-row entry')
+        _lib.check(lib.dav_attn_drop_bwd_f32(q_ptr, k_ptr, v_ptr, _ptr(O), _ptr(dO), _ptr(LSE), _ptr(Delta), dq_ptr, dk_ptr, dv_ptr,
+                                             B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, do_bs, do_rs,
+                                             dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, float(scale), _ptr(keep), keep_ld,
+                                             float(keep_scale), part, _stream()), 'dav_attn_drop_bwd_f32')
+        return
+    _lib.check(lib.dav_attn_drop_bwd(q_ptr, k_ptr, v_ptr, _ptr(O), _ptr(dO), _ptr(LSE), _ptr(Delta), dq_ptr, dk_ptr, dv_ptr,
+                                     B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, do_bs, do_rs,
+                                     dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, float(scale), _ptr(keep), keep_ld, float(keep_scale),
+                                     dq_ctx_rows, part, _stream()), 'dav_attn_drop_bwd')
+
+
+def dropout_rows(x, keep, keep_scale, B, rows, D, out, res=None, rowscale=None):
+    """out[b, r] = (res[b, r] if res else 0) + (rowscale[b] if rowscale else 1) * keep[b, r] * keep_scale * x[b, r]
+    (dav_dropout_rows; x / out bf16 or fp32, keep bytes [B * rows, D] or None; out may alias x or res)."""
+    lib = _lib.load()
+    _lib.check(lib.dav_dropout_rows(_ptr(x), int(x.dtype == F32), _ptr(res), _ptr(keep), float(keep_scale), _ptr(rowscale), B, rows, D,
+                                    _ptr(out), int(out.dtype == F32), _stream()), 'dav_dropout_rows')
+
+
 def cast_transpose_grouped(pairs):
     """pairs: [(x fp32 [R, C], y bf16 [C, R]), ...] -> every y = bf16(x^T) in one launch (dav_cast_transpose_grouped)."""
     if not pairs:

@@ -37,7 +37,7 @@ typedef struct ihipStream_t* hipStream_t;
 extern "C" {
 #endif
 
-#define DAV_ABI_VERSION 8   /* 8: LayerNorm folded into the GEMMs either side of it (dav_gemm_nt_ln_bf16, dav_ln_fold_grouped, dav_rowstats_cast, dav_layernorm_bwd_twin); 2: DavTnProblem.flags, dav_adamw_flat keep_grad + gscale_dev, dav_step_guard; 3: dav_attn_bwd_ctx, dav_add_cast; 4: fused fusion tails, grouped cast-transpose; 5: dav_gemm_tn_grouped_adamw_bf16; 6: dav_gemm_tn_gang_bf16; 7: the fused fusion tails and dav_gemm_tn_grouped_adamw_bf16 are gone (measured slower, DESIGN_HISTORY section 11) */
+#define DAV_ABI_VERSION 9   /* 9: dropout (dav_attn_drop_fwd / _bwd (+ _f32), dav_dropout_rows); 8: LayerNorm folded into the GEMMs either side of it (dav_gemm_nt_ln_bf16, dav_ln_fold_grouped, dav_rowstats_cast, dav_layernorm_bwd_twin); 2: DavTnProblem.flags, dav_adamw_flat keep_grad + gscale_dev, dav_step_guard; 3: dav_attn_bwd_ctx, dav_add_cast; 4: fused fusion tails, grouped cast-transpose; 5: dav_gemm_tn_grouped_adamw_bf16; 6: dav_gemm_tn_gang_bf16; 7: the fused fusion tails and dav_gemm_tn_grouped_adamw_bf16 are gone (measured slower, DESIGN_HISTORY section 11) */
 int dav_abi_version(void);
 int dav_build_flags(void);   /* bit 0: experimental build (make EXPERIMENTAL=1): the rejected GEMM tile configurations exist */
 /* text of the last HIP error latched by a kernel launch of the calling thread (diagnostics) */
@@ -178,6 +178,22 @@ int dav_attn_bias_bwd(const void* Q, const void* K, const void* V, const void* O
                       int dk_rs, long dv_bs, int dv_rs, float scale, const float* bias, int bias_nb, int bias_ld, float* dS,
                       int part, hipStream_t stream);
 
+/* Attention dropout (nn.Dropout on the softmax probabilities: timm Attention.attn_drop of the tower blocks, models/vits.py:33, and
+ * models/fusion_blocks.py:14,25,42,54,99,112,164,181,231,256 — the fine-tuning constructors' attn_drop > 0; every pre-training
+ * config has 0): O = (P .* keep * keep_scale) V with P the full softmax (LSE unchanged).  keep: bytes 0 / 1,
+ * [B][H][Nq][keep_ld], keep_ld >= Nk rounded up to 32 and a multiple of 4, 4-byte aligned; keep_scale = 1 / (1 - p).  The draw
+ * itself is the caller's (torch's generator): the kernels are deterministic in the mask.  Kernels of their own (head widths
+ * 64/64, 32/32, 16/64): the pre-training kernels carry no dropout code.  Backward: dP = keep * keep_scale * (dO V^T),
+ * Delta = dO . O as without dropout; dq_ctx_rows as dav_attn_bwd_ctx, part as dav_attn_bwd_part. */
+int dav_attn_drop_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int Nq, int Nk, int dqk,
+                      int dv, long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, float scale,
+                      const void* keep, int keep_ld, float keep_scale, hipStream_t stream);
+int dav_attn_drop_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, float* Delta,
+                      void* dQ, void* dK, void* dV, int B, int H, int Nq, int Nk, int dqk, int dv, long q_bs, int q_rs, long k_bs,
+                      int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, long do_bs, int do_rs, long dq_bs, int dq_rs, long dk_bs,
+                      int dk_rs, long dv_bs, int dv_rs, float scale, const void* keep, int keep_ld, float keep_scale,
+                      int dq_ctx_rows, int part, hipStream_t stream);
+
 /* ---- Swin decoder data movers (csrc/swin.hip) --------------------------------------------- */
 /* A decoder activation is [B][nF fusion rows | L = nW * A token rows][C]; a window sequence is [A window tokens | nF fusion
  * tokens], B * nW of them.  rows[w * A + i] = token (0-based, within the L token rows) at slot i of window w after the cyclic
@@ -271,6 +287,12 @@ int dav_rows_gather_cast(const float* x, long x_bs, int row_off, const int* ids3
  * the branch side out_bf16[b,r,:] = bf16(s[b]*g[b,r,:]) (the residual side passes g through unchanged). */
 int dav_rows_axpy(const float* res, const float* y, const float* scale, int B, int rows, int D, float* out, hipStream_t stream);
 int dav_rows_scale_cast(const float* g, const float* scale, int B, int rows, int D, void* out_bf16, hipStream_t stream);
+/* Dropout on activations (timm Mlp.drop1 / drop2, the attention modules' proj_drop; fine-tuning constructors' drop > 0), DropPath
+ * folded in: out[b,r,:] = (res ? res[b,r,:] : 0) + (rowscale ? rowscale[b] : 1) * (keep[b,r,:] ? keep_scale : 0) * in[b,r,:].
+ * keep: bytes 0 / 1 [B*rows][D] (null = all kept), in / out bf16 (in_f32 / out_f32 = 0) or fp32 (1), D % 4 == 0; out may alias
+ * in or res.  The backward is the same call on the gradient (res = null). */
+int dav_dropout_rows(const void* in, int in_f32, const float* res, const void* keep, float keep_scale, const float* rowscale,
+                     int B, int rows, int D, void* out, int out_f32, hipStream_t stream);
 /* dpos[r] += sum_b dx[b, off+r]; dmask_token += sum over masked (b, r) */
 int dav_unshuffle_bwd_reduce(const float* dx, long dx_bs, int row_off, const int* ids_restore32, int B, int L, int nk, int D,
                              float* dpos, float* dmask_token, hipStream_t stream);
@@ -365,6 +387,14 @@ int dav_attn_bias_bwd_f32(const float* Q, const float* K, const float* V, const 
                           int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, long do_bs, int do_rs,
                           long dq_bs, int dq_rs, long dk_bs, int dk_rs, long dv_bs, int dv_rs, float scale, const float* bias,
                           int bias_nb, int bias_ld, float* dS, int part, hipStream_t stream);
+int dav_attn_drop_fwd_f32(const float* Q, const float* K, const float* V, float* O, float* LSE, int B, int H, int Nq, int Nk,
+                          int dqk, int dv, long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs,
+                          float scale, const void* keep, int keep_ld, float keep_scale, hipStream_t stream);   /* keep_ld >= Nk */
+int dav_attn_drop_bwd_f32(const float* Q, const float* K, const float* V, const float* O, const float* dO, const float* LSE,
+                          float* Delta, float* dQ, float* dK, float* dV, int B, int H, int Nq, int Nk, int dqk, int dv, long q_bs,
+                          int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, long do_bs, int do_rs,
+                          long dq_bs, int dq_rs, long dk_bs, int dk_rs, long dv_bs, int dv_rs, float scale, const void* keep,
+                          int keep_ld, float keep_scale, int part, hipStream_t stream);
 int dav_patch_gather_f32(const float* img, int B, int C, int T, int H, int W, int pt, const int* ids_keep32, int nk, float* A,
                          hipStream_t stream);
 int dav_rows_gather_f32(const float* x, long x_bs, int row_off, const int* ids32, int B, int n, int D, float* out, long out_bs,

@@ -409,6 +409,99 @@ def attention():
 
 
 @check
+def dropout():
+    """Attention dropout (dav_attn_drop_fwd / _bwd, bf16 and fp32 kernels) and dropout on activations (dav_dropout_rows) against
+    torch with the SAME keep masks: the kernels are deterministic in the mask, the draw is the caller's."""
+    for (B, H, Nq, Nk, dqk, dv, off, pdrop) in [(2, 3, 49, 81, 64, 64, 32, 0.1), (3, 2, 8, 49, 64, 64, 0, 0.5), (2, 16, 228, 228, 32, 32, 0, 0.1),
+                                               (2, 12, 16, 64, 16, 64, 0, 0.2), (3, 2, 4, 6, 16, 64, 0, 0.3), (1, 1, 1, 1, 32, 32, 0, 0.5),
+                                               (2, 12, 63, 95, 64, 64, 32, 0.1), (2, 2, 204, 204, 64, 64, 0, 0.1),
+                                               # chunked variants (keys / queries stream through LDS)
+                                               (2, 3, 784, 816, 64, 64, 32, 0.1), (1, 2, 100, 1000, 64, 64, 0, 0.2), (1, 2, 1000, 40, 64, 64, 0, 0.1),
+                                               (2, 2, 1300, 1300, 32, 32, 0, 0.1), (1, 3, 17, 530, 16, 64, 0, 0.25)]:
+        scale = 0.125 if dqk == 16 else dqk ** -0.5
+        keep_p = 1.0 - pdrop
+        ld = (Nk + 31) // 32 * 32
+        g = torch.Generator(device='cpu'); g.manual_seed(1000 + Nq * 7 + Nk)
+        keep = (torch.rand(B, H, Nq, ld, generator=g) < keep_p).to(torch.uint8).to(dev)
+        km = keep[..., :Nk].float() / keep_p
+        for f32 in (False, True):
+            dt = F32 if f32 else BF16
+            es = 4 if f32 else 2
+            fused = dqk == dv and Nq <= Nk
+            if fused:
+                buf = rnd(B, Nk, 3, H, dqk, dtype=dt, seed=21)
+                qo = off if Nq + off == Nk else 0
+                qt = (buf, qo * 3 * H * dqk); kt = (buf, H * dqk); vt = (buf, 2 * H * dqk)
+                strides = (Nk * 3 * H * dqk, 3 * H * dqk) * 3
+                q = buf[:, qo:qo + Nq, 0].permute(0, 2, 1, 3).float()
+                k = buf[:, :, 1].permute(0, 2, 1, 3).float()
+                v = buf[:, :, 2].permute(0, 2, 1, 3).float()
+            else:
+                qo = 0
+                qb, kb, vb = rnd(B, Nq, H, dqk, dtype=dt, seed=22), rnd(B, Nk, H, dqk, dtype=dt, seed=23), rnd(B, Nk, H, dv, dtype=dt, seed=24)
+                qt, kt, vt = (qb, 0), (kb, 0), (vb, 0)
+                strides = (Nq * H * dqk, H * dqk, Nk * H * dqk, H * dqk, Nk * H * dv, H * dv)
+                q, k, v = qb.permute(0, 2, 1, 3).float(), kb.permute(0, 2, 1, 3).float(), vb.permute(0, 2, 1, 3).float()
+            q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
+            ref = (((q @ k.transpose(-2, -1)) * scale).softmax(-1) * km) @ v
+            O = torch.empty(B * Nq, H * dv, device=dev, dtype=dt)
+            LSE = torch.empty(B, H, Nq, device=dev)
+            p = lambda t: t[0].data_ptr() + es * t[1]
+            ops.attn_drop_fwd(p(qt), p(kt), p(vt), O, LSE, B, H, Nq, Nk, dqk, dv, *strides, Nq * H * dv, H * dv, scale, keep, ld, 1.0 / keep_p)
+            tag = f'attn_drop {"f32" if f32 else "bf16"} B{B} H{H} {Nq}x{Nk} d{dqk}/{dv} p{pdrop}'
+            tf, tb = (2e-5, 5e-5) if f32 else (1e-2, 2e-2)
+            report(tag + ' fwd', rel(O.view(B, Nq, H, dv).permute(0, 2, 1, 3), ref), tf)
+            report(tag + ' lse', rel(LSE, torch.logsumexp((q @ k.transpose(-2, -1)) * scale, -1)), 1e-4)
+            dO = rnd(B * Nq, H * dv, dtype=dt, seed=25)
+            ref.backward(dO.view(B, Nq, H, dv).permute(0, 2, 1, 3).float())
+            fill = float('nan') if (fused and qo > 0 and not f32) else 0.0       # bf16: the dQ kernel zero-fills the context rows' q slots
+            if fused:
+                dbuf = torch.full_like(buf, fill)
+                dqt = (dbuf, qt[1]); dkt = (dbuf, kt[1]); dvt = (dbuf, vt[1])
+            else:
+                dqb, dkb, dvb = torch.zeros_like(qb), torch.zeros_like(kb), torch.zeros_like(vb)
+                dqt, dkt, dvt = (dqb, 0), (dkb, 0), (dvb, 0)
+            Delta = torch.empty_like(LSE)
+            ops.attn_drop_bwd(p(qt), p(kt), p(vt), O, dO, LSE, Delta, p(dqt), p(dkt), p(dvt), B, H, Nq, Nk, dqk, dv, *strides,
+                              Nq * H * dv, H * dv, Nq * H * dv, H * dv, *strides, scale, keep, ld, 1.0 / keep_p,
+                              dq_ctx_rows=qo if not f32 else 0)
+            if fused:
+                gq = dbuf[:, qo:qo + Nq, 0].permute(0, 2, 1, 3); gk = dbuf[:, :, 1].permute(0, 2, 1, 3); gv = dbuf[:, :, 2].permute(0, 2, 1, 3)
+                if fill != 0.0:
+                    report(tag + f' ctx rows {qo}', float(dbuf[:, :qo, 0].abs().max().nan_to_num(nan=1.0)), 1e-9)
+            else:
+                gq, gk, gv = dqb.permute(0, 2, 1, 3), dkb.permute(0, 2, 1, 3), dvb.permute(0, 2, 1, 3)
+            report(tag + ' dq', rel(gq, q.grad), tb)
+            report(tag + ' dk', rel(gk, k.grad), tb)
+            report(tag + ' dv', rel(gv, v.grad), tb)
+    # dropout on activations, DropPath folded in
+    for (B, rows, D) in [(4, 49, 768), (3, 7, 128), (2, 204, 3072), (1, 1, 4)]:
+        g = torch.Generator(device='cpu'); g.manual_seed(7 + rows)
+        keep = (torch.rand(B * rows, D, generator=g) < 0.8).to(torch.uint8).to(dev)
+        rs = (torch.rand(B, generator=g) < 0.7).float().to(dev) / 0.7
+        res = rnd(B * rows, D, seed=3)
+        for din in (F32, BF16):
+            for dout in (F32, BF16):
+                x = rnd(B * rows, D, dtype=din, seed=5)
+                for (kp, rsc, rr) in [(keep, None, None), (keep, rs, res), (None, rs, None), (keep, None, res)]:
+                    ref = x.float()
+                    if kp is not None:
+                        ref = ref * kp.float() / 0.8
+                    if rsc is not None:
+                        ref = (ref.view(B, rows, D) * rsc.view(B, 1, 1)).reshape(B * rows, D)
+                    if rr is not None:
+                        ref = ref + rr
+                    out = torch.empty(B * rows, D, device=dev, dtype=dout)
+                    ops.dropout_rows(x, kp, 1.0 / 0.8, B, rows, D, out, res=rr, rowscale=rsc)
+                    report(f'dropout_rows {B}x{rows}x{D} {str(din)[6:]}->{str(dout)[6:]} keep{kp is not None} rs{rsc is not None} res{rr is not None}',
+                           rel(out, ref.to(dout)), 1e-6 if dout == F32 else 4e-3)
+                if din == dout:         # in place
+                    y = x.clone()
+                    ops.dropout_rows(y, keep, 1.25, B, rows, D, y)
+                    report(f'dropout_rows in place {B}x{rows}x{D} {str(din)[6:]}', rel(y, (x.float() * keep.float() * 1.25).to(din)), 1e-6 if din == F32 else 4e-3)
+
+
+@check
 def window_attention():
     """Swin decoder kernels (models/swin.py): attention with the relative-position bias + shift mask on the A x A corner of
     [A window tokens | nF fusion tokens] sequences (bias table per window, b % nb), its dS output and the table gradient
@@ -862,7 +955,7 @@ def main():
         if ':' in kv:
             from deepavfusion_amd import _lib
             _lib.check(_lib.load().dav_tune(int(kv.split(':')[0]), int(kv.split(':')[1])), 'dav_tune')
-    for fn in (gemm_nt, gemm_tn, gemm_tn_gang, attention, window_attention, layernorm, ln_fused, masking, misc_kernels, patch_gather3d):
+    for fn in (gemm_nt, gemm_tn, gemm_tn_gang, attention, dropout, window_attention, layernorm, ln_fused, masking, misc_kernels, patch_gather3d):
         if flt in fn.__name__:
             fn()
     bad = [r for r in RESULTS if not r[3]]

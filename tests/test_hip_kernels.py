@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('name', ['gemm_nt', 'gemm_tn', 'gemm_tn_gang', 'attention', 'window_attention', 'layernorm', 'ln_fused', 'masking', 'misc_kernels', 'patch_gather3d'])
+@pytest.mark.parametrize('name', ['gemm_nt', 'gemm_tn', 'gemm_tn_gang', 'attention', 'dropout', 'window_attention', 'layernorm', 'ln_fused', 'masking', 'misc_kernels', 'patch_gather3d'])
 def test_kernel_family(name):
     import gpu_selfcheck as sc
     sc.RESULTS.clear()
