@@ -69,6 +69,71 @@ def drop_path_scales(owner, blk, B, dev, tag):
     return one(0), one(1)
 
 
+def _sampler(owner, tag):
+    """``owner._dropout_sampler(name, shape)`` -> 0 / 1 keep tensor of the REFERENCE's shape for the nn.Dropout called ``name``
+    (e.g. 'visual.0.attn', 'fusion.1.attn_v.proj'); set by parity tests (the two RNG streams can never match)."""
+    smp = getattr(owner, '_dropout_sampler', None)
+    if smp is None:
+        return lambda site, shape, cut=None: None
+    def make(site, shape, cut=None):
+        def sample(_shape):
+            m = smp(f'{tag}.{site}', shape)
+            return m if cut is None else cut(m)
+        return sample
+    return make
+
+
+def block_drops(owner, blk, B, n, nF, dev, tag):
+    """Dropout masks of ONE tower-block call (engine.block_fwd's ``dr``), or None when the block has no dropout or the model is in
+    eval mode.  The reference runs the block over cat((x_fusion, x_modality)) and drops the fusion rows' outputs
+    (models/deepavfusion.py:104-105): its masks span nF + n rows, of which the engine computes — and draws — the n modality rows
+    (a sampler is asked for the reference's shape and cut)."""
+    pa, pp = getattr(blk, 'attn_drop_prob', 0.0), getattr(blk, 'proj_drop_prob', 0.0)
+    if (pa <= 0.0 and pp <= 0.0) or not owner.training:
+        return None
+    S = _sampler(owner, tag)
+    R, H, D, Hd = nF + n, blk.num_heads, blk.norm1.weight.shape[0], blk.mlp.fc1.weight.shape[0]
+    rows = lambda m: m[:, nF:].reshape(B * n, -1)
+    dr = {}
+    if pa > 0.0:        # call order of the reference: attn_drop, proj_drop, Mlp.drop1, Mlp.drop2
+        dr['attn'] = E.draw_attn_keep(pa, B, H, n, R, dev, S('attn', (B, H, R, R), lambda m: m[:, :, nF:]))
+    if pp > 0.0:
+        dr['proj'] = E.draw_keep(pp, B * n, D, dev, S('proj', (B, R, D), rows))
+        dr['fc1'] = E.draw_keep(pp, B * n, Hd, dev, S('fc1', (B, R, Hd), rows))
+        dr['fc2'] = E.draw_keep(pp, B * n, D, dev, S('fc2', (B, R, D), rows))
+    return dr
+
+
+def fusion_drops(owner, fb, B, nF, nI, nA, dev, tag):
+    """Dropout masks of ONE fusion-block call (engine.fusion_block_fwd's ``dr``) in the reference's call order; nI / nA = rows of
+    the 2nd / 3rd positional argument."""
+    pa, pp = getattr(fb, 'attn_drop_prob', 0.0), getattr(fb, 'proj_drop_prob', 0.0)
+    if (pa <= 0.0 and pp <= 0.0) or not owner.training:
+        return None
+    S = _sampler(owner, tag)
+    H, D, Hd = fb.num_heads, fb.norm1_mm.weight.shape[0], fb.mlp.fc1.weight.shape[0]
+    flat = lambda m: m.reshape(-1, m.shape[-1])
+    arch = getattr(fb, 'arch', 'factorized_mmi')
+    dr = {}
+    if arch == 'factorized_mmi':
+        nmm, nv, na = fb.fusion_tkns
+        for name, nq, nk in (('attn_v', nv, nI), ('attn_a', na, nA)):       # models/fusion_blocks.py:241-242, each :54, :58
+            if pa > 0.0:
+                dr[name + '.attn'] = E.draw_attn_keep(pa, B, H, nq, nk, dev, S(name + '.attn', (B, H, nq, nk)))
+            if pp > 0.0:
+                dr[name + '.proj'] = E.draw_keep(pp, B * nq, D, dev, S(name + '.proj', (B, nq, D), flat))
+        nq, nk = nmm, nv * na
+    else:
+        nq, nk = nF, (nI + nA if arch == 'token' else nI * nA)
+    if pa > 0.0:
+        dr['attn'] = E.draw_attn_keep(pa, B, H, nq, nk, dev, S('attn', (B, H, nq, nk)))
+    if pp > 0.0:
+        dr['proj'] = E.draw_keep(pp, B * nq, D, dev, S('proj', (B, nq, D), flat))
+        dr['fc1'] = E.draw_keep(pp, B * nF, Hd, dev, S('fc1', (B, nF, Hd), flat))
+        dr['fc2'] = E.draw_keep(pp, B * nF, D, dev, S('fc2', (B, nF, D), flat))
+    return dr
+
+
 def _vis(enc):
     """The visual tower: ``.image`` of DeepAVFusion (models/deepavfusion.py:20) or ``.video`` of VideoEarlyFusion
     (models/video_earlyfusion.py:32) — the layer loop is the same."""
@@ -102,28 +167,33 @@ def _encoder_fwd(enc, image, audio, ik32, ak32, want_f32=False, collect_embs=Fal
         dpf = drop_path_scales(enc, fb, B, image.device, f'fusion.{l}') if fb is not None else None
         xf_ctx = x_f if fb is not None else None
         tf = None
+        # dropout masks (attn_drop / drop > 0, training mode): drawn here, before the layer's launch batch opens
+        nFc = x_f.shape[1] if fb is not None else 0
+        dri = block_drops(enc, bi, B, x_i.shape[1], nFc, image.device, f'visual.{l}')
+        dra = block_drops(enc, ba, B, x_a.shape[1], nFc, image.device, f'audio.{l}')
+        drf = fusion_drops(enc, fb, B, x_f.shape[1], x_i.shape[1], x_a.shape[1], image.device, f'fusion.{l}') if fb is not None else None
         if batched:
             # ONE launch batch per layer, three lanes — image block, audio block, fusion block (all read the layer inputs
             # only, models/deepavfusion.py:104-107): LayerNorms / GEMMs / attentions of equal rank go out as grouped grids
             # on one stream.  (hipGraph branches of this weight start ~150 us late on MI355X)
-            lane_f = fb is not None and E.fusion_block_batchable(fb, dpf) and not E.FUSION_ON_STREAM
+            lane_f = fb is not None and E.fusion_block_batchable(fb, dpf, drf) and not E.FUSION_ON_STREAM
             if fb is not None and E.FUSION_ON_STREAM:
                 # mixed schedule: the fusion block's ~11 small dependent steps run on their own stream (its independent launches
                 # still grouped per region) BESIDE the two tower lanes, which then need no idle steps
                 sf.wait_stream(main)
                 with torch.cuda.stream(sf):
-                    n_f, tf = E.fusion_block_fwd(fb, x_f, x_i, x_a, Hf, enc.num_fusion, dpf)
+                    n_f, tf = E.fusion_block_fwd(fb, x_f, x_i, x_a, Hf, enc.num_fusion, dpf, drf)
             elif fb is not None and not lane_f:
-                n_f, tf = E.fusion_block_fwd(fb, x_f, x_i, x_a, Hf, enc.num_fusion, dpf)      # reads the layer INPUT x_i / x_a (:106-107)
+                n_f, tf = E.fusion_block_fwd(fb, x_f, x_i, x_a, Hf, enc.num_fusion, dpf, drf)      # reads the layer INPUT x_i / x_a (:106-107)
             idle = E.FUSION_IDLE_FWD if lane_f else 0
             with E.batch() as bt:
                 bt.lane()
-                n_i, ti = E.block_fwd(bi, x_i, xf_ctx, Hi, bi.norm1.eps, dpi, idle_before_mlp=idle)
+                n_i, ti = E.block_fwd(bi, x_i, xf_ctx, Hi, bi.norm1.eps, dpi, idle_before_mlp=idle, dr=dri)
                 bt.lane()
-                n_a, ta = E.block_fwd(ba, x_a, xf_ctx, Ha, ba.norm1.eps, dpa, idle_before_mlp=idle)
+                n_a, ta = E.block_fwd(ba, x_a, xf_ctx, Ha, ba.norm1.eps, dpa, idle_before_mlp=idle, dr=dra)
                 if lane_f:
                     bt.lane()
-                    n_f, tf = E.fusion_block_fwd(fb, x_f, x_i, x_a, Hf, enc.num_fusion, dpf)
+                    n_f, tf = E.fusion_block_fwd(fb, x_f, x_i, x_a, Hf, enc.num_fusion, dpf, drf)
             if fb is not None and E.FUSION_ON_STREAM:
                 main.wait_stream(sf)
             if fb is not None:
@@ -133,11 +203,11 @@ def _encoder_fwd(enc, image, audio, ik32, ak32, want_f32=False, collect_embs=Fal
             sa.wait_stream(main)
             sf.wait_stream(main)
             with torch.cuda.stream(sa):
-                n_a, ta = E.block_fwd(ba, x_a, xf_ctx, Ha, ba.norm1.eps, dpa)
+                n_a, ta = E.block_fwd(ba, x_a, xf_ctx, Ha, ba.norm1.eps, dpa, dr=dra)
             if fb is not None:
                 with torch.cuda.stream(sf):
-                    n_f, tf = E.fusion_block_fwd(fb, x_f, x_i, x_a, Hf, enc.num_fusion, dpf)
-            n_i, ti = E.block_fwd(bi, x_i, xf_ctx, Hi, bi.norm1.eps, dpi)
+                    n_f, tf = E.fusion_block_fwd(fb, x_f, x_i, x_a, Hf, enc.num_fusion, dpf, drf)
+            n_i, ti = E.block_fwd(bi, x_i, xf_ctx, Hi, bi.norm1.eps, dpi, dr=dri)
             x_i, x_a = n_i, n_a
             if fb is not None:
                 x_f = n_f
@@ -190,7 +260,7 @@ def _encoder_bwd(enc, t, dxi_b, dxa_b, dxf_b, dxi32, dxa32, dxf32, layer_cb=None
             # whole backward.  The towers' last kernel — the norm1 backward — accumulates into the buffers the fusion
             # block's backward produces, so it forms a second (two-lane) batch behind the first.
             dx_f = dx_i = dx_a = None
-            lane_f = fb is not None and E.fusion_block_batchable(fb, tf.get('dp')) and not E.FUSION_ON_STREAM
+            lane_f = fb is not None and E.fusion_block_batchable(fb, tf.get('dp'), tf.get('dr')) and not E.FUSION_ON_STREAM
             if fb is not None and E.FUSION_ON_STREAM:
                 sf.wait_stream(main)
                 with torch.cuda.stream(sf):
@@ -321,14 +391,22 @@ class _CrossAttentionFn(torch.autograd.Function):
         B, N1, D = x1.shape
         N2 = x2.shape[1]
         x1b, x2b = E.to_bf16(x1.reshape(B * N1, D)), E.to_bf16(x2.reshape(B * N2, D))
-        c = E._cross_fwd_seq(ca, x1b, None, N1, x2b, N2, B, D, ca.num_heads, x1.device)
+        H, hd = ca.num_heads, D // ca.num_heads
+        S = _sampler(ca, 'cross')
+        pa, pp = (ca.attn_drop_prob, ca.proj_drop_prob) if ca.training else (0.0, 0.0)
+        keep = E.draw_attn_keep(pa, B, H, N1, N2, x1.device, S('attn', (B, H, N1, N2))) if pa > 0.0 else None
+        ctx.pm = E.draw_keep(pp, B * N1, D, x1.device, S('proj', (B, N1, D), lambda m: m.reshape(B * N1, D))) if pp > 0.0 else None
+        c = E._cross_fwd_seq(ca, x1b, None, N1, x2b, N2, B, D, ca.num_heads, x1.device, keep=keep)
         out = E.lin_fwd(ca.proj, c['o'], B * N1)
+        if ctx.pm is not None:
+            E._drop(out, ctx.pm, B, N1, D)
         ctx.ca, ctx.c, ctx.x1b, ctx.x2b, ctx.dims, ctx.np = ca, c, x1b, x2b, (B, N1, N2, D), len(params)
         # the attention matrix the reference also returns: softmax rebuilt from the kernels' own q / k and log-sum-exp
-        H, hd = ca.num_heads, D // ca.num_heads
         q = c['q'].view(B, N1, H, hd).permute(0, 2, 1, 3).float()
         k = c['kv'].view(B, N2, 2, H, hd)[:, :, 0].permute(0, 2, 1, 3).float()
         attn = torch.exp((q @ k.transpose(-2, -1)) * ca.scale - c['lse'].unsqueeze(-1))
+        if keep is not None:          # returned AFTER attn_drop (models/fusion_blocks.py:54-59)
+            attn = attn * keep[0][..., :N2].float() * keep[2]
         ctx.mark_non_differentiable(attn)
         return out.view(B, N1, D), attn
 
@@ -337,7 +415,11 @@ class _CrossAttentionFn(torch.autograd.Function):
         B, N1, N2, D = ctx.dims
         ca = ctx.ca
         with E.deferred_wgrads():
-            do = E.lin_bwd(ca.proj, E.to_bf16(g.contiguous().view(B * N1, D)), ctx.c['o'], B * N1)
+            gb = E.to_bf16(g.contiguous().view(B * N1, D))
+            if ctx.pm is not None:
+                gb = gb.clone() if gb.data_ptr() == g.data_ptr() else gb      # (fp32 engine: to_bf16 is the identity; autograd's g stays)
+                E._drop(gb, ctx.pm, B, N1, D)
+            do = E.lin_bwd(ca.proj, gb, ctx.c['o'], B * N1)
             dx1 = torch.empty(B * N1, D, dtype=E.BF16, device=g.device)
             dx2 = E._cross_bwd_seq(ca, ctx.c, do, ctx.x1b, None, N1, ctx.x2b, N2, B, D, ca.num_heads, dx1, None)
         return (None, dx1.float().view(B, N1, D), dx2.float().view(B, N2, D)) + (None,) * ctx.np
@@ -379,7 +461,8 @@ class _FusionBlockFn(torch.autograd.Function):
     def forward(ctx, fb, xmm, xv, xa, *params):
         ctx.set_materialize_grads(False)
         out, tape = E.fusion_block_fwd(fb, xmm, xv, xa, fb.num_heads, getattr(fb, 'fusion_tkns', None),
-                                       drop_path_scales(fb, fb, xmm.shape[0], xmm.device, 'fusion'))
+                                       drop_path_scales(fb, fb, xmm.shape[0], xmm.device, 'fusion'),
+                                       fusion_drops(fb, fb, xmm.shape[0], xmm.shape[1], xv.shape[1], xa.shape[1], xmm.device, 'fusion'))
         ctx.fb, ctx.tape, ctx.np = fb, tape, len(params)
         return out
 

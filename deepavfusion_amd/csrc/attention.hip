@@ -1077,6 +1077,7 @@ static int attn_fwd_any(const void* Q, const void* K, const void* V, void* O, fl
     if (dqk == 64 && dv == 64) return launch_fwd_drop<64, 64>(p, stream);
     if (dqk == 32 && dv == 32) return launch_fwd_drop<32, 32>(p, stream);
     if (dqk == 16 && dv == 64) return launch_fwd_drop<16, 64>(p, stream);
+    if (dqk == 16 && dv == 16) return launch_fwd_drop<16, 16>(p, stream);
     return DAV_ERR_SHAPE;
   }
   if (dqk == 64 && dv == 64) return launch_fwd<64, 64>(p, stream);
@@ -1130,6 +1131,7 @@ static int attn_bwd_any(const void* Q, const void* K, const void* V, const void*
     if (dqk == 64 && dv == 64) return launch_bwd_drop<64, 64>(p, stream, part);
     if (dqk == 32 && dv == 32) return launch_bwd_drop<32, 32>(p, stream, part);
     if (dqk == 16 && dv == 64) return launch_bwd_drop<16, 64>(p, stream, part);
+    if (dqk == 16 && dv == 16) return launch_bwd_drop<16, 16>(p, stream, part);
     return DAV_ERR_SHAPE;
   }
   if (dqk == 64 && dv == 64) return launch_bwd<64, 64>(p, stream, part);

@@ -767,12 +767,17 @@ def ln_bwd_tw(norm, eps, t0, r0, t1, r1, B, dy_bf16=None, dy_f32=None, *, h_out=
         _DEFERRED_LN_READY.append((norm.weight, norm.bias))
 
 
-def attention_fwd(q, k, v, B, H, Nq, Nk, dqk, dv, scale, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, dev):
-    """q/k/v are (tensor, element_offset) pairs into bf16 buffers. Returns O [B*Nq, H*dv] bf16 and LSE."""
+def attention_fwd(q, k, v, B, H, Nq, Nk, dqk, dv, scale, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, dev, keep=None):
+    """q/k/v are (tensor, element_offset) pairs into bf16 buffers. Returns O [B*Nq, H*dv] bf16 and LSE.
+    ``keep`` = (bytes 0 / 1 [B, H, Nq, ld], ld, 1 / (1 - p)): attention dropout (see draw_attn_keep)."""
     O = _e((B * Nq, H * dv), BF16, dev)
     LSE = _e((B, H, Nq), F32, dev)
     ops.hold(q[0], k[0], v[0])
     es = q[0].element_size()
+    if keep is not None:
+        ops.attn_drop_fwd(q[0].data_ptr() + es * q[1], k[0].data_ptr() + es * k[1], v[0].data_ptr() + es * v[1], O, LSE, B, H, Nq, Nk,
+                          dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, Nq * H * dv, H * dv, scale, keep[0], keep[1], keep[2])
+        return O, LSE
     ops.attn_fwd(q[0].data_ptr() + es * q[1], k[0].data_ptr() + es * k[1], v[0].data_ptr() + es * v[1], O, LSE, B, H, Nq, Nk,
                  dqk, dv, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, Nq * H * dv, H * dv, scale)
     return O, LSE
@@ -782,13 +787,18 @@ _ATTN_CTX = True      # (False: a torch fill pass zeroes the context rows' dq sl
 
 
 def attention_bwd(q, k, v, O, dO, LSE, dq, dk, dvv, B, H, Nq, Nk, dqk, dv, scale, q_bs, q_rs, k_bs, k_rs, v_bs, v_rs,
-                  dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, part=3, Delta=None, dq_ctx_rows=0):
+                  dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, part=3, Delta=None, dq_ctx_rows=0, keep=None):
     """``part`` 1 / 2: only the dQ (+ Delta) / only the dK-dV kernel, with the same ``Delta`` buffer passed to both calls
     (lets a caller put the two kernels of several attentions into two regions of a launch batch)."""
     if Delta is None:
         Delta = torch.empty_like(LSE)
     ops.hold(q[0], k[0], v[0], dq[0], dk[0], dvv[0])
     p = lambda t: t[0].data_ptr() + t[0].element_size() * t[1]
+    if keep is not None:
+        ops.attn_drop_bwd(p(q), p(k), p(v), O, dO, LSE, Delta, p(dq), p(dk), p(dvv), B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs,
+                          v_bs, v_rs, Nq * H * dv, H * dv, Nq * H * dv, H * dv, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, scale,
+                          keep[0], keep[1], keep[2], part=part, dq_ctx_rows=dq_ctx_rows)
+        return
     ops.attn_bwd(p(q), p(k), p(v), O, dO, LSE, Delta, p(dq), p(dk), p(dvv), B, H, Nq, Nk, dqk, dv, q_bs, q_rs, k_bs, k_rs,
                  v_bs, v_rs, Nq * H * dv, H * dv, Nq * H * dv, H * dv, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, scale, part=part,
                  dq_ctx_rows=dq_ctx_rows)
@@ -805,40 +815,88 @@ def to_bf16(x):
 # ------------------------------------------------------------------------------------------------
 # timm Block (pre-LN) with optional fusion-token context rows
 # ------------------------------------------------------------------------------------------------
-def _res_add(lin, a, M, res, B, rows, D, scale, **kw):
-    """res + [scale[b] *] lin(a): fused into the GEMM epilogue, or — with a DropPath scale — GEMM to a temporary followed
-    by the per-sample scaled add (timm DropPath: x + drop_path(branch(x)))."""
-    if scale is None:
-        return lin_fwd(lin, a, M, res=res, **kw)
-    y = lin_fwd(lin, a, M, **kw)
-    out = _e((M, D), F32, a.device)
-    ops.rows_axpy(res, y, scale, B, rows, D, out)
+# ---- dropout (nn.Dropout with p > 0 in training mode: the fine-tuning constructors' attn_drop / drop; every pre-training config
+# has 0 and none of this runs).  The DRAW is torch's (draw_attn_keep / draw_keep, made by the caller BEFORE a launch batch opens: a
+# torch RNG kernel must not overtake recorded launches); the kernels are deterministic in the byte masks.
+def draw_attn_keep(p, B, H, Nq, Nk, dev, sample=None):
+    """Keep mask of an attention-probability dropout: (bytes 0 / 1 [B, H, Nq, ld], ld, 1 / (1 - p)), ld = Nk rounded up to 32.
+    ``sample((B, H, Nq, Nk))`` -> 0 / 1 tensor replaces the Bernoulli draw (parity tests inject the reference's masks)."""
+    ld = (Nk + 31) // 32 * 32
+    if sample is None:
+        m = (torch.rand((B, H, Nq, ld), device=dev) >= p).to(torch.uint8)
+    else:
+        m = torch.zeros((B, H, Nq, ld), device=dev, dtype=torch.uint8)
+        m[..., :Nk] = sample((B, H, Nq, Nk)).to(device=dev, dtype=torch.uint8)
+    return m, ld, 1.0 / (1.0 - p)
+
+
+def draw_keep(p, rows, D, dev, sample=None):
+    """Keep mask of a dropout on a [rows, D] activation: (bytes 0 / 1 [rows, D], 1 / (1 - p))."""
+    if sample is None:
+        m = (torch.rand((rows, D), device=dev) >= p).to(torch.uint8)
+    else:
+        m = sample((rows, D)).to(device=dev, dtype=torch.uint8).contiguous()
+    return m, 1.0 / (1.0 - p)
+
+
+def _drop(x, m, B, rows, D):
+    """x <- keep * x / (1 - p), in place (x: operand-dtype or fp32 [B * rows, D]; forward and backward of an nn.Dropout alike)."""
+    ops.dropout_rows(x, m[0], m[1], B, rows, D, x)
+
+
+def _branch_grad(g, scale, drop, B, rows, D):
+    """Gradient entering a residual BRANCH that ended in [Dropout ->] DropPath: operand-dtype(scale[b] * keep / (1 - p) * g); the
+    residual path passes g through unchanged."""
+    out = _e((B * rows, D), BF16, g.device)
+    if drop is None and PRECISION != 'fp32':
+        ops.rows_scale_cast(g, scale, B, rows, D, out)
+    else:
+        ops.dropout_rows(g, None if drop is None else drop[0], 1.0 if drop is None else drop[1], B, rows, D, out, rowscale=scale)
     return out
 
 
-def block_fwd(blk, x_mod, x_fus, heads, eps, dp=None, idle_before_mlp=0):
+def _res_add(lin, a, M, res, B, rows, D, scale, drop=None, **kw):
+    """res + [scale[b] *] [dropout] lin(a): fused into the GEMM epilogue, or — with a DropPath scale and / or a dropout mask — GEMM
+    to a temporary followed by one masked, per-sample scaled add (timm: x + drop_path(proj_drop(proj(...))))."""
+    if scale is None and drop is None:
+        return lin_fwd(lin, a, M, res=res, **kw)
+    y = lin_fwd(lin, a, M, **kw)
+    out = _e((M, D), F32, a.device)
+    if drop is None:
+        ops.rows_axpy(res, y, scale, B, rows, D, out)
+    else:
+        ops.dropout_rows(y, drop[0], drop[1], B, rows, D, out, res=res, rowscale=scale)
+    return out
+
+
+def block_fwd(blk, x_mod, x_fus, heads, eps, dp=None, idle_before_mlp=0, dr=None):
     """x_mod fp32 [B,n,D]; x_fus fp32 [B,nF,D] or None (context rows: keys/values only —
     models/deepavfusion.py:104-105).  ``dp`` = (s_attn, s_mlp): per-sample DropPath scales (fp32 [B], 0 or 1/keep) of the
-    two residual branches, None when inactive.  Returns (x_out fp32 [B,n,D], tape)."""
+    two residual branches, None when inactive.  ``dr``: dropout masks of this call — {'attn': draw_attn_keep(...), 'proj' / 'fc1' /
+    'fc2': draw_keep(...)}, a missing key = p 0 (timm Attention.attn_drop / proj_drop, Mlp.drop1 / drop2); None when inactive.
+    Returns (x_out fp32 [B,n,D], tape)."""
     B, n, D = x_mod.shape
     nF = x_fus.shape[1] if x_fus is not None else 0
     R, hd, dev = nF + n, D // heads, x_mod.device
     M, Mq = B * R, B * n
-    if dp is None and ln_fuse_ok(D):
+    if dp is None and not dr and ln_fuse_ok(D):
         return _block_fwd_ln(blk, x_mod, x_fus, heads, eps, idle_before_mlp)
+    dr = dr or {}
     h1, _, st1 = ln_fwd(blk.norm1, x_fus, x_mod, B, eps)
     qkv = lin_fwd(blk.attn.qkv, h1, M, out_bf16=True)                                       # [B*R, 3D]
     o, lse = attention_fwd((qkv, nF * 3 * D), (qkv, D), (qkv, 2 * D), B, heads, n, R, hd, hd, hd ** -0.5,
-                           R * 3 * D, 3 * D, R * 3 * D, 3 * D, R * 3 * D, 3 * D, dev)
-    x1 = _res_add(blk.attn.proj, o, Mq, x_mod, B, n, D, None if dp is None else dp[0]).view(B, n, D)
+                           R * 3 * D, 3 * D, R * 3 * D, 3 * D, R * 3 * D, 3 * D, dev, keep=dr.get('attn'))
+    x1 = _res_add(blk.attn.proj, o, Mq, x_mod, B, n, D, None if dp is None else dp[0], drop=dr.get('proj')).view(B, n, D)
     lane_skip(idle_before_mlp)          # batched beside a fusion block: line norm2 / fc1 / fc2 up with its norm2 / fc1 / fc2
     h2, _, st2 = ln_fwd(blk.norm2, None, x1, B, eps)
     Hd = blk.mlp.fc1.weight.shape[0]
     z = _e((Mq, Hd), BF16, dev)
     u = lin_fwd(blk.mlp.fc1, h2, Mq, act=1, out_bf16=True, C2=z, c2_mode=4)
-    x2 = _res_add(blk.mlp.fc2, u, Mq, x1, B, n, D, None if dp is None else dp[1]).view(B, n, D)
+    if 'fc1' in dr:
+        _drop(u, dr['fc1'], B, n, Hd)       # fc2 (and its weight gradient) contract the DROPPED activation; z keeps GELU's input
+    x2 = _res_add(blk.mlp.fc2, u, Mq, x1, B, n, D, None if dp is None else dp[1], drop=dr.get('fc2')).view(B, n, D)
     tape = dict(x_mod=x_mod, x_fus=x_fus, h1=h1, st1=st1, qkv=qkv, o=o, lse=lse, x1=x1, h2=h2, st2=st2, z=z, u=u,
-                heads=heads, nF=nF, dp=dp)
+                heads=heads, nF=nF, dp=dp, dr=dr or None)
     return x2, tape
 
 
@@ -888,13 +946,15 @@ def block_bwd_head(blk, t, g2, g2b, idle_before_attn=0):
     R, hd, dev = nF + n, D // heads, x_mod.device
     M, Mq = B * R, B * n
     dp = t.get('dp')
-    if dp is not None:                      # the branch sees s[b] * g, the residual path g itself
-        g2b = _e((Mq, D), BF16, dev)
-        ops.rows_scale_cast(g2, dp[1], B, n, D, g2b)
+    dr = t.get('dr') or {}
+    if dp is not None or 'fc2' in dr:       # the branch sees s[b] * keep / (1 - p) * g, the residual path g itself
+        g2b = _branch_grad(g2, None if dp is None else dp[1], dr.get('fc2'), B, n, D)
     elif g2b is None:
         g2b = to_bf16(g2)
     fused = t.get('ln_fused', False)
     dz = lin_bwd(blk.mlp.fc2, g2b, t['u'], Mq, gelu_aux=t['z'])                              # [Mq, Hd] bf16 (already * GELU')
+    if 'fc1' in dr:
+        _drop(dz, dr['fc1'], B, n, dz.shape[1])
     g1 = _e((B, n, D), F32, dev)
     g1b = _e((Mq, D), BF16, dev)
     if fused:       # the norm2 backward re-makes fc1's weight-gradient operand (the LayerNorm output) from the twin of x1
@@ -905,8 +965,8 @@ def block_bwd_head(blk, t, g2, g2b, idle_before_attn=0):
     else:
         dh2 = lin_bwd(blk.mlp.fc1, dz, t['h2'], Mq)
         ln_bwd(blk.norm2, None, t['x1'], B, t['st2'], dy_bf16=dh2, dx1=g1, res1=g2, dx1_bf16=g1b)
-    if dp is not None:
-        ops.rows_scale_cast(g1, dp[0], B, n, D, g1b)
+    if dp is not None or 'proj' in dr:
+        g1b = _branch_grad(g1, None if dp is None else dp[0], dr.get('proj'), B, n, D)
     do = lin_bwd(blk.attn.proj, g1b, t['o'], Mq)
     lane_skip(idle_before_attn)         # batched beside a fusion block: line the attention backward up with its cross-attentions
     dqkv = _e((M, 3 * D), BF16, dev)
@@ -919,7 +979,7 @@ def block_bwd_head(blk, t, g2, g2b, idle_before_attn=0):
     attention_bwd((qkv, nF * 3 * D), (qkv, D), (qkv, 2 * D), t['o'], do, t['lse'],
                   (dqkv, nF * 3 * D), (dqkv, D), (dqkv, 2 * D), B, heads, n, R, hd, hd, hd ** -0.5,
                   R * 3 * D, 3 * D, R * 3 * D, 3 * D, R * 3 * D, 3 * D,
-                  R * 3 * D, 3 * D, R * 3 * D, 3 * D, R * 3 * D, 3 * D, dq_ctx_rows=nF if ctx_in_kernel else 0)
+                  R * 3 * D, 3 * D, R * 3 * D, 3 * D, R * 3 * D, 3 * D, dq_ctx_rows=nF if ctx_in_kernel else 0, keep=dr.get('attn'))
     if fused:
         dh1 = lin_bwd(blk.attn.qkv, dqkv, None, M, wgrad=False)
         return dict(dh1=dh1, g1=g1, dqkv=dqkv)
@@ -967,13 +1027,13 @@ def block_bwd_tail(blk, t, st, *, dx_fus=None, dx_fus_acc=0, dx_mod=None, dx_mod
 # ------------------------------------------------------------------------------------------------
 # FusionBlock_FactorizedAVInteractions (models/fusion_blocks.py:216-289)
 # ------------------------------------------------------------------------------------------------
-def _factorized_fwd(fb, x_f, x_i, x_a, heads, tkns, dp=None):
+def _factorized_fwd(fb, x_f, x_i, x_a, heads, tkns, dp=None, dr=None):
     """FusionBlock_FactorizedAVInteractions forward (models/fusion_blocks.py:266-289) as 11 dependent steps; the
     independent launches of a step sit in a ``region()`` so that they go out as one grouped grid (and, when the block is a
-    lane of the layer's launch batch, together with the tower blocks' launches of that step).  With DropPath scales the
-    sequential form below is used (it needs torch ops between kernels)."""
-    if dp is not None:
-        return _factorized_fwd_seq(fb, x_f, x_i, x_a, heads, tkns, dp)
+    lane of the layer's launch batch, together with the tower blocks' launches of that step).  With DropPath scales or dropout
+    masks the sequential form below is used (it needs torch ops between kernels)."""
+    if dp is not None or dr:
+        return _factorized_fwd_seq(fb, x_f, x_i, x_a, heads, tkns, dp, dr)
     B, nF, D = x_f.shape
     nI, nA = x_i.shape[1], x_a.shape[1]
     nmm, nv, na = tkns
@@ -1057,7 +1117,7 @@ def _factorized_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
     """g fp32 [B,nF,D] grad of the block output.  Returns (dx_f fp32, dx_i, dx_a);
     dx_i / dx_a are freshly STORED (fp32 [B,n,D]) unless buffers are passed.  Same step / region structure as the forward;
     library launches only (no torch op touches a buffer a recorded kernel produces)."""
-    if t.get('dp') is not None:
+    if t.get('dp') is not None or t.get('dr'):
         return _factorized_bwd_seq(fb, t, g, gb, dx_i=dx_i, dx_a=dx_a)
     x_f, x_i, x_a, heads = t['x_f'], t['x_i'], t['x_a'], t['heads']
     B, nF, D = x_f.shape
@@ -1163,15 +1223,15 @@ def _factorized_bwd_cross(fb, t, g1, dov, doa, dxmm_b, dx_i, dx_a):
 
 
 # ---- sequential form (DropPath active: per-sample scaled branches need torch ops between the kernels) --------------------
-def _cross_fwd_seq(ca, xq_b, q_rowmap, nq, xkv_b, nk, B, D, heads, dev):
+def _cross_fwd_seq(ca, xq_b, q_rowmap, nq, xkv_b, nk, B, D, heads, dev, keep=None):
     """CrossAttention (models/fusion_blocks.py:46-59) up to (not incl.) proj. xq_b rows come from the
     normed fusion tokens through q_rowmap; xkv_b is the normed modality [B*nk, D]."""
     hd = D // heads
     q = lin_fwd(ca.q, xq_b, B * nq, a_rowmap=q_rowmap, out_bf16=True)                        # [B*nq, D]
     kv = lin_fwd(ca.kv, xkv_b, B * nk, out_bf16=True)                                        # [B*nk, 2D]
     o, lse = attention_fwd((q, 0), (kv, 0), (kv, D), B, heads, nq, nk, hd, hd, hd ** -0.5,
-                           nq * D, D, nk * 2 * D, 2 * D, nk * 2 * D, 2 * D, dev)
-    return dict(q=q, kv=kv, o=o, lse=lse)
+                           nq * D, D, nk * 2 * D, 2 * D, nk * 2 * D, 2 * D, dev, keep=keep)
+    return dict(q=q, kv=kv, o=o, lse=lse, keep=keep)
 
 
 def _cross_bwd_seq(ca, c, do, xq_b, q_rowmap, nq, xkv_b, nk, B, D, heads, dxq_out, dxq_rowmap):
@@ -1182,12 +1242,15 @@ def _cross_bwd_seq(ca, c, do, xq_b, q_rowmap, nq, xkv_b, nk, B, D, heads, dxq_ou
     dkv = _e((B * nk, 2 * D), BF16, dev)
     attention_bwd((c['q'], 0), (c['kv'], 0), (c['kv'], D), c['o'], do, c['lse'], (dq, 0), (dkv, 0), (dkv, D),
                   B, heads, nq, nk, hd, hd, hd ** -0.5, nq * D, D, nk * 2 * D, 2 * D, nk * 2 * D, 2 * D,
-                  nq * D, D, nk * 2 * D, 2 * D, nk * 2 * D, 2 * D)
+                  nq * D, D, nk * 2 * D, 2 * D, nk * 2 * D, 2 * D, keep=c.get('keep'))
     lin_bwd(ca.q, dq, xq_b, B * nq, a_rowmap=q_rowmap, dx=dxq_out, dx_rowmap=dxq_rowmap)
     return lin_bwd(ca.kv, dkv, xkv_b, B * nk)
 
 
-def _factorized_fwd_seq(fb, x_f, x_i, x_a, heads, tkns, dp=None):
+def _factorized_fwd_seq(fb, x_f, x_i, x_a, heads, tkns, dp=None, dr=None):
+    """``dr``: dropout masks {'attn_v.attn' / 'attn_a.attn' / 'attn': draw_attn_keep, 'attn_v.proj' [B*nv, D] / 'attn_a.proj' [B*na, D] /
+    'proj' [B*nmm, D] / 'fc1' / 'fc2': draw_keep} (models/fusion_blocks.py:54,58 in both aggregations, :256,260, Mlp.drop1 / drop2)."""
+    dr = dr or {}
     B, nF, D = x_f.shape
     nI, nA = x_i.shape[1], x_a.shape[1]
     nmm, nv, na = tkns
@@ -1198,16 +1261,23 @@ def _factorized_fwd_seq(fb, x_f, x_i, x_a, heads, tkns, dp=None):
     xv_b, _, st_v = ln_fwd(fb.norm1_img, None, x_i, B)
     xa_b, _, st_a = ln_fwd(fb.norm1_aud, None, x_a, B)
     rm2, rmv, rma = (nmm, nF, 0), (nv, nF, nmm), (na, nF, nmm + nv)
-    cv = _cross_fwd_seq(at.attn_v, xmm_b, rmv, nv, xv_b, nI, B, D, heads, dev)
-    ca = _cross_fwd_seq(at.attn_a, xmm_b, rma, na, xa_b, nA, B, D, heads, dev)
+    cv = _cross_fwd_seq(at.attn_v, xmm_b, rmv, nv, xv_b, nI, B, D, heads, dev, keep=dr.get('attn_v.attn'))
+    ca = _cross_fwd_seq(at.attn_a, xmm_b, rma, na, xa_b, nA, B, D, heads, dev, keep=dr.get('attn_a.attn'))
     xmm1 = _e((B, nF, D), F32, dev)
     # proj of the two aggregations: fp32 result lands in its rows of xmm1 (+ normed-xmm residual),
     # bf16 twin of the pre-residual value feeds the pair projections
     xvo_b, xao_b = _e((B * nv, D), BF16, dev), _e((B * na, D), BF16, dev)
-    # with DropPath the three projections land WITHOUT the residual; it is added below with the per-sample scale
-    r32 = xmm32 if dp is None else None
+    # with DropPath / projection dropout the three projections land WITHOUT the residual; it is added below, masked and scaled
+    pdrop = [dr.get('proj'), dr.get('attn_v.proj'), dr.get('attn_a.proj')]
+    seq_res = dp is not None or any(m is not None for m in pdrop)
+    r32 = None if seq_res else xmm32
     lin_fwd(at.attn_v.proj, cv['o'], B * nv, res=r32, res_rowmap=rmv, out=xmm1, c_rowmap=rmv, C2=xvo_b, c2_mode=2)
     lin_fwd(at.attn_a.proj, ca['o'], B * na, res=r32, res_rowmap=rma, out=xmm1, c_rowmap=rma, C2=xao_b, c2_mode=2)
+    # the pairs are built from what the two CrossAttention modules RETURN, i.e. after their proj_drop (:58, :240-248)
+    if pdrop[1] is not None:
+        _drop(xvo_b, pdrop[1], B, nv, D)
+    if pdrop[2] is not None:
+        _drop(xao_b, pdrop[2], B, na, D)
     # all (v, a) pairs: Linear(cat(xv_i, xa_j)) = W[:, :D] xv_i + W[:, D:] xa_j + b  (never materialised)
     kv_p = lin_fwd(at.k, xvo_b, B * nv, k=D)
     ka_p = lin_fwd(at.k, xao_b, B * na, k=D, w_col_off=D, use_bias=False)
@@ -1220,16 +1290,26 @@ def _factorized_fwd_seq(fb, x_f, x_i, x_a, heads, tkns, dp=None):
     q2 = lin_fwd(at.q, xmm_b, B * nmm, a_rowmap=rm2, out_bf16=True)                          # [B*nmm, Da]
     scale = (D // heads) ** -0.5                                                             # NOT (Da/heads)^-0.5 (:220-222)
     o2, lse2 = attention_fwd((q2, 0), (Kp, 0), (Vp, 0), B, heads, nmm, P, Da // heads, D // heads, scale,
-                             nmm * Da, Da, P * Da, Da, P * D, D, dev)
+                             nmm * Da, Da, P * Da, Da, P * D, D, dev, keep=dr.get('attn'))
     lin_fwd(at.proj, o2, B * nmm, res=r32, res_rowmap=rm2, out=xmm1, c_rowmap=rm2)
-    if dp is not None:
+    keep_rows = None
+    if any(m is not None for m in pdrop):
+        # one [B * nF, D] mask over the rows of cat((xmm2, xmm_v, xmm_a)) (:262), a site without dropout all ones
+        ks = next(m[1] for m in pdrop if m is not None)
+        parts = [(m[0].view(B, r, D) if m is not None else torch.ones((B, r, D), device=dev, dtype=torch.uint8))
+                 for m, r in zip(pdrop, (nmm, nv, na))]
+        keep_rows = (torch.cat(parts, dim=1).view(B * nF, D).contiguous(), ks)
+        ops.dropout_rows(xmm1, keep_rows[0], ks, B, nF, D, xmm1, res=xmm32, rowscale=None if dp is None else dp[0])
+    elif dp is not None:
         ops.rows_axpy(xmm32, xmm1, dp[0], B, nF, D, xmm1)               # xmm + s[b] * attn(xmm, xv, xa)
     h2, _, st2 = ln_fwd(fb.norm2, None, xmm1, B)
     Hd = fb.mlp.fc1.weight.shape[0]
     z = _e((B * nF, Hd), BF16, dev)
     u = lin_fwd(fb.mlp.fc1, h2, B * nF, act=1, out_bf16=True, C2=z, c2_mode=4)
-    out = _res_add(fb.mlp.fc2, u, B * nF, xmm1, B, nF, D, None if dp is None else dp[1]).view(B, nF, D)
-    tape = dict(dp=dp, x_f=x_f, x_i=x_i, x_a=x_a, xmm_b=xmm_b, st_mm=st_mm, xv_b=xv_b, st_v=st_v, xa_b=xa_b, st_a=st_a, cv=cv, ca=ca,
+    if 'fc1' in dr:
+        _drop(u, dr['fc1'], B, nF, Hd)
+    out = _res_add(fb.mlp.fc2, u, B * nF, xmm1, B, nF, D, None if dp is None else dp[1], drop=dr.get('fc2')).view(B, nF, D)
+    tape = dict(dp=dp, dr=dr or None, keep_rows=keep_rows, x_f=x_f, x_i=x_i, x_a=x_a, xmm_b=xmm_b, st_mm=st_mm, xv_b=xv_b, st_v=st_v, xa_b=xa_b, st_a=st_a, cv=cv, ca=ca,
                 xvo_b=xvo_b, xao_b=xao_b, Kp=Kp, Vp=Vp, q2=q2, o2=o2, lse2=lse2, xmm1=xmm1, h2=h2, st2=st2, z=z, u=u,
                 heads=heads, tkns=tkns)
     return out, tape
@@ -1247,23 +1327,29 @@ def _factorized_bwd_seq(fb, t, g, gb, *, dx_i=None, dx_a=None):
     P = nv * na
     rm2, rmv, rma = (nmm, nF, 0), (nv, nF, nmm), (na, nF, nmm + nv)
     dp = t.get('dp')
-    if dp is not None:
-        gb = _e((B * nF, D), BF16, dev)
-        ops.rows_scale_cast(g, dp[1], B, nF, D, gb)
+    dr = t.get('dr') or {}
+    if dp is not None or 'fc2' in dr:
+        gb = _branch_grad(g, None if dp is None else dp[1], dr.get('fc2'), B, nF, D)
     elif gb is None:
         gb = to_bf16(g)
     dz = lin_bwd(fb.mlp.fc2, gb, t['u'], B * nF, gelu_aux=t['z'])
+    if 'fc1' in dr:
+        _drop(dz, dr['fc1'], B, nF, dz.shape[1])
     dh2 = lin_bwd(fb.mlp.fc1, dz, t['h2'], B * nF)
     g1 = _e((B, nF, D), F32, dev)
     g1b = _e((B * nF, D), BF16, dev)
     ln_bwd(fb.norm2, None, t['xmm1'], B, t['st2'], dy_bf16=dh2, dx1=g1, res1=g, dx1_bf16=g1b)
     # g1 = gradient at xmm1: unchanged it is the residual-path gradient of the normed xmm (norm1_mm backward below);
-    # the attention branch sees it scaled per sample when DropPath is on
+    # the attention branch sees it scaled per sample when DropPath is on, and masked where its projections were dropped:
+    #   gy   gradient of the branch output cat((xmm2, xmm_v, xmm_a)) AFTER the dropouts (what the pairs' gradients add to),
+    #   g1b  the same through the masks = gradient of the three projections' outputs (only proj's rows are read from it)
     gy = g1
+    keep_rows = t.get('keep_rows')
     if dp is not None:
         gy = _e((B, nF, D), F32, dev)
-        ops.rows_axpy(torch.zeros_like(g1), g1, dp[0], B, nF, D, gy)
-        ops.rows_scale_cast(g1, dp[0], B, nF, D, g1b)
+        ops.dropout_rows(g1, None, 1.0, B, nF, D, gy, rowscale=dp[0])
+    if dp is not None or keep_rows is not None:
+        g1b = _branch_grad(g1, None if dp is None else dp[0], keep_rows, B, nF, D)
     # d(normed xmm) from the three projections of its row groups lands in one bf16 buffer
     dxmm_b = _e((B * nF, D), BF16, dev)
     # --- pair attention branch (rows [0, nmm)) ---
@@ -1271,7 +1357,7 @@ def _factorized_bwd_seq(fb, t, g, gb, *, dx_i=None, dx_a=None):
     dq2, dKp, dVp = _e((B * nmm, Da), BF16, dev), _e((B * P, Da), BF16, dev), _e((B * P, D), BF16, dev)
     attention_bwd((t['q2'], 0), (t['Kp'], 0), (t['Vp'], 0), t['o2'], do2, t['lse2'], (dq2, 0), (dKp, 0), (dVp, 0),
                   B, heads, nmm, P, Da // heads, D // heads, (D // heads) ** -0.5, nmm * Da, Da, P * Da, Da, P * D, D,
-                  nmm * Da, Da, P * Da, Da, P * D, D)
+                  nmm * Da, Da, P * Da, Da, P * D, D, keep=dr.get('attn'))
     lin_bwd(at.q, dq2, t['xmm_b'], B * nmm, a_rowmap=rm2, dx=dxmm_b, dx_rowmap=rm2)
     dkv_p, dka_p = _e((B * nv, Da), BF16, dev), _e((B * na, Da), BF16, dev)
     dvv_p, dva_p = _e((B * nv, D), BF16, dev), _e((B * na, D), BF16, dev)
@@ -1289,6 +1375,10 @@ def _factorized_bwd_seq(fb, t, g, gb, *, dx_i=None, dx_a=None):
     lin_bwd(at.k, dka_p, t['xao_b'], B * na, k=D, w_col_off=D, use_bias=False, dx=dxao, dx_beta=1)
     lin_bwd(at.v, dva_p, t['xao_b'], B * na, k=D, w_col_off=D, use_bias=False, dx=dxao, dx_beta=1, dx_C2=dxao_b, dx_c2_mode=3)
     # --- the two aggregation cross-attentions ---
+    if 'attn_v.proj' in dr:          # through CrossAttention.proj_drop (:58): everything that consumed its output is summed by now
+        _drop(dxvo_b, dr['attn_v.proj'], B, nv, D)
+    if 'attn_a.proj' in dr:
+        _drop(dxao_b, dr['attn_a.proj'], B, na, D)
     dov = lin_bwd(at.attn_v.proj, dxvo_b, t['cv']['o'], B * nv)
     doa = lin_bwd(at.attn_a.proj, dxao_b, t['ca']['o'], B * na)
     dxv_b = _cross_bwd_seq(at.attn_v, t['cv'], dov, t['xmm_b'], rmv, nv, t['xv_b'], nI, B, D, heads, dxmm_b, rmv)
@@ -1314,35 +1404,41 @@ def _factorized_bwd_seq(fb, t, g, gb, *, dx_i=None, dx_a=None):
 #   dense_mmi : norms in order; inside the attention pairs are (audio_i, image_j), p = i*nI + j, features [audio || image]
 # Both share the norm-then-residual form and the norm2 + MLP tail of the factorised block.
 # ------------------------------------------------------------------------------------------------
-def _alt_tail_fwd(fb, xmm1, B, nF, D, dev, dp=None):
+def _alt_tail_fwd(fb, xmm1, B, nF, D, dev, dp=None, dr=None):
+    dr = dr or {}
     h2, _, st2 = ln_fwd(fb.norm2, None, xmm1, B)
     Hd = fb.mlp.fc1.weight.shape[0]
     z = _e((B * nF, Hd), BF16, dev)
     u = lin_fwd(fb.mlp.fc1, h2, B * nF, act=1, out_bf16=True, C2=z, c2_mode=4)
-    out = _res_add(fb.mlp.fc2, u, B * nF, xmm1, B, nF, D, None if dp is None else dp[1]).view(B, nF, D)
-    return out, dict(h2=h2, st2=st2, z=z, u=u, xmm1=xmm1, dp=dp)
+    if 'fc1' in dr:
+        _drop(u, dr['fc1'], B, nF, Hd)
+    out = _res_add(fb.mlp.fc2, u, B * nF, xmm1, B, nF, D, None if dp is None else dp[1], drop=dr.get('fc2')).view(B, nF, D)
+    return out, dict(h2=h2, st2=st2, z=z, u=u, xmm1=xmm1, dp=dp, dr=dr or None)
 
 
 def _alt_tail_bwd(fb, tt, g, gb, B, nF, D, dev):
     """-> (g1 fp32 [B,nF,D], g1b bf16): gradient at xmm1 (the attention residual output); with DropPath g1b is the
     gradient of the attention BRANCH (scaled per sample), g1 stays the residual-path gradient."""
     dp = tt.get('dp')
-    if dp is not None:
-        gb = _e((B * nF, D), BF16, dev)
-        ops.rows_scale_cast(g, dp[1], B, nF, D, gb)
+    dr = tt.get('dr') or {}
+    if dp is not None or 'fc2' in dr:
+        gb = _branch_grad(g, None if dp is None else dp[1], dr.get('fc2'), B, nF, D)
     elif gb is None:
         gb = to_bf16(g)
     dz = lin_bwd(fb.mlp.fc2, gb, tt['u'], B * nF, gelu_aux=tt['z'])
+    if 'fc1' in dr:
+        _drop(dz, dr['fc1'], B, nF, dz.shape[1])
     dh2 = lin_bwd(fb.mlp.fc1, dz, tt['h2'], B * nF)
     g1 = _e((B, nF, D), F32, dev)
     g1b = _e((B * nF, D), BF16, dev)
     ln_bwd(fb.norm2, None, tt['xmm1'], B, tt['st2'], dy_bf16=dh2, dx1=g1, res1=g, dx1_bf16=g1b)
-    if dp is not None:
-        ops.rows_scale_cast(g1, dp[0], B, nF, D, g1b)
+    if dp is not None or 'proj' in dr:
+        g1b = _branch_grad(g1, None if dp is None else dp[0], dr.get('proj'), B, nF, D)
     return g1, g1b
 
 
-def _token_fwd(fb, x_f, x_2, x_3, heads, dp=None):
+def _token_fwd(fb, x_f, x_2, x_3, heads, dp=None, dr=None):
+    dr = dr or {}
     B, nF, D = x_f.shape
     n2, n3 = x_2.shape[1], x_3.shape[1]
     dev, at = x_f.device, fb.attn
@@ -1357,9 +1453,9 @@ def _token_fwd(fb, x_f, x_2, x_3, heads, dp=None):
     lin_fwd(at.kv, x2_b, B * n2, out=kv, c_rowmap=(n2, nS, n3))
     q = lin_fwd(at.q, xmm_b, B * nF, out_bf16=True)
     o, lse = attention_fwd((q, 0), (kv, 0), (kv, Da), B, heads, nF, nS, hd, hd, hd ** -0.5,
-                           nF * Da, Da, nS * 2 * Da, 2 * Da, nS * 2 * Da, 2 * Da, dev)
-    xmm1 = _res_add(at.proj, o, B * nF, xmm32, B, nF, D, None if dp is None else dp[0]).view(B, nF, D)
-    out, tt = _alt_tail_fwd(fb, xmm1, B, nF, D, dev, dp)
+                           nF * Da, Da, nS * 2 * Da, 2 * Da, nS * 2 * Da, 2 * Da, dev, keep=dr.get('attn'))
+    xmm1 = _res_add(at.proj, o, B * nF, xmm32, B, nF, D, None if dp is None else dp[0], drop=dr.get('proj')).view(B, nF, D)
+    out, tt = _alt_tail_fwd(fb, xmm1, B, nF, D, dev, dp, dr)
     tt.update(arch='token', x_f=x_f, x_2=x_2, x_3=x_3, xmm_b=xmm_b, st_mm=st_mm, x2_b=x2_b, st_2=st_2, x3_b=x3_b, st_3=st_3,
               kv=kv, q=q, o=o, lse=lse, heads=heads)
     return out, tt
@@ -1378,7 +1474,7 @@ def _token_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
     dq, dkv = _e((B * nF, Da), BF16, dev), _e((B * nS, 2 * Da), BF16, dev)
     attention_bwd((t['q'], 0), (t['kv'], 0), (t['kv'], Da), t['o'], do, t['lse'], (dq, 0), (dkv, 0), (dkv, Da),
                   B, heads, nF, nS, hd, hd, hd ** -0.5, nF * Da, Da, nS * 2 * Da, 2 * Da, nS * 2 * Da, 2 * Da,
-                  nF * Da, Da, nS * 2 * Da, 2 * Da, nS * 2 * Da, 2 * Da)
+                  nF * Da, Da, nS * 2 * Da, 2 * Da, nS * 2 * Da, 2 * Da, keep=(t.get('dr') or {}).get('attn'))
     dxmm_b = lin_bwd(at.q, dq, t['xmm_b'], B * nF)
     dx3_b = lin_bwd(at.kv, dkv, t['x3_b'], B * n3, dy_rowmap=(n3, nS, 0), final=False)
     dx2_b = lin_bwd(at.kv, dkv, t['x2_b'], B * n2, dy_rowmap=(n2, nS, n3))
@@ -1394,7 +1490,8 @@ def _token_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
     return dx_f, dx_i, dx_a
 
 
-def _dense_fwd(fb, x_f, x_i, x_a, heads, dp=None):
+def _dense_fwd(fb, x_f, x_i, x_a, heads, dp=None, dr=None):
+    dr = dr or {}
     B, nF, D = x_f.shape
     nI, nA = x_i.shape[1], x_a.shape[1]
     dev, at = x_f.device, fb.attn
@@ -1413,9 +1510,9 @@ def _dense_fwd(fb, x_f, x_i, x_a, heads, dp=None):
     q = lin_fwd(at.q, xmm_b, B * nF, out_bf16=True)
     scale = (D // heads) ** -0.5                                  # from the FULL dim (:157-158)
     o, lse = attention_fwd((q, 0), (KV, 0), (KV, Da), B, heads, nF, P, hd, hd, scale,
-                           nF * Da, Da, P * 2 * Da, 2 * Da, P * 2 * Da, 2 * Da, dev)
-    xmm1 = _res_add(at.proj, o, B * nF, xmm32, B, nF, D, None if dp is None else dp[0]).view(B, nF, D)
-    out, tt = _alt_tail_fwd(fb, xmm1, B, nF, D, dev, dp)
+                           nF * Da, Da, P * 2 * Da, 2 * Da, P * 2 * Da, 2 * Da, dev, keep=dr.get('attn'))
+    xmm1 = _res_add(at.proj, o, B * nF, xmm32, B, nF, D, None if dp is None else dp[0], drop=dr.get('proj')).view(B, nF, D)
+    out, tt = _alt_tail_fwd(fb, xmm1, B, nF, D, dev, dp, dr)
     tt.update(arch='dense_mmi', x_f=x_f, x_i=x_i, x_a=x_a, xmm_b=xmm_b, st_mm=st_mm, xi_b=xi_b, st_i=st_i, xa_b=xa_b, st_a=st_a,
               KV=KV, q=q, o=o, lse=lse, heads=heads)
     return out, tt
@@ -1435,7 +1532,7 @@ def _dense_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
     scale = (D // heads) ** -0.5
     attention_bwd((t['q'], 0), (t['KV'], 0), (t['KV'], Da), t['o'], do, t['lse'], (dq, 0), (dKV, 0), (dKV, Da),
                   B, heads, nF, P, hd, hd, scale, nF * Da, Da, P * 2 * Da, 2 * Da, P * 2 * Da, 2 * Da,
-                  nF * Da, Da, P * 2 * Da, 2 * Da, P * 2 * Da, 2 * Da)
+                  nF * Da, Da, P * 2 * Da, 2 * Da, P * 2 * Da, 2 * Da, keep=(t.get('dr') or {}).get('attn'))
     dxmm_b = lin_bwd(at.q, dq, t['xmm_b'], B * nF)
     dpa, dpi = _e((B * nA, 2 * Da), BF16, dev), _e((B * nI, 2 * Da), BF16, dev)
     ops.pair_reduce(dKV, B, nA, nI, 2 * Da, dpa, dpi)
@@ -1459,21 +1556,21 @@ def _dense_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):
 FUSION_IDLE_FWD, FUSION_IDLE_BWD = 4, 6
 
 
-def fusion_block_batchable(fb, dp=None):
+def fusion_block_batchable(fb, dp=None, dr=None):
     """True when the block's forward / backward consist of library launches only, i.e. may run as a lane of a launch batch
-    (the factorised block without DropPath; the token / dense blocks and DropPath use torch ops between kernels)."""
-    return dp is None and getattr(fb, 'arch', 'factorized_mmi') == 'factorized_mmi'
+    (the factorised block without DropPath / dropout; the token / dense blocks, DropPath and dropout use torch ops between kernels)."""
+    return dp is None and not dr and getattr(fb, 'arch', 'factorized_mmi') == 'factorized_mmi'
 
 
-def fusion_block_fwd(fb, x_f, x_i, x_a, heads, tkns, dp=None):
+def fusion_block_fwd(fb, x_f, x_i, x_a, heads, tkns, dp=None, dr=None):
     """Dispatch on the block's architecture (models/deepavfusion.py:28-35); x_i / x_a = the 2nd / 3rd positional
     argument of the reference call ``blk_fusion(x_fusion, x_image, x_audio)``."""
     arch = getattr(fb, 'arch', 'factorized_mmi')
     if arch == 'token':
-        return _token_fwd(fb, x_f, x_i, x_a, heads, dp)
+        return _token_fwd(fb, x_f, x_i, x_a, heads, dp, dr)
     if arch == 'dense_mmi':
-        return _dense_fwd(fb, x_f, x_i, x_a, heads, dp)
-    return _factorized_fwd(fb, x_f, x_i, x_a, heads, tkns, dp)
+        return _dense_fwd(fb, x_f, x_i, x_a, heads, dp, dr)
+    return _factorized_fwd(fb, x_f, x_i, x_a, heads, tkns, dp, dr)
 
 
 def fusion_block_bwd(fb, t, g, gb, *, dx_i=None, dx_a=None):

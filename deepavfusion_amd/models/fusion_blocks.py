@@ -3,7 +3,7 @@
 interactions (:154-213)."""
 import torch.nn as nn
 
-from .vits import Mlp
+from .vits import Mlp, _prob
 
 
 class CrossAttention(nn.Module):
@@ -15,6 +15,7 @@ class CrossAttention(nn.Module):
         self.q = nn.Linear(dim, dim, bias=qkv_bias)
         self.kv = nn.Linear(dim, dim * 2, bias=qkv_bias)
         self.proj = nn.Linear(dim, dim)
+        self.attn_drop_prob, self.proj_drop_prob = _prob(attn_drop), _prob(proj_drop)     # nn.Dropout at :42,44 (training mode only)
 
     def forward(self, x1, x2):
         """-> (x1', attn) as models/fusion_blocks.py:46-59; attn [B, heads, N1, N2] is returned detached."""
@@ -31,8 +32,8 @@ class CrossAttention_FactorizedAVInteractions(nn.Module):
         self.scale = (dim // num_heads) ** -0.5
         self.dim = int(dim * dim_ratio)
         self.fusion_tkns = tuple(fusion_tkns)
-        self.attn_v = CrossAttention(dim, num_heads=num_heads, qkv_bias=qkv_bias)
-        self.attn_a = CrossAttention(dim, num_heads=num_heads, qkv_bias=qkv_bias)
+        self.attn_v = CrossAttention(dim, num_heads=num_heads, qkv_bias=qkv_bias, attn_drop=attn_drop, proj_drop=proj_drop)
+        self.attn_a = CrossAttention(dim, num_heads=num_heads, qkv_bias=qkv_bias, attn_drop=attn_drop, proj_drop=proj_drop)
         self.q = nn.Linear(dim, self.dim, bias=qkv_bias)
         self.k = nn.Linear(dim * 2, self.dim, bias=qkv_bias)
         self.v = nn.Linear(dim * 2, dim, bias=qkv_bias)
@@ -45,15 +46,15 @@ class FusionBlock_FactorizedAVInteractions(nn.Module):
     def __init__(self, dim, num_heads, attn_ratio=0.25, mlp_ratio=4., qkv_bias=False, fusion_tkns=(8, 4, 4), drop=0.,
                  attn_drop=0., drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm):
         super().__init__()
-        if drop or attn_drop:
-            raise NotImplementedError('attention / projection dropout is not on the gfx950 path (drop_path is)')
+        # nn.Dropout(attn_drop) on every softmax of the block, nn.Dropout(drop) behind every proj and inside the Mlp (:225-233, :278)
+        self.attn_drop_prob, self.proj_drop_prob = _prob(attn_drop), _prob(drop)
         self.drop_path_prob = float(drop_path)        # one DropPath module called on both branches (models/fusion_blocks.py:278)
         self.num_heads, self.fusion_tkns = num_heads, tuple(fusion_tkns)
         self.norm1_mm = norm_layer(dim)
         self.norm1_aud = norm_layer(dim)
         self.norm1_img = norm_layer(dim)
-        self.attn = CrossAttention_FactorizedAVInteractions(dim, num_heads=num_heads, qkv_bias=qkv_bias, dim_ratio=attn_ratio,
-                                                            fusion_tkns=fusion_tkns)
+        self.attn = CrossAttention_FactorizedAVInteractions(dim, num_heads=num_heads, qkv_bias=qkv_bias, attn_drop=attn_drop,
+                                                            proj_drop=drop, dim_ratio=attn_ratio, fusion_tkns=fusion_tkns)
         self.norm2 = norm_layer(dim)
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
 
@@ -95,8 +96,7 @@ class _FusionBlockAlt(nn.Module):
     def __init__(self, dim, num_heads, attn_ratio=0.25, mlp_ratio=4., qkv_bias=False, drop=0., attn_drop=0., drop_path=0.,
                  act_layer=nn.GELU, norm_layer=nn.LayerNorm):
         super().__init__()
-        if drop or attn_drop:
-            raise NotImplementedError('attention / projection dropout is not on the gfx950 path (drop_path is)')
+        self.attn_drop_prob, self.proj_drop_prob = _prob(attn_drop), _prob(drop)      # models/fusion_blocks.py:99,101,133 / :164,166,202
         self.drop_path_prob = float(drop_path)
         self.num_heads = num_heads
         self.norm1_mm = norm_layer(dim)

@@ -54,13 +54,22 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden_features, in_features)
 
 
+def _prob(p):
+    """A dropout probability as nn.Dropout accepts it, short of 1 (the kept values are scaled by 1 / (1 - p))."""
+    p = float(p)
+    if not 0.0 <= p < 1.0:
+        raise ValueError(f'dropout probability has to be in [0, 1), got {p}')
+    return p
+
+
 class Block(nn.Module):
     """Parameter holder of timm's pre-LN Block (no LayerScale; DropPath on both residual branches when drop_path > 0)."""
     def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=True, norm_layer=nn.LayerNorm, drop_path=0., attn_drop=0.,
                  proj_drop=0.):
         super().__init__()
-        if attn_drop or proj_drop:
-            raise NotImplementedError('attention / projection dropout is not on the gfx950 path (drop_path is)')
+        # timm Block: Attention(attn_drop, proj_drop) and Mlp(drop=proj_drop) — nn.Dropout on the softmax probabilities, behind
+        # proj, behind GELU and behind fc2; active in training mode only (every pre-training config has 0)
+        self.attn_drop_prob, self.proj_drop_prob = _prob(attn_drop), _prob(proj_drop)
         self.num_heads = num_heads
         self.drop_path_prob = float(drop_path)        # timm DropPath on both residual branches (training mode only)
         self.norm1 = norm_layer(dim)

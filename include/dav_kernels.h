@@ -182,8 +182,8 @@ int dav_attn_bias_bwd(const void* Q, const void* K, const void* V, const void* O
  * models/fusion_blocks.py:14,25,42,54,99,112,164,181,231,256 — the fine-tuning constructors' attn_drop > 0; every pre-training
  * config has 0): O = (P .* keep * keep_scale) V with P the full softmax (LSE unchanged).  keep: bytes 0 / 1,
  * [B][H][Nq][keep_ld], keep_ld >= Nk rounded up to 32 and a multiple of 4, 4-byte aligned; keep_scale = 1 / (1 - p).  The draw
- * itself is the caller's (torch's generator): the kernels are deterministic in the mask.  Kernels of their own (head widths
- * 64/64, 32/32, 16/64): the pre-training kernels carry no dropout code.  Backward: dP = keep * keep_scale * (dO V^T),
+ * itself is the caller's (torch's generator): the kernels are deterministic in the mask.  Kernels of their own (the head widths
+ * of dav_attn_fwd): the pre-training kernels carry no dropout code.  Backward: dP = keep * keep_scale * (dO V^T),
  * Delta = dO . O as without dropout; dq_ctx_rows as dav_attn_bwd_ctx, part as dav_attn_bwd_part. */
 int dav_attn_drop_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int Nq, int Nk, int dqk,
                       int dv, long q_bs, int q_rs, long k_bs, int k_rs, long v_bs, int v_rs, long o_bs, int o_rs, float scale,

@@ -177,12 +177,25 @@ def layer_norm(x: Tensor, sd: Dict[str, Tensor], name: str, eps: float) -> Tenso
     return F.layer_norm(x, (x.shape[-1],), sd[name + '.weight'], sd[name + '.bias'], eps)
 
 
-def softmax_attention(q: Tensor, k: Tensor, v: Tensor, scale: float) -> Tensor:
+def dropout_keep_mask(seed: int, name: str, shape, p: float) -> np.ndarray:
+    """Closed-form 0 / 1 keep mask of the nn.Dropout called ``name`` (fixtures and tests regenerate it instead of storing it)."""
+    import zlib
+    rs = np.random.RandomState((seed * 1000003 + zlib.crc32(name.encode())) & 0x7fffffff)
+    return (rs.uniform(size=tuple(shape)) >= p).astype(np.float32)
+
+
+def _do(dm, site: str, x: Tensor) -> Tensor:
+    """nn.Dropout in training mode with the draw made elsewhere: ``dm(site, x)`` returns keep_mask * x / (1 - p) for the Dropout
+    module called ``site`` of the current block ('attn', 'proj', 'fc1', 'fc2', 'attn_v.attn', ...); None = eval mode / p = 0."""
+    return x if dm is None else dm(site, x)
+
+
+def softmax_attention(q: Tensor, k: Tensor, v: Tensor, scale: float, dm=None, site: str = 'attn') -> Tensor:
     """q [B,H,Nq,dqk], k [B,H,Nk,dqk], v [B,H,Nk,dv] -> [B,H,Nq,dv].
     Explicit form of F.scaled_dot_product_attention / the reference's
-    ``(q @ k.T) * scale -> softmax -> @ v`` (models/fusion_blocks.py:52-56)."""
+    ``(q @ k.T) * scale -> softmax -> attn_drop -> @ v`` (models/fusion_blocks.py:52-56)."""
     attn = (q @ k.transpose(-2, -1)) * scale
-    attn = attn.softmax(dim=-1)
+    attn = _do(dm, site, attn.softmax(dim=-1))
     return attn @ v
 
 
@@ -197,17 +210,19 @@ def patch_embed(x: Tensor, sd: Dict[str, Tensor], name: str, patch: int) -> Tens
     return cols @ w.t() + sd[name + '.proj.bias']
 
 
-def timm_attention(x: Tensor, sd, name: str, heads: int) -> Tensor:
+def timm_attention(x: Tensor, sd, name: str, heads: int, dm=None) -> Tensor:
+    """timm 0.9.2 Attention.forward (attn_drop on the probabilities, proj_drop behind proj)."""
     B, N, C = x.shape
     hd = C // heads
     qkv = linear(x, sd, name + '.qkv').reshape(B, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
-    o = softmax_attention(qkv[0], qkv[1], qkv[2], hd ** -0.5)
+    o = softmax_attention(qkv[0], qkv[1], qkv[2], hd ** -0.5, dm)
     o = o.transpose(1, 2).reshape(B, N, C)
-    return linear(o, sd, name + '.proj')
+    return _do(dm, 'proj', linear(o, sd, name + '.proj'))
 
 
-def timm_mlp(x: Tensor, sd, name: str) -> Tensor:
-    return linear(F.gelu(linear(x, sd, name + '.fc1')), sd, name + '.fc2')   # exact erf GELU
+def timm_mlp(x: Tensor, sd, name: str, dm=None) -> Tensor:
+    """timm Mlp: fc1 -> GELU -> drop1 -> fc2 -> drop2."""
+    return _do(dm, 'fc2', linear(_do(dm, 'fc1', F.gelu(linear(x, sd, name + '.fc1'))), sd, name + '.fc2'))   # exact erf GELU
 
 
 def _dp(branch: Tensor, s: Optional[Tensor]) -> Tensor:
@@ -215,10 +230,11 @@ def _dp(branch: Tensor, s: Optional[Tensor]) -> Tensor:
     return branch if s is None else branch * s.view(-1, *([1] * (branch.ndim - 1)))
 
 
-def timm_block(x: Tensor, sd, name: str, heads: int, eps: float, dp=None) -> Tensor:
-    """Pre-LN block, no LayerScale; ``dp`` = (s_attn, s_mlp) DropPath scales of drop_path1 / drop_path2 (fine-tuning)."""
-    x = x + _dp(timm_attention(layer_norm(x, sd, name + '.norm1', eps), sd, name + '.attn', heads), None if dp is None else dp[0])
-    x = x + _dp(timm_mlp(layer_norm(x, sd, name + '.norm2', eps), sd, name + '.mlp'), None if dp is None else dp[1])
+def timm_block(x: Tensor, sd, name: str, heads: int, eps: float, dp=None, dm=None) -> Tensor:
+    """Pre-LN block, no LayerScale; ``dp`` = (s_attn, s_mlp) DropPath scales of drop_path1 / drop_path2 (fine-tuning);
+    ``dm``: the block's dropout, see _do."""
+    x = x + _dp(timm_attention(layer_norm(x, sd, name + '.norm1', eps), sd, name + '.attn', heads, dm), None if dp is None else dp[0])
+    x = x + _dp(timm_mlp(layer_norm(x, sd, name + '.norm2', eps), sd, name + '.mlp', dm), None if dp is None else dp[1])
     return x
 
 
@@ -256,19 +272,19 @@ def video_prepare_patch_tokens(x: Tensor, sd, name: str, patch: Tuple[int, int, 
 # --------------------------------------------------------------------------- #
 # models/fusion_blocks.py
 # --------------------------------------------------------------------------- #
-def cross_attention(x1: Tensor, x2: Tensor, sd, name: str, heads: int) -> Tensor:
+def cross_attention(x1: Tensor, x2: Tensor, sd, name: str, heads: int, dm=None, site: str = '') -> Tensor:
     """models/fusion_blocks.py:46-59."""
     B, N1, C = x1.shape
     N2 = x2.shape[1]
     hd = C // heads
     q = linear(x1, sd, name + '.q').reshape(B, N1, heads, hd).permute(0, 2, 1, 3)
     kv = linear(x2, sd, name + '.kv').reshape(B, N2, 2, heads, hd).permute(2, 0, 3, 1, 4)
-    o = softmax_attention(q, kv[0], kv[1], hd ** -0.5)
-    return linear(o.transpose(1, 2).reshape(B, N1, C), sd, name + '.proj')
+    o = softmax_attention(q, kv[0], kv[1], hd ** -0.5, dm, site + 'attn')
+    return _do(dm, site + 'proj', linear(o.transpose(1, 2).reshape(B, N1, C), sd, name + '.proj'))
 
 
 def factorized_attention(xmm: Tensor, xv: Tensor, xa: Tensor, sd, name: str, heads: int,
-                         tkns: Sequence[int]) -> Tensor:
+                         tkns: Sequence[int], dm=None) -> Tensor:
     """models/fusion_blocks.py:235-263.
 
     Pair p = i*na + j carries features [xmm_v[i] || xmm_a[j]] (:245-248); the
@@ -277,31 +293,31 @@ def factorized_attention(xmm: Tensor, xv: Tensor, xa: Tensor, sd, name: str, hea
     B, _, C = xmm.shape
     nmm, nv, na = tkns
     x2, x_v, x_a = xmm.split((nmm, nv, na), dim=1)
-    x_v = cross_attention(x_v, xv, sd, name + '.attn_v', heads)
-    x_a = cross_attention(x_a, xa, sd, name + '.attn_a', heads)
+    x_v = cross_attention(x_v, xv, sd, name + '.attn_v', heads, dm, 'attn_v.')
+    x_a = cross_attention(x_a, xa, sd, name + '.attn_a', heads, dm, 'attn_a.')
     pairs = torch.cat((x_v[:, :, None, :].expand(B, nv, na, C),
                        x_a[:, None, :, :].expand(B, nv, na, C)), dim=3).reshape(B, nv * na, 2 * C)
     q = linear(x2, sd, name + '.q').reshape(B, nmm, heads, -1).permute(0, 2, 1, 3)
     k = linear(pairs, sd, name + '.k').reshape(B, nv * na, heads, -1).permute(0, 2, 1, 3)
     v = linear(pairs, sd, name + '.v').reshape(B, nv * na, heads, -1).permute(0, 2, 1, 3)
-    o = softmax_attention(q, k, v, (C // heads) ** -0.5)
-    x2 = linear(o.transpose(1, 2).flatten(2), sd, name + '.proj')
+    o = softmax_attention(q, k, v, (C // heads) ** -0.5, dm)
+    x2 = _do(dm, 'proj', linear(o.transpose(1, 2).flatten(2), sd, name + '.proj'))
     return torch.cat((x2, x_v, x_a), dim=1)
 
 
 def fusion_block_factorized(xmm: Tensor, xv: Tensor, xa: Tensor, sd, name: str, heads: int,
-                            tkns: Sequence[int], eps: float, dp=None) -> Tensor:
+                            tkns: Sequence[int], eps: float, dp=None, dm=None) -> Tensor:
     """models/fusion_blocks.py:280-289 — norm-THEN-residual: the residual base
     is the normed xmm (:281-283)."""
     xmm = layer_norm(xmm, sd, name + '.norm1_mm', eps)
     xv = layer_norm(xv, sd, name + '.norm1_img', eps)
     xa = layer_norm(xa, sd, name + '.norm1_aud', eps)
-    xmm = xmm + _dp(factorized_attention(xmm, xv, xa, sd, name + '.attn', heads, tkns), None if dp is None else dp[0])
-    xmm = xmm + _dp(timm_mlp(layer_norm(xmm, sd, name + '.norm2', eps), sd, name + '.mlp'), None if dp is None else dp[1])
+    xmm = xmm + _dp(factorized_attention(xmm, xv, xa, sd, name + '.attn', heads, tkns, dm), None if dp is None else dp[0])
+    xmm = xmm + _dp(timm_mlp(layer_norm(xmm, sd, name + '.norm2', eps), sd, name + '.mlp', dm), None if dp is None else dp[1])
     return xmm
 
 
-def local_av_attention(xmm: Tensor, xv: Tensor, xa: Tensor, sd, name: str, heads: int) -> Tensor:
+def local_av_attention(xmm: Tensor, xv: Tensor, xa: Tensor, sd, name: str, heads: int, dm=None) -> Tensor:
     """CrossAttention_LocalAVTokens.forward, models/fusion_blocks.py:103-117: fusion tokens attend to
     cat(xv, xa); q/k/v all of width Da = dim*dim_ratio, scale (Da/heads)^-0.5 (:93-95)."""
     B, nmm, _ = xmm.shape
@@ -310,11 +326,11 @@ def local_av_attention(xmm: Tensor, xv: Tensor, xa: Tensor, sd, name: str, heads
     src = torch.cat((xv, xa), dim=1)
     q = linear(xmm, sd, name + '.q').reshape(B, nmm, heads, hd).permute(0, 2, 1, 3)
     kv = linear(src, sd, name + '.kv').reshape(B, src.shape[1], 2, heads, hd).permute(2, 0, 3, 1, 4)
-    o = softmax_attention(q, kv[0], kv[1], hd ** -0.5)
-    return linear(o.transpose(1, 2).reshape(B, nmm, Da), sd, name + '.proj')
+    o = softmax_attention(q, kv[0], kv[1], hd ** -0.5, dm)
+    return _do(dm, 'proj', linear(o.transpose(1, 2).reshape(B, nmm, Da), sd, name + '.proj'))
 
 
-def fusion_block_token(x_f: Tensor, x_image: Tensor, x_audio: Tensor, sd, name: str, heads: int, eps: float, dp=None) -> Tensor:
+def fusion_block_token(x_f: Tensor, x_image: Tensor, x_audio: Tensor, sd, name: str, heads: int, eps: float, dp=None, dm=None) -> Tensor:
     """FusionBlock_LocalAVTokens, models/fusion_blocks.py:120-145, as CALLED by models/deepavfusion.py:106
     ``blk_fusion(x_fusion, x_image, x_audio)`` against the signature ``forward(self, xmm, xa, xv)`` (:135):
     xa := x_image, xv := x_audio, so norm1_img normalises the AUDIO tokens and norm1_aud the IMAGE tokens (:136),
@@ -322,11 +338,11 @@ def fusion_block_token(x_f: Tensor, x_image: Tensor, x_audio: Tensor, sd, name: 
     xmm = layer_norm(x_f, sd, name + '.norm1_mm', eps)
     xv = layer_norm(x_audio, sd, name + '.norm1_img', eps)
     xa = layer_norm(x_image, sd, name + '.norm1_aud', eps)
-    xmm = xmm + _dp(local_av_attention(xmm, xv, xa, sd, name + '.attn', heads), None if dp is None else dp[0])
-    return xmm + _dp(timm_mlp(layer_norm(xmm, sd, name + '.norm2', eps), sd, name + '.mlp'), None if dp is None else dp[1])
+    xmm = xmm + _dp(local_av_attention(xmm, xv, xa, sd, name + '.attn', heads, dm), None if dp is None else dp[0])
+    return xmm + _dp(timm_mlp(layer_norm(xmm, sd, name + '.norm2', eps), sd, name + '.mlp', dm), None if dp is None else dp[1])
 
 
-def dense_av_attention(xmm: Tensor, first: Tensor, second: Tensor, sd, name: str, heads: int) -> Tensor:
+def dense_av_attention(xmm: Tensor, first: Tensor, second: Tensor, sd, name: str, heads: int, dm=None) -> Tensor:
     """CrossAttention_DenseAVInteractions.forward(self, xmm, xa, xv), models/fusion_blocks.py:168-188, with
     ``first`` bound to its ``xa`` and ``second`` to its ``xv``: pairs p = i*na + j carry [xv[i] || xa[j]] =
     [second[i] || first[j]] (:171-174); k/v width Da, scale (dim/heads)^-0.5 from the FULL dim (:157-158)."""
@@ -338,11 +354,11 @@ def dense_av_attention(xmm: Tensor, first: Tensor, second: Tensor, sd, name: str
     pairs = pairs.reshape(B, nv * na, 2 * C)
     q = linear(xmm, sd, name + '.q').reshape(B, nmm, heads, hd).permute(0, 2, 1, 3)
     kv = linear(pairs, sd, name + '.kv').reshape(B, nv * na, 2, heads, hd).permute(2, 0, 3, 1, 4)
-    o = softmax_attention(q, kv[0], kv[1], (C // heads) ** -0.5)
-    return linear(o.transpose(1, 2).reshape(B, nmm, Da), sd, name + '.proj')
+    o = softmax_attention(q, kv[0], kv[1], (C // heads) ** -0.5, dm)
+    return _do(dm, 'proj', linear(o.transpose(1, 2).reshape(B, nmm, Da), sd, name + '.proj'))
 
 
-def fusion_block_dense(x_f: Tensor, x_image: Tensor, x_audio: Tensor, sd, name: str, heads: int, eps: float, dp=None) -> Tensor:
+def fusion_block_dense(x_f: Tensor, x_image: Tensor, x_audio: Tensor, sd, name: str, heads: int, eps: float, dp=None, dm=None) -> Tensor:
     """FusionBlock_DenseAVInteractions, models/fusion_blocks.py:191-213: forward(xmm, xv, xa) takes the call of
     models/deepavfusion.py:106 in order, but passes ``self.attn(xmm, xv, xa)`` (:206) to a forward declared
     ``(xmm, xa, xv)`` (:168) — inside the attention the image tokens play "xa" and the audio tokens "xv", i.e.
@@ -350,14 +366,14 @@ def fusion_block_dense(x_f: Tensor, x_image: Tensor, x_audio: Tensor, sd, name: 
     xmm = layer_norm(x_f, sd, name + '.norm1_mm', eps)
     xv = layer_norm(x_image, sd, name + '.norm1_img', eps)
     xa = layer_norm(x_audio, sd, name + '.norm1_aud', eps)
-    xmm = xmm + _dp(dense_av_attention(xmm, xv, xa, sd, name + '.attn', heads), None if dp is None else dp[0])
-    return xmm + _dp(timm_mlp(layer_norm(xmm, sd, name + '.norm2', eps), sd, name + '.mlp'), None if dp is None else dp[1])
+    xmm = xmm + _dp(dense_av_attention(xmm, xv, xa, sd, name + '.attn', heads, dm), None if dp is None else dp[0])
+    return xmm + _dp(timm_mlp(layer_norm(xmm, sd, name + '.norm2', eps), sd, name + '.mlp', dm), None if dp is None else dp[1])
 
 
 # --------------------------------------------------------------------------- #
 # models/deepavfusion.py
 # --------------------------------------------------------------------------- #
-def _early_fusion_layers(sd, cfg, x_v: Tensor, x_a: Tensor, prefix: str, vis: str, return_embs: bool, drop=None):
+def _early_fusion_layers(sd, cfg, x_v: Tensor, x_a: Tensor, prefix: str, vis: str, return_embs: bool, drop=None, dropout=None):
     """The layer loop shared by models/deepavfusion.py:96-118 and models/video_earlyfusion.py:107-131
     (``vis`` = 'image' / 'video'; the video Block in 'joint_all' mode is the timm pre-LN block,
     models/video_vits.py:46-47,94)."""
@@ -366,23 +382,25 @@ def _early_fusion_layers(sd, cfg, x_v: Tensor, x_a: Tensor, prefix: str, vis: st
     nF = x_f.shape[1]
     embs = []
     dpo = (lambda tag: None) if drop is None else (lambda tag: drop.get(tag))     # drop: {'visual.l' | 'audio.l' | 'fusion.l': (s_attn, s_mlp)}
+    # dropout(name, x) -> keep * x / (1 - p) for the nn.Dropout called name = '<visual|audio|fusion>.<l>.<site>' (training mode, attn_drop / drop > 0)
+    dmo = (lambda tag: None) if dropout is None else (lambda tag: (lambda site, x: dropout(f'{tag}.{site}', x)))
     for l in range(cfg.depth):
         if l not in cfg.fusion_layers:
-            x_v = timm_block(x_v, sd, f'{prefix}{vis}.blocks.{l}', cfg.num_heads, cfg.enc_eps, dpo(f'visual.{l}'))
-            x_a = timm_block(x_a, sd, f'{prefix}audio.blocks.{l}', cfg.num_heads, cfg.enc_eps, dpo(f'audio.{l}'))
+            x_v = timm_block(x_v, sd, f'{prefix}{vis}.blocks.{l}', cfg.num_heads, cfg.enc_eps, dpo(f'visual.{l}'), dmo(f'visual.{l}'))
+            x_a = timm_block(x_a, sd, f'{prefix}audio.blocks.{l}', cfg.num_heads, cfg.enc_eps, dpo(f'audio.{l}'), dmo(f'audio.{l}'))
         else:
             # fusion tokens are context rows whose own outputs are dropped (:104-105);
             # the fusion block reads the layer's INPUT x_v / x_a (:106-107)
-            n_v = timm_block(torch.cat((x_f, x_v), 1), sd, f'{prefix}{vis}.blocks.{l}', cfg.num_heads, cfg.enc_eps, dpo(f'visual.{l}'))[:, nF:]
-            n_a = timm_block(torch.cat((x_f, x_a), 1), sd, f'{prefix}audio.blocks.{l}', cfg.num_heads, cfg.enc_eps, dpo(f'audio.{l}'))[:, nF:]
+            n_v = timm_block(torch.cat((x_f, x_v), 1), sd, f'{prefix}{vis}.blocks.{l}', cfg.num_heads, cfg.enc_eps, dpo(f'visual.{l}'), dmo(f'visual.{l}'))[:, nF:]
+            n_a = timm_block(torch.cat((x_f, x_a), 1), sd, f'{prefix}audio.blocks.{l}', cfg.num_heads, cfg.enc_eps, dpo(f'audio.{l}'), dmo(f'audio.{l}'))[:, nF:]
             arch = getattr(cfg, 'fusion_arch', 'factorized_mmi')
             if arch == 'token':
-                x_f = fusion_block_token(x_f, x_v, x_a, sd, f'{prefix}fusion_blocks.{l}', cfg.fusion_num_heads, cfg.fus_eps, dpo(f'fusion.{l}'))
+                x_f = fusion_block_token(x_f, x_v, x_a, sd, f'{prefix}fusion_blocks.{l}', cfg.fusion_num_heads, cfg.fus_eps, dpo(f'fusion.{l}'), dmo(f'fusion.{l}'))
             elif arch == 'dense_mmi':
-                x_f = fusion_block_dense(x_f, x_v, x_a, sd, f'{prefix}fusion_blocks.{l}', cfg.fusion_num_heads, cfg.fus_eps, dpo(f'fusion.{l}'))
+                x_f = fusion_block_dense(x_f, x_v, x_a, sd, f'{prefix}fusion_blocks.{l}', cfg.fusion_num_heads, cfg.fus_eps, dpo(f'fusion.{l}'), dmo(f'fusion.{l}'))
             else:
                 x_f = fusion_block_factorized(x_f, x_v, x_a, sd, f'{prefix}fusion_blocks.{l}', cfg.fusion_num_heads,
-                                              cfg.fusion_tkns, cfg.fus_eps, dpo(f'fusion.{l}'))
+                                              cfg.fusion_tkns, cfg.fus_eps, dpo(f'fusion.{l}'), dmo(f'fusion.{l}'))
             x_v, x_a = n_v, n_a
         if return_embs:
             embs.append((x_v, x_a, x_f))
@@ -396,12 +414,12 @@ def _early_fusion_layers(sd, cfg, x_v: Tensor, x_a: Tensor, prefix: str, vis: st
 
 def deepavfusion_forward(sd, cfg: PathConfig, image: Tensor, audio: Tensor,
                          image_ids_keep: Optional[Tensor] = None, audio_ids_keep: Optional[Tensor] = None,
-                         prefix: str = '', return_embs: bool = False, drop=None):
-    """models/deepavfusion.py:88-118.  ``drop``: DropPath scales per block (training with drop_path > 0), see
-    _early_fusion_layers."""
+                         prefix: str = '', return_embs: bool = False, drop=None, dropout=None):
+    """models/deepavfusion.py:88-118.  ``drop``: DropPath scales per block (training with drop_path > 0), ``dropout``: the
+    nn.Dropout modules' draws (training with attn_drop / drop > 0), see _early_fusion_layers."""
     x_i = prepare_patch_tokens(image, sd, prefix + 'image', cfg.patch, image_ids_keep)
     x_a = prepare_patch_tokens(audio, sd, prefix + 'audio', cfg.patch, audio_ids_keep)
-    return _early_fusion_layers(sd, cfg, x_i, x_a, prefix, 'image', return_embs, drop)
+    return _early_fusion_layers(sd, cfg, x_i, x_a, prefix, 'image', return_embs, drop, dropout)
 
 
 def video_earlyfusion_forward(sd, cfg: VideoConfig, video: Tensor, audio: Tensor,

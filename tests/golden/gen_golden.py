@@ -17,6 +17,7 @@ from functools import partial
 
 import numpy as np
 import torch
+import torch.nn.functional as F_torch
 from torch import nn
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -489,6 +490,81 @@ def gen_droppath(B=4, seed=41, p=0.25):
     print(f'droppath loss_probe={float(loss):.6f}, kept {masks.mean():.2f}')
 
 
+def dropout_site_names(cfg, arch):
+    """The nn.Dropout modules of a DeepAVFusion forward in CALL order (models/deepavfusion.py:96-107: image block, audio block,
+    fusion block per layer), named as the oracle / the engine name them."""
+    names = []
+    for l in range(cfg.depth):
+        for t in ('visual', 'audio'):
+            names += [f'{t}.{l}.{s}' for s in ('attn', 'proj', 'fc1', 'fc2')]
+        if arch == 'factorized_mmi':
+            names += [f'fusion.{l}.{s}' for s in ('attn_v.attn', 'attn_v.proj', 'attn_a.attn', 'attn_a.proj', 'attn', 'proj', 'fc1', 'fc2')]
+        else:
+            names += [f'fusion.{l}.{s}' for s in ('attn', 'proj', 'fc1', 'fc2')]
+    return names
+
+
+def gen_dropout(name='micro', B=3, seed=61, p_attn=0.2, p_proj=0.1, p_path=0.0):
+    """DeepAVFusion in TRAINING mode with attn_drop / drop > 0 (the constructor surface of eval_finetune.py:170-171; every
+    shipped config sets 0): every nn.Dropout draw is replaced, in call order, by the closed-form mask
+    oracle.dropout_keep_mask(seed, name, shape, p) — the fixture stores seed and probabilities, not the masks."""
+    from timm.models.vision_transformer import Attention as TimmAttention
+    cfg = CONFIGS[name]
+    arch = cfg.fusion_arch
+    TimmAttention.fused_attn = False
+    try:
+        enc = DeepAVFusion(image_arch=ARCH_OF[name], image_pretrained='', image_size=cfg.image_size,
+                           audio_arch=ARCH_OF[name], audio_pretrained='', audio_size=cfg.audio_size,
+                           fusion_arch=arch, fusion_layers='all', num_fusion_tkns=cfg.fusion_tkns,
+                           fusion_mlp_ratio=cfg.fusion_mlp_ratio, fusion_attn_ratio=cfg.fusion_attn_ratio,
+                           fusion_num_heads=cfg.fusion_num_heads, attn_drop=p_attn, drop=p_proj, drop_path=p_path)
+        sd = {k[len('encoder.'):]: v for k, v in O.closed_form_state(cfg, seed=0).items() if k.startswith('encoder.')}
+        enc.load_state_dict(sd, strict=True)
+        enc.train()
+        image, audio, ni, na = O.synthetic_batch(cfg, B, seed=seed)
+        ik = torch.from_numpy(O.random_masking_from_noise(ni, cfg.image_mask_ratio)[0])
+        ak = torch.from_numpy(O.random_masking_from_noise(na, cfg.audio_mask_ratio)[0])
+        names = dropout_site_names(cfg, arch)
+        calls, shapes = [0], []
+        real = F_torch.dropout
+
+        def fake(x, p=0.5, training=True, inplace=False):
+            assert training and p in (p_attn, p_proj), (p, training)
+            nm = names[calls[0]]
+            assert p == (p_attn if nm.endswith('attn') else p_proj), (nm, p)
+            calls[0] += 1
+            shapes.append(list(x.shape))
+            m = torch.from_numpy(O.dropout_keep_mask(seed, nm, x.shape, p))
+            return x * m / (1.0 - p)
+        F_torch.dropout = fake
+        try:
+            xi, xa, xf = enc(image, audio, ik, ak)
+        finally:
+            F_torch.dropout = real
+    finally:
+        TimmAttention.fused_attn = True
+    assert calls[0] == len(names), (calls[0], len(names))
+    w = probe_weights([xi.shape, xa.shape, xf.shape], seed + 1)
+    loss = (xi * w[0]).sum() + (xa * w[1]).sum() + (xf * w[2]).sum()
+    loss.backward()
+    out = {'B': np.int64(B), 'seed': np.int64(seed), 'p_attn': np.float64(p_attn), 'p_proj': np.float64(p_proj),
+           'site_names': np.array(names), 'site_shapes': np.array([s + [0] * (4 - len(s)) for s in shapes], dtype=np.int64),
+           'x_image': xi.detach().numpy(), 'x_audio': xa.detach().numpy(), 'x_fusion': xf.detach().numpy(),
+           'loss_probe': np.float64(loss.item())}
+    gn, norms = [], []
+    for n, q in enc.named_parameters():
+        if q.grad is not None:
+            gn.append(n)
+            norms.append(float(q.grad.double().norm()))
+    out['grad_names'] = np.array(gn)
+    out['grad_norms'] = np.array(norms, dtype=np.float64)
+    for n in ('fusion_tokens', 'image.blocks.0.mlp.fc1.weight', 'audio.blocks.1.attn.qkv.weight', 'fusion_blocks.0.attn.q.weight',
+              'fusion_blocks.1.mlp.fc2.bias'):
+        out['grad.' + n] = dict(enc.named_parameters())[n].grad.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, f'dropout_{name}.npz'), **out)
+    print(f'dropout[{name}] loss_probe={float(loss):.6f} over {len(names)} Dropout calls')
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--curve', action='store_true')
@@ -502,6 +578,8 @@ if __name__ == '__main__':
             'lr': gen_lr_and_groups, 'trainer': gen_trainer_steps,
             'video_micro': lambda: gen_video('video_micro', 2, 31),
             'droppath': gen_droppath,
+            'dropout_micro': lambda: gen_dropout('micro'), 'dropout_micro_token': lambda: gen_dropout('micro_token', seed=62),
+            'dropout_micro_dense': lambda: gen_dropout('micro_dense', seed=63),
             'e2e_micro_token': lambda: gen_e2e('micro_token', 3, 23, False),
             'e2e_micro_dense': lambda: gen_e2e('micro_dense', 3, 24, False),
             'e2e_micro_swin': lambda: gen_e2e('micro_swin', 2, 25, True),

@@ -27,7 +27,12 @@ class Attention(nn.Module):
         qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4)
         q, k, v = qkv.unbind(0)
         q, k = self.q_norm(q), self.k_norm(k)
-        x = F.scaled_dot_product_attention(q, k, v, dropout_p=self.attn_drop.p if self.training else 0.)
+        if self.fused_attn:
+            x = F.scaled_dot_product_attention(q, k, v, dropout_p=self.attn_drop.p if self.training else 0.)
+        else:       # timm 0.9.2 with TIMM_FUSED_ATTN=0: the explicit form, attn_drop as a module call (lets a fixture inject its mask)
+            attn = (q * self.scale) @ k.transpose(-2, -1)
+            attn = self.attn_drop(attn.softmax(dim=-1))
+            x = attn @ v
         x = x.transpose(1, 2).reshape(B, N, C)
         return self.proj_drop(self.proj(x))
 

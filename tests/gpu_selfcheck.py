@@ -415,6 +415,7 @@ def dropout():
     for (B, H, Nq, Nk, dqk, dv, off, pdrop) in [(2, 3, 49, 81, 64, 64, 32, 0.1), (3, 2, 8, 49, 64, 64, 0, 0.5), (2, 16, 228, 228, 32, 32, 0, 0.1),
                                                (2, 12, 16, 64, 16, 64, 0, 0.2), (3, 2, 4, 6, 16, 64, 0, 0.3), (1, 1, 1, 1, 32, 32, 0, 0.5),
                                                (2, 12, 63, 95, 64, 64, 32, 0.1), (2, 2, 204, 204, 64, 64, 0, 0.1),
+                                               (2, 12, 32, 112, 16, 16, 0, 0.2), (1, 3, 32, 3087, 16, 16, 0, 0.1), (2, 2, 9, 20, 16, 16, 0, 0.3),
                                                # chunked variants (keys / queries stream through LDS)
                                                (2, 3, 784, 816, 64, 64, 32, 0.1), (1, 2, 100, 1000, 64, 64, 0, 0.2), (1, 2, 1000, 40, 64, 64, 0, 0.1),
                                                (2, 2, 1300, 1300, 32, 32, 0, 0.1), (1, 3, 17, 530, 16, 64, 0, 0.25)]:

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in include/dav_kernels.h but not exported'
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.dav_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.dav_abi_version() == _lib.ABI_VERSION == 9
 
 
 def test_no_cpu_fallback():
@@ -342,6 +342,33 @@ def test_error_codes_for_dtype_alignment_and_workspace():
     fold[0].K, fold[0].w = 64, 4096 + 4
     assert lib.dav_ln_fold_grouped(fold, 1, None) == -5
     assert lib.dav_ln_fold_grouped(fold, 49, None) == -1                     # more pairs than one launch carries
+    # ---- ABI 9: dropout (dav_attn_drop_fwd / _bwd + fp32 twins, dav_dropout_rows)
+    for fn in ('dav_attn_drop_fwd', 'dav_attn_drop_fwd_f32'):
+        a = _zero_args(S[fn])
+        for i, v in zip(range(5), (4096, 8192, 12288, 16384, 20480)):
+            a[i] = p(v)
+        for i, v in zip(range(5, 11), (2, 3, 40, 70, 64, 64)):            # B, H, Nq, Nk, dqk, dv
+            a[i] = C.c_int(v)
+        for i, (bs, rs) in zip(range(11, 19, 2), ((70 * 192, 192),) * 3 + ((40 * 192, 192),)):
+            a[i], a[i + 1] = C.c_long(bs), C.c_int(rs)
+        a[19] = C.c_float(0.125)
+        a[20], a[21], a[22] = None, C.c_int(96), C.c_float(1.25)
+        assert getattr(lib, fn)(*a) == -1                                    # no mask: the plain entry points are the ones to call
+        a[20], a[21] = p(24576), C.c_int(64)                                 # keep_ld < Nk (rounded up to 32 for the bf16 kernels)
+        assert getattr(lib, fn)(*a) == -1
+        a[21], a[22] = C.c_int(96), C.c_float(0.0)                           # keep_scale = 1 / (1 - p) > 0
+        assert getattr(lib, fn)(*a) == -1
+        if fn == 'dav_attn_drop_fwd':
+            a[20], a[22] = p(24576 + 2), C.c_float(1.25)                     # the bf16 kernels read mask rows four bytes at a time
+            assert getattr(lib, fn)(*a) == -5
+    dr = _zero_args(S['dav_dropout_rows'])
+    dr[0], dr[3], dr[4], dr[9] = p(4096), p(8192), C.c_float(1.25), p(12288)
+    dr[6], dr[7], dr[8] = C.c_int(2), C.c_int(3), C.c_int(10)               # D % 4
+    assert lib.dav_dropout_rows(*dr) == -1
+    dr[8], dr[4] = C.c_int(16), C.c_float(0.0)
+    assert lib.dav_dropout_rows(*dr) == -1                                   # a mask needs its scale
+    dr[4], dr[3] = C.c_float(1.25), p(8192 + 1)
+    assert lib.dav_dropout_rows(*dr) == -5
 
 
 def test_written_first_contribution_bookkeeping(monkeypatch):

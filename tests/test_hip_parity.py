@@ -601,6 +601,123 @@ def test_drop_path_training_mode_vs_oracle_and_golden(golden):
     assert all(v == 0.0 or abs(v - 1.0 / keep) < 1e-6 for v in vals) and abs(float((s > 0).float().mean()) - keep) < 0.03
 
 
+def _dropout_encoder(name, g, **kw):
+    from deepavfusion_amd.models.deepavfusion import DeepAVFusion
+    from oracle import avmae_oracle as O
+    from oracle.configs import CONFIGS as OC
+    cfg = OC[name]
+    enc = DeepAVFusion(image_arch='vit_micro', image_pretrained='', image_size=cfg.image_size, audio_arch='vit_micro',
+                       audio_pretrained='', audio_size=cfg.audio_size, fusion_arch=cfg.fusion_arch, num_fusion_tkns=cfg.fusion_tkns,
+                       fusion_mlp_ratio=cfg.fusion_mlp_ratio, fusion_attn_ratio=cfg.fusion_attn_ratio,
+                       fusion_num_heads=cfg.fusion_num_heads, attn_drop=float(g['p_attn']), drop=float(g['p_proj']), **kw).cuda()
+    esd = {k[len('encoder.'):]: v for k, v in O.closed_form_state(cfg, 0).items() if k.startswith('encoder.')}
+    enc.load_state_dict(esd, strict=True)
+    image, audio, ni, na = O.synthetic_batch(cfg, int(g['B']), seed=int(g['seed']))
+    ik = torch.from_numpy(O.random_masking_from_noise(ni, cfg.image_mask_ratio)[0])
+    ak = torch.from_numpy(O.random_masking_from_noise(na, cfg.audio_mask_ratio)[0])
+    seed, pa, pp = int(g['seed']), float(g['p_attn']), float(g['p_proj'])
+    asked = []
+
+    def sampler(nm, shape):          # the engine asks for the mask of the reference's nn.Dropout call `nm` (reference shape)
+        asked.append((nm, list(shape)))
+        return torch.from_numpy(O.dropout_keep_mask(seed, nm, shape, pa if nm.endswith('attn') else pp))
+
+    def dropout(nm, x):              # the oracle's nn.Dropout
+        p = pa if nm.endswith('attn') else pp
+        return x * torch.from_numpy(O.dropout_keep_mask(seed, nm, x.shape, p)).to(x.dtype) / (1.0 - p)
+    enc._dropout_sampler = sampler
+    return enc, esd, cfg, O, (image, audio, ik, ak), asked, dropout
+
+
+@pytest.mark.parametrize('name', ['micro', 'micro_token', 'micro_dense'])
+@pytest.mark.parametrize('precision', ['bf16', 'fp32'])
+def test_dropout_training_mode_vs_oracle_and_golden(golden, name, precision):
+    """attn_drop / drop > 0 in training mode (the constructor surface of eval_finetune.py:170-171; no shipped config sets them):
+    dropout on the attention probabilities inside the attention kernels, dropout behind every proj and inside the Mlps, for the
+    three fusion-block architectures — against the reference's own outputs (fixture, every nn.Dropout draw injected) and, gradient
+    by gradient, against the oracle; on the bf16 kernels and on their fp32 twins (1e-4)."""
+    from deepavfusion_amd import engine as E
+    g = golden(f'dropout_{name}')
+    E.set_precision(precision)
+    try:
+        enc, esd, cfg, O, (image, audio, ik, ak), asked, dropout = _dropout_encoder(name, g)
+        act_tol = ACT_TOL if precision == 'bf16' else 1e-4
+        enc.train()
+        xi, xa, xf = enc(image.cuda(), audio.cuda(), ik.cuda(), ak.cuda())
+        # the engine asked for exactly the reference's Dropout calls (names and shapes; its own order may differ)
+        ref_calls = {n: [d for d in row if d] for n, row in zip(g['site_names'].tolist(), g['site_shapes'].tolist())}
+        assert dict(asked) == ref_calls
+        for got, key in ((xi, 'x_image'), (xa, 'x_audio'), (xf, 'x_fusion')):
+            assert rel(got, g[key]) < act_tol, key
+        w, loss = _probe((xi, xa, xf), int(g['seed']) + 1)
+        terms = float(sum(((t.detach().cpu() * wi) ** 2).sum() for t, wi in zip((xi, xa, xf), w)) ** 0.5)
+        assert abs(float(loss) - float(g['loss_probe'])) <= act_tol * terms
+        loss.backward()
+        sdo = {k: v.clone().requires_grad_(('encoder.' + k) not in O.FROZEN) for k, v in esd.items()}
+        ov = O.deepavfusion_forward(sdo, cfg, image, audio, ik, ak, dropout=dropout)
+        sum((t * wi).sum() for t, wi in zip(ov, w)).backward()
+        if precision == 'bf16':
+            _check_video_grads(enc, sdo)
+        else:
+            g_all = sum(float(v.grad.double().norm()) ** 2 for v in sdo.values() if v.grad is not None) ** 0.5
+            for n, p in enc.named_parameters():
+                if p.requires_grad and sdo[n].grad is not None:
+                    d = float((p.grad.detach().double().cpu() - sdo[n].grad.double()).norm())
+                    assert d <= 1e-4 * float(sdo[n].grad.double().norm()) + 1e-6 * g_all, (n, d)
+            for k in g.files:
+                if k.startswith('grad.'):
+                    got = dict(enc.named_parameters())[k[5:]].grad.detach().double().cpu().numpy()
+                    assert float(np.linalg.norm(got - g[k])) <= 1e-4 * float(np.linalg.norm(g[k])) + 1e-6 * g_all, k
+        # eval mode ignores the dropout modules
+        enc.eval()
+        with torch.no_grad():
+            xe = enc(image.cuda(), audio.cuda(), ik.cuda(), ak.cuda())[0]
+        assert rel(xe, O.deepavfusion_forward(esd, cfg, image, audio, ik, ak)[0]) < act_tol
+    finally:
+        E.set_precision('bf16')
+
+
+def test_dropout_with_drop_path_and_default_draws(golden):
+    """Dropout and DropPath together (x + drop_path(proj_drop(proj(...)))) against the oracle with both sets of draws injected; then
+    the default draws: Bernoulli(1 - p) bytes from torch's generator — a different mask every call, reproducible under a seed."""
+    from deepavfusion_amd import engine as E
+    g = golden('dropout_micro')
+    p_path = 0.25
+    enc, esd, cfg, O, (image, audio, ik, ak), asked, dropout = _dropout_encoder('micro', g, drop_path=p_path)
+    B = int(g['B'])
+    rs = np.random.RandomState(5)
+    pm = torch.from_numpy((rs.uniform(size=(cfg.depth * 6, B)) < (1 - p_path)).astype(np.float32))
+    pm[0, :] = torch.tensor([1.0, 0.0, 1.0][:B])
+    order = {'visual': 0, 'audio': 1, 'fusion': 2}
+    enc._drop_path_sampler = lambda tag, branch, n: pm[6 * int(tag.split('.')[1]) + 2 * order[tag.split('.')[0]] + branch]
+    enc.train()
+    outs = enc(image.cuda(), audio.cuda(), ik.cuda(), ak.cuda())
+    w, loss = _probe(outs, 77)
+    loss.backward()
+    keep = 1.0 - p_path
+    drop = {f'{t}.{l}': (pm[6 * l + 2 * j] / keep, pm[6 * l + 2 * j + 1] / keep)
+            for l in range(cfg.depth) for j, t in enumerate(('visual', 'audio', 'fusion'))}
+    sdo = {k: v.clone().requires_grad_(('encoder.' + k) not in O.FROZEN) for k, v in esd.items()}
+    ov = O.deepavfusion_forward(sdo, cfg, image, audio, ik, ak, drop=drop, dropout=dropout)
+    for got, ref in zip(outs, ov):
+        assert rel(got, ref) < ACT_TOL
+    sum((t * wi).sum() for t, wi in zip(ov, w)).backward()
+    _check_video_grads(enc, sdo)
+    # default draws
+    enc._dropout_sampler = enc._drop_path_sampler = None
+    args = (image.cuda(), audio.cuda(), ik.cuda(), ak.cuda())
+    with torch.no_grad():
+        torch.manual_seed(3)
+        a = enc(*args)[0]
+        b = enc(*args)[0]
+        torch.manual_seed(3)
+        c = enc(*args)[0]
+    assert torch.equal(a, c) and not torch.equal(a, b)
+    m, ld, ks = E.draw_attn_keep(0.2, 2, 3, 100, 70, torch.device('cuda'))
+    assert m.dtype == torch.uint8 and m.shape == (2, 3, 100, 96) and ld == 96 and abs(ks - 1.25) < 1e-9
+    assert abs(float(m[..., :70].float().mean()) - 0.8) < 0.02 and set(m.unique().tolist()) <= {0, 1}
+
+
 def test_random_masking_api_bit_exact(golden):
     g = golden('masking')
     model, *_ = _build('micro')

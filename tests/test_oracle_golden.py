@@ -304,6 +304,53 @@ def test_drop_path_training_mode(golden):
     assert float((xi0 - xi).abs().max()) > 1e-2
 
 
+def dropout_from_fixture(g, calls=None):
+    """oracle ``dropout(name, x)``: the closed-form masks the fixture generator injected into the reference's nn.Dropout calls."""
+    seed, pa, pp = int(g['seed']), float(g['p_attn']), float(g['p_proj'])
+
+    def dropout(name, x):
+        p = pa if name.endswith('attn') else pp
+        if calls is not None:
+            calls.append((name, tuple(x.shape)))
+        m = torch.from_numpy(O.dropout_keep_mask(seed, name, x.shape, p)).to(device=x.device, dtype=x.dtype)
+        return x * m / (1.0 - p)
+    return dropout
+
+
+@pytest.mark.parametrize('name', ['micro', 'micro_token', 'micro_dense'])
+def test_dropout_training_mode(golden, name):
+    """DeepAVFusion(attn_drop=0.2, drop=0.1).train() through the reference with every nn.Dropout draw injected (the constructor
+    surface of eval_finetune.py:170-171): attention dropout on the probabilities, dropout behind every proj and inside the Mlps, for
+    the three fusion-block architectures; the oracle makes the reference's Dropout calls, with the same shapes, in the same order."""
+    g = golden(f'dropout_{name}')
+    cfg = CONFIGS[name]
+    full = O.closed_form_state(cfg, 0)
+    sd = {k[len('encoder.'):]: v.clone().requires_grad_(k not in O.FROZEN) for k, v in full.items() if k.startswith('encoder.')}
+    image, audio, ni, na = O.synthetic_batch(cfg, int(g['B']), seed=int(g['seed']))
+    ik = torch.from_numpy(O.random_masking_from_noise(ni, cfg.image_mask_ratio)[0])
+    ak = torch.from_numpy(O.random_masking_from_noise(na, cfg.audio_mask_ratio)[0])
+    calls = []
+    xi, xa, xf = O.deepavfusion_forward(sd, cfg, image, audio, ik, ak, dropout=dropout_from_fixture(g, calls))
+    assert [c[0] for c in calls] == g['site_names'].tolist()
+    assert [list(c[1]) for c in calls] == [[d for d in row if d] for row in g['site_shapes'].tolist()]
+    close(xi.detach().numpy(), g['x_image'], rtol=5e-5)
+    close(xa.detach().numpy(), g['x_audio'], rtol=5e-5)
+    close(xf.detach().numpy(), g['x_fusion'], rtol=5e-5)
+    w = probe_weights([xi.shape, xa.shape, xf.shape], int(g['seed']) + 1)
+    loss = (xi * w[0]).sum() + (xa * w[1]).sum() + (xf * w[2]).sum()
+    assert abs(float(loss) - float(g['loss_probe'])) < 1e-4 * abs(float(g['loss_probe']))
+    loss.backward()
+    norms = dict(zip(g['grad_names'].tolist(), g['grad_norms'].tolist()))
+    for k, ref in norms.items():
+        got = float(sd[k].grad.double().norm())
+        assert abs(got - ref) <= 2e-4 * max(ref, 1e-6) + 1e-6, (k, got, ref)
+    for k in g.files:
+        if k.startswith('grad.'):
+            close(sd[k[5:]].grad.numpy(), g[k], rtol=1e-4)
+    xi0 = O.deepavfusion_forward(sd, cfg, image, audio, ik, ak)[0]          # eval mode: a different result
+    assert float((xi0 - xi).abs().max()) > 1e-2
+
+
 def test_lr_schedule_and_param_groups(golden):
     g = golden('lr_groups')
     cfg = CONFIGS['micro']
