@@ -49,5 +49,9 @@ python3 tools/runs_r06/fwd_only.py > $OUT/r06_ln_fwd_only.txt 2>&1
 # 6. single-rank cost of the data-parallel machinery
 DAV_FORCE_DIST=1 timeout 600 python bench.py --no-cpu-baseline --no-roofline --steps 40 > $OUT/r06_bench_dp1.json 2> $OUT/dp1.err
 bash tools/runs_r06/dp1_tax.sh > $OUT/r06_dp1_tax.txt 2>&1
+# 7. ViT-L (configs[3]): phases / concurrency / families of its step, launch-batch policy A/B
+bash tools/runs_r06/large_probe.sh > /dev/null 2>&1
+# 8. dropout kernels (ABI 9) against torch with the same masks
+timeout 300 python tests/gpu_selfcheck.py dropout > $OUT/r06_dropout_selfcheck.txt 2>&1
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*agent_info.csv" -delete
 ls $OUT
