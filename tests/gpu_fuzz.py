@@ -115,6 +115,44 @@ def fuzz_attn(rng, n):
         check(tag + ' dv', rel(dvv.permute(0, 2, 1, 3).float(), vf.grad), 2.5e-2)
 
 
+def fuzz_attn_drop(rng, n):
+    """Attention dropout (dav_attn_drop_fwd / _bwd): random lengths / head widths / probabilities / mask row strides, against torch with the
+    same keep mask."""
+    for it in range(n):
+        dqk, dv = rng.choice([(64, 64), (32, 32), (16, 64), (16, 16)])
+        B, H = rng.randint(1, 3), rng.randint(1, 4)
+        Nk = rng.choice([1, 2, 15, 16, 17, 31, 32, 33, 64, 100, 255, 256, 257, 320, 511, 513, 700, rng.randint(1, 1200)])
+        Nq = rng.choice([1, 5, 16, 17, 33, 64, 129, rng.randint(1, 600)])
+        pd = rng.choice([0.05, 0.1, 0.25, 0.5, 0.9])
+        ld = (Nk + 31) // 32 * 32 + 4 * rng.choice([0, 0, 1, 8])          # any multiple of 4 from Nk rounded up to 32
+        keep = (torch.rand(B, H, Nq, ld, device=dev) >= pd).to(torch.uint8)
+        km = keep[..., :Nk].float() / (1.0 - pd)
+        q = torch.randn(B, Nq, H, dqk, device=dev).to(BF16)
+        k = torch.randn(B, Nk, H, dqk, device=dev).to(BF16)
+        v = torch.randn(B, Nk, H, dv, device=dev).to(BF16)
+        scale = rng.choice([dqk ** -0.5, 0.125])
+        qf, kf, vf = (t.float().permute(0, 2, 1, 3).requires_grad_(True) for t in (q, k, v))
+        s = (qf @ kf.transpose(-2, -1)) * scale
+        ref = (s.softmax(-1) * km) @ vf
+        O = torch.empty(B * Nq, H * dv, device=dev, dtype=BF16)
+        LSE = torch.empty(B, H, Nq, device=dev)
+        st = (Nq * H * dqk, H * dqk, Nk * H * dqk, H * dqk, Nk * H * dv, H * dv)
+        ops.attn_drop_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), O, LSE, B, H, Nq, Nk, dqk, dv, *st, Nq * H * dv, H * dv, scale,
+                          keep, ld, 1.0 / (1.0 - pd))
+        tag = f'attn_drop B{B} H{H} {Nq}x{Nk} d{dqk}/{dv} p{pd} ld{ld}'
+        check(tag + ' fwd', rel(O.view(B, Nq, H, dv).permute(0, 2, 1, 3).float(), ref), 1.2e-2)
+        check(tag + ' lse', rel(LSE, torch.logsumexp(s, -1)), 2e-4)
+        dO = torch.randn(B * Nq, H * dv, device=dev).to(BF16)
+        ref.backward(dO.view(B, Nq, H, dv).permute(0, 2, 1, 3).float())
+        dq, dk, dvv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+        Delta = torch.empty_like(LSE)
+        ops.attn_drop_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), O, dO, LSE, Delta, dq.data_ptr(), dk.data_ptr(), dvv.data_ptr(), B, H, Nq, Nk,
+                          dqk, dv, *st, Nq * H * dv, H * dv, Nq * H * dv, H * dv, *st, scale, keep, ld, 1.0 / (1.0 - pd))
+        check(tag + ' dq', rel(dq.permute(0, 2, 1, 3).float(), qf.grad), 2.5e-2)
+        check(tag + ' dk', rel(dk.permute(0, 2, 1, 3).float(), kf.grad), 2.5e-2)
+        check(tag + ' dv', rel(dvv.permute(0, 2, 1, 3).float(), vf.grad), 2.5e-2)
+
+
 def fuzz_ln(rng, n):
     for it in range(n):
         B = rng.randint(1, 5)
@@ -270,6 +308,7 @@ if __name__ == '__main__':
     torch.manual_seed(seed)
     fuzz_gemm(rng, ng)
     fuzz_attn(rng, na)
+    fuzz_attn_drop(rng, na)
     fuzz_ln(rng, nl)
     fuzz_ln_fused(rng, nl)
     fuzz_gang(rng, ngg)

@@ -22,7 +22,7 @@ def test_kernel_family(name):
 
 def test_kernel_shape_fuzz():
     """A fixed-seed slice of tests/gpu_fuzz.py: random GEMM shapes with random epilogue options (+ their weight gradients),
-    random attention lengths / head widths, random two-segment LayerNorms, random LayerNorm-folding chains (producer GEMM -> consumer GEMM -> backward from the twin), random weight-gradient problem lists through the gang launch —
+    random attention lengths / head widths (with and without dropout masks), random two-segment LayerNorms, random LayerNorm-folding chains (producer GEMM -> consumer GEMM -> backward from the twin), random weight-gradient problem lists through the gang launch —
     each against a torch fp32 reference."""
     import random
 
@@ -34,6 +34,7 @@ def test_kernel_shape_fuzz():
     torch.manual_seed(7)
     fz.fuzz_gemm(rng, 60)
     fz.fuzz_attn(rng, 25)
+    fz.fuzz_attn_drop(rng, 15)
     fz.fuzz_ln(rng, 25)
     fz.fuzz_ln_fused(rng, 25)
     fz.fuzz_gang(rng, 25)
