@@ -1444,13 +1444,13 @@ def test_published_configs_vs_reference_fixture(golden, name):
     _fixture_grads_check({n: p.grad for n, p in model.named_parameters() if p.requires_grad}, g, float(g['grad_norm_total']))
 
 
-@pytest.mark.parametrize('name,batch', [('base_as', 64), ('large', 32)])
+@pytest.mark.parametrize('name,batch', [('base_as', 64)])
 def test_published_sizes_are_batch_consistent(name, batch):
-    """``base_as-64`` and ``large-32`` are the sizes profiles/*bench_base_as.json / *bench_large.json are timed at: other tile
-    configurations than the small batches above, the tuned table's entries, the merged gang-scheduled weight-gradient launch.  Checked
-    through a size-independent property (the reference arithmetic is pinned by the fixtures above): every sample masks the same number
-    of patches, so the batch losses are the means of the two half-batch losses and every gradient is the mean of the half-batch
-    gradients.  For ``large-32`` the issue log must show that entries of the shipped tuned table really fired."""
+    """``base_as-64`` is the size profiles/*bench_base_as.json is timed at: other tile configurations than the small batches above, the
+    tuned table's entries, the merged gang-scheduled weight-gradient launch.  Checked through a size-independent property (the
+    reference arithmetic is pinned by the fixtures above): every sample masks the same number of patches, so the batch losses are the
+    means of the two half-batch losses and every gradient is the mean of the half-batch gradients.  (``large-32`` ran here too until
+    round 6; it now meets the oracle itself in test_published_sizes_vs_oracle_on_the_device, which also carries its tuned-table check.)"""
     from deepavfusion_amd import ops
     model, sd, cfg, O = _build(name)
     image, audio, ni, na = O.synthetic_batch(cfg, batch, seed=25)
@@ -1492,10 +1492,16 @@ def test_published_sizes_vs_oracle_on_the_device(name, batch):
     the stock PyTorch-ROCm kernels (hipBLASLt / MIOpen / ATen: nothing of libdavfusion_hip.so) in a few seconds where the host needs
     minutes.  An implementation independent of the library checks losses, predictions, masking indices and every gradient at the
     sizes the throughput is published for (the batch-consistency property above compares the library with itself)."""
+    from deepavfusion_amd import ops
     model, sd, cfg, O = _build(name)
     image, audio, ni, na = O.synthetic_batch(cfg, batch, seed=25)
+    ops.nt_issue_log(True)
     out = model(image.cuda(), audio.cuda(), torch.from_numpy(ni).cuda(), torch.from_numpy(na).cuda())
     (out[0] + out[1]).backward()
+    hits = _tuned_hits(ops.nt_issue_log(with_flags=True))
+    ops.nt_issue_log(False)
+    if (name, batch) == ('large', 32) and os.environ.get('DAV_NT_TUNE', '1') != '0' and not os.environ.get('DAV_BATCH'):
+        assert hits >= 8, hits          # the shipped tuned table's entries really fire: the decoders' single-problem entries ([11264, 1536, 512] ...)
     torch.cuda.synchronize()
     prev = torch.backends.cuda.matmul.allow_tf32
     torch.backends.cuda.matmul.allow_tf32 = False
