@@ -301,6 +301,8 @@ def main():
                    'global_batch': B * world, 'parallelism': f'dp{world}', 'graph': not (a.no_graph or a.roofline_only)},
         'pairs_per_s_per_gpu': round(pairs_per_s / world, 2),
         'median_ms_per_step_device_events': round(median_ms, 3),
+        'ms_per_step_quantiles_device_events': {k: round(step_ms[min(len(step_ms) - 1, int(f * (len(step_ms) - 1) + 0.5))], 3)
+                                                for k, f in (('min', 0.0), ('p10', 0.1), ('p50', 0.5), ('p90', 0.9), ('max', 1.0))},
         'loss': round(loss, 5),
         'step_necessary_gflop_per_pair': round(flops_pair / 1e9, 1),
         'step_mfma_frac': round(flops_pair * pairs_per_s / world / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),

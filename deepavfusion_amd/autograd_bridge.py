@@ -35,6 +35,43 @@ def _streams(dev):
     return main, sa, sf
 
 
+# Cross-joins between the two decoders' streams, every DEC_JOIN decoder blocks (0 = never, the default).  The decoders are two independent
+# chains of ~60 launches.  Under rocprofv3 the replayed graph starts the second of two such unjoined branches only when the first is most of
+# the way through (profiles/r06_streams_base.txt: 2.2 ms late in the forward, 2.9 ms in the backward; tools/runs_r06/graph_fork_probe.py shows
+# the same on a bare two-chain graph), and joins every 1-4 blocks give the overlap back (decoder phases 10.0 -> 9.2 ms in the trace).  WITHOUT
+# the profiler the branches do start together: tools/runs_r06/dec_overlap_probe.py times the two decoders' forward as graphs — alone 1.84 and
+# 2.80 ms, both 4.08-4.10 ms with or without joins — and the step A/B is flat (24.27-24.58 vs 24.28-24.45 ms).  So the late start is an
+# artefact of the tracing, the kernel-trace timelines under profiles/ understate the overlap of the decoders, and the switch stays off;
+# what limits the pair is that each decoder's kernels already fill most of the GPU alone (both = 0.88 x the sum).
+DEC_JOIN = int(os.environ.get('DAV_DEC_JOIN', '0'))
+_PENDING = object()
+
+
+def paired_steps(gen_a, stream_a, gen_b, stream_b, every):
+    """Advance two step generators alternately, each under its stream; while both still have steps, cross-join the two streams after
+    every ``every`` steps (0: never).  Returns the generators' values."""
+    ra = rb = _PENDING
+    i = 0
+    while ra is _PENDING or rb is _PENDING:
+        if ra is _PENDING:
+            with torch.cuda.stream(stream_a):
+                try:
+                    next(gen_a)
+                except StopIteration as e:
+                    ra = e.value
+        if rb is _PENDING:
+            with torch.cuda.stream(stream_b):
+                try:
+                    next(gen_b)
+                except StopIteration as e:
+                    rb = e.value
+        i += 1
+        if every and i % every == 0 and ra is _PENDING and rb is _PENDING and stream_a is not stream_b:
+            stream_a.wait_stream(stream_b)
+            stream_b.wait_stream(stream_a)
+    return ra, rb
+
+
 def _batched(rows):
     """Launch batching (engine.batch, csrc/batch.h) with the paired tower blocks / decoders as LANES of one batch, or one HIP
     stream per tower: engine.lanes_for (DAV_BATCH = 1 / 0 force either; default: by the step's size)."""
@@ -507,13 +544,21 @@ def _avmae_fwd(model, image, audio, noise_i, noise_a):
             pred_a, t_da = E.decoder_fwd(dec_a, xa_b, xf_b, ar32, B, nka, nF)
             loss_a, t_la = E.loss_fwd(audio, pred_a, am, model.audio_norm_loss)
     else:
+        si = main
         sa.wait_stream(main)
-        with torch.cuda.stream(sa):
-            pred_a, t_da = E.decoder_fwd(dec_a, xa_b, xf_b, ar32, B, nka, nF)
-            loss_a, t_la = E.loss_fwd(audio, pred_a, am, model.audio_norm_loss)
-        pred_i, t_di = E.decoder_fwd(dec_i, xi_b, xf_b, ir32, B, nki, nF)
-        loss_i, t_li = E.loss_fwd(image, pred_i, im, model.image_norm_loss)
+        if si is not main:
+            si.wait_stream(main)
+
+        def chain(dec, x_b, r32, nk, target, mask, norm_loss):
+            pred, t_d = yield from E.decoder_fwd_steps(dec, x_b, xf_b, r32, B, nk, nF)
+            loss, t_l = E.loss_fwd(target, pred, mask, norm_loss)
+            return pred, t_d, loss, t_l
+        (pred_a, t_da, loss_a, t_la), (pred_i, t_di, loss_i, t_li) = paired_steps(
+            chain(dec_a, xa_b, ar32, nka, audio, am, model.audio_norm_loss), sa,
+            chain(dec_i, xi_b, ir32, nki, image, im, model.image_norm_loss), si, DEC_JOIN)
         main.wait_stream(sa)
+        if si is not main:
+            main.wait_stream(si)
     tape = dict(image=image, audio=audio, im=im, am=am, ik32=ik32, ak32=ak32, dec_lanes=lanes, t_enc=t_enc, t_di=t_di, t_da=t_da, t_li=t_li,
                 t_la=t_la, pred_i=pred_i, pred_a=pred_a, B=B)
     aux = dict(image_ids_keep=ik, image_mask=im, image_ids_restore=ir, audio_ids_keep=ak, audio_mask=am, audio_ids_restore=ar)
@@ -547,18 +592,23 @@ def avmae_bwd(model, t, g_li, g_la, g_pi=None, g_pa=None, layer_cb=None):
         # contraction length, then two small heads: 1944 + 504 us and 914 + 227 us), the union of both lists fills the tail
         # of one with the tiles of the other (2.7 ms instead of 3.7 ms of weight-gradient time per step)
         with E.deferred_wgrads():
+            si = main
             sa.wait_stream(main)
-            with torch.cuda.stream(sa):
-                dpa = E.loss_bwd(t['audio'], t['pred_a'], t['am'], t['t_la'], g_la)
-                if g_pa is not None:
-                    dpa = (dpa.float() + g_pa.reshape(dpa.shape)).to(E.BF16)
-                dxa_b, dxf_a = E.decoder_bwd(dec_a, t['t_da'], dpa, t['ak32'], B)
-            dpi = E.loss_bwd(t['image'], t['pred_i'], t['im'], t['t_li'], g_li)
-            if g_pi is not None:
-                dpi = (dpi.float() + g_pi.reshape(dpi.shape)).to(E.BF16)
-            dxi_b, dxf_i = E.decoder_bwd(dec_i, t['t_di'], dpi, t['ik32'], B)
+            if si is not main:
+                si.wait_stream(main)
+
+            def chain(dec, target, pred, mask, t_l, g_l, g_p, t_d, k32):
+                dp = E.loss_bwd(target, pred, mask, t_l, g_l)
+                if g_p is not None:
+                    dp = (dp.float() + g_p.reshape(dp.shape)).to(E.BF16)
+                return (yield from E.decoder_bwd_steps(dec, t_d, dp, k32, B))
+            (dxa_b, dxf_a), (dxi_b, dxf_i) = paired_steps(
+                chain(dec_a, t['audio'], t['pred_a'], t['am'], t['t_la'], g_la, g_pa, t['t_da'], t['ak32']), sa,
+                chain(dec_i, t['image'], t['pred_i'], t['im'], t['t_li'], g_li, g_pi, t['t_di'], t['ik32']), si, DEC_JOIN)
             main.wait_stream(sa)
-            E.deferred_operands_to(main)          # (the audio decoder's operands were allocated on its stream)
+            if si is not main:
+                main.wait_stream(si)
+            E.deferred_operands_to(main)          # (the decoders' operands were allocated on their streams)
     else:
         sa.wait_stream(main)
         # each decoder's weight gradients are queued and launched as ONE grouped GEMM on that decoder's stream

@@ -1641,9 +1641,24 @@ def patch_embed_bwd(vit, t, g, gb):
 # ------------------------------------------------------------------------------------------------
 # MAE decoder (models/avmae.py:147-180, decoder_arch='plain')
 # ------------------------------------------------------------------------------------------------
+def drain(steps):
+    """Run a step generator (decoder_fwd_steps / decoder_bwd_steps) to its end; returns its value."""
+    try:
+        while True:
+            next(steps)
+    except StopIteration as e:
+        return e.value
+
+
 def decoder_fwd(dec, x_b, xf_b, ids_restore32, B, nk, nF):
     """dec: namespace with embed, mask_token, pos_embed, blocks, norm, pred, heads.  x_b bf16 [B*nk, D]
     (normed encoder tokens), xf_b bf16 [B*nF, D].  Returns pred fp32 [B, L, P]."""
+    return drain(decoder_fwd_steps(dec, x_b, xf_b, ids_restore32, B, nk, nF))
+
+
+def decoder_fwd_steps(dec, x_b, xf_b, ids_restore32, B, nk, nF):
+    """decoder_fwd as a generator that yields after every decoder block: the caller advances the two decoders alternately on their two
+    streams and may cross-join the streams between blocks (autograd_bridge.paired_steps: why)."""
     L = ids_restore32.shape[1]
     Dd = dec.embed.weight.shape[0]
     dev = x_b.device
@@ -1659,6 +1674,7 @@ def decoder_fwd(dec, x_b, xf_b, ids_restore32, B, nk, nF):
         else:
             x, bt = block_fwd(blk, x, None, dec.heads, blk.norm1.eps)
         tapes.append(bt)
+        yield
     # decoder_norm + pred on the patch rows only (x[:, nF:]) — the LN reads them through the batch stride
     D_ = Dd
     if not swin and ln_fuse_ok(Dd):       # decoder_norm folded into decoder_pred: the head contracts the twin's patch rows through a row map
@@ -1678,6 +1694,11 @@ def decoder_fwd(dec, x_b, xf_b, ids_restore32, B, nk, nF):
 
 
 def decoder_bwd(dec, t, dpred_b, ids_keep32, B):
+    return drain(decoder_bwd_steps(dec, t, dpred_b, ids_keep32, B))
+
+
+def decoder_bwd_steps(dec, t, dpred_b, ids_keep32, B):
+    """decoder_bwd as a generator that yields after the head's backward and after every decoder block (see decoder_fwd_steps)."""
     nk, nF, L = t['nk'], t['nF'], t['L']
     Dd = dec.embed.weight.shape[0]
     dev = dpred_b.device
@@ -1702,11 +1723,13 @@ def decoder_bwd(dec, t, dpred_b, ids_keep32, B):
                           None, 0, 0, None, 0, None, 0, gbuf(dec.norm.weight), gbuf(dec.norm.bias))
     _ready(dec.norm.weight, dec.norm.bias)
     swin = getattr(dec, 'arch', 'plain') == 'swin'
+    yield
     for blk, bt in zip(reversed(list(dec.blocks)), reversed(t['tapes'])):
         if swin:
             g, gb = swin_block_bwd(blk, bt, g, gb)
         else:
             g, gb, _ = block_bwd(blk, bt, g, gb)
+        yield
     d_emb = _e((B * nk, Dd), BF16, dev)
     d_embf = _e((B * nF, Dd), BF16, dev)
     ops.rows_gather_cast(g, (nF + L) * Dd, nF, ids_keep32, B, nk, Dd, d_emb)

@@ -106,6 +106,34 @@ def test_lane_batched_and_stream_schedules_agree():
             assert rel(got[3][n], g) < 1e-5, (policy, n)
 
 
+def test_decoder_cross_joins_change_nothing_but_the_schedule():
+    """autograd_bridge.DEC_JOIN: cross-joins between the two decoders' streams every n decoder blocks (the decoders advance as step
+    generators, alternately) are a schedule of the same kernels — losses, predictions and gradients equal the unjoined branches'
+    (the weight gradients are queued in another order: fp32 accumulation order into shared buffers may differ)."""
+    from deepavfusion_amd import autograd_bridge as bridge
+    from deepavfusion_amd import engine as E
+    res = {}
+    prev = bridge.DEC_JOIN
+    try:
+        E.set_batch_policy('auto')
+        for k in (0, 1, 3):
+            bridge.DEC_JOIN = k
+            model, sd, cfg, O = _build('micro')
+            image, audio, ni, na = O.synthetic_batch(cfg, 3, seed=21)
+            out = model(image.cuda(), audio.cuda(), torch.from_numpy(ni).cuda(), torch.from_numpy(na).cuda())
+            (out[0] + out[1]).backward()
+            torch.cuda.synchronize()
+            res[k] = (float(out[0]), float(out[1]), out[2].detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+    finally:
+        bridge.DEC_JOIN = prev
+        E.set_batch_policy({'1': 'on', '0': 'off'}.get(os.environ.get('DAV_BATCH', ''), 'auto'))
+    for k in (1, 3):
+        assert res[k][0] == res[0][0] and res[k][1] == res[0][1] and torch.equal(res[k][2], res[0][2])
+        assert set(res[k][3]) == set(res[0][3])
+        for n, g in res[0][3].items():
+            assert rel(res[k][3][n], g) < 1e-5, (k, n)
+
+
 @pytest.mark.parametrize('name', ['micro', 'tiny'])
 def test_ln_folded_and_layernorm_kernel_paths_agree(golden, name):
     """engine.LN_FUSE: the LayerNorms folded into the GEMMs either side of them (producer epilogues write twin + row statistics, consumer

@@ -20,6 +20,7 @@ S = {
     'DAV_BATCH': ('auto', 'schedule', "launch batching policy (engine.BATCH_POLICY): unset = one HIP stream per independent chain with batched regions; 1 = the towers / decoders as lanes of one launch batch; 0 = no batching at all", 'test_lane_batched_and_stream_schedules_agree, test_full_size_step_is_schedule_independent_and_repeatable'),
     'DAV_LANE_MIN_ROWS': ('2^30', 'schedule', "with DAV_BATCH unset: lanes from this many rows (B x tokens per tower block) upwards", 'test_lane_batched_and_stream_schedules_agree (policy values)'),
     'DAV_FUSION_STREAM': ('1', 'schedule', "lanes schedule only: the fusion block on its own stream (1) or as a third lane of the batch (0)", 'bench.py roofline.lanes_schedule (runs it), test_full_size_step...'),
+    'DAV_DEC_JOIN': ('0', 'schedule', "streams schedule: cross-join the two decoders' streams every n decoder blocks (0 = two unjoined branches).  Under rocprofv3 the second branch of the replayed graph starts 2-3 ms late and joins give the overlap back; without the profiler the branches start together and the step is flat (tools/runs_r06/dec_overlap_probe.py, profiles/r06_dec_overlap.txt): the traces under profiles/ understate the decoders' overlap", 'test_decoder_cross_joins_change_nothing_but_the_schedule'),
     'DAV_STREAMS': ('1', 'schedule', "0: everything on the current stream (serial schedule; tools/instep_gemm_bound.py uses it)", 'tools/instep_gemm_bound.py (profiles/r04_gemm_instep_bound.txt)'),
     'DAV_WGRAD_GANG': ('1', 'kernel', "weight gradients of a flush as ONE gang-scheduled launch of 256 x 256 tiles (dav_gemm_tn_gang_bf16: per-XCD ticket queues of tiles that share operand panels); 0 = the 128 x 128 grouped kernel, one launch per layer (profiles/r05_tn_gang_*.txt)", 'test_gang_weight_gradients_equal_the_grouped_kernel_and_the_oracle, test_baseline_config_shapes_vs_oracle (default path), tools/tn_gang_bench.py check()'),
     'DAV_WGRAD_MERGE': ('0 (all layers of a captured segment)', 'schedule', "encoder layers whose queued weight gradients share one launch (n > 0: a flush every n layers); with 0 an EAGER data-parallel backward (grad-ready hook installed, no captured segments) still flushes every 3 layers, so that gradient buckets become ready under the backward and operands are released (engine.WGRAD_EAGER_DP_MERGE)", 'test_gang_weight_gradients_equal_the_grouped_kernel_and_the_oracle (1 and 0)'),
