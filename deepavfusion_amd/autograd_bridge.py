@@ -534,7 +534,7 @@ def _avmae_fwd(model, image, audio, noise_i, noise_a):
     nF = enc.fusion_tokens.shape[1]
     dec_i, dec_a = model.decoder('image'), model.decoder('audio')
     main, sa, _ = _streams(image.device)
-    lanes = t_enc['lanes']                                                        # the two decoders follow the encoder's schedule
+    lanes = t_enc['lanes']                                                        # the two decoders follow the encoder's schedule (as lanes beside a STREAMED encoder: +1.6 ms, profiles/r06_dec_overlap.txt)
     if lanes:
         with E.batch() as bt:                 # the two MAE decoders (models/avmae.py:147-180) in lockstep
             bt.lane()

@@ -67,6 +67,14 @@ def both(k):
     return fn
 
 
+def lanes():
+    with E.batch() as bt:
+        bt.lane()
+        E.decoder_fwd(dec_i, xi_b, xf_b, ir32, B, nki, nF)
+        bt.lane()
+        E.decoder_fwd(dec_a, xa_b, xf_b, ar32, B, nka, nF)
+
+
 for rnd in range(2):
     ti = timed(lambda: E.decoder_fwd(dec_i, xi_b, xf_b, ir32, B, nki, nF))
     ta = timed(lambda: E.decoder_fwd(dec_a, xa_b, xf_b, ar32, B, nka, nF))
@@ -74,4 +82,5 @@ for rnd in range(2):
     for k in (0, 1, 2, 4):
         tb = timed(both(k))
         line += f'  k={k}: {tb:6.3f} ms (overlap {(ti + ta - tb) / min(ti, ta):4.2f})'
+    line += f'  as lanes of one launch batch (grouped grids): {timed(lanes):6.3f} ms'
     print(line, flush=True)
