@@ -225,6 +225,46 @@ def test_ln_folded_captured_step_tracks_the_kernel_path():
     assert abs(np.mean(curves['on'][-3:]) - np.mean(curves['off'][-3:])) < 0.1 * abs(np.mean(curves['off'][-3:]))
 
 
+def test_dropout_in_a_captured_step_draws_fresh_masks():
+    """A captured training step of a model whose encoder has attn_drop / drop > 0: the keep masks are drawn by torch's generator INSIDE
+    the hipGraph (graph-safe Philox offsets), so every replay draws new masks — observed on the mask tensors themselves — and the
+    training still descends."""
+    from deepavfusion_amd import engine as E
+    from deepavfusion_amd.util import lr_sched
+    from deepavfusion_amd.util.flat import FlatAdamW
+    from deepavfusion_amd.util.misc import GraphedStep, Trainer
+    model, sd, cfg, O = _build('micro')
+    for blk in list(model.encoder.image.blocks) + list(model.encoder.audio.blocks) + [b for b in model.encoder.fusion_blocks if b is not None]:
+        blk.attn_drop_prob, blk.proj_drop_prob = 0.1, 0.1
+    image, audio, _, _ = O.structured_batch(cfg, 8, seed=3)
+    image, audio = image.cuda(), audio.cuda()
+    nd = [n for n, p in model.named_parameters() if 'bias' in n or 'norm' in n]
+    groups = lr_sched.param_groups_pretrained(model, 0.05, no_weight_decay_list=nd, image_pt='', audio_pt='')
+    opt = FlatAdamW(groups, lr=1e-3, betas=(0.9, 0.95), model=model)
+    tr = Trainer(model, optimizer=opt, accum_iter=1)
+    seen, real = [], E.draw_keep
+
+    def spy(p, rows, D, dev, sample=None):
+        m = real(p, rows, D, dev, sample)
+        seen.append(m[0])
+        return m
+    E.draw_keep = spy
+    try:
+        torch.manual_seed(9)
+        gs = GraphedStep(tr, image.shape, audio.shape, warmup=1)
+    finally:
+        E.draw_keep = real
+    captured = seen[-1]                                   # the last mask tensor of the captured pass: rewritten by every replay
+    losses, snaps = [], []
+    for _ in range(12):
+        li, la, _ = gs(image, audio)
+        losses.append(float(li) + float(la))
+        snaps.append(captured.clone())
+    assert all(np.isfinite(losses)) and np.mean(losses[-3:]) < np.mean(losses[:3])
+    assert not torch.equal(snaps[0], snaps[1]) and not torch.equal(snaps[1], snaps[2])
+    assert abs(float(torch.stack(snaps).float().mean()) - 0.9) < 0.02
+
+
 def test_full_size_step_is_schedule_independent_and_repeatable():
     """BASELINE configs[1] at its full size (ViT-B, B = 64 — the bench workload; the oracle would need minutes there): the
     size-independent properties instead.  The step computed as merged-grid lanes on one queue and as three streams with batched
